@@ -1,0 +1,152 @@
+"""Pin the CPU oracle (oracle/ref_torch.py) against the reference's outputs
+captured in tests/golden (tools/make_goldens.py) and against the known-answer
+inputs of the reference's own third_party/cuda_gridsample_grad2/test3d.py."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import ref_torch as R
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _load(name):
+    return np.load(gc.golden_path(name))
+
+
+@pytest.mark.parametrize("name", ["small", "cfg1", "cfg2"])
+@pytest.mark.parametrize("impl", ["stock", "gather"])
+def test_encode_decode_matches_reference(name, impl):
+    if name == "cfg2" and impl == "gather":
+        pytest.skip("covered by small/cfg1; cfg2 gather restatement is slow on CPU")
+    case = gc.CASES[name]
+    g = _load(name)
+    feats = [T(f).requires_grad_(True) for f in gc.make_features(case)]
+    stab = [T(f) for f in gc.make_stability(case)]
+    bound = torch.tensor(case["bound"], dtype=torch.float32)
+    ws, bs = R.decoder_params({k: T(v) for k, v in gc.make_decoder(case).items()})
+    x = T(gc.make_points(case)).requires_grad_(True)
+    n = x.shape[0]
+    sdf_t, valid, sign, weight = [T(a) for a in gc.make_targets(case, n)]
+    enc = R.encode_stock if impl == "stock" else R.encode_gather
+    f = enc(feats, bound, x)
+    tol = dict(rtol=0, atol=1e-7) if impl == "stock" else dict(rtol=1e-5, atol=2e-7)
+    torch.testing.assert_close(f.detach(), T(g["feats"]), **tol)
+    torch.testing.assert_close(enc(stab, bound, x).detach(), T(g["stab"]), rtol=1e-5, atol=1e-6)
+    pred = R.mlp_forward(f, ws, bs)
+    torch.testing.assert_close(pred.detach(), T(g["sdf"]), rtol=1e-5, atol=1e-6)
+    l1 = R.miso_loss_regression(pred, sdf_t, valid, weight, "L1")
+    fs = R.miso_loss_free_space(pred, sdf_t, sign, 0.15)
+    assert abs(l1.item() - float(g["loss_l1"])) < 1e-6
+    assert abs(fs.item() - float(g["loss_fs"])) < 1e-6
+    grads = torch.autograd.grad(l1 + 0.1 * fs, feats + [x])
+    torch.testing.assert_close(grads[-1], T(g["grad_x"]), rtol=1e-4, atol=1e-7)
+    for l in range(case["n_levels"]):
+        gl = grads[l].reshape(-1)
+        idx = T(g[f"gfeat{l}_idx"])
+        torch.testing.assert_close(gl[idx], T(g[f"gfeat{l}_val"]), rtol=1e-4, atol=1e-9)
+        assert abs(gl.double().abs().sum().item() - float(g[f"gfeat{l}_abssum"])) \
+            <= 1e-4 * float(g[f"gfeat{l}_abssum"])
+
+
+def test_known_answers_from_reference_test3d():
+    """third_party/cuda_gridsample_grad2/test3d.py:17-35 inputs; values
+    cross-checked against F.grid_sample (the reference's forward, cuda_gridsample.py:84)."""
+    cases = [
+        (torch.arange(27, dtype=torch.float64).reshape(1, 1, 3, 3, 3), [0.1, 0.1, 0.1], "border", True),
+        (torch.arange(8, dtype=torch.float64).reshape(1, 1, 2, 2, 2), [0.1, 1.1, 0.1], "border", True),
+        (torch.arange(27, dtype=torch.float64).reshape(1, 1, 3, 3, 3), [-2.1, 0.1, 0.1], "zeros", True),
+        (torch.arange(27, dtype=torch.float64).reshape(1, 1, 3, 3, 3), [-0.95, 0.99, 0.3], "zeros", False),
+    ]
+    for inp, q, pad, ac in cases:
+        xn = torch.tensor([q], dtype=torch.float64)
+        a = R.trilinear_gather(inp, xn, align_corners=ac, padding_mode=pad)
+        b = R.grid_sample_stock(inp, xn, align_corners=ac, padding_mode=pad)
+        torch.testing.assert_close(a, b)
+    # arange(27) volume, align_corners=True, centre+0.1 -> 13 + 0.1*(1+3+9)
+    v = R.trilinear_gather(cases[0][0], torch.tensor([[0.1, 0.1, 0.1]], dtype=torch.float64), True, "border")
+    assert abs(v.item() - (13 + 0.1 * 13)) < 1e-12
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+@pytest.mark.parametrize("ac", [False, True])
+def test_gather_first_derivatives_match_aten(pad, ac):
+    torch.manual_seed(0)
+    inp = torch.randn(1, 3, 5, 6, 7, dtype=torch.float64, requires_grad=True)
+    xn = (torch.rand(200, 3, dtype=torch.float64) * 2.6 - 1.3).requires_grad_(True)
+    go = torch.randn(200, 3, dtype=torch.float64)
+    a = R.trilinear_gather(inp, xn, ac, pad)
+    b = R.grid_sample_stock(inp, xn, ac, pad)
+    torch.testing.assert_close(a, b)
+    ga = torch.autograd.grad((a * go).sum(), [inp, xn])
+    gb = torch.autograd.grad((b * go).sum(), [inp, xn])
+    torch.testing.assert_close(ga[0], gb[0])
+    torch.testing.assert_close(ga[1], gb[1])
+
+
+def test_gather_gradgradcheck():
+    """Style of test3d.py:37-72: gradcheck + gradgradcheck in fp64, in- and out-of-bounds."""
+    torch.manual_seed(1)
+    inp = torch.randn(1, 2, 4, 3, 5, dtype=torch.float64, requires_grad=True)
+    xn = (torch.rand(12, 3, dtype=torch.float64) * 2.4 - 1.2).requires_grad_(True)
+    fn = lambda i, g: R.trilinear_gather(i, g, False, "zeros")
+    assert torch.autograd.gradcheck(fn, (inp, xn))
+    assert torch.autograd.gradgradcheck(fn, (inp, xn))
+
+
+def test_so3_and_pose_goldens():
+    g = _load("so3")
+    R0 = T(gc.rodrigues([0.2, 0.1, -0.3]).astype(np.float32))
+    t0 = torch.tensor([[1.0], [2.0], [3.0]])
+    for i, w in enumerate([[0.0, 0.0, 0.0], [1e-3, -2e-3, 5e-4], [0.3, -0.2, 0.1], [1.2, 0.4, -0.9]]):
+        dr = torch.tensor([w], dtype=torch.float32, requires_grad=True)
+        dt = torch.tensor([[0.1], [-0.2], [0.3]], dtype=torch.float32)
+        Rn, tn = R.apply_pose_correction(R0, t0, dr, dt)
+        wgt = torch.arange(9, dtype=torch.float32).reshape(3, 3) / 10
+        (Rn * wgt).sum().backward()
+        torch.testing.assert_close(Rn.detach(), T(g[f"R_{i}"]), rtol=0, atol=1e-7)
+        torch.testing.assert_close(tn, T(g[f"t_{i}"]))
+        torch.testing.assert_close(dr.grad, T(g[f"gdr_{i}"]), rtol=1e-5, atol=1e-6)
+
+
+def test_pairwise_latent_matches_reference():
+    g = _load("atlas")
+    c = gc.ATLAS
+    subs = gc.atlas_inputs()
+    bound = torch.tensor(c["bound"], dtype=torch.float32)
+    # cached coordinates: voxel centres whose multi-level feature norm > 1e-5 (grid_atlas.py:565-579)
+    coords = {}
+    for s, sub in enumerate(subs):
+        feats = [T(f) for f in sub["features"]]
+        for l, f in enumerate(feats):
+            _, _, nz, ny, nx = f.shape
+            ax = [2 * torch.linspace(0.5 / n, 1 - 0.5 / n, n) - 1 for n in (nx, ny, nz)]
+            zz, yy, xx = torch.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+            pn = torch.stack([xx, yy, zz], -1).reshape(-1, 3)
+            p = R.denormalize_coordinates(pn, bound)
+            fe = R.encode_stock(feats, bound, p)
+            keep = torch.linalg.norm(fe, dim=1) > 1e-5
+            coords[(s, l)] = p[keep]
+            assert coords[(s, l)].shape[0] == int(g[f"ncoords_s{s}_l{l}"])
+    for (a, b) in [(0, 1), (0, 2), (1, 2)]:
+        for l in range(c["n_levels"]):
+            for lt in ("L2", "L1"):
+                prm = {}
+                for s in (a, b):
+                    prm[s] = (T(subs[s]["dr"]).clone().requires_grad_(True),
+                              T(subs[s]["dt"]).clone().requires_grad_(True))
+                Ra, ta = R.apply_pose_correction(T(subs[a]["R"]), T(subs[a]["t"]), *prm[a])
+                Rb, tb = R.apply_pose_correction(T(subs[b]["R"]), T(subs[b]["t"]), *prm[b])
+                loss = R.pairwise_latent_loss([T(f) for f in subs[a]["features"]], bound,
+                                              [T(f) for f in subs[b]["features"]], bound,
+                                              coords[(a, l)], Ra, ta, Rb, tb, l, c["fdim"],
+                                              align_loss=lt)
+                key = f"latent_{a}_{b}_l{l}_{lt}"
+                assert abs(loss.item() - float(g[key])) <= 2e-5 * abs(float(g[key])), key
+                loss.backward()
+                for which, s in (("src", a), ("dst", b)):
+                    torch.testing.assert_close(prm[s][0].grad, T(g[key + f"_gR_{which}"]), rtol=2e-3, atol=2e-3)
+                    torch.testing.assert_close(prm[s][1].grad, T(g[key + f"_gt_{which}"]), rtol=2e-3, atol=2e-3)

@@ -1,0 +1,455 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING the reference (MISO) on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference can
+not travel to the GPU box, so its outputs on seed-pinned inputs
+(tests/golden_cases.py) are committed as small fixtures instead.
+
+Import recipe: stub packages for GUI / IO dependencies that are
+absent from the image and irrelevant to the arithmetic (open3d, trimesh, ...);
+pytorch3d.transforms is provided by tools/ref_shims (so3_exp_map / hat restated
+-> that boundary is "parity unpinned").  Harness-only patches: PerfTimer (needs
+torch.cuda.Event) and prepare_batch's default device.
+
+    python tools/make_goldens.py            # writes tests/golden/*.npz
+"""
+import importlib.abc
+import importlib.machinery
+import logging
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("MISO_REFERENCE", "/root/reference")
+
+STUB_ROOTS = {"open3d", "trimesh", "mcubes", "cv2", "torchvision", "evo", "pysdf", "sdf",
+              "lpips", "dearpygui"}
+EXTRA = {"pytorch3d.ops", "torch.utils.tensorboard"}
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return type(name, (), {})
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in STUB_ROOTS or fullname in EXTRA:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _Stub(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def import_reference():
+    sys.meta_path.insert(0, _Finder())
+    sys.path.insert(0, os.path.join(HERE, "ref_shims"))
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    logging.disable(logging.CRITICAL)
+    import grid_opt.utils.utils as ru
+
+    class _Timer:  # harness patch: upstream PerfTimer needs torch.cuda.Event
+        def __init__(self, *a, **k):
+            pass
+
+        def reset(self):
+            pass
+
+        def check(self, *a, **k):
+            return 0.0, 0.0
+
+    ru.PerfTimer = _Timer
+    ru.prepare_batch.__defaults__ = ("cpu",)
+    ru.get_batch.__defaults__ = ("cpu",)
+    return ru
+
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build_gridnet(GridNet, gc, case, num_poses=1, optimize_pose=False, stability=False):
+    cfg = gc.model_cfg(case["bound"], case["base_cell"], case["scale"], case["n_levels"],
+                       case["fdim"], case["hidden"], num_poses=num_poses,
+                       optimize_pose=optimize_pose)
+    net = GridNet(cfg, device="cpu")
+    feats = gc.make_features(case)
+    with torch.no_grad():
+        for l, f in enumerate(feats):
+            assert tuple(net.features[l].feature.shape) == f.shape, (net.features[l].feature.shape, f.shape)
+            net.features[l].feature.copy_(T(f))
+        if stability:
+            for l, f in enumerate(gc.make_stability(case)):
+                net.feature_stability[l].feature.copy_(T(f))
+    sd = {k: T(v) for k, v in gc.make_decoder(case).items()}
+    net.decoder.load_state_dict(sd)
+    return net
+
+
+def gen_encode_decode(name, GridNet, rloss, gc):
+    case = gc.CASES[name]
+    net = build_gridnet(GridNet, gc, case, stability=True)
+    net.unlock_feature()
+    x = T(gc.make_points(case)).requires_grad_(True)
+    n = x.shape[0]
+    sdf_t, valid, sign, weight = [T(a) for a in gc.make_targets(case, n)]
+    feats = net.query_feature(x)
+    stab = net.query_stability(x)
+    pred = net(x)
+    l1 = rloss.miso_loss_regression(pred, sdf_t, valid, weight, "L1")
+    fs = rloss.miso_loss_free_space(pred, sdf_t, sign, 0.15)
+    loss = l1 + 0.1 * fs
+    params = [g.feature for g in net.features]
+    grads = torch.autograd.grad(loss, params + [x])
+    # second scalar with a smooth (L2) loss: better conditioned gradient check
+    pred2 = net(x)
+    l2 = rloss.miso_loss_regression(pred2, sdf_t, valid, weight, "L2")
+    grads2 = torch.autograd.grad(l2, params + [x])
+    out = dict(feats=feats.detach().numpy(), stab=stab.detach().numpy(),
+               sdf=pred.detach().numpy(), loss_l1=l1.item(), loss_fs=fs.item(),
+               loss_l2=l2.item(), grad_x=grads[-1].numpy(), grad2_x=grads2[-1].numpy())
+    for l in range(case["n_levels"]):
+        g = grads[l].numpy().reshape(-1)
+        g2 = grads2[l].numpy().reshape(-1)
+        idx = gc.sample_indices(g.size, 512, seed=7 + l)
+        # nonzero entries are sparse in big grids: also store the top-|g| ones
+        top = np.argsort(-np.abs(g))[:256].astype(np.int64)
+        out[f"gfeat{l}_sum"] = np.float64(g.astype(np.float64).sum())
+        out[f"gfeat{l}_abssum"] = np.float64(np.abs(g.astype(np.float64)).sum())
+        out[f"gfeat{l}_idx"] = np.concatenate([idx, top])
+        out[f"gfeat{l}_val"] = g[out[f"gfeat{l}_idx"]]
+        out[f"g2feat{l}_abssum"] = np.float64(np.abs(g2.astype(np.float64)).sum())
+        out[f"g2feat{l}_val"] = g2[out[f"gfeat{l}_idx"]]
+        if name == "small":
+            out[f"gfeat{l}_full"] = grads[l].numpy()
+            out[f"g2feat{l}_full"] = grads2[l].numpy()
+    np.savez_compressed(gc.golden_path(name), **out)
+    print(f"[{name}] N={n} loss_l1={l1.item():.6f} fs={fs.item():.6f} l2={l2.item():.6e}")
+
+
+def build_atlas(GridAtlas, gc):
+    c = gc.ATLAS
+    cfg = gc.model_cfg(c["bound"], c["base_cell"], c["scale"], c["n_levels"], c["fdim"],
+                       c["hidden"])
+    atlas = GridAtlas(cfg, device="cpu")
+    subs = gc.atlas_inputs()
+    dec = {k: T(v) for k, v in gc.make_decoder(c).items()}
+    for s, sub in enumerate(subs):
+        atlas.add_submap(torch.tensor(c["bound"], dtype=torch.float32), T(sub["R"]), T(sub["t"]),
+                         num_poses=2)
+        atlas.add_kf(torch.eye(3), torch.zeros(3, 1))
+        net = atlas.get_submap(s)
+        with torch.no_grad():
+            for l, f in enumerate(sub["features"]):
+                net.features[l].feature.copy_(T(f))
+        net.decoder.load_state_dict(dec)
+        atlas.set_submap_pose_correction(s, T(sub["dr"]), T(sub["dt"]))
+    return atlas
+
+
+def gen_atlas(GridAtlas, miso, rbase, gc):
+    atlas = build_atlas(GridAtlas, gc)
+    c = gc.ATLAS
+    out = {}
+    xw = T(gc.atlas_world_points())
+    out["forward"] = atlas(xw).detach().numpy()
+    out["query_feature"] = atlas.query_feature(xw).detach().numpy()
+    atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+    for s in range(c["n_submaps"]):
+        for l in range(c["n_levels"]):
+            out[f"ncoords_s{s}_l{l}"] = np.int64(atlas.coordinates_for_alignment(s, l).shape[0])
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    for (a, b) in pairs:
+        out[f"intersect_{a}_{b}"] = np.bool_(bool(atlas.check_submap_intersection(a, b)))
+        for l in range(c["n_levels"]):
+            for lt in ("L2", "L1"):
+                for p in atlas.parameters():
+                    p.grad = None
+                d = miso.pairwise_loss_latent(atlas, None, a, b, level=l, fdim=c["fdim"],
+                                              align_loss=lt, device="cpu")
+                (val,) = d.values()
+                key = f"latent_{a}_{b}_l{l}_{lt}"
+                out[key] = np.float64(val.item())
+                if val.requires_grad:
+                    val.backward()
+                    for which, s in (("src", a), ("dst", b)):
+                        gr = atlas.rotation_corrections[s].grad
+                        gt_ = atlas.translation_corrections[s].grad
+                        out[key + f"_gR_{which}"] = (gr if gr is not None else torch.zeros(1, 3)).numpy().copy()
+                        out[key + f"_gt_{which}"] = (gt_ if gt_ is not None else torch.zeros(3, 1)).numpy().copy()
+    # 3 (+1: upstream loops num_iters+1 times) Adam iterations of multi-submap alignment
+    for p in atlas.parameters():
+        p.grad = None
+    for s in range(c["n_submaps"]):
+        atlas.get_submap(s).lock_feature()
+    for l in range(c["n_levels"]):
+        loss_tuple = (f"latent{l}", lambda at, ld, a, b, _l=l: miso.pairwise_loss_latent(
+            at, ld, a, b, level=_l, fdim=c["fdim"], align_loss="L2", device="cpu"))
+
+        class _DS(torch.utils.data.Dataset):
+            def __len__(self):
+                return 1
+
+            def __getitem__(self, i):
+                return 0
+
+        rbase.generic_align_multiple_submaps(atlas, _DS(), loss_tuple, num_iters=3, lr=1e-2,
+                                             verbose=False)
+        out[f"align_l{l}_dr"] = np.stack([p.detach().numpy().copy() for p in atlas.rotation_corrections])
+        out[f"align_l{l}_dt"] = np.stack([p.detach().numpy().copy() for p in atlas.translation_corrections])
+    np.savez_compressed(gc.golden_path("atlas"), **out)
+    print("[atlas]", {k: (v.item() if np.ndim(v) == 0 else v.shape) for k, v in out.items()
+                      if k.startswith("latent") and k.endswith(("L2", "L1"))})
+
+
+def gen_losses(GridNet, rloss, risdf, gc):
+    """MisoLossMapping / MisoLossTracking on a 3-keyframe GridNet + iSDF helpers."""
+    case = dict(gc.CASES["small"])
+    K = 3
+    net = build_gridnet(GridNet, gc, case, num_poses=K, optimize_pose=True)
+    rs = np.random.RandomState(99)
+    for k in range(K):
+        Rk = T(gc.rodrigues(rs.uniform(-0.2, 0.2, 3)).astype(np.float32))
+        tk = T(rs.uniform(-0.1, 0.1, (3, 1)).astype(np.float32))
+        net.set_initial_kf_pose(k, Rk, tk, kf_key=f"KF{k}")
+    with torch.no_grad():
+        net.rotation_corrections.copy_(T(rs.uniform(-0.05, 0.05, (K, 3)).astype(np.float32)))
+        net.translation_corrections.copy_(T(rs.uniform(-0.05, 0.05, (K, 3, 1)).astype(np.float32)))
+    net.unlock_feature()
+    net.unlock_pose()
+    pts = gc.make_points(case)
+    n = pts.shape[0]
+    ids = rs.randint(0, K, size=(n, 1)).astype(np.int64)
+    sdf_t, valid, sign, weight = gc.make_targets(case, n)
+    model_input = {"coords_frame": T(pts)[None], "sample_frame_ids": T(ids)[None],
+                   "weights": T(weight)[None]}
+    gt = {"sdf": T(sdf_t)[None], "sdf_valid": T(valid)[None], "sdf_signs": T(sign)[None]}
+    out = dict(frame_ids=ids, kf_R=net.Rwk.numpy().copy(), kf_t=net.twk.numpy().copy(),
+               kf_dr=net.rotation_corrections.detach().numpy().copy(),
+               kf_dt=net.translation_corrections.detach().numpy().copy())
+    for lt in ("L1", "L2"):
+        lossf = rloss.MisoLossMapping(loss_type=lt, weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1,
+                                      trunc_dist=0.15)
+        for p in net.parameters():
+            p.grad = None
+        d = lossf.compute(net, model_input, gt)
+        tot = sum(v.mean() for v in d.values())
+        tot.backward()
+        for k_, v in d.items():
+            out[f"map_{lt}_{k_}"] = np.float64(v.item())
+        out[f"map_{lt}_gdr"] = net.rotation_corrections.grad.numpy().copy()
+        out[f"map_{lt}_gdt"] = net.translation_corrections.grad.numpy().copy()
+        for l in range(case["n_levels"]):
+            out[f"map_{lt}_gfeat{l}"] = net.features[l].feature.grad.numpy().copy()
+    gt_valid_all = dict(gt)
+    gt_valid_all["sdf_valid"] = torch.ones_like(gt["sdf_valid"])
+    for lt in ("L1", "L2", "GM"):
+        lossf = rloss.MisoLossTracking(weight_sdf=1.0, loss_type=lt, trunc_dist=0.12, gm_scale_sdf=0.1)
+        for p in net.parameters():
+            p.grad = None
+        d = lossf.compute(net, model_input, gt_valid_all)
+        tot = sum(v.mean() for v in d.values())
+        tot.backward()
+        for k_, v in d.items():
+            out[f"track_{lt}_{k_}"] = np.float64(v.item())
+        out[f"track_{lt}_gdr"] = net.rotation_corrections.grad.numpy().copy()
+        out[f"track_{lt}_gdt"] = net.translation_corrections.grad.numpy().copy()
+    # iSDF helpers on fixed random inputs (loss_isdf.py:280-365)
+    sdf_p = T((0.2 * rs.standard_normal((1, n, 1))).astype(np.float32))
+    bounds = T(np.abs(0.3 * rs.standard_normal((1, n, 1))).astype(np.float32))
+    for lt in ("L1", "L2"):
+        mat, fsix = risdf.sdf_loss(sdf_p.clone(), bounds, 0.15, loss_type=lt)
+        tot, tot_mat, _ = risdf.tot_loss(mat, None, None, fsix, bounds, 0.1, 5.0, 0.0, 0.0)
+        out[f"isdf_{lt}_total"] = np.float64(tot.item())
+        out[f"isdf_{lt}_mat"] = tot_mat.numpy().copy()
+    out["isdf_sdf"] = sdf_p.numpy()
+    out["isdf_bounds"] = bounds.numpy()
+    # iSDFLoss.compute_slam on the GridNet (loss_isdf.py:46-93)
+    il = risdf.iSDFLoss("grid_net", trunc_weight=5.0, trunc_distance=0.15, loss_type="L1",
+                        slam_mode=True)
+    for p in net.parameters():
+        p.grad = None
+    gt_b = {"sdf": T(np.abs(sdf_t))[None]}
+    d = il.compute(net, model_input, gt_b)
+    d["sdf"].backward()
+    out["isdf_slam_sdf"] = np.float64(d["sdf"].item())
+    out["isdf_slam_gdr"] = net.rotation_corrections.grad.numpy().copy()
+    for l in range(case["n_levels"]):
+        out[f"isdf_slam_gfeat{l}"] = net.features[l].feature.grad.numpy().copy()
+    np.savez_compressed(gc.golden_path("losses"), **out)
+    print("[losses]", {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
+
+
+def gen_trainer(GridNet, rloss, rtrainer, gc):
+    """GridTrainer: 6 epochs, coordinate+joint, max_epochs_in_level=2 -> features."""
+    case = dict(gc.CASES["small"])
+    rs = np.random.RandomState(123)
+    pts = gc.make_points(case)
+    n = pts.shape[0]
+    sdf_t, valid, sign, weight = gc.make_targets(case, n)
+
+    class _DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            mi = {"coords_frame": T(pts), "sample_frame_ids": torch.zeros(n, 1, dtype=torch.int64),
+                  "weights": T(weight)}
+            g = {"sdf": T(sdf_t), "sdf_valid": T(valid), "sdf_signs": T(sign)}
+            return mi, g
+
+    out = {}
+    for mode in ("joint", "coordinate+joint"):
+        net = build_gridnet(GridNet, gc, case, num_poses=1, optimize_pose=False, stability=True)
+        net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+        net.unlock_feature()
+        net.lock_pose()
+        cfg_train = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 6,
+                     "ckpt_every": -1, "eval_every": -1, "eval_metric": None,
+                     "pretrained_model": None, "log_dir": "/tmp/miso_golden_log",
+                     "relchange_tol": 0, "max_epochs_in_level": 2, "grid_training_mode": mode}
+        lossf = rloss.MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1,
+                                      trunc_dist=0.15)
+        loader = torch.utils.data.DataLoader(_DS(), batch_size=1, shuffle=False, num_workers=0)
+
+        class _Writer:  # harness patch: tensorboard is absent from the image
+            def __init__(self, *a, **k):
+                pass
+
+            def add_scalar(self, *a, **k):
+                pass
+
+        rtrainer.SummaryWriter = _Writer
+        tr = rtrainer.GridTrainer(cfg_train, net, lossf, loader, None, "cpu", torch.float32)
+        tr.train()
+        tag = mode.replace("+", "_")
+        for l in range(case["n_levels"]):
+            out[f"{tag}_feat{l}"] = net.features[l].feature.detach().numpy().copy()
+            out[f"{tag}_stab{l}"] = net.feature_stability[l].feature.detach().numpy().copy()
+    np.savez_compressed(gc.golden_path("trainer"), **out)
+    print("[trainer] ok", {k: float(np.abs(v).sum()) for k, v in out.items()})
+
+
+def gen_tracker(GridNet, rtracker, gc):
+    """Tracker.lm_step (tracker.py:148-212) on a one-KF synthetic batch."""
+    case = dict(gc.CASES["small"])
+    net = build_gridnet(GridNet, gc, case, num_poses=2, optimize_pose=True)
+    rs = np.random.RandomState(321)
+    R0 = T(gc.rodrigues(rs.uniform(-0.1, 0.1, 3)).astype(np.float32))
+    t0 = T(rs.uniform(-0.05, 0.05, (3, 1)).astype(np.float32))
+    net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+    net.set_initial_kf_pose(1, R0, t0, kf_key="KF1")
+    pts = gc.make_points(case)
+    n = pts.shape[0]
+    sdf_t = (0.05 * rs.standard_normal((n, 1))).astype(np.float32)
+
+    class _DS(torch.utils.data.Dataset):
+        def select_keyframes(self, kfs):
+            pass
+
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            mi = {"coords_frame": T(pts), "sample_frame_ids": torch.ones(n, 1, dtype=torch.int64),
+                  "weights": torch.ones(n, 1)}
+            g = {"sdf": T(sdf_t), "sdf_valid": torch.ones(n, 1), "sdf_signs": torch.zeros(n, 1)}
+            return mi, g
+
+    out = dict(R0=R0.numpy(), t0=t0.numpy(), sdf=sdf_t)
+    for lt in ("GM", "L2"):
+        with torch.no_grad():
+            net.rotation_corrections.zero_()
+            net.translation_corrections.zero_()
+        cfg = {"device": "cpu", "train": {},
+               "tracking": {"learning_rate": 1e-3, "verbose": False, "gm_scale_sdf": 0.1,
+                            "lm_lambda": 5.0, "lm_max_iter": 3, "lm_tol_deg": 0.0, "lm_tol_m": 0.0,
+                            "loss_type": lt, "trunc_dist": 0.12, "solver": "lm"}}
+        trk = rtracker.Tracker.__new__(rtracker.Tracker)
+        # bypass the ctor's isinstance(SubmapDataset) plumbing: set the fields lm_step reads
+        trk.grid = net
+        trk.dataset = _DS()
+        trk.train_loader = torch.utils.data.DataLoader(trk.dataset, shuffle=False, batch_size=1)
+        trk.cfg = cfg
+        for k_, v in cfg["tracking"].items():
+            setattr(trk, k_, v)
+        trk.lr = 1e-3
+        infos = []
+        for it in range(3):
+            info = trk.lm_step(1)
+            infos.append([info["delta_R_deg"], info["delta_t_norm"], info["grad_norm"], info["fov_overlap"]])
+            out[f"lm_{lt}_dr_{it}"] = net.rotation_corrections.detach().numpy().copy()
+            out[f"lm_{lt}_dt_{it}"] = net.translation_corrections.detach().numpy().copy()
+        out[f"lm_{lt}_info"] = np.array(infos, dtype=np.float64)
+    np.savez_compressed(gc.golden_path("tracker"), **out)
+    print("[tracker]", out["lm_GM_info"])
+
+
+def gen_so3(rgeom, gc):
+    """so3_exp_map / apply_pose_correction values + grads (restated shim => the
+    pytorch3d boundary stays 'parity unpinned'; this pins OUR restatement)."""
+    out = {}
+    for i, w in enumerate([[0.0, 0.0, 0.0], [1e-3, -2e-3, 5e-4], [0.3, -0.2, 0.1], [1.2, 0.4, -0.9]]):
+        dr = torch.tensor([w], dtype=torch.float32, requires_grad=True)
+        dt = torch.tensor([[0.1], [-0.2], [0.3]], dtype=torch.float32, requires_grad=True)
+        R0 = T(gc.rodrigues([0.2, 0.1, -0.3]).astype(np.float32))
+        t0 = torch.tensor([[1.0], [2.0], [3.0]])
+        R, t = rgeom.apply_pose_correction(R0, t0, dr, dt)
+        wgt = torch.arange(9, dtype=torch.float32).reshape(3, 3) / 10
+        (R * wgt).sum().backward()
+        out[f"R_{i}"] = R.detach().numpy()
+        out[f"t_{i}"] = t.detach().numpy()
+        out[f"gdr_{i}"] = dr.grad.numpy().copy()
+    np.savez_compressed(gc.golden_path("so3"), **out)
+    print("[so3] ok")
+
+
+def main():
+    import_reference()
+    import golden_cases as gc
+    from grid_opt.models.grid_net import GridNet
+    from grid_opt.models.grid_atlas import GridAtlas
+    import grid_opt.loss as rloss
+    import grid_opt.loss_isdf as risdf
+    import grid_opt.align.miso as miso
+    import grid_opt.align.base as rbase
+    import grid_opt.trainer as rtrainer
+    import grid_opt.slam.tracker as rtracker
+    import grid_opt.utils.utils_geometry as rgeom
+
+    os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3"]
+    for name in which:
+        if name in gc.CASES:
+            gen_encode_decode(name, GridNet, rloss, gc)
+        elif name == "atlas":
+            gen_atlas(GridAtlas, miso, rbase, gc)
+        elif name == "losses":
+            gen_losses(GridNet, rloss, risdf, gc)
+        elif name == "trainer":
+            gen_trainer(GridNet, rloss, rtrainer, gc)
+        elif name == "tracker":
+            gen_tracker(GridNet, rtracker, gc)
+        elif name == "so3":
+            gen_so3(rgeom, gc)
+
+
+if __name__ == "__main__":
+    main()
