@@ -1,0 +1,141 @@
+/*
+ * miso_hip.h -- C ABI of libmiso_hip.so, the MI355X (gfx950) implementation of
+ * MISO's encode/decode hot path.
+ *
+ * Every entry point takes raw DEVICE pointers, sizes and element strides plus a
+ * hipStream_t (passed as void*), allocates nothing, launches asynchronously on
+ * that stream and returns 0 on success or a non-zero code (MISO_E_* below, or a
+ * hipError_t from the launch).  All arithmetic is fp32, index math is 32-bit
+ * per level (grids up to 2^31-1 elements) and 64-bit across points.
+ *
+ * Paths are relative to the reference repository (ExistentialRobotics/MISO).
+ *
+ * What each entry replaces in the reference:
+ *   miso_encode_fwd   ATen grid_sampler_3d forward as called per level by
+ *                     grid_opt/models/grid_modules.py:72-95 (FeatureGrid.interpolate)
+ *                     + utils.normalize_coordinates (grid_opt/utils/utils.py:22-51)
+ *                     + the level loop / torch.cat of grid_opt/utils/utils.py:143-164;
+ *                     also third_party/cuda_gridsample_grad2/cuda_gridsample.py:76-95.
+ *   miso_encode_bwd   aten::grid_sampler_3d_backward as bound at
+ *                     third_party/cuda_gridsample_grad2/cuda_gridsample.py:99-113
+ *                     (output_mask = which of grad_grid / grad_x are non-NULL).
+ *   miso_encode_bwd2  gridsample_grad2.grad2_3d, pybind at
+ *                     third_party/cuda_gridsample_grad2/gridsample_cuda.cpp:39-56,
+ *                     kernel gridsample_cuda.cu:212-533, launcher :601-666.
+ *   miso_mlp_pack / miso_sdf_fwd / miso_sdf_bwd
+ *                     GridNet.forward = query_feature + utils.grid_decode + MLPNet
+ *                     (grid_opt/models/grid_net.py:288-325, grid_opt/utils/utils.py:194-208,
+ *                     grid_opt/models/modules.py:11-32) and its autograd backward
+ *                     with a frozen decoder (configs/rgbd/scannet.yaml:16).
+ *   miso_pair_latent  pairwise_loss_latent, grid_opt/align/miso.py:116-211 (L2),
+ *                     with the rigid maps of grid_opt/utils/utils_geometry.py:214-240.
+ *   miso_lm_normal_eq Tracker.lm_step normal equations, grid_opt/slam/tracker.py:171-196.
+ *   miso_adam_dense   torch.optim.Adam.step on one dense tensor as used by
+ *                     grid_opt/trainer.py:196-228 / :410-452.
+ */
+#ifndef MISO_HIP_H
+#define MISO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISO_MAX_LEVELS 8
+#define MISO_MAX_LINEAR 4 /* Linear layers in the decoder: hidden_layers + 2 */
+
+/* return codes (besides hipError_t values, which are > 0 and < 2000) */
+#define MISO_OK 0
+#define MISO_E_BADARG 2001      /* NULL pointer / negative size / bad flag */
+#define MISO_E_UNSUPPORTED 2002 /* shape outside what the fused kernels cover */
+#define MISO_E_TOOLARGE 2003    /* a level has >= 2^31 elements */
+
+/* flags */
+#define MISO_F_ALIGN_CORNERS 1u    /* grid_sample align_corners=True (MISO uses False) */
+#define MISO_F_PAD_BORDER 2u       /* padding_mode='border' (MISO uses 'zeros') */
+#define MISO_F_COORDS_NORMALIZED 4u /* x is already in [-1,1]: skip normalize_coordinates */
+
+/* One feature-grid level: logical tensor (1,C,Z,Y,X) (grid_modules.py:54-57)
+ * with arbitrary element strides, so both the reference's NCDHW layout and the
+ * channels-last layout (sC==1) preferred on MI355X are accepted. */
+typedef struct {
+  const float* data; /* read-only values (may be NULL where only `grad` is used) */
+  float* grad;       /* scatter-add target with the SAME strides, or NULL        */
+  int32_t C, Z, Y, X;
+  int64_t sC, sZ, sY, sX;
+} miso_level_t;
+
+typedef struct {
+  int32_t n_levels;
+  uint32_t ignore_mask;                /* bit l set => level l contributes zeros (utils.py:160-163) */
+  float bound_min[3], bound_max[3];    /* x,y,z metres (unused with COORDS_NORMALIZED) */
+  uint32_t flags;
+  miso_level_t level[MISO_MAX_LEVELS];
+} miso_grid_t;
+
+/* Decoder MLP = MLPNet(input_dim, output_dim, hidden_dim, hidden_layers, bias)
+ * (modules.py:11-21): n_linear = hidden_layers + 2 nn.Linear weights (out,in)
+ * row-major, optional biases. */
+typedef struct {
+  int32_t in_dim, hidden_dim, out_dim, n_linear;
+  const float* weight[MISO_MAX_LINEAR];
+  const float* bias[MISO_MAX_LINEAR]; /* NULL = no bias */
+} miso_mlp_t;
+
+const char* miso_version(void);
+const char* miso_error_string(int code);
+
+/* feats[n, F] (row stride `ld_out` floats, F = sum of C over levels) =
+ * concat_l trilinear(level l, x[n]) ; x is (N,3) row-major metres. */
+int miso_encode_fwd(const miso_grid_t* grid, const float* x, int64_t n,
+                    float* feats, int64_t ld_out, void* stream);
+
+/* First backward.  grad_feats (N,F) row stride ld_g.  For each level with
+ * level[l].grad != NULL: grad += scatter (caller zero-initialises).  grad_x (N,3)
+ * may be NULL; when non-NULL level[l].data must be valid. */
+int miso_encode_bwd(const miso_grid_t* grid, const float* x, int64_t n,
+                    const float* grad_feats, int64_t ld_g, float* grad_x, void* stream);
+
+/* Second backward (double backward of the encode).  gg_grid->level[l].data is
+ * the cotangent of grad_grid (NULL per level = zero), gg_x (N,3) the cotangent of
+ * grad_x (NULL = zero).  Outputs: gg_out (N,F) written; grid->level[l].grad +=
+ * scatter where non-NULL; g_x (N,3) written where non-NULL. */
+int miso_encode_bwd2(const miso_grid_t* grid, const miso_grid_t* gg_grid, const float* x,
+                     int64_t n, const float* grad_feats, int64_t ld_g, const float* gg_x,
+                     float* gg_out, int64_t ld_gg, float* g_x, void* stream);
+
+/* --- fused encode + decoder (frozen decoder, out_dim == 1) ---------------- */
+/* Size in floats of the packed-weight buffer for this decoder, or 0 if the fused
+ * kernels do not cover the shape (then use miso_encode_* + a library GEMM). */
+int64_t miso_mlp_packed_floats(const miso_mlp_t* mlp);
+int miso_mlp_pack(const miso_mlp_t* mlp, float* packed, void* stream);
+/* 1 if (grid, mlp) is covered by miso_sdf_fwd/bwd, else 0 */
+int miso_sdf_supported(const miso_grid_t* grid, const miso_mlp_t* mlp);
+
+/* uint32 words of ReLU sign bits per point: (n_linear-1) * hidden_dim/32 */
+int64_t miso_sdf_mask_words(const miso_mlp_t* mlp);
+
+/* sdf[n] = MLP(encode(x[n])).  relu_mask: NULL (inference) or
+ * ceil(n/64)*64*miso_sdf_mask_words(mlp) uint32 words that miso_sdf_bwd consumes. */
+int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                 const float* x, int64_t n, float* sdf, uint32_t* relu_mask, void* stream);
+
+/* grad_sdf (N) -> scatter into level[l].grad (non-NULL levels) and/or grad_x. */
+int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                 const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
+                 float* grad_x, void* stream);
+
+/* --- dense Adam (torch.optim.Adam defaults: amsgrad=False, weight_decay=0) -
+ * One launch over one dense tensor; param/grad/exp_avg/exp_avg_sq share a
+ * layout.  Scalars are doubles like torch's Python-side hyper-parameters.
+ * zero_grad != 0 also clears grad in the same pass (the next backward then
+ * needs no memset). */
+int miso_adam_dense(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                    int64_t numel, double lr, double beta1, double beta2, double eps,
+                    int32_t step /* 1-based */, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISO_HIP_H */

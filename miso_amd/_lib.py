@@ -1,0 +1,90 @@
+"""ctypes binding of libmiso_hip.so (C ABI in include/miso_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback for the hot ops.
+A missing library, or a call with tensors that are not on a HIP device, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiso_hip.so")
+
+MAX_LEVELS = 8
+MAX_LINEAR = 4
+
+F_ALIGN_CORNERS = 1
+F_PAD_BORDER = 2
+F_COORDS_NORMALIZED = 4
+
+E_UNSUPPORTED = 2002
+
+
+class Level(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("grad", C.c_void_p),
+                ("C", C.c_int32), ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
+                ("sC", C.c_int64), ("sZ", C.c_int64), ("sY", C.c_int64), ("sX", C.c_int64)]
+
+
+class Grid(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("ignore_mask", C.c_uint32),
+                ("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3),
+                ("flags", C.c_uint32), ("level", Level * MAX_LEVELS)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("hidden_dim", C.c_int32), ("out_dim", C.c_int32),
+                ("n_linear", C.c_int32),
+                ("weight", C.c_void_p * MAX_LINEAR), ("bias", C.c_void_p * MAX_LINEAR)]
+
+
+# name -> (restype, argtypes); every symbol include/miso_hip.h declares
+SIGNATURES = {
+    "miso_version": (C.c_char_p, []),
+    "miso_error_string": (C.c_char_p, [C.c_int]),
+    "miso_encode_fwd": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                  C.c_void_p]),
+    "miso_encode_bwd": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                  C.c_void_p, C.c_void_p]),
+    "miso_encode_bwd2": (C.c_int, [C.POINTER(Grid), C.POINTER(Grid), C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p]),
+    "miso_mlp_packed_floats": (C.c_int64, [C.POINTER(Mlp)]),
+    "miso_mlp_pack": (C.c_int, [C.POINTER(Mlp), C.c_void_p, C.c_void_p]),
+    "miso_sdf_supported": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp)]),
+    "miso_sdf_mask_words": (C.c_int64, [C.POINTER(Mlp)]),
+    "miso_sdf_fwd": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_sdf_bwd": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_adam_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int,
+                                  C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmiso_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C miso_amd/csrc`.  miso_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().miso_error_string(rc).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")

@@ -1,0 +1,210 @@
+// extern "C" entry points of libmiso_hip.so (see include/miso_hip.h).
+// Argument validation + conversion to kernel-side structs + dispatch.
+#include <string.h>
+
+#include "common.hpp"
+
+namespace miso {
+hipError_t launch_encode_fwd(const GridK&, bool, const float*, int64_t, float*, int64_t, hipStream_t);
+hipError_t launch_encode_bwd(const GridK&, bool, const float*, int64_t, const float*, int64_t, float*,
+                             hipStream_t);
+hipError_t launch_encode_bwd2(const GridK&, const float*, int64_t, const float*, int64_t, const float*,
+                              float*, int64_t, float*, hipStream_t);
+bool fused_shape_supported(int C, int L, int H, int NH);
+hipError_t launch_sdf_fwd(int, int, int, int, const GridK&, const float*, const float*, int64_t, float*,
+                          uint32_t*, hipStream_t);
+hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const float*, int64_t,
+                          const float*, const uint32_t*, float*, bool, hipStream_t);
+hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
+int64_t mlp_packed_floats(int F, int H, int NH);
+hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
+                       hipStream_t);
+}  // namespace miso
+
+using namespace miso;
+
+namespace {
+
+// which pointer of a level a call needs
+enum Need { NEED_DATA = 1, NEED_GRAD_OPT = 2 };
+
+int convert_grid(const miso_grid_t* in, GridK* out, bool need_data, bool* vec4) {
+  if (!in || in->n_levels < 1 || in->n_levels > MISO_MAX_LEVELS) return MISO_E_BADARG;
+  if (in->flags & ~(MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER | MISO_F_COORDS_NORMALIZED))
+    return MISO_E_BADARG;
+  memset(out, 0, sizeof(*out));
+  out->n_levels = in->n_levels;
+  out->ignore_mask = in->ignore_mask;
+  out->flags = in->flags;
+  for (int a = 0; a < 3; ++a) { out->bmin[a] = in->bound_min[a]; out->bmax[a] = in->bound_max[a]; }
+  bool v4 = true;
+  int foff = 0;
+  for (int l = 0; l < in->n_levels; ++l) {
+    const miso_level_t& s = in->level[l];
+    if (s.C < 1 || s.X < 1 || s.Y < 1 || s.Z < 1) return MISO_E_BADARG;
+    if (need_data && !s.data) return MISO_E_BADARG;
+    if (s.sC < 0 || s.sX < 0 || s.sY < 0 || s.sZ < 0) return MISO_E_BADARG;
+    int64_t span = (int64_t)(s.C - 1) * s.sC + (int64_t)(s.X - 1) * s.sX + (int64_t)(s.Y - 1) * s.sY +
+                   (int64_t)(s.Z - 1) * s.sZ + 1;
+    if (span >= ((int64_t)1 << 31)) return MISO_E_TOOLARGE;
+    LevelK& d = out->lv[l];
+    d.data = s.data; d.grad = s.grad; d.gg = nullptr;
+    d.C = s.C; d.X = s.X; d.Y = s.Y; d.Z = s.Z;
+    d.sC = (int32_t)s.sC; d.sX = (int32_t)s.sX; d.sY = (int32_t)s.sY; d.sZ = (int32_t)s.sZ;
+    d.foff = foff;
+    foff += s.C;
+    bool ok = (s.C % 4 == 0) && (s.sC == 1 || s.C == 1) && (s.sX % 4 == 0) && (s.sY % 4 == 0) &&
+              (s.sZ % 4 == 0) && (((uintptr_t)s.data & 15u) == 0) && (((uintptr_t)s.grad & 15u) == 0);
+    v4 = v4 && ok;
+  }
+  out->F = foff;
+  if (vec4) *vec4 = v4;
+  return MISO_OK;
+}
+
+int fused_shape(const GridK& g, bool vec4, const miso_mlp_t* m, int* C, int* L, int* H, int* NH) {
+  if (!m || !vec4) return MISO_E_UNSUPPORTED;
+  if (m->n_linear < 2 || m->n_linear > MISO_MAX_LINEAR) return MISO_E_UNSUPPORTED;
+  int c = g.lv[0].C;
+  for (int l = 0; l < g.n_levels; ++l)
+    if (g.lv[l].C != c) return MISO_E_UNSUPPORTED;
+  if (m->in_dim != g.F || m->out_dim != 1) return MISO_E_UNSUPPORTED;
+  int nh = m->n_linear - 2;
+  if (!fused_shape_supported(c, g.n_levels, m->hidden_dim, nh)) return MISO_E_UNSUPPORTED;
+  *C = c; *L = g.n_levels; *H = m->hidden_dim; *NH = nh;
+  return MISO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* miso_version(void) { return "miso_hip 0.1 (gfx950)"; }
+
+const char* miso_error_string(int code) {
+  switch (code) {
+    case MISO_OK: return "ok";
+    case MISO_E_BADARG: return "bad argument";
+    case MISO_E_UNSUPPORTED: return "shape not covered by the fused kernels";
+    case MISO_E_TOOLARGE: return "a grid level spans >= 2^31 elements";
+    default: return hipGetErrorString((hipError_t)code);
+  }
+}
+
+int miso_encode_fwd(const miso_grid_t* grid, const float* x, int64_t n, float* feats, int64_t ld_out,
+                    void* stream) {
+  if (n < 0 || (n > 0 && (!x || !feats))) return MISO_E_BADARG;
+  GridK g; bool v4;
+  int rc = convert_grid(grid, &g, true, &v4);
+  if (rc) return rc;
+  if (ld_out < g.F) return MISO_E_BADARG;
+  return (int)launch_encode_fwd(g, v4, x, n, feats, ld_out, (hipStream_t)stream);
+}
+
+int miso_encode_bwd(const miso_grid_t* grid, const float* x, int64_t n, const float* grad_feats,
+                    int64_t ld_g, float* grad_x, void* stream) {
+  if (n < 0 || (n > 0 && (!x || !grad_feats))) return MISO_E_BADARG;
+  GridK g; bool v4;
+  int rc = convert_grid(grid, &g, grad_x != nullptr, &v4);
+  if (rc) return rc;
+  if (ld_g < g.F) return MISO_E_BADARG;
+  return (int)launch_encode_bwd(g, v4, x, n, grad_feats, ld_g, grad_x, (hipStream_t)stream);
+}
+
+int miso_encode_bwd2(const miso_grid_t* grid, const miso_grid_t* gg_grid, const float* x, int64_t n,
+                     const float* grad_feats, int64_t ld_g, const float* gg_x, float* gg_out,
+                     int64_t ld_gg, float* g_x, void* stream) {
+  if (n < 0 || (n > 0 && (!x || !grad_feats || !gg_out))) return MISO_E_BADARG;
+  GridK g;
+  int rc = convert_grid(grid, &g, true, nullptr);
+  if (rc) return rc;
+  if (ld_g < g.F || ld_gg < g.F) return MISO_E_BADARG;
+  if (gg_grid) {
+    if (gg_grid->n_levels != grid->n_levels) return MISO_E_BADARG;
+    for (int l = 0; l < g.n_levels; ++l) {
+      const miso_level_t& a = grid->level[l];
+      const miso_level_t& b = gg_grid->level[l];
+      if (!b.data) continue;
+      if (a.C != b.C || a.X != b.X || a.Y != b.Y || a.Z != b.Z || a.sC != b.sC || a.sX != b.sX ||
+          a.sY != b.sY || a.sZ != b.sZ)
+        return MISO_E_BADARG;  // cotangent must share the layout of the grid
+      g.lv[l].gg = b.data;
+    }
+  }
+  return (int)launch_encode_bwd2(g, x, n, grad_feats, ld_g, gg_x, gg_out, ld_gg, g_x,
+                                 (hipStream_t)stream);
+}
+
+int64_t miso_mlp_packed_floats(const miso_mlp_t* mlp) {
+  if (!mlp || mlp->n_linear < 2 || mlp->n_linear > MISO_MAX_LINEAR) return 0;
+  if (mlp->out_dim != 1 || mlp->in_dim < 1 || mlp->in_dim > 32) return 0;
+  if (mlp->hidden_dim != 32 && mlp->hidden_dim != 64) return 0;
+  return mlp_packed_floats(mlp->in_dim, mlp->hidden_dim, mlp->n_linear - 2);
+}
+
+int64_t miso_sdf_mask_words(const miso_mlp_t* mlp) {
+  if (!mlp) return 0;
+  return (int64_t)(mlp->n_linear - 1) * (mlp->hidden_dim / 32);
+}
+
+int miso_mlp_pack(const miso_mlp_t* mlp, float* packed, void* stream) {
+  if (!packed || miso_mlp_packed_floats(mlp) == 0) return MISO_E_UNSUPPORTED;
+  MlpK k;
+  memset(&k, 0, sizeof(k));
+  for (int i = 0; i < mlp->n_linear; ++i) {
+    if (!mlp->weight[i]) return MISO_E_BADARG;
+    k.w[i] = mlp->weight[i];
+    k.b[i] = mlp->bias[i];
+  }
+  return (int)launch_mlp_pack(k, mlp->in_dim, mlp->hidden_dim, mlp->n_linear - 2, packed,
+                              (hipStream_t)stream);
+}
+
+int miso_sdf_supported(const miso_grid_t* grid, const miso_mlp_t* mlp) {
+  GridK g; bool v4;
+  if (convert_grid(grid, &g, false, &v4)) return 0;
+  int C, L, H, NH;
+  return fused_shape(g, v4, mlp, &C, &L, &H, &NH) == MISO_OK ? 1 : 0;
+}
+
+int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
+                 int64_t n, float* sdf, uint32_t* relu_mask, void* stream) {
+  if (n < 0 || !packed || (n > 0 && (!x || !sdf))) return MISO_E_BADARG;
+  if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
+  GridK g; bool v4;
+  int rc = convert_grid(grid, &g, true, &v4);
+  if (rc) return rc;
+  int C, L, H, NH;
+  rc = fused_shape(g, v4, mlp, &C, &L, &H, &NH);
+  if (rc) return rc;
+  return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, (hipStream_t)stream);
+}
+
+int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
+                 int64_t n, const float* grad_sdf, const uint32_t* relu_mask, float* grad_x,
+                 void* stream) {
+  if (n < 0 || !packed || (n > 0 && (!x || !grad_sdf || !relu_mask))) return MISO_E_BADARG;
+  if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
+  GridK g; bool v4;
+  int rc = convert_grid(grid, &g, grad_x != nullptr, &v4);
+  if (rc) return rc;
+  int C, L, H, NH;
+  rc = fused_shape(g, v4, mlp, &C, &L, &H, &NH);
+  if (rc) return rc;
+  bool want_grid = false;
+  for (int l = 0; l < g.n_levels; ++l) want_grid = want_grid || (g.lv[l].grad != nullptr);
+  if (!want_grid && !grad_x) return MISO_OK;
+  return (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid,
+                             (hipStream_t)stream);
+}
+
+int miso_adam_dense(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,
+                    double lr, double beta1, double beta2, double eps, int32_t step, int zero_grad,
+                    void* stream) {
+  if (numel < 0 || step < 1 || (numel > 0 && (!param || !grad || !exp_avg || !exp_avg_sq)))
+    return MISO_E_BADARG;
+  return (int)launch_adam(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, step,
+                          zero_grad, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Shared device helpers for libmiso_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/miso_hip.h"
+
+namespace miso {
+
+// Kernel-side view of one level (no grad/data split: the launcher picks).
+struct LevelK {
+  const float* data;
+  float* grad;
+  const float* gg;  // cotangent-of-grad grid (second order), or nullptr
+  int32_t C, Z, Y, X;
+  int32_t sC, sZ, sY, sX;  // element strides, validated < 2^31 on the host
+  int32_t foff;            // first output column of this level
+};
+
+struct GridK {
+  int32_t n_levels;
+  uint32_t ignore_mask;
+  uint32_t flags;
+  int32_t F;
+  float bmin[3], bmax[3];
+  LevelK lv[MISO_MAX_LEVELS];
+};
+
+struct MlpK {
+  const float* w[MISO_MAX_LINEAR];
+  const float* b[MISO_MAX_LINEAR];
+};
+
+// Per-axis sample position.  Mirrors the reference op by op (no FMA
+// contraction) so coordinates are bit-identical to the PyTorch path:
+//   utils.normalize_coordinates (grid_opt/utils/utils.py:49):
+//       xn = 2 * (x - bmin) / (bmax - bmin) - 1
+//   ATen grid_sampler_unnormalize (align_corners=False): ix = ((xn + 1) * size - 1) / 2
+// `mult` is d(ix)/d(x) as autograd forms it.
+struct Axis {
+  float pos;   // continuous index ix
+  float mult;  // d ix / d x  (0 where border padding clipped the coordinate)
+};
+
+__device__ __forceinline__ Axis axis_coord(float x, float bmin, float bmax, int size, uint32_t flags) {
+  float xn = x;
+  float m = 1.0f;
+  if (!(flags & MISO_F_COORDS_NORMALIZED)) {
+    float len = __fsub_rn(bmax, bmin);
+    xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(x, bmin)), len), 1.0f);
+    m = __fdiv_rn(2.0f, len);
+  }
+  float fs = (float)size;
+  float ix;
+  if (flags & MISO_F_ALIGN_CORNERS) {
+    ix = __fmul_rn(__fdiv_rn(__fadd_rn(xn, 1.0f), 2.0f), (float)(size - 1));
+    m *= 0.5f * (float)(size - 1);
+  } else {
+    ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(xn, 1.0f), fs), 1.0f), 2.0f);
+    m *= 0.5f * fs;
+  }
+  if (flags & MISO_F_PAD_BORDER) {
+    float hi = (float)(size - 1);
+    if (ix <= 0.0f) { ix = 0.0f; m = 0.0f; }
+    else if (ix >= hi) { ix = hi; m = 0.0f; }
+  }
+  Axis a; a.pos = ix; a.mult = m;
+  return a;
+}
+
+// Trilinear cell: base corner, the two 1-D weights per axis (ATen forms them
+// as (i0+1-ix) and (ix-i0), gridsample_cuda.cu:335-342) and in-range flags.
+struct Cell {
+  int i0, j0, k0;
+  float wx[2], wy[2], wz[2];
+  bool inx[2], iny[2], inz[2];
+};
+
+__device__ __forceinline__ void axis_cell(float pos, int size, int& i0, float w[2], bool in[2]) {
+  float f = floorf(pos);
+  // clamp before the int conversion so far-away points cannot overflow
+  f = fminf(fmaxf(f, -2.0f), (float)size + 1.0f);
+  i0 = (int)f;
+  if (pos != pos) { i0 = -2; }  // NaN coordinate: every corner out of range
+  w[0] = __fsub_rn(f + 1.0f, pos);
+  w[1] = __fsub_rn(pos, f);
+  in[0] = (i0 >= 0) && (i0 < size);
+  in[1] = (i0 + 1 >= 0) && (i0 + 1 < size);
+}
+
+__device__ __forceinline__ Cell make_cell(const Axis& ax, const Axis& ay, const Axis& az,
+                                          const LevelK& lv) {
+  Cell c;
+  axis_cell(ax.pos, lv.X, c.i0, c.wx, c.inx);
+  axis_cell(ay.pos, lv.Y, c.j0, c.wy, c.iny);
+  axis_cell(az.pos, lv.Z, c.k0, c.wz, c.inz);
+  return c;
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  // hardware fp32 add at L2 (global_atomic_add_f32, no return value)
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace miso

@@ -1,0 +1,250 @@
+// Generic multi-level trilinear encode: forward, first backward, second backward.
+//
+// One lane per point; any channel count and any strides (the reference's NCDHW
+// layout as well as channels-last).  With channels-last and C % 4 == 0 a corner
+// is read / scattered as float4 vectors (one 16-B access per 4 channels instead
+// of 4 strided dwords).  These kernels back the autograd Functions that must be
+// differentiable to second order; the fused MFMA kernels in sdf_fused.hip cover
+// the frozen-decoder fast path.
+//
+// Math: SURVEY.md Appendix B; it restates ATen grid_sampler_3d (bilinear) and
+// the double backward of third_party/cuda_gridsample_grad2/gridsample_cuda.cu:443-531.
+#include "common.hpp"
+
+namespace miso {
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void encode_fwd_kernel(GridK g, const float* __restrict__ x,
+                                                        int64_t n, float* __restrict__ out,
+                                                        int64_t ld) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
+  float* o = out + p * ld;
+  for (int l = 0; l < g.n_levels; ++l) {
+    const LevelK& lv = g.lv[l];
+    if ((g.ignore_mask >> l) & 1u) {
+      for (int c = 0; c < lv.C; ++c) o[lv.foff + c] = 0.0f;
+      continue;
+    }
+    Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+    Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+    Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+    Cell c = make_cell(ax, ay, az, lv);
+    int off[8];
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
+      w[k] = in ? (c.wx[dx] * c.wy[dy]) * c.wz[dz] : 0.0f;
+      off[k] = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+    }
+    if (VEC4) {
+      for (int ch = 0; ch < lv.C; ch += 4) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(lv.data + off[k] + ch);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          acc.x += v[k].x * w[k]; acc.y += v[k].y * w[k];
+          acc.z += v[k].z * w[k]; acc.w += v[k].w * w[k];
+        }
+        o[lv.foff + ch + 0] = acc.x; o[lv.foff + ch + 1] = acc.y;
+        o[lv.foff + ch + 2] = acc.z; o[lv.foff + ch + 3] = acc.w;
+      }
+    } else {
+      for (int ch = 0; ch < lv.C; ++ch) {
+        const float* base = lv.data + (int64_t)ch * lv.sC;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += base[off[k]] * w[k];
+        o[lv.foff + ch] = acc;
+      }
+    }
+  }
+}
+
+// First backward: scatter grad_feats into level grads (where non-null) and/or
+// grad_x = sum_l mult * sum_c gF[c] * sum_corners (dw/dix) * G[c,corner].
+template <bool VEC4>
+__global__ __launch_bounds__(256) void encode_bwd_kernel(GridK g, const float* __restrict__ x,
+                                                        int64_t n, const float* __restrict__ gf,
+                                                        int64_t ld, float* __restrict__ gx) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
+  const float* go = gf + p * ld;
+  float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+  for (int l = 0; l < g.n_levels; ++l) {
+    const LevelK& lv = g.lv[l];
+    if ((g.ignore_mask >> l) & 1u) continue;
+    Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+    Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+    Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+    Cell c = make_cell(ax, ay, az, lv);
+    int off[8];
+    float w[8], dwx[8], dwy[8], dwz[8];
+    bool inb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
+      inb[k] = in;
+      float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
+      w[k] = in ? (c.wx[dx] * c.wy[dy]) * c.wz[dz] : 0.0f;
+      dwx[k] = in ? sx * c.wy[dy] * c.wz[dz] : 0.0f;
+      dwy[k] = in ? sy * c.wx[dx] * c.wz[dz] : 0.0f;
+      dwz[k] = in ? sz * c.wx[dx] * c.wy[dy] : 0.0f;
+      off[k] = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+    }
+    float ax_ = 0.f, ay_ = 0.f, az_ = 0.f;
+    if (VEC4) {
+      for (int ch = 0; ch < lv.C; ch += 4) {
+        float4 gv = make_float4(go[lv.foff + ch], go[lv.foff + ch + 1], go[lv.foff + ch + 2],
+                                go[lv.foff + ch + 3]);
+        if (gx) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float4 v = *reinterpret_cast<const float4*>(lv.data + off[k] + ch);
+            float d = gv.x * v.x + gv.y * v.y + gv.z * v.z + gv.w * v.w;
+            ax_ += d * dwx[k]; ay_ += d * dwy[k]; az_ += d * dwz[k];
+          }
+        }
+        if (lv.grad) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (!inb[k]) continue;
+            float* t = lv.grad + off[k] + ch;
+            atomic_add_f32(t + 0, gv.x * w[k]); atomic_add_f32(t + 1, gv.y * w[k]);
+            atomic_add_f32(t + 2, gv.z * w[k]); atomic_add_f32(t + 3, gv.w * w[k]);
+          }
+        }
+      }
+    } else {
+      for (int ch = 0; ch < lv.C; ++ch) {
+        float gv = go[lv.foff + ch];
+        int64_t cb = (int64_t)ch * lv.sC;
+        if (gx) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float d = gv * lv.data[cb + off[k]];
+            ax_ += d * dwx[k]; ay_ += d * dwy[k]; az_ += d * dwz[k];
+          }
+        }
+        if (lv.grad) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (inb[k]) atomic_add_f32(lv.grad + cb + off[k], gv * w[k]);
+        }
+      }
+    }
+    gpx += ax_ * ax.mult; gpy += ay_ * ay.mult; gpz += az_ * az.mult;
+  }
+  if (gx) { gx[p * 3 + 0] = gpx; gx[p * 3 + 1] = gpy; gx[p * 3 + 2] = gpz; }
+}
+
+// Second backward.  Inputs: ggG (= lv.gg, cotangent of grad_grid, may be null),
+// ggx (cotangent of grad_x, may be null), gF (= grad_feats of the first
+// backward).  Outputs: ggF (N,F); gG scatter (lv.grad, may be null); gx (may be null).
+//   ggF[c]      = sum inb * ( w * ggG[c,k] + G[c,k] * (grad w . d) ),   d = mult o ggx
+//   gG[c,k]    += inb * (grad w . d) * gF[c]
+//   gx_x        = mult_x * sum_c gF[c] * sum_k inb * ( dwx*ggG[c,k]
+//                          + G[c,k] * (d_y * dwxy + d_z * dwxz) )        (d2w/dx2 = 0)
+__global__ __launch_bounds__(256) void encode_bwd2_kernel(GridK g, const float* __restrict__ x,
+                                                         int64_t n, const float* __restrict__ gf,
+                                                         int64_t ld, const float* __restrict__ ggx,
+                                                         float* __restrict__ ggo, int64_t ldgg,
+                                                         float* __restrict__ gx) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
+  const float* go = gf + p * ld;
+  float* ggout = ggo + p * ldgg;
+  float ex = 0.f, ey = 0.f, ez = 0.f;
+  if (ggx) { ex = ggx[p * 3 + 0]; ey = ggx[p * 3 + 1]; ez = ggx[p * 3 + 2]; }
+  float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+  for (int l = 0; l < g.n_levels; ++l) {
+    const LevelK& lv = g.lv[l];
+    if ((g.ignore_mask >> l) & 1u) {
+      for (int c = 0; c < lv.C; ++c) ggout[lv.foff + c] = 0.0f;
+      continue;
+    }
+    Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+    Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+    Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+    Cell c = make_cell(ax, ay, az, lv);
+    float dxi = ex * ax.mult, dyi = ey * ay.mult, dzi = ez * az.mult;
+    int off[8];
+    float w[8], dwx[8], dwy[8], dwz[8], gwd[8], cx[8], cy[8], cz[8];
+    bool inb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
+      inb[k] = in;
+      float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
+      float m = in ? 1.0f : 0.0f;
+      w[k] = m * (c.wx[dx] * c.wy[dy]) * c.wz[dz];
+      dwx[k] = m * sx * c.wy[dy] * c.wz[dz];
+      dwy[k] = m * sy * c.wx[dx] * c.wz[dz];
+      dwz[k] = m * sz * c.wx[dx] * c.wy[dy];
+      float dwxy = m * sx * sy * c.wz[dz];
+      float dwxz = m * sx * sz * c.wy[dy];
+      float dwyz = m * sy * sz * c.wx[dx];
+      gwd[k] = dxi * dwx[k] + dyi * dwy[k] + dzi * dwz[k];
+      cx[k] = dyi * dwxy + dzi * dwxz;   // multiplies G in gx_x
+      cy[k] = dxi * dwxy + dzi * dwyz;
+      cz[k] = dxi * dwxz + dyi * dwyz;
+      off[k] = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+    }
+    float ax_ = 0.f, ay_ = 0.f, az_ = 0.f;
+    for (int ch = 0; ch < lv.C; ++ch) {
+      int64_t cb = (int64_t)ch * lv.sC;
+      float gv = go[lv.foff + ch];
+      float ggv = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float val = lv.data[cb + off[k]];
+        float g2 = lv.gg ? lv.gg[cb + off[k]] : 0.0f;
+        ggv += g2 * w[k] + val * gwd[k];
+        ax_ += gv * (g2 * dwx[k] + val * cx[k]);
+        ay_ += gv * (g2 * dwy[k] + val * cy[k]);
+        az_ += gv * (g2 * dwz[k] + val * cz[k]);
+        if (lv.grad && inb[k] && ggx) atomic_add_f32(lv.grad + cb + off[k], gwd[k] * gv);
+      }
+      ggout[lv.foff + ch] = ggv;
+    }
+    gpx += ax_ * ax.mult; gpy += ay_ * ay.mult; gpz += az_ * az.mult;
+  }
+  if (gx) { gx[p * 3 + 0] = gpx; gx[p * 3 + 1] = gpy; gx[p * 3 + 2] = gpz; }
+}
+
+// ---- host-side launch helpers (called from capi.hip) -----------------------
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t launch_encode_fwd(const GridK& g, bool vec4, const float* x, int64_t n, float* out,
+                             int64_t ld, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if (vec4) encode_fwd_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, out, ld);
+  else encode_fwd_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, out, ld);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_bwd(const GridK& g, bool vec4, const float* x, int64_t n, const float* gf,
+                             int64_t ld, float* gx, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  if (vec4) encode_bwd_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx);
+  else encode_bwd_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_bwd2(const GridK& g, const float* x, int64_t n, const float* gf, int64_t ld,
+                              const float* ggx, float* ggo, int64_t ldgg, float* gx, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  encode_bwd2_kernel<<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx);
+  return hipGetLastError();
+}
+
+}  // namespace miso

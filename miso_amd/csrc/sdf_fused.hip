@@ -1,0 +1,497 @@
+// Fused multi-level encode + frozen-decoder MLP, forward and backward, for gfx950.
+//
+// Replaces GridNet.forward (grid_opt/models/grid_net.py:306-325) and its autograd
+// backward with a frozen decoder: features never touch HBM, the decoder runs on
+// the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32), and the backward needs
+// only the ReLU sign bits saved by the forward (2*H bits per point) because the
+// decoder's weights take no gradient.
+//
+// Work decomposition: one 64-lane wavefront owns a chunk of 64 points and never
+// synchronises with other waves (no __syncthreads in the loop), so on one SIMD
+// the gather phase of one wave overlaps the MFMA phase of its neighbour.
+//
+// MFMA chaining.  With D = A(32x2) * B(2x32) + C, points are the N (column)
+// dimension and neurons the M (row) dimension.  The accumulator layout of
+// 32x32x2 (col = lane&31, row = (j&3) + 8*(j>>2) + 4*(lane>>5) for register j)
+// is, register by register, already a legal B operand of the next layer for the
+// k-pair {row(j), row(j)+4}: lanes 0-31 hold k=row(j,0), lanes 32-63 hold
+// k=row(j,1).  So activations stay in the accumulator registers from layer to
+// layer; only the A operands (weights, pre-permuted by mlp_pack_kernel) come
+// from LDS.  The first layer's B operand is built from the lane-per-point
+// features with one v_permlane32_swap per k-pair.
+#include "common.hpp"
+
+namespace miso {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int row_of(int j, int hi) { return (j & 3) + 8 * (j >> 2) + 4 * hi; }
+
+// ---------------------------------------------------------------------------
+// Packed decoder layout (floats).  RT = H/32 row tiles, KS0 = ceil(F/2),
+// KS1 = H/2 k-steps for an HxH layer, NH hidden (HxH) layers.
+//   fwd: W0p [KS0][64][RT]   A(l) = W0[32r + (l&31)][2s + (l>>5)]
+//        Whp [NH][KS1][64][RT] A(l) = Wh[32r + (l&31)][32rp + row_of(j, l>>5)], ks = 16rp + j
+//        b0 [H], bh [NH][H], wo [H], bo [4]
+//   bwd: WhTp [NH][KS1][64][RT] A(l) = Wh[32rp + row_of(j, l>>5)][32r + (l&31)]
+//        W0Tp [KS1][64]         A(l) = W0[32rp + row_of(j, l>>5)][l&31]   (0 for l&31 >= F)
+// ---------------------------------------------------------------------------
+struct PackLayout {
+  int F, H, NH, RT, KS0, KS1;
+  int o_w0, o_wh, o_b0, o_bh, o_wo, o_bo, fwd_end;
+  int o_whT, o_w0T, total;
+  __host__ __device__ PackLayout(int F_, int H_, int NH_) {
+    F = F_; H = H_; NH = NH_; RT = H / 32; KS0 = (F + 1) / 2; KS1 = H / 2;
+    int o = 0;
+    o_w0 = o; o += KS0 * 64 * RT;
+    o_wh = o; o += NH * KS1 * 64 * RT;
+    o_b0 = o; o += H;
+    o_bh = o; o += NH * H;
+    o_wo = o; o += H;
+    o_bo = o; o += 4;
+    fwd_end = o;
+    o_whT = o; o += NH * KS1 * 64 * RT;
+    o_w0T = o; o += KS1 * 64;
+    total = o;
+  }
+};
+
+
+__global__ void mlp_pack_kernel(MlpK m, int F, int H, int NH, float* __restrict__ out) {
+  PackLayout pl(F, H, NH);
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pl.total) return;
+  float v = 0.0f;
+  const int RT = pl.RT;
+  if (i < pl.o_wh) {  // W0p
+    int e = i - pl.o_w0;
+    int r = e % RT, l = (e / RT) % 64, s = e / (RT * 64);
+    int row = 32 * r + (l & 31), col = 2 * s + (l >> 5);
+    v = (col < F) ? m.w[0][row * F + col] : 0.0f;
+  } else if (i < pl.o_b0) {  // Whp
+    int e = i - pl.o_wh;
+    int r = e % RT, l = (e / RT) % 64, ks = (e / (RT * 64)) % pl.KS1, h = e / (RT * 64 * pl.KS1);
+    int rp = ks / 16, j = ks % 16;
+    int row = 32 * r + (l & 31), col = 32 * rp + row_of(j, l >> 5);
+    v = m.w[1 + h][row * H + col];
+  } else if (i < pl.o_bh) {
+    int e = i - pl.o_b0;
+    v = m.b[0] ? m.b[0][e] : 0.0f;
+  } else if (i < pl.o_wo) {
+    int e = i - pl.o_bh;
+    int h = e / H;
+    v = m.b[1 + h] ? m.b[1 + h][e % H] : 0.0f;
+  } else if (i < pl.o_bo) {
+    v = m.w[1 + NH][i - pl.o_wo];
+  } else if (i < pl.fwd_end) {
+    v = (i == pl.o_bo && m.b[1 + NH]) ? m.b[1 + NH][0] : 0.0f;
+  } else if (i < pl.o_w0T) {  // WhTp
+    int e = i - pl.o_whT;
+    int r = e % RT, l = (e / RT) % 64, ks = (e / (RT * 64)) % pl.KS1, h = e / (RT * 64 * pl.KS1);
+    int rp = ks / 16, j = ks % 16;
+    int k = 32 * rp + row_of(j, l >> 5), irow = 32 * r + (l & 31);
+    v = m.w[1 + h][k * H + irow];
+  } else {  // W0Tp
+    int e = i - pl.o_w0T;
+    int l = e % 64, ks = e / 64;
+    int rp = ks / 16, j = ks % 16;
+    int k = 32 * rp + row_of(j, l >> 5), f = l & 31;
+    v = (f < F) ? m.w[0][k * F + f] : 0.0f;
+  }
+  out[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, float* f) {
+  // lane-per-point gather of one level: 8 corners x C channels, channels-last.
+#pragma unroll
+  for (int q = 0; q < C; ++q) f[q] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+    bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
+    float w = in ? (c.wx[dx] * c.wy[dy]) * c.wz[dz] : 0.0f;
+    int off = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+#pragma unroll
+    for (int q = 0; q < C; q += 4) {
+      float4 v = *reinterpret_cast<const float4*>(lv.data + off + q);
+      f[q + 0] += v.x * w; f[q + 1] += v.y * w; f[q + 2] += v.z * w; f[q + 3] += v.w * w;
+    }
+  }
+}
+
+template <int C, int L, int H, int NH>
+__global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
+                                                        const float* __restrict__ x, int64_t n,
+                                                        float* __restrict__ sdf,
+                                                        uint32_t* __restrict__ mask) {
+  constexpr int F = C * L, RT = H / 32, KS0 = (F + 1) / 2, KS1 = H / 2;
+  constexpr int MW = (NH + 1) * RT;  // mask words per lane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const PackLayout pl(F, H, NH);
+  for (int i = threadIdx.x * 4; i < pl.fwd_end; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+  const int64_t nchunks = (n + 63) / 64;
+  const float* w0p = smem + pl.o_w0;
+  const float* whp = smem + pl.o_wh;
+  const float* b0 = smem + pl.o_b0;
+  const float* bh = smem + pl.o_bh;
+  const float* wo = smem + pl.o_wo;
+  const float bo = smem[pl.o_bo];
+
+  for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+    // keep the (chunk-invariant) LDS reads of biases / weights inside the loop:
+    // hoisted, they cost ~100 VGPRs and spill
+    asm volatile("" ::: "memory");
+    const int64_t p = chunk * 64 + lane;
+    const bool valid = p < n;
+    float f[2 * KS0];
+#pragma unroll
+    for (int i = 0; i < 2 * KS0; ++i) f[i] = 0.0f;
+    if (valid) {
+      float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const LevelK& lv = g.lv[l];
+        if ((g.ignore_mask >> l) & 1u) continue;
+        Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+        Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+        Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+        Cell c = make_cell(ax, ay, az, lv);
+        gather_level<C>(lv, c, &f[l * C]);
+      }
+    }
+    // ---- layer 0: buf[0][r][t] = b0 + W0 * feats -------------------------------
+    // Two accumulator sets ping-pong between layers (ReLU is applied in place, so
+    // no third copy of the 64 activation registers is ever live).
+    f32x16 buf[2][RT][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float b = b0[32 * r + row_of(j, hi)];
+        buf[0][r][0][j] = b; buf[0][r][1][j] = b;
+      }
+#pragma unroll
+    for (int s = 0; s < KS0; ++s) {
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[2 * s]), __float_as_uint(f[2 * s + 1]),
+                                                 false, false);
+      float bt0 = __uint_as_float(sw[0]), bt1 = __uint_as_float(sw[1]);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        float a = w0p[(s * 64 + lane) * RT + r];
+        buf[0][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt0, buf[0][r][0], 0, 0, 0);
+        buf[0][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt1, buf[0][r][1], 0, 0, 0);
+      }
+    }
+    uint32_t mw[MW];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          m |= (buf[0][r][t][j] > 0.0f ? 1u : 0u) << (t * 16 + j);
+          buf[0][r][t][j] = fmaxf(buf[0][r][t][j], 0.0f);
+        }
+      mw[r] = m;
+    }
+    // ---- hidden HxH layers ------------------------------------------------------
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int ci = h & 1, ni = ci ^ 1;
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float b = bh[h * H + 32 * r + row_of(j, hi)];
+          buf[ni][r][0][j] = b; buf[ni][r][1][j] = b;
+        }
+#pragma unroll
+      for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int ks = rp * 16 + j;
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
+            buf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], buf[ni][r][0], 0, 0, 0);
+            buf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], buf[ni][r][1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            m |= (buf[ni][r][t][j] > 0.0f ? 1u : 0u) << (t * 16 + j);
+            buf[ni][r][t][j] = fmaxf(buf[ni][r][t][j], 0.0f);
+          }
+        mw[(h + 1) * RT + r] = m;
+      }
+    }
+    f32x16 (&acc)[RT][2] = buf[NH & 1];
+    // ---- output layer (out_dim = 1) --------------------------------------------
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float wv = wo[32 * r + row_of(j, hi)];
+        p0 += wv * acc[r][0][j];
+        p1 += wv * acc[r][1][j];
+      }
+    p0 += __shfl_xor(p0, 32);
+    p1 += __shfl_xor(p1, 32);
+    if (valid) sdf[p] = (hi ? p1 : p0) + bo;
+    if (mask) {
+      uint32_t* mo = mask + (chunk * 64 + lane) * MW;
+#pragma unroll
+      for (int i = 0; i < MW; ++i) mo[i] = mw[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Backward: grad_sdf -> (MFMA chain through the transposed weights, gated by the
+// saved ReLU bits) -> d feats in accumulator layout -> scatter-add into the level
+// gradients and/or grad_x.  Lane (hi, l&31) holds, for tile t, point 32t+(l&31):
+//   C == 8: channels 4hi..4hi+3 of level j>>2      (registers j = 4*level + c)
+//   C == 4: channels 0..3 of level 2*(j>>2) + hi   (registers j = 4*g + c)
+template <int C, int L, int H, int NH, bool WANT_GRID, bool WANT_X>
+__global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* __restrict__ packed,
+                                                        const float* __restrict__ x, int64_t n,
+                                                        const float* __restrict__ gsdf,
+                                                        const uint32_t* __restrict__ mask,
+                                                        float* __restrict__ gx) {
+  constexpr int F = C * L, RT = H / 32, KS1 = H / 2;
+  constexpr int MW = (NH + 1) * RT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const PackLayout pl(F, H, NH);
+  // stage wo + the transposed weights: [o_wo, o_bo) and [o_whT, total)
+  const int nb = pl.total - pl.o_whT;
+  for (int i = threadIdx.x * 4; i < nb; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + pl.o_whT + i);
+  for (int i = threadIdx.x; i < H; i += blockDim.x) smem[nb + i] = packed[pl.o_wo + i];
+  __syncthreads();
+  const float* whT = smem;
+  const float* w0T = smem + (pl.o_w0T - pl.o_whT);
+  const float* wo = smem + nb;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+  const int64_t nchunks = (n + 63) / 64;
+
+  for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");  // see sdf_fwd_kernel
+    const int64_t pt[2] = {chunk * 64 + (lane & 31), chunk * 64 + 32 + (lane & 31)};
+    float ds[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) ds[t] = (pt[t] < n) ? gsdf[pt[t]] : 0.0f;
+    uint32_t mw[MW];
+    {
+      const uint32_t* mi = mask + (chunk * 64 + lane) * MW;
+#pragma unroll
+      for (int i = 0; i < MW; ++i) mw[i] = mi[i];
+    }
+    // d(last hidden) = wo * ds, gated.  Two accumulator sets ping-pong.
+    f32x16 dbuf[2][RT][2];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float wv = wo[32 * r + row_of(j, hi)];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          dbuf[0][r][t][j] = ((mw[NH * RT + r] >> (t * 16 + j)) & 1u) ? wv * ds[t] : 0.0f;
+      }
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+      const int h = NH - 1 - hh;
+      const int ci = hh & 1, ni = ci ^ 1;
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { dbuf[ni][r][0][j] = 0.0f; dbuf[ni][r][1][j] = 0.0f; }
+#pragma unroll
+      for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int ks = rp * 16 + j;
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            float a = whT[((h * KS1 + ks) * 64 + lane) * RT + r];
+            dbuf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dbuf[ci][rp][0][j], dbuf[ni][r][0], 0, 0, 0);
+            dbuf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dbuf[ci][rp][1][j], dbuf[ni][r][1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            dbuf[ni][r][t][j] = ((mw[h * RT + r] >> (t * 16 + j)) & 1u) ? dbuf[ni][r][t][j] : 0.0f;
+    }
+    f32x16 (&d)[RT][2] = dbuf[NH & 1];
+    // d feats = W0^T d   (one 32-row tile; rows >= F are zero)
+    f32x16 df[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { df[0][j] = 0.0f; df[1][j] = 0.0f; }
+#pragma unroll
+    for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float a = w0T[(rp * 16 + j) * 64 + lane];
+        df[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][0][j], df[0], 0, 0, 0);
+        df[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][1][j], df[1], 0, 0, 0);
+      }
+    // ---- scatter / coordinate gradient -----------------------------------------
+    float gacc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bool valid = pt[t] < n;
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (valid) { px = x[pt[t] * 3 + 0]; py = x[pt[t] * 3 + 1]; pz = x[pt[t] * 3 + 2]; }
+      constexpr int NG = (C == 8) ? L : (L + 1) / 2;  // register groups of 4
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        const int l = (C == 8) ? gi : 2 * gi + hi;
+        const int choff = (C == 8) ? 4 * hi : 0;
+        if (l >= L || !valid) continue;
+        if ((g.ignore_mask >> l) & 1u) continue;
+        // C == 4: the two lane halves work on different levels; pick the level's
+        // fields with per-lane selects (a lane-varying index into the kernel
+        // arguments would be spilled to scratch).
+        LevelK lv = g.lv[(C == 8) ? gi : 2 * gi];
+        if (C == 4 && 2 * gi + 1 < L && hi) lv = g.lv[(2 * gi + 1 < L) ? 2 * gi + 1 : 0];
+        Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+        Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+        Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+        Cell c = make_cell(ax, ay, az, lv);
+        const float v0 = df[t][4 * gi + 0], v1 = df[t][4 * gi + 1], v2 = df[t][4 * gi + 2],
+                    v3 = df[t][4 * gi + 3];
+        float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+          bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
+          if (!in) continue;
+          int off = (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX + choff;
+          if (WANT_GRID && lv.grad) {
+            float w = (c.wx[dx] * c.wy[dy]) * c.wz[dz];
+            float* tg = lv.grad + off;
+            atomic_add_f32(tg + 0, v0 * w); atomic_add_f32(tg + 1, v1 * w);
+            atomic_add_f32(tg + 2, v2 * w); atomic_add_f32(tg + 3, v3 * w);
+          }
+          if (WANT_X) {
+            float4 gv = *reinterpret_cast<const float4*>(lv.data + off);
+            float dot = gv.x * v0 + gv.y * v1 + gv.z * v2 + gv.w * v3;
+            float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
+            sx_ += dot * sx * c.wy[dy] * c.wz[dz];
+            sy_ += dot * sy * c.wx[dx] * c.wz[dz];
+            sz_ += dot * sz * c.wx[dx] * c.wy[dy];
+          }
+        }
+        if (WANT_X) {
+          gacc[t][0] += sx_ * ax.mult; gacc[t][1] += sy_ * ay.mult; gacc[t][2] += sz_ * az.mult;
+        }
+      }
+    }
+    if (WANT_X) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gacc[t][a] += __shfl_xor(gacc[t][a], 32);
+      const int64_t p = chunk * 64 + lane;
+      if (p < n) {
+        gx[p * 3 + 0] = hi ? gacc[1][0] : gacc[0][0];
+        gx[p * 3 + 1] = hi ? gacc[1][1] : gacc[0][1];
+        gx[p * 3 + 2] = hi ? gacc[1][2] : gacc[0][2];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------
+struct FusedKey { int C, L, H, NH; };
+
+template <int C, int L, int H, int NH>
+static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
+                               float* sdf, uint32_t* mask, hipStream_t s) {
+  PackLayout pl(C * L, H, NH);
+  size_t lds = (size_t)((pl.fwd_end + 3) / 4 * 4) * sizeof(float);
+  int64_t nchunks = (n + 63) / 64;
+  unsigned blocks = (unsigned)((nchunks + 3) / 4);
+  if (blocks > 512u) blocks = 512u;
+  auto k = sdf_fwd_kernel<C, L, H, NH>;
+  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, mask);
+  return hipGetLastError();
+}
+
+template <int C, int L, int H, int NH>
+static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
+                               const float* gsdf, const uint32_t* mask, float* gx, bool want_grid,
+                               hipStream_t s) {
+  PackLayout pl(C * L, H, NH);
+  size_t lds = (size_t)(pl.total - pl.o_whT + H + 4) * sizeof(float);
+  int64_t nchunks = (n + 63) / 64;
+  unsigned blocks = (unsigned)((nchunks + 3) / 4);
+  if (blocks > 512u) blocks = 512u;
+  if (want_grid && gx)
+    sdf_bwd_kernel<C, L, H, NH, true, true><<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx);
+  else if (want_grid)
+    sdf_bwd_kernel<C, L, H, NH, true, false><<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx);
+  else if (gx)
+    sdf_bwd_kernel<C, L, H, NH, false, true><<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx);
+  return hipGetLastError();
+}
+
+#define MISO_FUSED_SHAPES(X) \
+  X(4, 1, 32, 1) X(4, 1, 64, 1) X(4, 2, 32, 1) X(4, 2, 64, 1) X(4, 3, 64, 1) X(4, 4, 64, 1) \
+  X(8, 1, 64, 1) X(8, 2, 64, 1) X(8, 3, 64, 1) X(8, 4, 64, 1) X(8, 3, 32, 1)
+
+bool fused_shape_supported(int C, int L, int H, int NH) {
+#define X(c, l, h, nh) if (C == c && L == l && H == h && NH == nh) return true;
+  MISO_FUSED_SHAPES(X)
+#undef X
+  return false;
+}
+
+hipError_t launch_sdf_fwd(int C, int L, int H, int NH, const GridK& g, const float* packed,
+                          const float* x, int64_t n, float* sdf, uint32_t* mask, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+#define X(c, l, h, nh) \
+  if (C == c && L == l && H == h && NH == nh) return launch_fwd_t<c, l, h, nh>(g, packed, x, n, sdf, mask, s);
+  MISO_FUSED_SHAPES(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_sdf_bwd(int C, int L, int H, int NH, const GridK& g, const float* packed,
+                          const float* x, int64_t n, const float* gsdf, const uint32_t* mask,
+                          float* gx, bool want_grid, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+#define X(c, l, h, nh) \
+  if (C == c && L == l && H == h && NH == nh) \
+    return launch_bwd_t<c, l, h, nh>(g, packed, x, n, gsdf, mask, gx, want_grid, s);
+  MISO_FUSED_SHAPES(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_mlp_pack(const MlpK& m, int F, int H, int NH, float* out, hipStream_t s) {
+  PackLayout pl(F, H, NH);
+  mlp_pack_kernel<<<(pl.total + 255) / 256, 256, 0, s>>>(m, F, H, NH, out);
+  return hipGetLastError();
+}
+
+int64_t mlp_packed_floats(int F, int H, int NH) { return PackLayout(F, H, NH).total; }
+
+}  // namespace miso

@@ -1,0 +1,385 @@
+"""Operators of the MISO hot path on MI355X: thin autograd wrappers over the
+C ABI of libmiso_hip.so (include/miso_hip.h).
+
+* ``encode``      multi-level trilinear feature lookup, differentiable to second
+                  order (mirrors third_party/cuda_gridsample_grad2/cuda_gridsample.py:76-126:
+                  a forward Function whose backward is itself a Function).
+* ``sdf_fused``   encode + frozen decoder MLP in one kernel (GridNet.forward,
+                  grid_opt/models/grid_net.py:306-325), first-order fused backward.
+* ``adam_dense_`` dense Adam step (grid_opt/trainer.py:217).
+
+There is NO CPU / PyTorch fallback in this module: tensors must live on a HIP
+device and the library must be built, otherwise the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class GridMeta:
+    """Host-side description shared by all levels of one submap."""
+    bound_min: Tuple[float, float, float]
+    bound_max: Tuple[float, float, float]
+    ignore_mask: int = 0
+    flags: int = 0
+
+    @staticmethod
+    def from_bound(bound, ignore_level=None, flags: int = 0) -> "GridMeta":
+        """bound: (3,2) tensor / nested list, rows = x,y,z [min,max] (base_net.py:25-30)."""
+        b = bound.detach().cpu().tolist() if isinstance(bound, torch.Tensor) else bound
+        m = 0
+        if ignore_level is not None:
+            for l, ig in enumerate(ignore_level):
+                if bool(ig):
+                    m |= 1 << l
+        return GridMeta((float(b[0][0]), float(b[1][0]), float(b[2][0])),
+                        (float(b[0][1]), float(b[1][1]), float(b[2][1])), m, flags)
+
+
+NORMALIZED = GridMeta((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), 0, _lib.F_COORDS_NORMALIZED)
+
+
+def _require_hip(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("miso_amd ops run on the HIP device only (no CPU fallback); "
+                               f"got a tensor on {t.device}")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"miso_amd ops are fp32 (the reference hard-wires float32); got {t.dtype}")
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _fill_grid(features: Sequence[torch.Tensor], meta: GridMeta,
+               grads: Optional[Sequence[Optional[torch.Tensor]]] = None,
+               data: bool = True) -> _lib.Grid:
+    if not 1 <= len(features) <= _lib.MAX_LEVELS:
+        raise ValueError(f"1..{_lib.MAX_LEVELS} levels supported, got {len(features)}")
+    g = _lib.Grid()
+    g.n_levels = len(features)
+    g.ignore_mask = meta.ignore_mask
+    g.flags = meta.flags
+    for a in range(3):
+        g.bound_min[a] = meta.bound_min[a]
+        g.bound_max[a] = meta.bound_max[a]
+    for l, f in enumerate(features):
+        assert f.ndim == 5 and f.shape[0] == 1, f"feature must be (1,C,Z,Y,X), got {tuple(f.shape)}"
+        lv = g.level[l]
+        lv.data = f.data_ptr() if data else 0
+        gr = None if grads is None else grads[l]
+        if gr is not None:
+            assert gr.shape == f.shape and gr.stride() == f.stride(), "grad must share the feature layout"
+            lv.grad = gr.data_ptr()
+        else:
+            lv.grad = 0
+        lv.C, lv.Z, lv.Y, lv.X = f.shape[1], f.shape[2], f.shape[3], f.shape[4]
+        lv.sC, lv.sZ, lv.sY, lv.sX = f.stride(1), f.stride(2), f.stride(3), f.stride(4)
+    return g
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """(N,K) fp32 with unit inner stride (row stride passed to the kernel)."""
+    if t.stride(-1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _feature_dim(features) -> int:
+    return sum(int(f.shape[1]) for f in features)
+
+
+# --------------------------------------------------------------------------- #
+# raw calls
+# --------------------------------------------------------------------------- #
+def encode_fwd_raw(x, features, meta: GridMeta) -> torch.Tensor:
+    _require_hip(x, *features)
+    x = x.contiguous()
+    n = x.shape[0]
+    out = torch.empty((n, _feature_dim(features)), device=x.device, dtype=torch.float32)
+    g = _fill_grid(features, meta)
+    _lib.check(_lib.load().miso_encode_fwd(C.byref(g), _ptr(x), n, _ptr(out), out.stride(0) if n else out.shape[1],
+                                           _stream(x)), "miso_encode_fwd")
+    return out
+
+
+def encode_bwd_raw(x, features, meta: GridMeta, gout, need_x: bool, need_f: Sequence[bool]):
+    _require_hip(x, gout, *features)
+    x = x.contiguous()
+    gout = _rows(gout)
+    n = x.shape[0]
+    grads = [torch.zeros_like(f) if nf else None for f, nf in zip(features, need_f)]
+    gx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
+    g = _fill_grid(features, meta, grads)
+    ld = gout.stride(0) if n else _feature_dim(features)
+    _lib.check(_lib.load().miso_encode_bwd(C.byref(g), _ptr(x), n, _ptr(gout), ld, _ptr(gx), _stream(x)),
+               "miso_encode_bwd")
+    return gx, grads
+
+
+def encode_bwd2_raw(x, features, meta: GridMeta, gout, ggx, ggf, need_x: bool, need_f: Sequence[bool]):
+    _require_hip(x, gout, ggx, *features)
+    x = x.contiguous()
+    gout = _rows(gout)
+    n = x.shape[0]
+    F = _feature_dim(features)
+    grads = [torch.zeros_like(f) if (nf and ggx is not None) else None for f, nf in zip(features, need_f)]
+    g = _fill_grid(features, meta, grads)
+    gg = None
+    keep = []
+    if ggf is not None and any(t is not None for t in ggf):
+        gg = _fill_grid(features, meta, None, data=False)
+        for l, t in enumerate(ggf):
+            if t is None:
+                continue
+            _require_hip(t)
+            if t.stride() != features[l].stride():
+                t = torch.empty_like(features[l]).copy_(t)
+            keep.append(t)
+            gg.level[l].data = t.data_ptr()
+    if ggx is not None:
+        ggx = ggx.contiguous()
+    gg_out = torch.empty((n, F), device=x.device, dtype=torch.float32)
+    g_x = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
+    _lib.check(_lib.load().miso_encode_bwd2(
+        C.byref(g), C.byref(gg) if gg is not None else None, _ptr(x), n, _ptr(gout),
+        gout.stride(0) if n else F, _ptr(ggx), _ptr(gg_out), F, _ptr(g_x), _stream(x)), "miso_encode_bwd2")
+    return gg_out, g_x, grads
+
+
+# --------------------------------------------------------------------------- #
+# encode: autograd to second order
+# --------------------------------------------------------------------------- #
+class _EncodeBackward(torch.autograd.Function):
+    """First backward as a Function so that create_graph=True works (the role of
+    _GridSample3dBackward, cuda_gridsample.py:99-126)."""
+
+    @staticmethod
+    def forward(ctx, gout, x, meta, need_x, need_f, *features):
+        gx, grads = encode_bwd_raw(x, features, meta, gout, need_x, need_f)
+        ctx.save_for_backward(gout, x, *features)
+        ctx.meta = meta
+        return (gx, *grads)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ggx, *ggf):
+        gout, x, *features = ctx.saved_tensors
+        need_gout, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_f = ctx.needs_input_grad[5:]
+        if ggx is None and all(t is None for t in ggf):
+            return (None,) * (5 + len(features))
+        gg_out, g_x, g_f = encode_bwd2_raw(x, features, ctx.meta, gout, ggx, ggf, need_x, need_f)
+        return (gg_out if need_gout else None, g_x, None, None, None, *g_f)
+
+
+class _Encode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, meta, *features):
+        out = encode_fwd_raw(x, features, meta)
+        ctx.save_for_backward(x, *features)
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, *features = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        need_f = tuple(ctx.needs_input_grad[2:])
+        res = _EncodeBackward.apply(gout, x, ctx.meta, need_x, need_f, *features)
+        return (res[0], None, *res[1:])
+
+
+def encode(x: torch.Tensor, features: Sequence[torch.Tensor], meta: GridMeta) -> torch.Tensor:
+    """(N,3) metres -> (N, sum C) interpolated features of every level, concatenated
+    (utils.grid_interp_regular, grid_opt/utils/utils.py:143-164)."""
+    return _Encode.apply(x, meta, *features)
+
+
+def grid_sample_3d(input: torch.Tensor, grid: torch.Tensor, padding_mode: str = "zeros",
+                   align_corners: bool = True) -> torch.Tensor:
+    """Drop-in for cuda_gridsample.grid_sample_3d (cuda_gridsample.py:17-19) for the
+    batch-1 call shape MISO uses: input (1,C,D,H,W), grid (1,Do,Ho,Wo,3) -> (1,C,Do,Ho,Wo)."""
+    assert padding_mode in ("zeros", "border")
+    assert input.ndim == 5 and grid.ndim == 5 and grid.shape[4] == 3
+    assert input.shape[0] == grid.shape[0]
+    if input.shape[0] != 1:
+        raise RuntimeError("miso_amd.grid_sample_3d supports batch size 1 (MISO's call shape)")
+    flags = _lib.F_COORDS_NORMALIZED
+    if align_corners:
+        flags |= _lib.F_ALIGN_CORNERS
+    if padding_mode == "border":
+        flags |= _lib.F_PAD_BORDER
+    meta = GridMeta((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), 0, flags)
+    _, do, ho, wo, _ = grid.shape
+    out = _Encode.apply(grid.reshape(-1, 3), meta, input)          # (N,C)
+    return out.transpose(0, 1).reshape(1, input.shape[1], do, ho, wo)
+
+
+# --------------------------------------------------------------------------- #
+# fused encode + frozen decoder
+# --------------------------------------------------------------------------- #
+class DecoderPack:
+    """Weights of a frozen MLPNet pre-permuted into MFMA operand order
+    (miso_mlp_pack).  Re-packed automatically when a weight tensor changes."""
+
+    def __init__(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+        self.weights = list(weights)
+        self.biases = list(biases)
+        self._key = None
+        self._packed = None
+        self._mlp = None
+        self._keep = None
+
+    def _struct(self):
+        ws = [w.detach().contiguous() for w in self.weights]
+        bs = [None if b is None else b.detach().contiguous() for b in self.biases]
+        m = _lib.Mlp()
+        m.n_linear = len(ws)
+        if not 2 <= m.n_linear <= _lib.MAX_LINEAR:
+            return None, None
+        m.in_dim = ws[0].shape[1]
+        m.hidden_dim = ws[0].shape[0]
+        m.out_dim = ws[-1].shape[0]
+        for i in range(1, len(ws) - 1):
+            if tuple(ws[i].shape) != (m.hidden_dim, m.hidden_dim):
+                return None, None
+        if ws[-1].shape[1] != m.hidden_dim:
+            return None, None
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            m.weight[i] = w.data_ptr()
+            m.bias[i] = 0 if b is None else b.data_ptr()
+        return m, (ws, bs)
+
+    def get(self):
+        """-> (Mlp struct, packed tensor) or (None, None) if the shape is not covered."""
+        key = tuple((w.data_ptr(), w._version) for w in self.weights) + \
+            tuple((0, 0) if b is None else (b.data_ptr(), b._version) for b in self.biases)
+        if key == self._key:
+            return self._mlp, self._packed
+        _require_hip(*self.weights)
+        m, keep = self._struct()
+        self._key, self._mlp, self._packed, self._keep = key, None, None, None
+        if m is None:
+            return None, None
+        nf = _lib.load().miso_mlp_packed_floats(C.byref(m))
+        if nf == 0:
+            return None, None
+        packed = torch.empty(nf, device=self.weights[0].device, dtype=torch.float32)
+        _lib.check(_lib.load().miso_mlp_pack(C.byref(m), _ptr(packed), _stream(packed)), "miso_mlp_pack")
+        self._mlp, self._packed, self._keep = m, packed, keep
+        return m, packed
+
+
+def sdf_fused_supported(features, meta: GridMeta, pack: DecoderPack) -> bool:
+    if not all(f.is_cuda for f in features):
+        return False
+    m, packed = pack.get()
+    if m is None:
+        return False
+    g = _fill_grid(features, meta)
+    return bool(_lib.load().miso_sdf_supported(C.byref(g), C.byref(m)))
+
+
+def sdf_fwd_raw(x, features, meta, pack: DecoderPack, want_mask: bool):
+    _require_hip(x, *features)
+    m, packed = pack.get()
+    if m is None:
+        raise RuntimeError("decoder shape is not covered by the fused kernels")
+    x = x.contiguous()
+    n = x.shape[0]
+    sdf = torch.empty((n, 1), device=x.device, dtype=torch.float32)
+    mask = None
+    if want_mask:
+        mw = _lib.load().miso_sdf_mask_words(C.byref(m))
+        mask = torch.empty(((n + 63) // 64) * 64 * mw, device=x.device, dtype=torch.int32)
+    g = _fill_grid(features, meta)
+    _lib.check(_lib.load().miso_sdf_fwd(C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _ptr(sdf),
+                                        _ptr(mask), _stream(x)), "miso_sdf_fwd")
+    return sdf, mask
+
+
+def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f, grads=None):
+    _require_hip(x, gsdf, *features)
+    m, packed = pack.get()
+    x = x.contiguous()
+    gsdf = gsdf.contiguous()
+    n = x.shape[0]
+    if grads is None:
+        grads = [torch.zeros_like(f) if nf else None for f, nf in zip(features, need_f)]
+    gx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
+    g = _fill_grid(features, meta, grads)
+    _lib.check(_lib.load().miso_sdf_bwd(C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _ptr(gsdf),
+                                        _ptr(mask), _ptr(gx), _stream(x)), "miso_sdf_bwd")
+    return gx, grads
+
+
+def _mlp_torch(feats, weights, biases):
+    h = feats
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        h = torch.nn.functional.linear(h, w, b)
+        if i + 1 < len(weights):
+            h = torch.relu(h)
+    return h
+
+
+class _SdfFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, meta, pack, *features):
+        need = any(ctx.needs_input_grad)
+        sdf, mask = sdf_fwd_raw(x, features, meta, pack, want_mask=need)
+        ctx.save_for_backward(x, mask, *features)
+        ctx.meta, ctx.pack = meta, pack
+        return sdf
+
+    @staticmethod
+    def backward(ctx, gsdf):
+        x, mask, *features = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        need_f = tuple(ctx.needs_input_grad[3:])
+        if torch.is_grad_enabled():
+            # create_graph=True (eikonal / smoothness terms, loss_isdf.py:367-377):
+            # rebuild the differentiable graph from the second-order capable ops.
+            with torch.enable_grad():
+                out = _mlp_torch(encode(x, features, ctx.meta), ctx.pack.weights, ctx.pack.biases)
+                wanted = ([x] if need_x else []) + [f for f, nf in zip(features, need_f) if nf]
+                got = list(torch.autograd.grad(out, wanted, gsdf, create_graph=True, allow_unused=True))
+            gx = got.pop(0) if need_x else None
+            gfs = [got.pop(0) if nf else None for nf in need_f]
+            return (gx, None, None, *gfs)
+        gx, grads = sdf_bwd_raw(x, features, ctx.meta, ctx.pack, gsdf, mask, need_x, need_f)
+        return (gx, None, None, *grads)
+
+
+def sdf_fused(x, features, meta: GridMeta, pack: DecoderPack) -> torch.Tensor:
+    """(N,3) -> (N,1) SDF with a frozen decoder: one kernel forward, one backward."""
+    return _SdfFused.apply(x, meta, pack, *features)
+
+
+# --------------------------------------------------------------------------- #
+# dense Adam
+# --------------------------------------------------------------------------- #
+def adam_dense_(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, beta1: float = 0.9,
+                beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = False):
+    """In-place torch.optim.Adam step (amsgrad=False, weight_decay=0) on one dense tensor."""
+    _require_hip(param, grad, exp_avg, exp_avg_sq)
+    for t in (grad, exp_avg, exp_avg_sq):
+        assert t.shape == param.shape and t.stride() == param.stride(), "Adam state must share the param layout"
+    assert param.is_non_overlapping_and_dense()
+    _lib.check(_lib.load().miso_adam_dense(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                           param.numel(), lr, beta1, beta2, eps, step, int(zero_grad),
+                                           _stream(param)), "miso_adam_dense")

@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports
+every symbol include/miso_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "miso_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(miso_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from miso_amd import _lib
+    names = _declared()
+    assert len(names) >= 12
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in miso_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in miso_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.miso_version()
+    assert lib.miso_error_string(2001) == b"bad argument"
+
+
+def test_struct_layout_matches_header():
+    from miso_amd import _lib
+    # sizes implied by the C declarations (LP64)
+    assert ctypes.sizeof(_lib.Level) == 8 + 8 + 4 * 4 + 8 * 4
+    assert ctypes.sizeof(_lib.Grid) == 4 + 4 + 12 + 12 + 4 + 4 + 8 * ctypes.sizeof(_lib.Level)
+    assert ctypes.sizeof(_lib.Mlp) == 16 + 8 * 4 + 8 * 4
+
+
+def test_ops_refuse_cpu_tensors():
+    """No silent CPU fallback: the product ops raise on CPU tensors."""
+    from miso_amd import ops
+    f = torch.zeros(1, 4, 3, 3, 3)
+    x = torch.zeros(5, 3)
+    meta = ops.GridMeta.from_bound([[-1, 1]] * 3)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        ops.encode(x, [f], meta)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        ops.adam_dense_(f, f.clone(), f.clone(), f.clone(), 1, 1e-3)
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate arguments before touching the device."""
+    from miso_amd import _lib
+    lib = _lib.load()
+    g = _lib.Grid()
+    g.n_levels = 0
+    assert lib.miso_encode_fwd(ctypes.byref(g), None, 0, None, 0, None) == 2001
+    g.n_levels = 1
+    g.level[0].C = 4; g.level[0].X = 2; g.level[0].Y = 2; g.level[0].Z = 2
+    g.level[0].sC = 1; g.level[0].sX = 4; g.level[0].sY = 8; g.level[0].sZ = 16
+    assert lib.miso_encode_fwd(ctypes.byref(g), None, 0, None, 4, None) == 2001  # data NULL
+    g.flags = 64
+    assert lib.miso_encode_fwd(ctypes.byref(g), None, 0, None, 4, None) == 2001  # bad flag
+    m = _lib.Mlp()
+    m.in_dim, m.hidden_dim, m.out_dim, m.n_linear = 24, 64, 1, 3
+    assert lib.miso_mlp_packed_floats(ctypes.byref(m)) > 0
+    assert lib.miso_sdf_mask_words(ctypes.byref(m)) == 4
+    m.hidden_dim = 48
+    assert lib.miso_mlp_packed_floats(ctypes.byref(m)) == 0

@@ -1,0 +1,302 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and
+the golden vectors captured from the reference.
+
+Tolerances (fp32; atomics make the scatter order non-deterministic, the
+reference's own tests allow nondet_tol=1e-5, test3d.py:149):
+  features  max|d| <= 1e-6 * max(1, |f|inf)
+  sdf       mean|d| <= 1e-5 (BASELINE north-star), max|d| <= 1e-5
+  gradients rel. error <= 1e-4 (+ small absolute floor)
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def G(name):
+    return np.load(gc.golden_path(name))
+
+
+def to_dev(feats, layout):
+    out = []
+    for f in feats:
+        f = f.to(DEV)
+        if layout == "cl":
+            f = f.contiguous(memory_format=torch.channels_last_3d)
+        out.append(f)
+    return out
+
+
+def setup_case(name, layout="cl"):
+    from miso_amd import ops
+    case = gc.CASES[name]
+    feats = [T(f) for f in gc.make_features(case)]
+    bound = torch.tensor(case["bound"], dtype=torch.float32)
+    ws, bs = R.decoder_params({k: T(v) for k, v in gc.make_decoder(case).items()})
+    x = T(gc.make_points(case))
+    meta = ops.GridMeta.from_bound(bound)
+    fd = [f.requires_grad_(True) for f in to_dev(feats, layout)]
+    pack = ops.DecoderPack([w.to(DEV) for w in ws], [b.to(DEV) for b in bs])
+    return case, feats, bound, ws, bs, x, meta, fd, pack
+
+
+def relerr(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", ["small", "cfg1", "cfg2"])
+@pytest.mark.parametrize("layout", ["cl", "ncdhw"])
+def test_encode_forward_vs_golden(name, layout):
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x, meta, fd, pack = setup_case(name, layout)
+    out = ops.encode(x.to(DEV), fd, meta).cpu()
+    g = G(name)
+    torch.testing.assert_close(out.detach(), T(g["feats"]), rtol=0, atol=1e-6)
+    # stability grids: C = 1 (generic scalar path)
+    stab = to_dev([T(f) for f in gc.make_stability(case)], layout)
+    s = ops.encode(x.to(DEV), stab, meta).cpu()
+    torch.testing.assert_close(s, T(g["stab"]), rtol=1e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["small", "cfg1"])
+@pytest.mark.parametrize("layout", ["cl", "ncdhw"])
+def test_encode_backward_vs_oracle(name, layout):
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x, meta, fd, pack = setup_case(name, layout)
+    torch.manual_seed(3)
+    go = torch.randn(x.shape[0], case["fdim"] * case["n_levels"])
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.encode(xd, fd, meta)
+    grads = torch.autograd.grad(out, fd + [xd], go.to(DEV))
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    xc = x.clone().requires_grad_(True)
+    ref = R.encode_stock(fc, bound, xc)
+    rg = torch.autograd.grad(ref, fc + [xc], go)
+    for a, b in zip(grads, rg):
+        assert a.shape == b.shape
+        assert relerr(a.cpu(), b) < 1e-4
+
+
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+@pytest.mark.parametrize("ac", [False, True])
+def test_grid_sample_3d_dropin(pad, ac):
+    """cuda_gridsample.grid_sample_3d call shape (cuda_gridsample.py:17-19), value,
+    first and second derivatives, in- and out-of-bounds (test3d.py:37-72)."""
+    from miso_amd import ops
+    torch.manual_seed(0)
+    inp = torch.randn(1, 3, 5, 6, 7)
+    grid = torch.rand(1, 50, 1, 1, 3) * 2.6 - 1.3
+    go = torch.randn(1, 3, 50, 1, 1)
+    a_in = inp.to(DEV).requires_grad_(True)
+    a_gr = grid.to(DEV).requires_grad_(True)
+    out = ops.grid_sample_3d(a_in, a_gr, padding_mode=pad, align_corners=ac)
+    b_in = inp.clone().requires_grad_(True)
+    b_gr = grid.clone().requires_grad_(True)
+    ref = torch.nn.functional.grid_sample(b_in, b_gr, mode="bilinear", padding_mode=pad, align_corners=ac)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+    ga = torch.autograd.grad(out, [a_in, a_gr], go.to(DEV), create_graph=True)
+    gb = torch.autograd.grad(ref, [b_in, b_gr], go)
+    torch.testing.assert_close(ga[0].cpu(), gb[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ga[1].cpu(), gb[1], rtol=1e-4, atol=1e-5)
+    # second order against the any-order restatement
+    c_in = inp.clone().requires_grad_(True)
+    c_gr = grid.clone().requires_grad_(True)
+    r2 = R.trilinear_gather(c_in, c_gr.reshape(-1, 3), ac, pad)                   # (N,C)
+    gc_ = torch.autograd.grad(r2, [c_in, c_gr], go[0, :, :, 0, 0].t(), create_graph=True)
+    s_a = (ga[1] ** 2).sum() + (ga[0] ** 2).sum()
+    s_c = (gc_[1] ** 2).sum() + (gc_[0] ** 2).sum()
+    h_a = torch.autograd.grad(s_a, [a_in, a_gr])
+    h_c = torch.autograd.grad(s_c, [c_in, c_gr])
+    assert relerr(h_a[0].cpu(), h_c[0]) < 1e-4
+    assert relerr(h_a[1].cpu(), h_c[1]) < 1e-4
+
+
+def test_second_order_eikonal_vs_oracle():
+    """L = mean((|grad_x sdf| - 1)^2) through encode + torch MLP: dL/dfeature, dL/dx
+    against the fp32 any-order restatement."""
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x, meta, fd, pack = setup_case("small")
+    x = x[:256]
+
+    def eik(enc, fs, xx, w, b):
+        sdf = R.mlp_forward(enc(fs, xx), w, b)
+        (gx,) = torch.autograd.grad(sdf, xx, torch.ones_like(sdf), create_graph=True)
+        return ((gx.norm(dim=-1) - 1) ** 2).mean()
+
+    xd = x.to(DEV).requires_grad_(True)
+    la = eik(lambda fs, xx: ops.encode(xx, fs, meta), fd, xd, [w.to(DEV) for w in ws], [b.to(DEV) for b in bs])
+    ga = torch.autograd.grad(la, fd + [xd])
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    xc = x.clone().requires_grad_(True)
+    lc = eik(lambda fs, xx: R.encode_gather(fs, bound, xx), fc, xc, ws, bs)
+    gcpu = torch.autograd.grad(lc, fc + [xc])
+    assert abs(la.item() - lc.item()) < 1e-5 * max(1.0, abs(lc.item()))
+    for a, b in zip(ga, gcpu):
+        assert relerr(a.cpu(), b) < 2e-4
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", ["small", "cfg1", "cfg2"])
+def test_sdf_fused_vs_golden(name):
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x, meta, fd, pack = setup_case(name)
+    assert ops.sdf_fused_supported(fd, meta, pack)
+    g = G(name)
+    xd = x.to(DEV).requires_grad_(True)
+    n = x.shape[0]
+    sdf_t, valid, sign, weight = [T(a).to(DEV) for a in gc.make_targets(case, n)]
+    pred = ops.sdf_fused(xd, fd, meta, pack)
+    d = (pred.detach().cpu() - T(g["sdf"])).abs()
+    assert d.mean().item() <= 1e-5 and d.max().item() <= 1e-5
+    l1 = R.miso_loss_regression(pred, sdf_t, valid, weight, "L1")
+    fs = R.miso_loss_free_space(pred, sdf_t, sign, 0.15)
+    assert abs(l1.item() - float(g["loss_l1"])) < 1e-6
+    grads = torch.autograd.grad(l1 + 0.1 * fs, fd + [xd])
+    assert relerr(grads[-1].cpu(), T(g["grad_x"])) < 1e-4
+    for l in range(case["n_levels"]):
+        gl = grads[l].cpu().reshape(-1)
+        idx = T(g[f"gfeat{l}_idx"])
+        ref = T(g[f"gfeat{l}_val"])
+        assert (gl[idx] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-10
+        s = gl.double().abs().sum().item()
+        assert abs(s - float(g[f"gfeat{l}_abssum"])) <= 1e-4 * float(g[f"gfeat{l}_abssum"])
+    # smooth loss as well (better conditioned)
+    pred2 = ops.sdf_fused(xd, fd, meta, pack)
+    l2 = R.miso_loss_regression(pred2, sdf_t, valid, weight, "L2")
+    g2 = torch.autograd.grad(l2, fd + [xd])
+    assert relerr(g2[-1].cpu(), T(g["grad2_x"])) < 1e-4
+    for l in range(case["n_levels"]):
+        gl = g2[l].cpu().reshape(-1)
+        ref = T(g[f"g2feat{l}_val"])
+        assert (gl[T(g[f"gfeat{l}_idx"])] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000])
+def test_ragged_sizes_and_ignore_level(n):
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x, meta, fd, pack = setup_case("small")
+    x = x[:n] if n <= x.shape[0] else torch.cat([x, x[: n - x.shape[0]]])
+    meta_ig = ops.GridMeta.from_bound(bound, ignore_level=[True, False])
+    for m, ig in ((meta, None), (meta_ig, [True, False])):
+        xd = x.to(DEV).requires_grad_(True)
+        out = ops.sdf_fused(xd, fd, m, pack)
+        enc = ops.encode(xd, fd, m)
+        xc = x.clone().requires_grad_(True)
+        fc = [f.clone().requires_grad_(True) for f in feats]
+        ref_e = R.encode_stock(fc, bound, xc, ig)
+        ref = R.mlp_forward(ref_e, ws, bs)
+        assert out.shape == (n, 1) and enc.shape == ref_e.shape
+        if n == 0:
+            continue
+        torch.testing.assert_close(enc.detach().cpu(), ref_e.detach(), rtol=0, atol=1e-6)
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=0, atol=1e-5)
+        ga = torch.autograd.grad(out.sum(), fd + [xd])
+        gb = torch.autograd.grad(ref.sum(), fc + [xc], allow_unused=True)
+        for a, b in zip(ga, gb):
+            b = torch.zeros_like(a.cpu()) if b is None else b
+            assert (a.cpu() - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-3)
+
+
+def test_far_outside_and_nan_points_are_safe():
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x, meta, fd, pack = setup_case("small")
+    x = torch.tensor([[1e9, 0, 0], [-1e9, 1e9, 3e9], [float("nan"), 0.1, 0.2], [float("inf"), 0, 1.0],
+                      [0.1, 0.1, 1.0]], dtype=torch.float32)
+    enc = ops.encode(x.to(DEV), fd, meta).cpu()
+    assert torch.all(enc[:2] == 0) and torch.all(enc[3] == 0)
+    ref = R.encode_stock(feats, bound, x[4:5])
+    torch.testing.assert_close(enc[4:5].detach(), ref, rtol=0, atol=1e-6)
+    out = ops.sdf_fused(x.to(DEV), fd, meta, pack)
+    out.sum().backward()
+    torch.cuda.synchronize()
+    for f in fd:
+        assert torch.isfinite(f.grad).all()
+
+
+# --------------------------------------------------------------------------- #
+def test_full_size_properties_cfg2():
+    """BASELINE cfg-2 full size (262 144 points): size-independent properties.
+    (a) partition of unity on an all-ones grid, (b) linearity in the features,
+    (c) adjointness <encode(G;x), r> == <G, encode_bwd(r;x)>, (d) the fused
+    forward equals encode + torch MLP, (e) fused backward equals unfused backward."""
+    from miso_amd import ops
+    case = gc.CASES["cfg2"]
+    n = 262144
+    gen = torch.Generator().manual_seed(1234)
+    x = (torch.rand(n, 3, generator=gen) * 2 - 1).to(DEV)
+    bound = torch.tensor(case["bound"], dtype=torch.float32)
+    meta = ops.GridMeta.from_bound(bound)
+    shapes = [gc.grid_shape(case["bound"], c, case["fdim"]) for c in gc.level_cells(case)]
+    g0 = torch.Generator(device=DEV).manual_seed(0)
+    mk = lambda: [(torch.randn(s, device=DEV, generator=g0) * 1e-2).contiguous(
+        memory_format=torch.channels_last_3d) for s in shapes]
+    A, B = mk(), mk()
+    ones = [torch.ones_like(a) for a in A]
+    e1 = ops.encode(x, ones, meta)
+    half = 1.0 / 256  # points at least half a finest cell inside the bound see all 8 corners
+    inner = (x.abs() < 1 - 2 * half).all(dim=1)
+    assert (e1[inner] - 1).abs().max().item() < 2e-6
+    ea, eb = ops.encode(x, A, meta), ops.encode(x, B, meta)
+    comb = ops.encode(x, [2.5 * a - 0.75 * b for a, b in zip(A, B)], meta)
+    assert (comb - (2.5 * ea - 0.75 * eb)).abs().max().item() < 1e-6
+    r = torch.randn(n, ea.shape[1], device=DEV, generator=g0)
+    Ag = [a.requires_grad_(True) for a in A]
+    ea = ops.encode(x, Ag, meta)
+    grads = torch.autograd.grad(ea, Ag, r)
+    lhs = (ea.detach().double() * r.double()).sum().item()
+    rhs = sum((a.detach().double() * g.double()).sum().item() for a, g in zip(Ag, grads))
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+    # fused vs unfused
+    sd = {k: T(v).to(DEV) for k, v in gc.make_decoder(case).items()}
+    ws, bs = R.decoder_params(sd)
+    pack = ops.DecoderPack(ws, bs)
+    fused = ops.sdf_fused(x, Ag, meta, pack)
+    unf = R.mlp_forward(ops.encode(x, Ag, meta), ws, bs)
+    d = (fused - unf).abs()
+    assert d.mean().item() <= 1e-6 and d.max().item() <= 1e-5
+    go = torch.randn(n, 1, device=DEV, generator=g0) / n
+    gf = torch.autograd.grad(fused, Ag, go)
+    gu = torch.autograd.grad(unf, Ag, go)
+    for a, b in zip(gf, gu):
+        assert relerr(a, b) < 1e-4
+
+
+def test_adam_dense_vs_torch():
+    from miso_amd import ops
+    torch.manual_seed(0)
+    p0 = torch.randn(1, 4, 9, 7, 5)
+    grads = [torch.randn_like(p0) * (i + 1) * 1e-3 for i in range(4)]
+    pc = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pc], lr=1e-3)
+    for g in grads:
+        pc.grad = g.clone()
+        opt.step()
+    for fmt in (torch.contiguous_format, torch.channels_last_3d):
+        p = p0.to(DEV).contiguous(memory_format=fmt)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for i, g in enumerate(grads):
+            gd = torch.empty_like(p).copy_(g.to(DEV))
+            ops.adam_dense_(p, gd, m, v, i + 1, 1e-3, zero_grad=(i % 2 == 0))
+            assert (gd == 0).all() == (i % 2 == 0)
+        torch.testing.assert_close(p.cpu(), pc.detach(), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(m.cpu(), opt.state[pc]["exp_avg"], rtol=1e-6, atol=1e-9)
+        torch.testing.assert_close(v.cpu(), opt.state[pc]["exp_avg_sq"], rtol=1e-6, atol=1e-12)
+
+
+def test_native_library_is_loaded():
+    """The ops above ran through libmiso_hip.so (no eager fallback exists)."""
+    from miso_amd import _lib
+    assert _lib._lib is not None
+    maps = open("/proc/self/maps").read()
+    assert "libmiso_hip.so" in maps
