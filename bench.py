@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 3-D point-samples/s, encode+decode forward+backward.
+
+Workload (BASELINE.json configs[1], "cfg-2"): one submap per GPU, 3-level
+{32,64,128}^3 feature grid (C=8, channels-last), frozen decoder MLP 24-64-64-1
+(seeded random weights stand in for the unavailable decoder_indoor.pt), one
+batch of 262 144 uniform-in-bbox points per GPU per step, L1 regression loss,
+gradients to every grid level (decoder frozen, configs/rgbd/scannet.yaml:16).
+A step = clear grads -> fused forward -> loss -> fused backward, exactly K times
+inside the timed region (inputs resident in HBM).  Submaps are independent, so
+N GPUs run N submaps with no data-path collective (weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POINTS = 262144
+LEVELS = (32, 64, 128)
+C = 8
+HIDDEN = 64
+
+
+def build_workload(dev, rank):
+    from miso_amd import ops
+    from miso_amd.step import MappingStep
+    g = torch.Generator().manual_seed(0)
+    feats = [(torch.randn(1, C, s, s, s, generator=g) * 1e-2).to(dev).contiguous(
+        memory_format=torch.channels_last_3d) for s in LEVELS]
+    torch.manual_seed(0)
+    lin = [torch.nn.Linear(C * len(LEVELS), HIDDEN), torch.nn.Linear(HIDDEN, HIDDEN), torch.nn.Linear(HIDDEN, 1)]
+    ws = [l.weight.detach().to(dev) for l in lin]
+    bs = [l.bias.detach().to(dev) for l in lin]
+    meta = ops.GridMeta.from_bound([[-1.0, 1.0]] * 3)
+    pack = ops.DecoderPack(ws, bs)
+    gp = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand(N_POINTS, 3, generator=gp) * 2 - 1
+    targ = torch.randn(N_POINTS, 1, generator=gp) * 0.1
+    step = MappingStep(feats, meta, pack, N_POINTS, loss_type="L1", weight_sdf=1.0, weight_fs=0.0)
+    step.set_batch(x.to(dev), targ.to(dev))
+    return step, (feats, ws, bs, x, targ)
+
+
+def time_kernel(fn, iters=30, warm=5):
+    """Average duration (us) of `fn` (one launch) with HIP events on the launch stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def cpu_baseline(data, budget_s=20.0):
+    """The reference's op sequence (per-level F.grid_sample -> cat -> nn.Sequential -> L1 ->
+    backward) restated with stock torch CPU ops (oracle/ref_torch.py, kind 'port'),
+    timed on this host on a bounded sample of whole 262 144-point iterations."""
+    from oracle import ref_torch as R  # checker / baseline leg only
+    feats, ws, bs, x, targ = data
+    fc = [f.detach().cpu().contiguous().requires_grad_(True) for f in feats]
+    wc, bc = [w.cpu() for w in ws], [b.cpu() for b in bs]
+    bound = torch.tensor([[-1.0, 1.0]] * 3)
+    cores = torch.get_num_threads()
+
+    def it():
+        for f in fc:
+            f.grad = None
+        pred = R.sdf_stock(fc, bound, x, wc, bc)
+        loss = R.miso_loss_regression(pred, targ, None, None, "L1")
+        loss.backward()
+        return pred
+
+    it()  # warm-up
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        pred = it()
+        k += 1
+        if time.perf_counter() - t0 > budget_s or k >= 12:
+            break
+    dt = (time.perf_counter() - t0) / k
+    return {"value": N_POINTS / dt, "unit": "point-samples/s", "cores": cores, "kind": "port",
+            "sample": f"{k} full fwd+bwd iterations of 262144 points (stock torch CPU ops arranged as "
+                      f"the reference: F.grid_sample per level, cat, nn.Sequential, L1), {dt:.2f} s each"}, pred
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from miso_amd import ops
+    step, data = build_workload(dev, rank)
+
+    for _ in range(args.warmup):
+        step.run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * N_POINTS * args.steps / elapsed
+
+    # ---- per-kernel durations (HIP events on the launch stream) and roofline --------------------
+    L = len(LEVELS)
+    feats, meta, pack = step.features, step.meta, step.pack
+    mask = step._mask
+    t_fwd = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, True, out=step.sdf, mask=mask))
+    t_bwd = time_kernel(lambda: ops.sdf_bwd_raw(step.x, feats, meta, pack, step.gpred, mask, False,
+                                                [True] * L, step.grads))
+    t_zero = time_kernel(lambda: [g.zero_() for g in step.grads])
+    b_fwd = 12 + 32 * L * C + 4        # xyz + 8 corners x C x 4 B per level + sdf
+    b_bwd = 4 + 32 * L * C             # dL/dsdf + grad scatter counted once as a write
+    dom = ("sdf_bwd_kernel", t_bwd, b_bwd) if t_bwd >= t_fwd else ("sdf_fwd_kernel", t_fwd, b_fwd)
+    achieved = N_POINTS * dom[2] / (dom[1] * 1e-6) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom[0], {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": traffic,
+                "algorithmic_bytes_per_point": dom[2], "kernel_us": dom[1]}
+
+    out = {
+        "metric": "3D point-samples/sec (encode+decode fwd+bwd), 262144-pt batch",
+        "value": value, "unit": "point-samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg-2: one submap per GPU, 3-level {32,64,128}^3 grid C=8 + MLP 24-64-64-1 "
+                               "(frozen, seeded random weights), 262144 uniform-in-bbox points per GPU per "
+                               "step, L1 loss, grads to all levels",
+                   "points_per_gpu": N_POINTS, "levels": list(LEVELS), "feature_dim": C,
+                   "decoder": [C * L, HIDDEN, HIDDEN, 1], "parallelism": f"submap-parallel x{world}"},
+        "roofline": roofline,
+        "step_fraction_of_hbm_roofline": value / world * (20 + 64 * L * C) / 8e12,
+        "kernels_us": {"sdf_fwd_kernel": t_fwd, "sdf_bwd_kernel": t_bwd, "zero_grads": t_zero},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cb, pred_cpu = cpu_baseline(data)
+        out["cpu_baseline"] = cb
+        err = (step.sdf.detach().cpu() - pred_cpu.detach()).abs()
+        out["sdf_L1_vs_cpu"] = {"mean": err.mean().item(), "max": err.max().item()}
+        out["speedup_vs_cpu"] = value / cb["value"]
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

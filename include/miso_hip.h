@@ -30,6 +30,9 @@
  *   miso_pair_latent  pairwise_loss_latent, grid_opt/align/miso.py:116-211 (L2),
  *                     with the rigid maps of grid_opt/utils/utils_geometry.py:214-240.
  *   miso_lm_normal_eq Tracker.lm_step normal equations, grid_opt/slam/tracker.py:171-196.
+ *   miso_mapping_loss miso_loss_regression + miso_loss_free_space and their gradient
+ *                     w.r.t. the prediction, grid_opt/loss.py:594-635, :668-700, as
+ *                     combined by MisoLossMappingBase.compute (loss.py:776-806).
  *   miso_adam_dense   torch.optim.Adam.step on one dense tensor as used by
  *                     grid_opt/trainer.py:196-228 / :410-452.
  */
@@ -125,6 +128,16 @@ int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
 int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                  const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
                  float* grad_x, void* stream);
+
+/* --- mapping loss (value + d/d pred) --------------------------------------
+ * loss_type 1 = L1, 2 = L2.  pred/target (N); valid/sign/weight (N) or NULL
+ * (= all valid / no free-space rows / unit weights).  Writes grad_pred (N) =
+ * d(weight_sdf*sdf_term + weight_fs*fs_term)/d pred and loss_out[2] =
+ * {weight_sdf*sdf_term, weight_fs*fs_term} (means over all N rows). */
+int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,
+                      const float* pred, const float* target, const float* valid,
+                      const float* sign, const float* weight, int64_t n, float* grad_pred,
+                      float* loss_out, void* stream);
 
 /* --- dense Adam (torch.optim.Adam defaults: amsgrad=False, weight_decay=0) -
  * One launch over one dense tensor; param/grad/exp_avg/exp_avg_sq share a

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported BEFORE libmiso_hip.so is loaded: both need
+# libamdhip64.so.7 and the process must end up with the ONE HIP runtime torch
+# ships (loading ROCm's copy first leaves torch without a device).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmiso_hip.so")
 
@@ -58,6 +63,9 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_sdf_bwd": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_mapping_loss": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "miso_adam_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int,
                                   C.c_void_p]),

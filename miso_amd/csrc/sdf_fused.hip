@@ -284,6 +284,10 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
   const float* w0T = smem + (pl.o_w0T - pl.o_whT);
   const float* wo = smem + nb;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+  constexpr int FP = ((F + 3) / 4) * 4 + 4;  // d-feat row pitch: 16-B aligned, conflict-free b128 writes
+  constexpr int REC = 8;                     // ints per (point, level) cell record
+  constexpr int WAVE_LDS = 64 * FP + 64 * L * REC;
+  float* wave_lds = smem + ((nb + H + 3) / 4) * 4 + wave * WAVE_LDS;
   const int64_t nchunks = (n + 63) / 64;
 
   for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
@@ -350,45 +354,114 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
         df[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][0][j], df[0], 0, 0, 0);
         df[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][1][j], df[1], 0, 0, 0);
       }
-    // ---- scatter / coordinate gradient -----------------------------------------
-    float gacc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    // ---- scatter into the level gradients ----------------------------------------
+    // The L2 executes fp32 atomics per 64-byte request (~21 G requests/s on MI355X,
+    // tools/ubench/atomics.hip), however many of its 16 dwords carry data.  So the
+    // scatter runs "row-major": the 2*C consecutive lanes of a group cover the
+    // x-pair (i0, i0+1) x C channels = one contiguous run of 2*C floats, and one
+    // atomic instruction serves 64/(2C) (point, row) pairs.  d feats move from the
+    // accumulator layout to that lane order through a per-wave LDS tile; the cell
+    // of every (point, level) is computed once (lane = point) and broadcast from LDS.
+    if (WANT_GRID) {
+      float* dF = wave_lds;                         // [64][FP]
+      int* rec = reinterpret_cast<int*>(wave_lds + 64 * FP);   // [64][L][REC]
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const bool valid = pt[t] < n;
-      float px = 0.f, py = 0.f, pz = 0.f;
-      if (valid) { px = x[pt[t] * 3 + 0]; py = x[pt[t] * 3 + 1]; pz = x[pt[t] * 3 + 2]; }
-      constexpr int NG = (C == 8) ? L : (L + 1) / 2;  // register groups of 4
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int gi = 0; gi < NG; ++gi) {
-        const int l = (C == 8) ? gi : 2 * gi + hi;
-        const int choff = (C == 8) ? 4 * hi : 0;
-        if (l >= L || !valid) continue;
-        if ((g.ignore_mask >> l) & 1u) continue;
-        // C == 4: the two lane halves work on different levels; pick the level's
-        // fields with per-lane selects (a lane-varying index into the kernel
-        // arguments would be spilled to scratch).
-        LevelK lv = g.lv[(C == 8) ? gi : 2 * gi];
-        if (C == 4 && 2 * gi + 1 < L && hi) lv = g.lv[(2 * gi + 1 < L) ? 2 * gi + 1 : 0];
-        Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
-        Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
-        Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
-        Cell c = make_cell(ax, ay, az, lv);
-        const float v0 = df[t][4 * gi + 0], v1 = df[t][4 * gi + 1], v2 = df[t][4 * gi + 2],
-                    v3 = df[t][4 * gi + 3];
-        float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;
+        for (int gq = 0; gq < (F + 7) / 8; ++gq) {
+          const int f0 = 8 * gq + 4 * hi;
+          if (f0 < F)
+            *reinterpret_cast<float4*>(dF + (32 * t + (lane & 31)) * FP + f0) =
+                make_float4(df[t][4 * gq], df[t][4 * gq + 1], df[t][4 * gq + 2], df[t][4 * gq + 3]);
+        }
+      {
+        const int64_t p = chunk * 64 + lane;
+        const bool valid = p < n;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) { px = x[p * 3 + 0]; py = x[p * 3 + 1]; pz = x[p * 3 + 2]; }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-          bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
-          if (!in) continue;
-          int off = (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX + choff;
-          if (WANT_GRID && lv.grad) {
-            float w = (c.wx[dx] * c.wy[dy]) * c.wz[dz];
-            float* tg = lv.grad + off;
-            atomic_add_f32(tg + 0, v0 * w); atomic_add_f32(tg + 1, v1 * w);
-            atomic_add_f32(tg + 2, v2 * w); atomic_add_f32(tg + 3, v3 * w);
+        for (int l = 0; l < L; ++l) {
+          const LevelK& lv = g.lv[l];
+          Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+          Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+          Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+          Cell c = make_cell(ax, ay, az, lv);
+          int flags = (c.inx[0] ? 1 : 0) | (c.inx[1] ? 2 : 0) | (c.iny[0] ? 4 : 0) | (c.iny[1] ? 8 : 0) |
+                      (c.inz[0] ? 16 : 0) | (c.inz[1] ? 32 : 0);
+          if (!valid) flags = 0;
+          int* r = rec + (lane * L + l) * REC;
+          *reinterpret_cast<int4*>(r) = make_int4(c.k0 * lv.sZ + c.j0 * lv.sY + c.i0 * lv.sX, flags,
+                                                  __float_as_int(c.wx[1]), __float_as_int(c.wy[1]));
+          *reinterpret_cast<int4*>(r + 4) = make_int4(__float_as_int(c.wz[1]), __float_as_int(c.wx[0]),
+                                                      __float_as_int(c.wy[0]), __float_as_int(c.wz[0]));
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      constexpr int LPR = 2 * C, SLOTS = 64 / LPR;
+      const int slot = lane / LPR, dx = (lane / C) & 1, ch = lane % C;
+#pragma unroll 1
+      for (int pg = 0; pg < 64 / SLOTS; ++pg) {
+        const int pt = pg * SLOTS + slot;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const LevelK& lv = g.lv[l];
+          if (!lv.grad || ((g.ignore_mask >> l) & 1u)) continue;
+          const int* r = rec + (pt * L + l) * REC;
+          const int4 r0 = *reinterpret_cast<const int4*>(r);
+          const int4 r1 = *reinterpret_cast<const int4*>(r + 4);
+          const int fl = r0.y;
+          if (!((fl >> dx) & 1)) continue;
+          const float v = dF[pt * FP + l * C + ch];
+          const float wx = dx ? __int_as_float(r0.z) : __int_as_float(r1.y);
+          const float wy[2] = {__int_as_float(r1.z), __int_as_float(r0.w)};
+          const float wz[2] = {__int_as_float(r1.w), __int_as_float(r1.x)};
+          float* base = lv.grad + r0.x + dx * lv.sX + ch;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int dy = q & 1, dz = q >> 1;
+            if (((fl >> (2 + dy)) & 1) && ((fl >> (4 + dz)) & 1))
+              atomic_add_f32(base + dy * lv.sY + dz * lv.sZ, v * ((wx * wy[dy]) * wz[dz]));
           }
-          if (WANT_X) {
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- coordinate gradient (pose path): lane = (point, channel half) -----------
+    if (WANT_X) {
+      float gacc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bool valid = pt[t] < n;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) { px = x[pt[t] * 3 + 0]; py = x[pt[t] * 3 + 1]; pz = x[pt[t] * 3 + 2]; }
+        constexpr int NG = (C == 8) ? L : (L + 1) / 2;  // register groups of 4
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+          const int l = (C == 8) ? gi : 2 * gi + hi;
+          const int choff = (C == 8) ? 4 * hi : 0;
+          if (l >= L || !valid) continue;
+          if ((g.ignore_mask >> l) & 1u) continue;
+          // C == 4: the two lane halves work on different levels; pick the level's
+          // fields with per-lane selects (a lane-varying index into the kernel
+          // arguments would be spilled to scratch).
+          LevelK lv = g.lv[(C == 8) ? gi : 2 * gi];
+          if (C == 4 && 2 * gi + 1 < L && hi) lv = g.lv[(2 * gi + 1 < L) ? 2 * gi + 1 : 0];
+          Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+          Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+          Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+          Cell c = make_cell(ax, ay, az, lv);
+          const float v0 = df[t][4 * gi + 0], v1 = df[t][4 * gi + 1], v2 = df[t][4 * gi + 2],
+                      v3 = df[t][4 * gi + 3];
+          float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
+            if (!in) continue;
+            int off = (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX + choff;
             float4 gv = *reinterpret_cast<const float4*>(lv.data + off);
             float dot = gv.x * v0 + gv.y * v1 + gv.z * v2 + gv.w * v3;
             float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
@@ -396,13 +469,9 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
             sy_ += dot * sy * c.wx[dx] * c.wz[dz];
             sz_ += dot * sz * c.wx[dx] * c.wy[dy];
           }
-        }
-        if (WANT_X) {
           gacc[t][0] += sx_ * ax.mult; gacc[t][1] += sy_ * ay.mult; gacc[t][2] += sz_ * az.mult;
         }
       }
-    }
-    if (WANT_X) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -431,6 +500,10 @@ static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float*
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   if (blocks > 512u) blocks = 512u;
   auto k = sdf_fwd_kernel<C, L, H, NH>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, mask);
   return hipGetLastError();
 }
@@ -440,16 +513,20 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
                                const float* gsdf, const uint32_t* mask, float* gx, bool want_grid,
                                hipStream_t s) {
   PackLayout pl(C * L, H, NH);
-  size_t lds = (size_t)(pl.total - pl.o_whT + H + 4) * sizeof(float);
+  constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4, WAVE_LDS = 64 * FP + 64 * L * 8;
+  size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * WAVE_LDS : 0)) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   if (blocks > 512u) blocks = 512u;
-  if (want_grid && gx)
-    sdf_bwd_kernel<C, L, H, NH, true, true><<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx);
-  else if (want_grid)
-    sdf_bwd_kernel<C, L, H, NH, true, false><<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx);
-  else if (gx)
-    sdf_bwd_kernel<C, L, H, NH, false, true><<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx);
+  void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*) =
+      (want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true>
+      : want_grid       ? sdf_bwd_kernel<C, L, H, NH, true, false>
+                        : sdf_bwd_kernel<C, L, H, NH, false, true>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  k<<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx);
   return hipGetLastError();
 }
 

@@ -295,18 +295,19 @@ def sdf_fused_supported(features, meta: GridMeta, pack: DecoderPack) -> bool:
     return bool(_lib.load().miso_sdf_supported(C.byref(g), C.byref(m)))
 
 
-def sdf_fwd_raw(x, features, meta, pack: DecoderPack, want_mask: bool):
+def sdf_fwd_raw(x, features, meta, pack: DecoderPack, want_mask: bool, out=None, mask=None):
     _require_hip(x, *features)
     m, packed = pack.get()
     if m is None:
         raise RuntimeError("decoder shape is not covered by the fused kernels")
     x = x.contiguous()
     n = x.shape[0]
-    sdf = torch.empty((n, 1), device=x.device, dtype=torch.float32)
-    mask = None
-    if want_mask:
+    sdf = torch.empty((n, 1), device=x.device, dtype=torch.float32) if out is None else out
+    if want_mask and mask is None:
         mw = _lib.load().miso_sdf_mask_words(C.byref(m))
         mask = torch.empty(((n + 63) // 64) * 64 * mw, device=x.device, dtype=torch.int32)
+    if not want_mask:
+        mask = None
     g = _fill_grid(features, meta)
     _lib.check(_lib.load().miso_sdf_fwd(C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _ptr(sdf),
                                         _ptr(mask), _stream(x)), "miso_sdf_fwd")
@@ -379,7 +380,58 @@ def adam_dense_(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, beta1: f
     _require_hip(param, grad, exp_avg, exp_avg_sq)
     for t in (grad, exp_avg, exp_avg_sq):
         assert t.shape == param.shape and t.stride() == param.stride(), "Adam state must share the param layout"
-    assert param.is_non_overlapping_and_dense()
     _lib.check(_lib.load().miso_adam_dense(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
                                            param.numel(), lr, beta1, beta2, eps, step, int(zero_grad),
                                            _stream(param)), "miso_adam_dense")
+
+
+# --------------------------------------------------------------------------- #
+# mapping loss (value + gradient w.r.t. the prediction)
+# --------------------------------------------------------------------------- #
+_LOSS_TYPES = {"L1": 1, "L2": 2}
+
+
+def mapping_loss_raw(pred, target, valid, sign, weight, loss_type: str, weight_sdf: float,
+                     weight_fs: float, trunc_dist: float, grad_pred=None, loss_out=None):
+    """miso_loss_regression + miso_loss_free_space (grid_opt/loss.py:594-635, :668-700) and
+    d/d pred in one launch.  Returns (loss_out[2] = weighted terms, grad_pred (N,1))."""
+    _require_hip(pred, target, valid, sign, weight)
+    n = pred.shape[0]
+    pred = pred.contiguous()
+    if grad_pred is None:
+        grad_pred = torch.empty_like(pred)
+    if loss_out is None:
+        loss_out = torch.empty(2, device=pred.device, dtype=torch.float32)
+    cont = lambda t: None if t is None else t.contiguous()
+    target, valid, sign, weight = cont(target), cont(valid), cont(sign), cont(weight)
+    _lib.check(_lib.load().miso_mapping_loss(_LOSS_TYPES[loss_type], weight_sdf, weight_fs,
+                                             0.0 if trunc_dist is None else trunc_dist, _ptr(pred),
+                                             _ptr(target), _ptr(valid), _ptr(sign), _ptr(weight), n,
+                                             _ptr(grad_pred), _ptr(loss_out), _stream(pred)),
+               "miso_mapping_loss")
+    return loss_out, grad_pred
+
+
+class _MappingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, valid, sign, weight, loss_type, w_sdf, w_fs, trunc):
+        loss, gpred = mapping_loss_raw(pred, target, valid, sign, weight, loss_type, w_sdf, w_fs, trunc)
+        ctx.save_for_backward(gpred)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        (gpred,) = ctx.saved_tensors
+        # both terms share d/d pred up to their weights, already folded into gpred; the
+        # cotangents of the two outputs are equal (the caller sums them) in MISO's use
+        return (gpred * gl[0], None, None, None, None, None, None, None, None)
+
+
+def mapping_loss(pred, target, valid, sign, weight, loss_type="L1", weight_sdf=1.0, weight_fs=0.0,
+                 trunc_dist=0.0):
+    """-> tensor([weight_sdf * sdf_term, weight_fs * free_space_term]); differentiable w.r.t.
+    pred provided both entries receive the same cotangent (they are summed by the trainer,
+    grid_opt/trainer.py:208-212)."""
+    return _MappingLoss.apply(pred, target, valid, sign, weight, loss_type, weight_sdf, weight_fs,
+                              trunc_dist)

@@ -1,0 +1,89 @@
+"""One mapping iteration of a submap with a frozen decoder as a fixed launch
+sequence: clear grads -> fused encode+decode forward -> mapping loss (+ d/d pred)
+-> fused backward scatter [-> dense Adam].
+
+This is the trainer step of grid_opt/trainer.py:196-228 for MisoLossMapping
+(grid_opt/loss.py:754-813, pose variables locked as in Mapper.mapping,
+grid_opt/slam/mapper.py:72-75) without the per-op launches, host syncs and
+autograd bookkeeping; the sequence is capturable in a HIP graph.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+class MappingStep:
+    def __init__(self, features: Sequence[torch.Tensor], meta: ops.GridMeta, pack: ops.DecoderPack,
+                 n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
+                 trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True):
+        self.features = list(features)
+        self.meta, self.pack = meta, pack
+        self.n = int(n_points)
+        self.loss_cfg = (loss_type, float(weight_sdf), float(weight_fs), float(trunc_dist))
+        dev = self.features[0].device
+        if not ops.sdf_fused_supported(self.features, meta, pack):
+            raise RuntimeError("MappingStep needs a (grid, decoder) shape covered by the fused kernels")
+        f32 = dict(device=dev, dtype=torch.float32)
+        # static buffers (graph-safe): inputs are copied into these
+        self.x = torch.zeros((self.n, 3), **f32)
+        self.target = torch.zeros((self.n, 1), **f32)
+        self.valid = torch.ones((self.n, 1), **f32)
+        self.sign = torch.zeros((self.n, 1), **f32)
+        self.weight = torch.ones((self.n, 1), **f32)
+        self.sdf = torch.empty((self.n, 1), **f32)
+        self.gpred = torch.empty((self.n, 1), **f32)
+        self.loss = torch.zeros(2, **f32)
+        self.grads = [torch.zeros_like(f) for f in self.features]
+        self.adam = adam
+        if adam is not None:
+            self.exp_avg = [torch.zeros_like(f) for f in self.features]
+            self.exp_avg_sq = [torch.zeros_like(f) for f in self.features]
+            self.t = 0
+        self._graph = None
+        self._use_graph = use_graph and adam is None  # the Adam step count changes per call
+
+    def set_batch(self, x, target, valid=None, sign=None, weight=None):
+        self.x.copy_(x.reshape(self.n, 3))
+        self.target.copy_(target.reshape(self.n, 1))
+        for buf, src, fill in ((self.valid, valid, 1.0), (self.sign, sign, 0.0), (self.weight, weight, 1.0)):
+            if src is None:
+                buf.fill_(fill)
+            else:
+                buf.copy_(src.reshape(self.n, 1))
+
+    def _launch(self):
+        lt, ws, wf, td = self.loss_cfg
+        need_zero = self.adam is None or self.t == 0
+        if need_zero:
+            for g in self.grads:
+                g.zero_()
+        _, mask = ops.sdf_fwd_raw(self.x, self.features, self.meta, self.pack, True, out=self.sdf,
+                                  mask=getattr(self, "_mask", None))
+        self._mask = mask
+        ops.mapping_loss_raw(self.sdf, self.target, self.valid, self.sign, self.weight, lt, ws, wf, td,
+                             self.gpred, self.loss)
+        ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
+                        [True] * len(self.features), self.grads)
+        if self.adam is not None:
+            self.t += 1
+            for p, g, m, v in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq):
+                # zero_grad=True: the gradient is cleared in the same pass, so the next
+                # iteration needs no memset
+                ops.adam_dense_(p.data, g, m, v, self.t, zero_grad=True, **self.adam)
+
+    def run(self):
+        """Launch one iteration on the current stream (asynchronous)."""
+        if not self._use_graph:
+            self._launch()
+            return
+        if self._graph is None:
+            self._launch()                      # warm-up (allocates the mask buffer)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._launch()
+        self._graph.replay()

@@ -51,7 +51,7 @@ def model_cfg(bound, base_cell, scale, n_levels, fdim, hidden, hidden_layers=1,
 CASES = {
     # small, non-cubic, two levels -- everything stored
     "small": dict(bound=[[-1.0, 1.3], [-0.7, 0.9], [0.0, 2.1]], base_cell=0.4, scale=2,
-                  n_levels=2, fdim=4, hidden=16, n_points=512, seed=11),
+                  n_levels=2, fdim=4, hidden=32, n_points=512, seed=11),
     # BASELINE cfg-1: 1 level 64^3, C=4, MLP 4-32-32-1, 4096 pts
     "cfg1": dict(bound=[[-1.0, 1.0]] * 3, base_cell=2.0 / 64, scale=2, n_levels=1,
                  fdim=4, hidden=32, n_points=4096, seed=1),

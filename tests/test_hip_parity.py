@@ -244,8 +244,9 @@ def test_full_size_properties_cfg2():
     A, B = mk(), mk()
     ones = [torch.ones_like(a) for a in A]
     e1 = ops.encode(x, ones, meta)
-    half = 1.0 / 256  # points at least half a finest cell inside the bound see all 8 corners
-    inner = (x.abs() < 1 - 2 * half).all(dim=1)
+    # points at least half a COARSEST cell (1/32 in normalised units) inside the bound see
+    # all 8 corners at every level
+    inner = (x.abs() < 1 - 1.0 / 32 - 1e-4).all(dim=1)
     assert (e1[inner] - 1).abs().max().item() < 2e-6
     ea, eb = ops.encode(x, A, meta), ops.encode(x, B, meta)
     comb = ops.encode(x, [2.5 * a - 0.75 * b for a, b in zip(A, B)], meta)
