@@ -129,6 +129,31 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
                  const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
                  float* grad_x, void* stream);
 
+/* --- spatially binned batches ----------------------------------------------
+ * Counting sort of a point batch by coarse tile (tiles_per_axis^3 tiles over the
+ * bound).  No reference counterpart: the reference gathers every level with
+ * independent random accesses (grid_modules.py:86-94); binning is what lets the
+ * backward pre-reduce coarse-level gradients on chip.  Results of the *_sorted
+ * calls are identical to the unsorted ones up to fp32 summation order; sdf,
+ * grad_sdf and grad_x stay in the caller's (original) point order. */
+typedef struct {
+  int32_t tiles_per_axis;      /* 1..16 */
+  const float* x_sorted;       /* (N,3) points grouped by tile                   */
+  const int32_t* perm;         /* (N) sorted position -> original index          */
+  const int32_t* tile_offsets; /* (tiles^3 + 1) start of every tile in x_sorted  */
+} miso_sorted_t;
+
+int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis);
+int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,
+                     void* workspace, float* x_sorted, int32_t* perm, int32_t* tile_offsets,
+                     void* stream);
+int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                        const miso_sorted_t* sorted, int64_t n, float* sdf, uint32_t* relu_mask,
+                        void* stream);
+int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                        const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,
+                        const uint32_t* relu_mask, float* grad_x, void* stream);
+
 /* --- mapping loss (value + d/d pred) --------------------------------------
  * loss_type 1 = L1, 2 = L2.  pred/target (N); valid/sign/weight (N) or NULL
  * (= all valid / no free-space rows / unit weights).  Writes grad_pred (N) =

@@ -44,6 +44,11 @@ class Mlp(C.Structure):
                 ("weight", C.c_void_p * MAX_LINEAR), ("bias", C.c_void_p * MAX_LINEAR)]
 
 
+class Sorted(C.Structure):
+    _fields_ = [("tiles_per_axis", C.c_int32), ("x_sorted", C.c_void_p), ("perm", C.c_void_p),
+                ("tile_offsets", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/miso_hip.h declares
 SIGNATURES = {
     "miso_version": (C.c_char_p, []),
@@ -63,6 +68,13 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_sdf_bwd": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_sort_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "miso_sort_points": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_sdf_fwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted),
+                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_sdf_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted),
+                                      C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_mapping_loss": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),

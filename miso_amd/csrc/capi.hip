@@ -12,9 +12,12 @@ hipError_t launch_encode_bwd2(const GridK&, const float*, int64_t, const float*,
                               float*, int64_t, float*, hipStream_t);
 bool fused_shape_supported(int C, int L, int H, int NH);
 hipError_t launch_sdf_fwd(int, int, int, int, const GridK&, const float*, const float*, int64_t, float*,
-                          uint32_t*, hipStream_t);
+                          uint32_t*, const int*, hipStream_t);
 hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const float*, int64_t,
-                          const float*, const uint32_t*, float*, bool, hipStream_t);
+                          const float*, const uint32_t*, float*, bool, const int*, const int*, int,
+                          hipStream_t);
+int64_t sort_workspace_bytes(int64_t n, int T);
+hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, int*, int*, hipStream_t);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
 int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
@@ -169,8 +172,9 @@ int miso_sdf_supported(const miso_grid_t* grid, const miso_mlp_t* mlp) {
   return fused_shape(g, v4, mlp, &C, &L, &H, &NH) == MISO_OK ? 1 : 0;
 }
 
-int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
-                 int64_t n, float* sdf, uint32_t* relu_mask, void* stream) {
+static int sdf_fwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                        const float* x, int64_t n, float* sdf, uint32_t* relu_mask, const int* perm,
+                        void* stream) {
   if (n < 0 || !packed || (n > 0 && (!x || !sdf))) return MISO_E_BADARG;
   if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
   GridK g; bool v4;
@@ -179,12 +183,12 @@ int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
   int C, L, H, NH;
   rc = fused_shape(g, v4, mlp, &C, &L, &H, &NH);
   if (rc) return rc;
-  return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, (hipStream_t)stream);
+  return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, perm, (hipStream_t)stream);
 }
 
-int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
-                 int64_t n, const float* grad_sdf, const uint32_t* relu_mask, float* grad_x,
-                 void* stream) {
+static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                        const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
+                        float* grad_x, const int* perm, const int* tile_off, int T, void* stream) {
   if (n < 0 || !packed || (n > 0 && (!x || !grad_sdf || !relu_mask))) return MISO_E_BADARG;
   if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
   GridK g; bool v4;
@@ -196,8 +200,59 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
   bool want_grid = false;
   for (int l = 0; l < g.n_levels; ++l) want_grid = want_grid || (g.lv[l].grad != nullptr);
   if (!want_grid && !grad_x) return MISO_OK;
-  return (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid,
-                             (hipStream_t)stream);
+  return (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
+                             tile_off, T, (hipStream_t)stream);
+}
+
+int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
+                 int64_t n, float* sdf, uint32_t* relu_mask, void* stream) {
+  return sdf_fwd_impl(grid, mlp, packed, x, n, sdf, relu_mask, nullptr, stream);
+}
+
+int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
+                 int64_t n, const float* grad_sdf, const uint32_t* relu_mask, float* grad_x,
+                 void* stream) {
+  return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, 0, stream);
+}
+
+static int check_sorted(const miso_sorted_t* s) {
+  if (!s || !s->x_sorted || !s->perm || !s->tile_offsets) return MISO_E_BADARG;
+  if (s->tiles_per_axis < 1 || s->tiles_per_axis > 16) return MISO_E_BADARG;
+  return MISO_OK;
+}
+
+int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis) {
+  if (n < 0 || tiles_per_axis < 1 || tiles_per_axis > 16) return 0;
+  return sort_workspace_bytes(n, tiles_per_axis);
+}
+
+int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,
+                     void* workspace, float* x_sorted, int32_t* perm, int32_t* tile_offsets,
+                     void* stream) {
+  if (n < 0 || n >= ((int64_t)1 << 31) || tiles_per_axis < 1 || tiles_per_axis > 16) return MISO_E_BADARG;
+  if (!workspace || !tile_offsets || (n > 0 && (!x || !x_sorted || !perm))) return MISO_E_BADARG;
+  GridK g;
+  int rc = convert_grid(grid, &g, false, nullptr);
+  if (rc) return rc;
+  return (int)launch_sort(g, x, n, tiles_per_axis, workspace, x_sorted, perm, tile_offsets,
+                          (hipStream_t)stream);
+}
+
+int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                        const miso_sorted_t* sorted, int64_t n, float* sdf, uint32_t* relu_mask,
+                        void* stream) {
+  int rc = check_sorted(sorted);
+  if (rc) return rc;
+  return sdf_fwd_impl(grid, mlp, packed, sorted->x_sorted, n, sdf, relu_mask, sorted->perm, stream);
+}
+
+int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                        const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,
+                        const uint32_t* relu_mask, float* grad_x, void* stream) {
+  int rc = check_sorted(sorted);
+  if (rc) return rc;
+  return sdf_bwd_impl(grid, mlp, packed, sorted->x_sorted, n, grad_sdf, relu_mask, grad_x, sorted->perm,
+                      sorted->tile_offsets, sorted->tiles_per_axis, stream);
 }
 
 int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,

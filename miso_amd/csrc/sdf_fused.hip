@@ -19,6 +19,8 @@
 // layer; only the A operands (weights, pre-permuted by mlp_pack_kernel) come
 // from LDS.  The first layer's B operand is built from the lane-per-point
 // features with one v_permlane32_swap per k-pair.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace miso {
@@ -26,6 +28,33 @@ namespace miso {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int row_of(int j, int hi) { return (j & 3) + 8 * (j >> 2) + 4 * hi; }
+
+// Chunk schedule of the persistent waves.  Plain batches: chunk = global wave id,
+// grid-strided.  Tile-sorted batches (perm != nullptr): the chunk range is cut into 8
+// contiguous parts, one per XCD (blocks are dispatched round-robin over the XCDs,
+// block b -> XCD b % 8; a different placement only costs speed).  Spatially
+// neighbouring points then stay on one XCD, so its L2 keeps ownership of the grid
+// lines they gather from and scatter into: on MI355X an fp32 atomic that misses L2
+// costs ~50 ns of request slot (21 G requests/s chip-wide, tools/ubench/atomics.hip),
+// and a line bouncing between XCD L2s is the worst case.
+struct ChunkSched {
+  int64_t cur, end, step;
+  __device__ __forceinline__ ChunkSched(int64_t nchunks, int wave, int nw, bool xcd_local) {
+    if (xcd_local && gridDim.x >= 8) {
+      const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+      const int nlb = (gridDim.x - xcd + 7) >> 3;  // blocks that share this residue
+      const int64_t per = (nchunks + 7) / 8;
+      const int64_t lo = per * xcd;
+      end = lo + per < nchunks ? lo + per : nchunks;
+      cur = lo + (int64_t)lb * nw + wave;
+      step = (int64_t)nlb * nw;
+    } else {
+      cur = (int64_t)blockIdx.x * nw + wave;
+      end = nchunks;
+      step = (int64_t)gridDim.x * nw;
+    }
+  }
+};
 
 // ---------------------------------------------------------------------------
 // Packed decoder layout (floats).  RT = H/32 row tiles, KS0 = ceil(F/2),
@@ -125,7 +154,10 @@ template <int C, int L, int H, int NH>
 __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
                                                         const float* __restrict__ x, int64_t n,
                                                         float* __restrict__ sdf,
-                                                        uint32_t* __restrict__ mask) {
+                                                        uint32_t* __restrict__ mask,
+                                                        const int* __restrict__ perm) {
+  // perm != nullptr: x is the tile-sorted copy of the batch (sort.hip) and the
+  // result is written back in the caller's order, sdf[perm[p]].
   constexpr int F = C * L, RT = H / 32, KS0 = (F + 1) / 2, KS1 = H / 2;
   constexpr int MW = (NH + 1) * RT;  // mask words per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -142,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
   const float* wo = smem + pl.o_wo;
   const float bo = smem[pl.o_bo];
 
-  for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+  ChunkSched sched(nchunks, wave, 4, perm != nullptr);
+  for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     // keep the (chunk-invariant) LDS reads of biases / weights inside the loop:
     // hoisted, they cost ~100 VGPRs and spill
     asm volatile("" ::: "memory");
@@ -249,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
       }
     p0 += __shfl_xor(p0, 32);
     p1 += __shfl_xor(p1, 32);
-    if (valid) sdf[p] = (hi ? p1 : p0) + bo;
+    if (valid) sdf[perm ? (int64_t)perm[p] : p] = (hi ? p1 : p0) + bo;
     if (mask) {
       uint32_t* mo = mask + (chunk * 64 + lane) * MW;
 #pragma unroll
@@ -269,7 +302,10 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
                                                         const float* __restrict__ x, int64_t n,
                                                         const float* __restrict__ gsdf,
                                                         const uint32_t* __restrict__ mask,
-                                                        float* __restrict__ gx) {
+                                                        float* __restrict__ gx,
+                                                        const int* __restrict__ perm, int debug) {
+  // perm != nullptr: x and mask are in tile-sorted order, gsdf / gx in the caller's.
+  // debug: ablation switches (MISO_DEBUG_BWD, dev only): 1 = no atomics, 8 = no scatter.
   constexpr int F = C * L, RT = H / 32, KS1 = H / 2;
   constexpr int MW = (NH + 1) * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -290,12 +326,13 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
   float* wave_lds = smem + ((nb + H + 3) / 4) * 4 + wave * WAVE_LDS;
   const int64_t nchunks = (n + 63) / 64;
 
-  for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (int64_t)gridDim.x * 4) {
+  ChunkSched sched(nchunks, wave, 4, perm != nullptr);
+  for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     asm volatile("" ::: "memory");  // see sdf_fwd_kernel
     const int64_t pt[2] = {chunk * 64 + (lane & 31), chunk * 64 + 32 + (lane & 31)};
     float ds[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) ds[t] = (pt[t] < n) ? gsdf[pt[t]] : 0.0f;
+    for (int t = 0; t < 2; ++t) ds[t] = (pt[t] < n) ? gsdf[perm ? (int64_t)perm[pt[t]] : pt[t]] : 0.0f;
     uint32_t mw[MW];
     {
       const uint32_t* mi = mask + (chunk * 64 + lane) * MW;
@@ -362,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
     // atomic instruction serves 64/(2C) (point, row) pairs.  d feats move from the
     // accumulator layout to that lane order through a per-wave LDS tile; the cell
     // of every (point, level) is computed once (lane = point) and broadcast from LDS.
-    if (WANT_GRID) {
+    if (WANT_GRID && !(debug & 8)) {
       float* dF = wave_lds;                         // [64][FP]
       int* rec = reinterpret_cast<int*>(wave_lds + 64 * FP);   // [64][L][REC]
 #pragma unroll
@@ -421,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int dy = q & 1, dz = q >> 1;
-            if (((fl >> (2 + dy)) & 1) && ((fl >> (4 + dz)) & 1))
+            if (((fl >> (2 + dy)) & 1) && ((fl >> (4 + dz)) & 1) && !(debug & 1))
               atomic_add_f32(base + dy * lv.sY + dz * lv.sZ, v * ((wx * wy[dy]) * wz[dz]));
           }
         }
@@ -478,9 +515,10 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
         for (int a = 0; a < 3; ++a) gacc[t][a] += __shfl_xor(gacc[t][a], 32);
       const int64_t p = chunk * 64 + lane;
       if (p < n) {
-        gx[p * 3 + 0] = hi ? gacc[1][0] : gacc[0][0];
-        gx[p * 3 + 1] = hi ? gacc[1][1] : gacc[0][1];
-        gx[p * 3 + 2] = hi ? gacc[1][2] : gacc[0][2];
+        const int64_t po = perm ? (int64_t)perm[p] : p;
+        gx[po * 3 + 0] = hi ? gacc[1][0] : gacc[0][0];
+        gx[po * 3 + 1] = hi ? gacc[1][1] : gacc[0][1];
+        gx[po * 3 + 2] = hi ? gacc[1][2] : gacc[0][2];
       }
     }
   }
@@ -489,44 +527,45 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
-struct FusedKey { int C, L, H, NH; };
+static hipError_t allow_lds(const void* k, size_t lds) {
+  if (lds <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 
 template <int C, int L, int H, int NH>
 static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
-                               float* sdf, uint32_t* mask, hipStream_t s) {
+                               float* sdf, uint32_t* mask, const int* perm, hipStream_t s) {
   PackLayout pl(C * L, H, NH);
   size_t lds = (size_t)((pl.fwd_end + 3) / 4 * 4) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   if (blocks > 512u) blocks = 512u;
   auto k = sdf_fwd_kernel<C, L, H, NH>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, mask);
+  hipError_t e = allow_lds((const void*)k, lds);
+  if (e != hipSuccess) return e;
+  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, mask, perm);
   return hipGetLastError();
 }
 
 template <int C, int L, int H, int NH>
 static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
                                const float* gsdf, const uint32_t* mask, float* gx, bool want_grid,
-                               hipStream_t s) {
+                               const int* perm, hipStream_t s) {
   PackLayout pl(C * L, H, NH);
   constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4, WAVE_LDS = 64 * FP + 64 * L * 8;
   size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * WAVE_LDS : 0)) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   if (blocks > 512u) blocks = 512u;
-  void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*) =
+  int debug = 0;
+  if (const char* d = getenv("MISO_DEBUG_BWD")) debug = atoi(d);
+  void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*, const int*, int) =
       (want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true>
       : want_grid       ? sdf_bwd_kernel<C, L, H, NH, true, false>
                         : sdf_bwd_kernel<C, L, H, NH, false, true>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  k<<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx);
+  hipError_t e = allow_lds((const void*)k, lds);
+  if (e != hipSuccess) return e;
+  k<<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx, perm, debug);
   return hipGetLastError();
 }
 
@@ -542,10 +581,12 @@ bool fused_shape_supported(int C, int L, int H, int NH) {
 }
 
 hipError_t launch_sdf_fwd(int C, int L, int H, int NH, const GridK& g, const float* packed,
-                          const float* x, int64_t n, float* sdf, uint32_t* mask, hipStream_t s) {
+                          const float* x, int64_t n, float* sdf, uint32_t* mask, const int* perm,
+                          hipStream_t s) {
   if (n == 0) return hipSuccess;
 #define X(c, l, h, nh) \
-  if (C == c && L == l && H == h && NH == nh) return launch_fwd_t<c, l, h, nh>(g, packed, x, n, sdf, mask, s);
+  if (C == c && L == l && H == h && NH == nh) \
+    return launch_fwd_t<c, l, h, nh>(g, packed, x, n, sdf, mask, perm, s);
   MISO_FUSED_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;
@@ -553,11 +594,13 @@ hipError_t launch_sdf_fwd(int C, int L, int H, int NH, const GridK& g, const flo
 
 hipError_t launch_sdf_bwd(int C, int L, int H, int NH, const GridK& g, const float* packed,
                           const float* x, int64_t n, const float* gsdf, const uint32_t* mask,
-                          float* gx, bool want_grid, hipStream_t s) {
+                          float* gx, bool want_grid, const int* perm, const int* tile_off, int T,
+                          hipStream_t s) {
+  (void)tile_off; (void)T;
   if (n == 0) return hipSuccess;
 #define X(c, l, h, nh) \
   if (C == c && L == l && H == h && NH == nh) \
-    return launch_bwd_t<c, l, h, nh>(g, packed, x, n, gsdf, mask, gx, want_grid, s);
+    return launch_bwd_t<c, l, h, nh>(g, packed, x, n, gsdf, mask, gx, want_grid, perm, s);
   MISO_FUSED_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;

@@ -19,7 +19,8 @@ from . import ops
 class MappingStep:
     def __init__(self, features: Sequence[torch.Tensor], meta: ops.GridMeta, pack: ops.DecoderPack,
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
-                 trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True):
+                 trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
+                 sort: bool = False):
         self.features = list(features)
         self.meta, self.pack = meta, pack
         self.n = int(n_points)
@@ -43,6 +44,7 @@ class MappingStep:
             self.exp_avg = [torch.zeros_like(f) for f in self.features]
             self.exp_avg_sq = [torch.zeros_like(f) for f in self.features]
             self.t = 0
+        self.sorted = ops.SortedBatch(self.n, dev) if sort else None
         self._graph = None
         self._use_graph = use_graph and adam is None  # the Adam step count changes per call
 
@@ -61,13 +63,15 @@ class MappingStep:
         if need_zero:
             for g in self.grads:
                 g.zero_()
+        if self.sorted is not None:
+            self.sorted.sort(self.x, self.meta)   # part of the step: a new batch arrives every iteration
         _, mask = ops.sdf_fwd_raw(self.x, self.features, self.meta, self.pack, True, out=self.sdf,
-                                  mask=getattr(self, "_mask", None))
+                                  mask=getattr(self, "_mask", None), sorted_batch=self.sorted)
         self._mask = mask
         ops.mapping_loss_raw(self.sdf, self.target, self.valid, self.sign, self.weight, lt, ws, wf, td,
                              self.gpred, self.loss)
         ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
-                        [True] * len(self.features), self.grads)
+                        [True] * len(self.features), self.grads, sorted_batch=self.sorted)
         if self.adam is not None:
             self.t += 1
             for p, g, m, v in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq):

@@ -301,3 +301,122 @@ def test_native_library_is_loaded():
     assert _lib._lib is not None
     maps = open("/proc/self/maps").read()
     assert "libmiso_hip.so" in maps
+
+
+# --------------------------------------------------------------------------- #
+# spatially binned (sorted) path
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n", [1, 777, 40000])
+def test_sort_points_is_a_tile_grouped_permutation(n):
+    from miso_amd import ops
+    bound = [[-1.0, 1.3], [-0.7, 0.9], [0.0, 2.1]]
+    meta = ops.GridMeta.from_bound(bound)
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, 3, generator=g) * torch.tensor([2.5, 1.8, 2.3]) + torch.tensor([-1.1, -0.8, -0.1])
+    x[0] = float("nan")
+    sb = ops.SortedBatch(n, DEV).sort(x.to(DEV), meta)
+    perm = sb.perm.cpu().long()
+    assert sorted(perm.tolist()) == list(range(n))
+    xs = sb.x_sorted.cpu()
+    assert torch.equal(torch.nan_to_num(xs, nan=7.0), torch.nan_to_num(x[perm], nan=7.0))
+    off = sb.tile_offsets.cpu().long()
+    assert off[0] == 0 and off[-1] == n and torch.all(off[1:] >= off[:-1])
+    b = torch.tensor(bound)
+    u = torch.nan_to_num((xs - b[:, 0]) / (b[:, 1] - b[:, 0]), nan=0.0)
+    t = torch.clamp(torch.floor(u * 16), 0, 15).long()
+    tid = (t[:, 2] * 16 + t[:, 1]) * 16 + t[:, 0]
+    expect = torch.repeat_interleave(torch.arange(4096), off[1:] - off[:-1])
+    assert torch.equal(tid, expect)
+
+
+@pytest.mark.parametrize("name,n", [("small", 5000), ("cfg2", 50000)])
+def test_sorted_path_matches_unsorted(name, n):
+    """Binned forward/backward (LDS pre-reduction per tile) == plain path up to fp32
+    summation order, including points outside the bound and ragged tile sizes."""
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x0, meta, fd, pack = setup_case(name)
+    g = torch.Generator().manual_seed(5)
+    b = torch.tensor(case["bound"])
+    x = torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) * 1.1 + b[:, 0] - 0.05 * (b[:, 1] - b[:, 0])
+    x[: n // 3] = x[: n // 3] * 0.05 + b.mean(dim=1)      # a dense cluster: very uneven tiles
+    x = x.to(DEV)
+    gs = torch.randn(n, 1, generator=g).to(DEV)
+    L = len(fd)
+    sdf_a, mask_a = ops.sdf_fwd_raw(x, fd, meta, pack, True)
+    gx_a, gr_a = ops.sdf_bwd_raw(x, fd, meta, pack, gs, mask_a, True, [True] * L)
+    sb = ops.SortedBatch(n, DEV).sort(x, meta)
+    sdf_b, mask_b = ops.sdf_fwd_raw(x, fd, meta, pack, True, sorted_batch=sb)
+    gx_b, gr_b = ops.sdf_bwd_raw(x, fd, meta, pack, gs, mask_b, True, [True] * L, sorted_batch=sb)
+    assert torch.equal(sdf_a, sdf_b) or (sdf_a - sdf_b).abs().max().item() < 1e-7
+    assert relerr(gx_b, gx_a) < 1e-5
+    for a, b_ in zip(gr_a, gr_b):
+        assert relerr(b_, a) < 2e-5
+    # grid-only variant (the mapping step) through autograd, which bins automatically
+    if n >= 40000:
+        old = ops.SortedBatch.AUTO_MIN_POINTS
+        ops.SortedBatch.AUTO_MIN_POINTS = 1
+        try:
+            out = ops.sdf_fused(x, fd, meta, pack)
+            gg = torch.autograd.grad(out, fd, gs)
+        finally:
+            ops.SortedBatch.AUTO_MIN_POINTS = old
+        for a, b_ in zip(gr_a, gg):
+            assert relerr(b_, a) < 2e-5
+
+
+def test_mapping_loss_kernel_vs_oracle():
+    from miso_amd import ops
+    case = gc.CASES["small"]
+    n = 5001
+    sdf_t, valid, sign, weight = [T(a) for a in gc.make_targets(case, n)]
+    torch.manual_seed(0)
+    pred = (torch.randn(n, 1) * 0.2)
+    for lt in ("L1", "L2"):
+        pc = pred.clone().requires_grad_(True)
+        ref = 1.3 * R.miso_loss_regression(pc, sdf_t, valid, weight, lt) + \
+            0.1 * R.miso_loss_free_space(pc, sdf_t, sign, 0.15)
+        ref.backward()
+        pd = pred.to(DEV).requires_grad_(True)
+        out = ops.mapping_loss(pd, sdf_t.to(DEV), valid.to(DEV), sign.to(DEV), weight.to(DEV), lt, 1.3, 0.1, 0.15)
+        out.sum().backward()
+        assert abs(out.sum().item() - ref.item()) < 1e-6
+        torch.testing.assert_close(pd.grad.cpu(), pc.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_mapping_step_matches_autograd_and_adam():
+    """MappingStep (captured launch sequence) == autograd through the same ops, and with
+    Adam == torch.optim.Adam on the CPU oracle after 3 iterations."""
+    from miso_amd import ops
+    from miso_amd.step import MappingStep
+    case, feats, bound, ws, bs, x0, meta, fd, pack = setup_case("small")
+    n = 40000
+    g = torch.Generator().manual_seed(9)
+    b = torch.tensor(case["bound"])
+    x = torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) + b[:, 0]
+    sdf_t, valid, sign, weight = [T(a) for a in gc.make_targets(case, n)]
+    params = [f.detach().clone() for f in fd]
+    step = MappingStep(params, meta, pack, n, "L1", 1.0, 0.1, 0.15, adam=dict(lr=1e-3), use_graph=False)
+    step.set_batch(x.to(DEV), sdf_t.to(DEV), valid.to(DEV), sign.to(DEV), weight.to(DEV))
+    fc = [torch.nn.Parameter(f.clone()) for f in feats]
+    opt = torch.optim.Adam(fc, lr=1e-3)
+    for it in range(3):
+        step.run()
+        opt.zero_grad()
+        pred = R.sdf_stock(fc, bound, x, ws, bs)
+        loss = R.miso_loss_regression(pred, sdf_t, valid, weight, "L1") + \
+            0.1 * R.miso_loss_free_space(pred, sdf_t, sign, 0.15)
+        loss.backward()
+        opt.step()
+        assert abs(step.loss.sum().item() - loss.item()) < 1e-6
+    for a, b_ in zip(step.features, fc):
+        assert (a.cpu() - b_.detach()).abs().max().item() < 2e-6
+    # graph-captured variant without Adam gives the same gradients as eager
+    s2 = MappingStep([f.detach() for f in fd], meta, pack, n, "L1", 1.0, 0.1, 0.15, use_graph=True, sort=True)
+    s2.set_batch(x.to(DEV), sdf_t.to(DEV), valid.to(DEV), sign.to(DEV), weight.to(DEV))
+    s2.run(); s2.run()
+    torch.cuda.synchronize()
+    out = ops.sdf_fused(x.to(DEV), fd, meta, pack)
+    l = ops.mapping_loss(out, sdf_t.to(DEV), valid.to(DEV), sign.to(DEV), weight.to(DEV), "L1", 1.0, 0.1, 0.15).sum()
+    gg = torch.autograd.grad(l, fd)
+    for a, b_ in zip(s2.grads, gg):
+        assert relerr(a, b_) < 2e-5
