@@ -157,12 +157,13 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
 /* --- mapping loss (value + d/d pred) --------------------------------------
  * loss_type 1 = L1, 2 = L2.  pred/target (N); valid/sign/weight (N) or NULL
  * (= all valid / no free-space rows / unit weights).  Writes grad_pred (N) =
- * d(weight_sdf*sdf_term + weight_fs*fs_term)/d pred and loss_out[2] =
+ * d(weight_sdf*sdf_term + weight_fs*fs_term)/d pred, optionally grad_pred_fs (N)
+ * = the free-space share of it (NULL to skip), and loss_out[2] =
  * {weight_sdf*sdf_term, weight_fs*fs_term} (means over all N rows). */
 int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,
                       const float* pred, const float* target, const float* valid,
                       const float* sign, const float* weight, int64_t n, float* grad_pred,
-                      float* loss_out, void* stream);
+                      float* grad_pred_fs, float* loss_out, void* stream);
 
 /* --- dense Adam (torch.optim.Adam defaults: amsgrad=False, weight_decay=0) -
  * One launch over one dense tensor; param/grad/exp_avg/exp_avg_sq share a

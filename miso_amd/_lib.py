@@ -77,7 +77,7 @@ SIGNATURES = {
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_mapping_loss": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                                    C.c_void_p]),
+                                    C.c_void_p, C.c_void_p]),
     "miso_adam_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int,
                                   C.c_void_p]),

@@ -23,7 +23,7 @@ int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
                        hipStream_t);
 hipError_t launch_mapping_loss(int, float, float, float, const float*, const float*, const float*,
-                               const float*, const float*, int64_t, float*, float*, hipStream_t);
+                               const float*, const float*, int64_t, float*, float*, float*, hipStream_t);
 }  // namespace miso
 
 using namespace miso;
@@ -257,11 +257,12 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
 
 int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,
                       const float* pred, const float* target, const float* valid, const float* sign,
-                      const float* weight, int64_t n, float* grad_pred, float* loss_out, void* stream) {
+                      const float* weight, int64_t n, float* grad_pred, float* grad_pred_fs,
+                      float* loss_out, void* stream) {
   if (n < 0 || (loss_type != 1 && loss_type != 2) || !loss_out) return MISO_E_BADARG;
   if (n > 0 && (!pred || !target || !grad_pred)) return MISO_E_BADARG;
   return (int)launch_mapping_loss(loss_type, weight_sdf, weight_fs, trunc_dist, pred, target, valid,
-                                  sign, weight, n, grad_pred, loss_out, (hipStream_t)stream);
+                                  sign, weight, n, grad_pred, grad_pred_fs, loss_out, (hipStream_t)stream);
 }
 
 int miso_adam_dense(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t numel,

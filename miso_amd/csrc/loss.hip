@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const flo
                                                           const float* __restrict__ sign,
                                                           const float* __restrict__ weight, int64_t n,
                                                           float* __restrict__ gpred,
+                                                          float* __restrict__ gpred_fs,
                                                           float* __restrict__ loss_out) {
   const float inv_n = 1.0f / (float)n;
   float s_sdf = 0.f, s_fs = 0.f;
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const flo
     const float s = pred[i], t = targ[i];
     const float w = weight ? weight[i] : 1.0f;
     const bool v = valid ? (valid[i] == 1.0f) : true;
-    float g = 0.f;
+    float g = 0.f, gf = 0.f;
     const float d = s - t;
     if (v) {
       if (p.loss_type == 1) {
@@ -43,10 +44,11 @@ __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const flo
       const float up = fmaxf(d, 0.f), lo = fmaxf(p.trunc - s, 0.f);
       s_fs += fmaxf(up, lo);
       // d/ds max(relu(s-t), relu(trunc-s)); ties carry zero slope on both sides
-      if (up > lo) g += p.w_fs;
-      else if (lo > up) g -= p.w_fs;
+      if (up > lo) gf = p.w_fs;
+      else if (lo > up) gf = -p.w_fs;
     }
-    gpred[i] = g * inv_n;
+    gpred[i] = (g + gf) * inv_n;
+    if (gpred_fs) gpred_fs[i] = gf * inv_n;  // free-space share, for callers weighting the terms apart
   }
   // wave reduction -> block reduction in LDS -> one atomic pair per block (same-address
   // atomics serialise at ~13 ns each: 8192 of them cost 106 us, 128 cost nothing)
@@ -65,14 +67,14 @@ __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const flo
 
 hipError_t launch_mapping_loss(int loss_type, float w_sdf, float w_fs, float trunc, const float* pred,
                                const float* targ, const float* valid, const float* sign,
-                               const float* weight, int64_t n, float* gpred, float* loss_out,
-                               hipStream_t s) {
+                               const float* weight, int64_t n, float* gpred, float* gpred_fs,
+                               float* loss_out, hipStream_t s) {
   hipError_t e = hipMemsetAsync(loss_out, 0, 2 * sizeof(float), s);
   if (e != hipSuccess || n == 0) return e;
   MapLossK p{loss_type, w_sdf, w_fs, trunc};
   unsigned blocks = (unsigned)((n + 1023) / 1024);
   if (blocks > 256u) blocks = 256u;
-  mapping_loss_kernel<<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, loss_out);
+  mapping_loss_kernel<<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, gpred_fs, loss_out);
   return hipGetLastError();
 }
 

@@ -1,0 +1,120 @@
+"""Pose-only Adam loops over submap pairs (reference: grid_opt/align/base.py)."""
+import logging
+
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+import miso_amd.grid_opt.utils.utils as utils
+import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
+from miso_amd.grid_opt.models.grid_atlas import GridAtlas
+from miso_amd.optim import DenseAdam
+
+logger = logging.getLogger(__name__)
+
+
+def grid_atlas_pose_l2_loss(model: GridAtlas, weight=1e3):
+    out = {}
+    for s in range(model.num_submaps):
+        out[f'submap{s}_l2_reg_R'] = weight * torch.sum(model.rotation_corrections[s] ** 2)
+        out[f'submap{s}_l2_reg_t'] = weight * torch.sum(model.translation_corrections[s] ** 2)
+    return out
+
+
+def grid_atlas_pose_trust_region_loss(model: GridAtlas, thresh_rad, thresh_m, weight=1e3):
+    relu = torch.nn.functional.relu
+    out = {}
+    for s in range(model.num_submaps):
+        out[f'submap{s}_trust_region_R'] = weight * relu(torch.linalg.norm(model.rotation_corrections[s]) - thresh_rad)
+        out[f'submap{s}_trust_region_t'] = weight * relu(torch.linalg.norm(model.translation_corrections[s]) - thresh_m)
+    return out
+
+
+def iteration_results_helper(model: GridAtlas):
+    """(S,4,4) snapshot of the current submap poses."""
+    assert isinstance(model, GridAtlas), "Model must be an instance of GridAtlas."
+    poses = torch.zeros((model.num_submaps, 4, 4), dtype=torch.float32, device=model.device)
+    for s in range(model.num_submaps):
+        poses[s] = utils_geometry.pose_matrix(*model.updated_submap_pose(s))
+    return poses.detach()
+
+
+def _adam_step(optimizer, loss_dict, what):
+    total = sum(loss_dict.values())
+    if not torch.isnan(total):
+        total.backward(retain_graph=False)
+        optimizer.step()
+    else:
+        logger.warning(f"Loss at {what} is nan! Skip backward step.")
+    return total
+
+
+def generic_align_submap_pair(grid_atlas: GridAtlas, dataset: Dataset, src_id: int, dst_id: int,
+                              pairwise_loss_tuple, num_iters=10, lr=1e-2, rel_change_thresh=0, verbose=True):
+    """Align dst to src by optimising dst's pose only (reference :41-87)."""
+    assert src_id < grid_atlas.num_submaps and dst_id < grid_atlas.num_submaps
+    grid_dst = grid_atlas.get_submap(dst_id)
+    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+    optimizer = DenseAdam([{'params': grid_atlas.params_for_submap_pose(dst_id), 'lr': lr}], lr=lr)
+    loss_name, loss_func = pairwise_loss_tuple
+    prev = None
+    timer = utils.PerfTimer(activate=True)
+    it = 0
+    while it <= num_iters:      # upstream runs num_iters + 1 iterations
+        optimizer.zero_grad()
+        total = _adam_step(optimizer, loss_func(grid_atlas, loader, src_id, dst_id), f"iter {it}")
+        cur = [p.clone().detach() for p in grid_dst.params_for_poses()]
+        change = utils.relative_param_change(cur, prev)
+        prev = cur
+        if verbose:
+            logger.info(f"AlignPair_{loss_name} iteration {it}: loss = {total.item():.2e}, pose_relchange={change:.2e}")
+        if change < rel_change_thresh:
+            break
+        it += 1
+    cpu_time, gpu_time = timer.check()
+    return {'cpu_time_sec': cpu_time, 'gpu_time_sec': gpu_time}
+
+
+def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pairwise_loss_tuple, num_iters=10,
+                                   lr=1e-2, rel_change_thresh=0, submap_pairs=None, check_intersection=True,
+                                   pose_reg_weight=0, pose_thresh_rad=1.0, pose_thresh_m=1.0, verbose=True,
+                                   save_iterations=False):
+    """Adam over the pose corrections of submaps 1..S-1 (submap 0 stays fixed) on the sum of
+    pairwise losses (reference :89-163)."""
+    def pose_params():
+        return [p for s in range(1, grid_atlas.num_submaps) for p in grid_atlas.params_for_submap_pose(s)]
+
+    optimizer = DenseAdam([{'params': pose_params(), 'lr': lr}], lr=lr)
+    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+    loss_name, loss_func = pairwise_loss_tuple
+    if submap_pairs is None:
+        n = grid_atlas.num_submaps
+        submap_pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
+    timer = utils.PerfTimer(activate=True)
+    iteration_results = dict()
+    prev = None
+    it = 0
+    while it <= num_iters:
+        if save_iterations:
+            iteration_results[it] = iteration_results_helper(grid_atlas)
+        optimizer.zero_grad()
+        loss_dict = {}
+        for src_id, dst_id in submap_pairs:
+            if check_intersection and not bool(grid_atlas.check_submap_intersection(src_id, dst_id)):
+                continue
+            pair = loss_func(grid_atlas, loader, src_id, dst_id)
+            loss_dict.update({k: torch.nan_to_num(v) for k, v in pair.items()})
+        if pose_reg_weight > 0:
+            loss_dict.update(grid_atlas_pose_trust_region_loss(grid_atlas, thresh_rad=pose_thresh_rad,
+                                                               thresh_m=pose_thresh_m, weight=pose_reg_weight))
+        total = _adam_step(optimizer, loss_dict, f"iter {it}")
+        cur = [p.clone().detach() for p in pose_params()]
+        change = utils.relative_param_change(cur, prev)
+        prev = cur
+        if verbose:
+            logger.info(f"AlignMulti_{loss_name} iteration {it}: loss = {float(total):.2e}, "
+                        f"pose_relchange={change:.2e}, lr={lr:.2e}")
+        if change < rel_change_thresh:
+            break
+        it += 1
+    cpu_time, gpu_time = timer.check()
+    return {'cpu_time_sec': cpu_time, 'gpu_time_sec': gpu_time, 'iteration_results': iteration_results}

@@ -1,0 +1,176 @@
+"""MISO's alignment losses and the hierarchical driver (reference: grid_opt/align/miso.py).
+
+pairwise_loss_latent keeps the reference's value and pose gradients but not its waste:
+grid features are read-only here (only submap poses are optimised), so they enter the
+lookup detached and the dense, unused grad scatter of both submaps never runs; and the
+L2 / L1 variants weight by the in-bound mask instead of compacting with nonzero, so an
+iteration has no host sync."""
+import logging
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import miso_amd.grid_opt.utils.utils as utils
+import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
+from miso_amd.grid_opt.align.base import *   # noqa: F401,F403
+from miso_amd.grid_opt.align.base import generic_align_multiple_submaps
+from miso_amd.grid_opt.models.grid_atlas import GridAtlas
+from miso_amd.grid_opt.utils.utils_geometry import transform_points_to
+
+logger = logging.getLogger(__name__)
+
+
+def _frozen_features(submap):
+    return [g.feature.detach() for g in submap.features]
+
+
+def _query_feature_readonly(submap, x):
+    from miso_amd import ops
+    meta = submap.features[0].grid_meta(submap.ignore_level_)
+    return ops.encode(x, _frozen_features(submap), meta)
+
+
+def pairwise_loss_latent(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id: int, level: int, fdim=4,
+                         align_weight=3000, align_loss='L2', use_bound=True, stability_thresh=0,
+                         covariance_thresh=None, subsample_points=None, trunc_factor=None, device="cuda:0"):
+    """Residual between src's features at its cached voxel centres and dst's features at the
+    same points mapped src -> world -> dst, over the channels of levels 0..level."""
+    key = f'align_latent_level{level}_{src_id}_{dst_id}'
+    assert src_id < grid_atlas.num_submaps and dst_id < grid_atlas.num_submaps
+    if covariance_thresh is not None:
+        raise NotImplementedError
+    end_ch = fdim * (level + 1)
+    sub_from, sub_to = grid_atlas.get_submap(src_id), grid_atlas.get_submap(dst_id)
+    R_from, t_from = grid_atlas.updated_submap_pose(src_id, device)
+    R_to, t_to = grid_atlas.updated_submap_pose(dst_id, device)
+    coords_from = grid_atlas.coordinates_for_alignment(submap_id=src_id, level=level)
+    if subsample_points is not None:
+        k = min(subsample_points, coords_from.shape[0])
+        coords_from = coords_from[np.random.choice(coords_from.shape[0], k, replace=False), :]
+    coords_world = utils_geometry.transform_points_to(coords_from, R_from, t_from)
+    coords_to = utils_geometry.transfrom_points_from(coords_world, R_to, t_to)
+    mask = torch.ones((coords_from.shape[0], 1), dtype=torch.bool, device=coords_from.device)
+    if use_bound:
+        mask = mask & utils_geometry.coords_in_bound(coords_to, sub_to.bound)
+    if stability_thresh > 0:
+        mu_to = sub_to.query_stability(coords_to)[:, [0]]
+        mu_from = sub_from.query_stability(coords_from)[:, [0]]
+        mask = mask & (mu_to > stability_thresh) & (mu_from > stability_thresh)
+    if trunc_factor is not None:
+        with torch.no_grad():
+            near = torch.abs(sub_from(coords_from)) < trunc_factor * sub_from.cell_sizes[level]
+        mask = mask & near
+    if align_loss in ('L2', 'L1'):
+        # sync-free: masked mean instead of nonzero-compaction (out-of-bound rows sample zeros)
+        w = mask.to(coords_from.dtype)
+        n_valid = w.sum().clamp(min=1.0)
+        diff = (_query_feature_readonly(sub_from, coords_from)[:, :end_ch]
+                - _query_feature_readonly(sub_to, coords_to)[:, :end_ch]) * w
+        if align_loss == 'L2':
+            val = diff.pow(2).sum() / (n_valid * end_ch)
+        else:
+            val = torch.linalg.vector_norm(diff, dim=1).sum() / n_valid
+        return {key: val * align_weight}
+    if torch.count_nonzero(mask) == 0:
+        return {key: torch.tensor(0)}
+    rows = torch.nonzero(mask, as_tuple=False)[:, 0]
+    out_from = _query_feature_readonly(sub_from, coords_from[rows])[:, :end_ch]
+    out_to = _query_feature_readonly(sub_to, coords_to[rows])[:, :end_ch]
+    if align_loss == 'cos':
+        val = torch.mean(1.0 - F.cosine_similarity(out_from, out_to, dim=1))
+    elif align_loss == 'InfoNCE':
+        val = utils.InfoNCE()(out_from, out_to)
+    else:
+        raise ValueError(f"Invalid align loss: {align_loss}!")
+    return {key: val * align_weight}
+
+
+def pairwise_loss_sdf(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id: int, align_weight=3000,
+                      align_loss='L2', use_bound=True, stability_thresh=0, covariance_thresh=None,
+                      subsample_points=None, gm_scale_sdf=0.1, device="cuda:0"):
+    """SDF-space variant on the observed samples of src's keyframes (reference :14-113)."""
+    from miso_amd.grid_opt.loss import transform_by_keyframe
+    assert src_id < grid_atlas.num_submaps and dst_id < grid_atlas.num_submaps
+    if covariance_thresh is not None:
+        raise NotImplementedError
+    model_input, gt = utils.get_batch(data_loader, device)
+    sub_from, sub_to = grid_atlas.get_submap(src_id), grid_atlas.get_submap(dst_id)
+    owner = grid_atlas.submap_id_for_kf_batch(kf_ids=model_input['sample_frame_ids'][0, :, 0])
+    rows = torch.nonzero(owner == src_id, as_tuple=False).squeeze(1)
+    if rows.numel() == 0:
+        return {}
+    coords_kf = model_input['coords_frame'][0, rows, :]
+    kf_idxs = model_input['sample_frame_ids'][0, rows, 0]
+    coords_from = transform_by_keyframe(coords_kf, kf_idxs,
+                                        lambda k: grid_atlas.updated_kf_pose_in_submap(k, src_id))
+    mask = gt['sdf_valid'][0][rows, :] == 1
+    R_from, t_from = grid_atlas.updated_submap_pose(src_id, device)
+    R_to, t_to = grid_atlas.updated_submap_pose(dst_id, device)
+    coords_world = utils_geometry.transform_points_to(coords_from, R_from, t_from)
+    coords_to = utils_geometry.transfrom_points_from(coords_world, R_to, t_to)
+    if subsample_points is not None:
+        k = min(subsample_points, coords_from.shape[0])
+        pick = np.random.choice(coords_from.shape[0], k, replace=False)
+        coords_from, coords_to, mask = coords_from[pick], coords_to[pick], mask[pick]
+    if use_bound:
+        mask = mask & utils_geometry.coords_in_bound(coords_to, sub_to.bound)
+    if stability_thresh > 0:
+        mask = mask & (sub_to.query_stability(coords_to)[:, [0]] > stability_thresh) \
+            & (sub_from.query_stability(coords_from)[:, [0]] > stability_thresh)
+    keep = torch.nonzero(mask, as_tuple=False)[:, 0]
+    resid = sub_from(coords_from[keep]) - sub_to(coords_to[keep])
+    key = f'align_sdf_{src_id}_{dst_id}'
+    if align_loss == 'L2':
+        val = torch.mean(resid ** 2)
+    elif align_loss == 'L1':
+        val = torch.mean(torch.linalg.vector_norm(resid, dim=1))
+    elif align_loss == 'GM':
+        e = resid.detach()
+        val = torch.mean(gm_scale_sdf / (gm_scale_sdf + e ** 2) ** 2 * resid ** 2)
+    else:
+        raise ValueError(f"Invalid align loss: {align_loss}!")
+    return {key: val * align_weight}
+
+
+def align_multiple_submaps_hierarchical(grid_atlas: GridAtlas, dataset, level_iters=10, finetune_iters=10,
+                                        level_thresh=0.0, lr=1e-2, align_weight=3000, align_loss="L2",
+                                        use_bound=True, stability_thresh=0, subsample_points=None,
+                                        latent_levels=None, skip_finetune=False, submap_pairs=None,
+                                        pose_reg_weight=0, pose_thresh_m=1.0, pose_thresh_rad=1.0,
+                                        gm_scale_sdf=0.1, device="cuda:0", verbose=True, save_iterations=False):
+    """Coarse-to-fine alignment in latent space, optional SDF-space fine-tune (reference :217-322).
+    ``info`` keys (hier_latent_level{l}_{loss}, hier_sdf_{loss}, cpu/gpu_time_sec) as upstream."""
+    grid_atlas.precompute_coordinates_for_alignment()
+    info = dict()
+    cpu_total = gpu_total = 0
+    common = dict(lr=lr, submap_pairs=submap_pairs, pose_reg_weight=pose_reg_weight, pose_thresh_m=pose_thresh_m,
+                  pose_thresh_rad=pose_thresh_rad, verbose=verbose, save_iterations=save_iterations)
+    levels = range(grid_atlas.num_levels) if latent_levels is None else latent_levels
+    for lvl in levels:
+        def latent(atlas, loader, a, b, _l=lvl):
+            return pairwise_loss_latent(atlas, loader, a, b, level=_l, align_weight=align_weight,
+                                        align_loss=align_loss, use_bound=use_bound,
+                                        stability_thresh=stability_thresh, subsample_points=subsample_points,
+                                        device=device)
+        name = f'hier_latent_level{lvl}_{align_loss}'
+        res = generic_align_multiple_submaps(grid_atlas, dataset, (name, latent), num_iters=level_iters,
+                                             rel_change_thresh=level_thresh, **common)
+        cpu_total += res['cpu_time_sec']
+        gpu_total += res['gpu_time_sec']
+        info[name] = res
+    if not skip_finetune:
+        sdf_loss_type = 'L2' if align_loss == 'cos' else align_loss
+
+        def sdf(atlas, loader, a, b):
+            return pairwise_loss_sdf(atlas, loader, a, b, align_weight=align_weight, align_loss=sdf_loss_type,
+                                     use_bound=use_bound, stability_thresh=stability_thresh,
+                                     subsample_points=subsample_points, gm_scale_sdf=gm_scale_sdf, device=device)
+        name = f'hier_sdf_{sdf_loss_type}'
+        res = generic_align_multiple_submaps(grid_atlas, dataset, (name, sdf), num_iters=finetune_iters, **common)
+        cpu_total += res['cpu_time_sec']
+        gpu_total += res['gpu_time_sec']
+        info[name] = res
+    info['cpu_time_sec'] = cpu_total
+    info['gpu_time_sec'] = gpu_total
+    return info

@@ -1,0 +1,63 @@
+"""Convenience API: initialise and optimise a GridNet / GridAtlas with the iSDF loss
+(reference: grid_opt/local_opt.py).  The learned-encoder initialisation is out of scope
+(needs pretrained encoder weights that are not shipped); 'zero' and 'randn' are kept."""
+from copy import deepcopy
+
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from .configs import cfg_loss
+from .models.grid_atlas import GridAtlas
+from .models.grid_net import GridNet
+from .trainer import GridTrainer
+
+
+def initialize_grid_net(grid: GridNet, init_mode='encode', encoder=None, encoder_observation=None,
+                        encoder_stop_level: int = None):
+    assert isinstance(grid, GridNet)
+    info = {'total_encoder_time': 0}
+    if init_mode == 'zero':
+        grid.zero_features()
+    elif init_mode == 'randn':
+        grid.randn_features(std=1e-4)
+    else:
+        raise NotImplementedError("encoder-based initialisation is outside the MI355X hot path")
+    return grid, info
+
+
+def _run(model, dataset, loss, cfg_train, device, eval_tuples=()):
+    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+    trainer = GridTrainer(cfg_train, model, loss, loader, None, device, torch.float32)
+    for name, func in eval_tuples:
+        trainer.register_eval_func(name=name, func=func)
+    trainer.train()
+    return {'trainer_epoch': trainer.train_dict['epochs'],
+            'trainer_epoch_time': trainer.train_dict['epoch_time'],
+            'trainer_total_loss': trainer.train_dict['total_loss']}
+
+
+def optimize_grid_net(grid: GridNet, dataset: Dataset, cfg: dict, iterations=0, learning_rate=1e-3,
+                      eval_every=-1, eval_tuples=[], train_mode='joint', iterations_per_level=50):
+    assert cfg['loss']['name'] == 'iSDF'
+    cfg_train = deepcopy(cfg['train'])
+    cfg_train.update(max_epochs_in_level=iterations_per_level, relchange_tol=0, grid_training_mode=train_mode,
+                     epochs=iterations, learning_rate=learning_rate, verbose=True, eval_every=eval_every)
+    return grid, _run(grid, dataset, cfg_loss(cfg), cfg_train, cfg['device'], eval_tuples)
+
+
+def initialize_grid_atlas(grid_atlas: GridAtlas, init_mode='encode', encoder=None, encoder_observations=None,
+                          encoder_stop_level: int = None):
+    for s in range(grid_atlas.num_submaps):
+        obs = encoder_observations[s] if init_mode == 'encode' else None
+        initialize_grid_net(grid_atlas.get_submap(s), init_mode, encoder, obs, encoder_stop_level)
+    return grid_atlas, {}
+
+
+def optimize_grid_atlas(grid_atlas: GridAtlas, dataset: Dataset, cfg: dict, iterations=0,
+                        learning_rate=0.0013, train_mode='coordinate'):
+    assert cfg['loss']['name'] == 'iSDFSubmap'
+    cfg_train = deepcopy(cfg['train'])
+    cfg_train.update(max_epochs_in_level=50, relchange_tol=0, grid_training_mode=train_mode,
+                     epochs=iterations, learning_rate=learning_rate, verbose=True, eval_every=-1)
+    info = _run(grid_atlas, dataset, cfg_loss(cfg), cfg_train, cfg['device'])
+    return grid_atlas, info

@@ -1,0 +1,247 @@
+"""Losses on the hot path (reference: grid_opt/loss.py -- MisoLoss* and helpers).
+
+MisoLossMappingBase.compute keeps the reference contract (dict of 0-d tensors) but
+removes its host work: the per-keyframe Python loop (np.unique + nonzero + indexed
+matmul per keyframe, loss.py:763-774) becomes one gathered batched transform, and
+when nothing needs the intermediate autograd graph the SDF and free-space terms
+come from one fused kernel (miso_amd.ops.mapping_loss)."""
+import torch
+import torch.nn.functional as F
+
+import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
+from miso_amd import ops
+from .diff import gradient3d
+from .models.base_net import BaseNet
+from .models.grid_atlas import GridAtlas
+from .models.grid_net import GridNet
+
+
+class BaseLoss:
+    def compute(self, model, model_input: dict, gt: dict) -> dict:
+        raise NotImplementedError
+
+
+# --------------------------------------------------------------------------- #
+# helpers
+# --------------------------------------------------------------------------- #
+def transform_by_keyframe(coords_frame, frame_ids, pose_of):
+    """coords_world[i] = R_k x_i + t_k with k = frame_ids[i].  ``pose_of(k) -> (R (3,3), t (3,1))``
+    is evaluated once per keyframe present in the batch; the points are then mapped with one
+    gather + batched product, so pose gradients flow as in the reference's per-keyframe loop."""
+    ids = torch.unique(frame_ids)
+    Rs, ts = zip(*(pose_of(int(k)) for k in ids.tolist()))
+    R = torch.stack(Rs)                       # (K,3,3)
+    t = torch.stack(ts).squeeze(-1)           # (K,3)
+    slot = torch.searchsorted(ids, frame_ids)
+    return torch.einsum('nij,nj->ni', R[slot], coords_frame) + t[slot]
+
+
+def miso_loss_regression(pred, targ, valid_mask=None, sample_weights=None, loss_type='L1'):
+    """Reference loss.py:594-635: mean over ALL rows (masked rows count as zeros)."""
+    assert pred.shape == targ.shape
+    n = pred.shape[0]
+    if valid_mask is None:
+        valid_mask = torch.ones((n, 1)).to(pred)
+    if sample_weights is None:
+        sample_weights = torch.ones((n, 1)).to(pred)
+    assert valid_mask.shape == (n, 1) and sample_weights.shape == (n, 1)
+    if loss_type == 'L2':
+        per_row = ((pred - targ) ** 2).sum(dim=1, keepdim=True)
+    elif loss_type == 'L1':
+        per_row = (pred - targ).abs().sum(dim=1, keepdim=True)
+    elif loss_type == 'Cosine':
+        per_row = 1.0 - F.cosine_similarity(pred, targ, dim=1, eps=1e-8).unsqueeze(1)
+    else:
+        raise ValueError(f"Invalid loss type: {loss_type}")
+    per_row = torch.where(valid_mask == 1, per_row, torch.zeros_like(per_row))
+    return torch.mean(sample_weights * per_row)
+
+
+def miso_loss_eikonal(model: BaseNet, coords_world, gt_sdf, eik_trunc_dist, grad_method, finite_diff_eps):
+    """Reference loss.py:638-665."""
+    if eik_trunc_dist is not None:
+        keep = torch.nonzero(torch.abs(gt_sdf) < eik_trunc_dist, as_tuple=False)[:, 0]
+        x = coords_world[keep, :].clone()
+    else:
+        x = coords_world.clone()
+    x.requires_grad_(True)
+    g = gradient3d(x, model, method=grad_method, finite_diff_eps=finite_diff_eps, create_graph=True)
+    return torch.mean((g.norm(dim=-1) - 1) ** 2)
+
+
+def miso_loss_free_space(pred_sdf, gt_sdf, gt_sdf_sign, trunc_dist):
+    """Reference loss.py:668-700."""
+    assert trunc_dist is not None
+    zero = torch.zeros_like(pred_sdf)
+    free = gt_sdf_sign == 1
+    above = torch.where(free, F.relu(pred_sdf - gt_sdf), zero)
+    below = torch.where(free, F.relu(trunc_dist - pred_sdf), zero)
+    return torch.mean(torch.maximum(above, below))
+
+
+def compute_feature_regularization_loss(model: GridNet, weight=1.0):
+    return {f'feat_reg_level{l}': torch.mean(model.features[l].feature ** 2) * weight
+            for l in range(model.num_levels)}
+
+
+def compute_pose_regularization_loss(model: GridNet, weight=1.0):
+    return {'pose_l2_reg_R': torch.mean(model.rotation_corrections ** 2) * weight,
+            'pose_l2_reg_t': torch.mean(model.translation_corrections ** 2) * weight}
+
+
+def compute_pose_trust_region_loss(model: GridNet, thresh_rad, thresh_m, weight=1e3):
+    rot = torch.linalg.norm(model.rotation_corrections, dim=1)
+    tran = torch.linalg.norm(model.translation_corrections.squeeze(2), dim=1)
+    return {'trust_region_R': weight * torch.sum(F.relu(rot - thresh_rad)),
+            'trust_region_t': weight * torch.sum(F.relu(tran - thresh_m))}
+
+
+def compute_feature_stability_loss(model: GridNet, coords, mask_valid=None):
+    """Reference loss.py:170-184."""
+    if mask_valid is None:
+        mask_valid = torch.ones((coords.shape[0], 1)).to(coords)
+    pred = model.query_stability(coords)
+    assert pred.shape[0] == mask_valid.shape[0]
+    resid = torch.where(mask_valid == 1, pred - torch.ones_like(pred), torch.zeros_like(pred))
+    out = {'stability': torch.mean(resid ** 2)}
+    for l in range(model.num_levels):
+        out[f'stability_reg_level{l}'] = 1e-2 * torch.mean(model.feature_stability[l].feature ** 2)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# tracking
+# --------------------------------------------------------------------------- #
+class MisoLossTracking(BaseLoss):
+    """Reference loss.py:517-586."""
+
+    def __init__(self, weight_sdf=1.0, loss_type='L2', trunc_dist=None, gm_scale_sdf=1.0, gm_scale_grad=None):
+        super().__init__()
+        self.weight_sdf = weight_sdf
+        self.loss_type = loss_type
+        self.trunc_dist = trunc_dist
+        self.gm_scale_sdf = gm_scale_sdf
+        self.gm_scale_grad = gm_scale_grad
+
+    def compute(self, model: GridNet, model_input: dict, gt: dict) -> dict:
+        coords_frame = model_input['coords_frame'][0]
+        frame_ids = model_input['sample_frame_ids'][0, :, 0]
+        gt_sdf = gt['sdf'][0]
+        assert coords_frame.ndim == 2 and gt_sdf.ndim == 2
+        valid = gt['sdf_valid'][0]
+        if self.trunc_dist is not None:
+            valid = torch.logical_and(valid, torch.abs(gt_sdf) < self.trunc_dist)
+        assert valid.shape == gt_sdf.shape
+        coords_world = transform_by_keyframe(coords_frame, frame_ids, model.updated_kf_pose_in_world)
+        pred = model(coords_world)
+        resid = torch.where(valid == 1, pred - gt_sdf, torch.zeros_like(pred))
+        if self.loss_type == 'L2':
+            val = torch.mean(resid ** 2)
+        elif self.loss_type == 'L1':
+            val = torch.mean(torch.abs(resid))
+        elif self.loss_type == 'GM':
+            e = resid.detach()
+            w = self.gm_scale_sdf / (self.gm_scale_sdf + e ** 2) ** 2
+            val = torch.mean(w * resid ** 2)
+        else:
+            raise ValueError(f"Invalid loss type: {self.loss_type}")
+        return {f'sdf_{self.loss_type}': self.weight_sdf * val}
+
+
+# --------------------------------------------------------------------------- #
+# mapping
+# --------------------------------------------------------------------------- #
+class MisoLossMappingBase(BaseLoss):
+    """Reference loss.py:703-844."""
+
+    def __init__(self, loss_type='L1', weight_sdf=1.0, weight_eik=0.5, weight_fs=0, trunc_dist=0,
+                 finite_diff_eps=1e-2, grad_method='autograd', eik_trunc_dist=0.1, use_stability=False,
+                 weight_clip=0):
+        super().__init__()
+        self.loss_type = loss_type
+        self.trunc_dist = trunc_dist
+        self.weight_sdf = weight_sdf
+        self.weight_eik = weight_eik
+        self.weight_fs = weight_fs
+        self.finite_diff_eps = finite_diff_eps
+        self.grad_method = grad_method
+        self.eik_trunc_dist = eik_trunc_dist
+        self.use_stability = use_stability
+        self.weight_clip = weight_clip
+        self.use_clip = weight_clip > 0   # upstream reads this attribute without defining it (loss.py:788)
+
+    def query_kf_pose(self, model: BaseNet, kf_id: int):
+        raise NotImplementedError("This function should be implemented in the derived class.")
+
+    def query_model(self, model, coords_world: torch.Tensor):
+        out = model(coords_world)
+        d = {'sdf': out[:, [0]]}
+        if self.weight_clip > 0:
+            d['clip'] = out[:, 1:]
+        return d
+
+    def world_coords(self, model, coords_frame, frame_ids):
+        return transform_by_keyframe(coords_frame, frame_ids, lambda k: self.query_kf_pose(model, k))
+
+    def compute(self, model, model_input: dict, gt: dict) -> dict:
+        coords_frame = model_input['coords_frame'][0]
+        frame_ids = model_input['sample_frame_ids'][0, :, 0]
+        weights = model_input['weights'][0]
+        gt_sdf, gt_valid, gt_sign = gt['sdf'][0], gt['sdf_valid'][0], gt['sdf_signs'][0]
+        assert coords_frame.ndim == 2 and gt_sdf.ndim == 2
+        assert weights.shape == gt_sdf.shape
+        coords_world = self.world_coords(model, coords_frame, frame_ids)
+        pred_sdf = self.query_model(model, coords_world)['sdf']
+        loss_dict = {}
+        fused = pred_sdf.is_cuda and self.loss_type in ('L1', 'L2') and pred_sdf.shape[1] == 1
+        if fused:
+            # both terms (value and d/d pred) from one kernel
+            terms = ops.mapping_loss(pred_sdf, gt_sdf, gt_valid, gt_sign, weights, self.loss_type,
+                                     float(self.weight_sdf), float(self.weight_fs) if self.weight_fs > 0 else 0.0,
+                                     0.0 if self.trunc_dist is None else float(self.trunc_dist))
+            loss_dict[f'sdf_{self.loss_type}'] = terms[0]
+        else:
+            loss_dict[f'sdf_{self.loss_type}'] = self.weight_sdf * miso_loss_regression(
+                pred=pred_sdf, targ=gt_sdf, valid_mask=gt_valid, sample_weights=weights, loss_type=self.loss_type)
+        if self.weight_eik > 0:
+            assert not self.use_clip, "Eikonal loss not supported with CLIP."
+            eik = miso_loss_eikonal(model=model, coords_world=coords_world, gt_sdf=gt_sdf,
+                                    eik_trunc_dist=self.eik_trunc_dist, grad_method=self.grad_method,
+                                    finite_diff_eps=self.finite_diff_eps)
+            loss_dict['eik'] = eik * self.weight_eik
+        if self.weight_fs > 0:
+            if fused:
+                loss_dict['free_space'] = terms[1]
+            else:
+                loss_dict['free_space'] = self.weight_fs * miso_loss_free_space(
+                    pred_sdf=pred_sdf, gt_sdf=gt_sdf, gt_sdf_sign=gt_sign, trunc_dist=self.trunc_dist)
+        if self.use_stability:
+            loss_dict.update(compute_feature_stability_loss(model, coords_world))
+        if self.weight_clip > 0:
+            loss_dict.update(self.compute_clip(model, model_input, gt))
+        return loss_dict
+
+    def compute_clip(self, model, model_input: dict, gt: dict) -> dict:
+        coords_frame = model_input['clip_coords_frame'][0]
+        frame_ids = model_input['clip_sample_frame_ids'][0, :, 0]
+        gt_clip = gt['clip_embeddings'][0]
+        assert coords_frame.ndim == 2 and gt_clip.ndim == 2
+        coords_world = self.world_coords(model, coords_frame, frame_ids)
+        pred = self.query_model(model, coords_world)['clip']
+        return {'clip_L1': self.weight_clip * miso_loss_regression(pred=pred, targ=gt_clip, loss_type='L1')}
+
+
+class MisoLossMapping(MisoLossMappingBase):
+    """Mapping inside one submap (GridNet)."""
+
+    def query_kf_pose(self, model, kf_id):
+        assert isinstance(model, GridNet)
+        return model.updated_kf_pose_from_key(f'KF{kf_id}')
+
+
+class MisoLossFusion(MisoLossMappingBase):
+    """Joint mapping over all submaps (GridAtlas)."""
+
+    def query_kf_pose(self, model, kf_id):
+        assert isinstance(model, GridAtlas)
+        return model.updated_kf_pose_in_world(kf_id)

@@ -1,0 +1,28 @@
+"""Common base of the scene models (reference: grid_opt/models/base_net.py)."""
+import torch
+import torch.nn as nn
+
+
+class BaseNet(nn.Module):
+    def __init__(self, cfg: dict, device='cpu', dtype=torch.float32):
+        super().__init__()
+        self.cfg = cfg
+        self.d = cfg['spatial_dim']
+        assert self.d in (2, 3)
+        self.device = device
+        self.dtype = dtype
+        self.bound = torch.tensor(cfg['grid']['bound'], device=device, dtype=dtype)
+        assert self.bound.shape == (self.d, 2)
+
+    def forward(self, x: torch.Tensor):
+        raise NotImplementedError
+
+    def params_at_level(self, level):
+        raise NotImplementedError
+
+    def print_trainable_params(self):
+        print("\n === Trainable parameters === ")
+        for name, param in self.named_parameters():
+            if param.requires_grad:
+                print(f"{name}: {param.shape}")
+        print("=== END trainable parameters === \n ")

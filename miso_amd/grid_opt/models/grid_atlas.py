@@ -1,0 +1,302 @@
+"""A scene as a collection of submaps (GridNet) with per-submap SE(3) corrections
+(reference: grid_opt/models/grid_atlas.py; visualisation methods are out of scope)."""
+import logging
+import math
+from copy import deepcopy
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+import miso_amd.grid_opt.utils.utils as utils
+import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
+from .base_net import BaseNet
+from .grid_net import GridNet
+
+logger = logging.getLogger(__name__)
+
+
+class GridAtlas(BaseNet):
+    def __init__(self, cfg: dict, device='cuda:0', dtype=torch.float32):
+        super().__init__(cfg, device, dtype)
+        self.cfg = cfg
+        self.submaps = torch.nn.ModuleList()
+        self.rotation_corrections = torch.nn.ParameterList()
+        self.translation_corrections = torch.nn.ParameterList()
+        self.R_world_submap_list = []
+        self.t_world_submap_list = []
+        self._submap_anchor_kf = []
+        self._kf_id_to_submap_id = []
+        self._submap_id_to_kf_ids = dict()
+        self.curr_submap_id = -1
+        self.curr_kf_id = -1
+
+    # ---- locks ---------------------------------------------------------------------------
+    def lock_submap(self, submap_id: int):
+        s = self.get_submap(submap_id)
+        s.lock_feature()
+        s.lock_pose()
+
+    def unlock_submap(self, submap_id: int):
+        s = self.get_submap(submap_id)
+        s.unlock_feature()
+        s.unlock_pose()
+
+    def _set_submap_pose_grad(self, flag: bool):
+        for p in list(self.rotation_corrections) + list(self.translation_corrections):
+            p.requires_grad_(flag)
+
+    def lock_submap_pose(self):
+        self._set_submap_pose_grad(False)
+
+    def unlock_submap_pose(self):
+        self._set_submap_pose_grad(True)
+
+    def lock_keyframe_pose(self):
+        for s in self.submaps:
+            s.lock_pose()
+
+    def unlock_keyframe_pose(self):
+        for s in self.submaps:
+            s.unlock_pose()
+
+    def print_keyframe_pose_info(self):
+        for i, s in enumerate(self.submaps):
+            rot = math.degrees(torch.linalg.norm(s.rotation_corrections, dim=1).max())
+            tran = torch.linalg.norm(s.translation_corrections.squeeze(2), dim=1).max()
+            print(f"KF submap {i} pose corrections: max_rot={rot:.2f}deg, max_tran={tran:.2f}m")
+
+    def print_submap_pose_info(self):
+        for i in range(self.num_submaps):
+            deg = math.degrees(torch.linalg.norm(self.rotation_corrections[i]))
+            print(f"Base submap {i} pose corrections: rot={deg:.2f}deg, "
+                  f"tran={torch.linalg.norm(self.translation_corrections[i]):.2f}m")
+
+    # ---- construction ----------------------------------------------------------------------
+    def anchor_kf_for_submap(self, submap_id: int):
+        return self._submap_anchor_kf[submap_id]
+
+    def add_submap(self, local_bound: Tensor, Rws: Tensor, tws: Tensor, num_poses=1, optimize_poses=True):
+        assert Rws.shape == (3, 3) and tws.shape == (3, 1)
+        submap_id = len(self.submaps)
+        cfg_model = deepcopy(self.cfg)
+        cfg_model['grid']['bound'] = local_bound.numpy()
+        cfg_model['pose']['num_poses'] = num_poses
+        cfg_model['pose']['optimize'] = optimize_poses
+        self.submaps.append(GridNet(cfg=cfg_model, device=self.device, dtype=self.dtype))
+        self.R_world_submap_list.append(Rws.to(self.device))
+        self.t_world_submap_list.append(tws.to(self.device))
+        anchor_kf = self.curr_kf_id + 1          # the next keyframe anchors the new submap
+        self._submap_anchor_kf.append(anchor_kf)
+        self.rotation_corrections.append(torch.nn.Parameter(torch.zeros(1, 3, device=self.device)))
+        self.translation_corrections.append(torch.nn.Parameter(torch.zeros(3, 1, device=self.device)))
+        self.active_submaps = range(self.num_submaps)
+        self.curr_submap_id = submap_id
+        self._submap_id_to_kf_ids[submap_id] = {anchor_kf}
+
+    def add_kf(self, Rsk: Tensor, tsk: Tensor):
+        assert Rsk.shape == (3, 3) and tsk.shape == (3, 1)
+        assert self.curr_submap_id >= 0, "No submap is created yet. Create a submap first."
+        submap_id = self.curr_submap_id
+        kf_global = self.curr_kf_id + 1
+        kf_local = kf_global - self.anchor_kf_for_submap(submap_id)
+        self._kf_id_to_submap_id.append(submap_id)
+        self.get_submap(submap_id).set_initial_kf_pose(kf_local, Rsk, tsk, kf_key=f'KF{kf_global}')
+        self._submap_id_to_kf_ids[submap_id].add(kf_global)
+        self.curr_kf_id = kf_global
+        return kf_global
+
+    def set_kf_pose(self, kf_id: int, Rsk: Tensor, tsk: Tensor):
+        assert Rsk.shape == (3, 3) and tsk.shape == (3, 1)
+        submap_id = self.submap_id_for_kf(kf_id)
+        kf_local = kf_id - self.anchor_kf_for_submap(submap_id)
+        self.get_submap(submap_id).set_initial_kf_pose(kf_local, Rsk, tsk, kf_key=f'KF{kf_id}')
+
+    def set_submap_pose(self, submap_id: int, Rws: Tensor, tws: Tensor):
+        assert Rws.shape == (3, 3) and tws.shape == (3, 1)
+        with torch.no_grad():
+            self.R_world_submap_list[submap_id].copy_(Rws.to(self.device))
+            self.t_world_submap_list[submap_id].copy_(tws.to(self.device))
+            self.rotation_corrections[submap_id].zero_()     # new base pose: corrections restart at 0
+            self.translation_corrections[submap_id].zero_()
+
+    def set_submap_pose_correction(self, submap_id: int, R_delta: Tensor, t_delta: Tensor):
+        assert R_delta.shape == (1, 3) and t_delta.shape == (3, 1)
+        with torch.no_grad():
+            self.rotation_corrections[submap_id].copy_(R_delta)
+            self.translation_corrections[submap_id].copy_(t_delta)
+
+    def set_active_submaps(self, active_submaps):
+        self.active_submaps = active_submaps
+
+    # ---- bookkeeping -----------------------------------------------------------------------
+    @property
+    def num_submaps(self):
+        return len(self.submaps)
+
+    @property
+    def num_active_submaps(self):
+        return len(self.active_submaps)
+
+    @property
+    def num_keyframes(self):
+        return self.curr_kf_id + 1
+
+    @property
+    def num_levels(self):
+        return self.get_submap(0).num_levels
+
+    def num_keyframes_in_submap(self, submap_id: int) -> int:
+        return len(self._submap_id_to_kf_ids[submap_id])
+
+    def submap_id_for_kf(self, kf_id: int):
+        return self._kf_id_to_submap_id[kf_id]
+
+    def submap_id_for_kf_batch(self, kf_ids: Tensor) -> Tensor:
+        table = torch.tensor(self._kf_id_to_submap_id, device=kf_ids.device)
+        return table[kf_ids]
+
+    def get_submap(self, submap_id: int) -> GridNet:
+        assert 0 <= submap_id < self.num_submaps
+        return self.submaps[submap_id]
+
+    # ---- poses -------------------------------------------------------------------------------
+    def initial_submap_pose(self, submap_id: int) -> Tuple[Tensor, Tensor]:
+        return self.R_world_submap_list[submap_id], self.t_world_submap_list[submap_id]
+
+    def updated_submap_pose(self, submap_id: int, device=None) -> Tuple[Tensor, Tensor]:
+        R0, t0 = self.initial_submap_pose(submap_id)
+        R, t = utils_geometry.apply_pose_correction(R=R0, t=t0, R_delta=self.rotation_corrections[submap_id],
+                                                    t_delta=self.translation_corrections[submap_id])
+        if device is not None:
+            R, t = R.to(device), t.to(device)
+        return R, t
+
+    def _local_kf(self, kf_id: int, submap_id: int) -> int:
+        expect = self.submap_id_for_kf(kf_id)
+        assert expect == submap_id, f"Wrong submap for KF {kf_id}! Expect {expect}, got {submap_id}."
+        return kf_id - self.anchor_kf_for_submap(submap_id)
+
+    def initial_kf_pose_in_submap(self, kf_id: int, submap_id: int):
+        return self.get_submap(submap_id).initial_kf_pose(self._local_kf(kf_id, submap_id))
+
+    def updated_kf_pose_in_submap(self, kf_id: int, submap_id: int):
+        return self.get_submap(submap_id).updated_kf_pose(self._local_kf(kf_id, submap_id))
+
+    def initial_kf_pose_in_world(self, kf_id: int):
+        s = self.submap_id_for_kf(kf_id)
+        return utils_geometry.transform_poses_to(*self.initial_kf_pose_in_submap(kf_id, s),
+                                                 *self.initial_submap_pose(s))
+
+    def updated_kf_pose_in_world(self, kf_id: int):
+        s = self.submap_id_for_kf(kf_id)
+        return utils_geometry.transform_poses_to(*self.updated_kf_pose_in_submap(kf_id, s),
+                                                 *self.updated_submap_pose(s))
+
+    def global_bound(self, device='cpu') -> Tensor:
+        corners = []
+        for s in range(self.num_submaps):
+            R, t = self.updated_submap_pose(s)
+            b = self.get_submap(s).bound.to(device)
+            xs, ys, zs = torch.meshgrid(b[0], b[1], b[2], indexing='ij')
+            pts = torch.stack((xs, ys, zs), dim=-1).reshape(-1, 3)
+            corners.append(utils_geometry.transform_points_to(pts, R.to(device), t.to(device)))
+        corners = torch.cat(corners, dim=0)
+        return torch.stack((corners.min(dim=0).values, corners.max(dim=0).values), dim=1)
+
+    # ---- level / feature management ------------------------------------------------------------
+    def ignore_level(self, l):
+        for s in self.submaps:
+            s.ignore_level(l)
+
+    def include_level(self, l):
+        for s in self.submaps:
+            s.include_level(l)
+
+    def zero_features(self):
+        for s in self.submaps:
+            s.zero_features()
+
+    # ---- queries (hot path) ----------------------------------------------------------------------
+    def query_feature(self, x_world: Tensor):
+        """Mean over the active submaps that contain the point of that submap's features
+        (reference :374-391; ignore_level is not applied here, as upstream)."""
+        total = 0
+        count = 0
+        for s in self.active_submaps:
+            submap = self.get_submap(s)
+            R, t = self.updated_submap_pose(s)
+            x_local = utils_geometry.transfrom_points_from(x_world, R, t)
+            inside = utils_geometry.coords_in_bound(x_local, submap.bound)
+            total = total + inside * utils.grid_interp_regular(submap.features, x_local, ignore_level=None)
+            count = count + inside
+        count = count.float()
+        count[count == 0] = 1
+        return total / count
+
+    def forward(self, x_world: Tensor, noise_std=0):
+        feats = self.query_feature(x_world)
+        pred = utils.grid_decode(feats, None, self.submaps[0].decoder, True)
+        if noise_std > 0:
+            pred = pred + torch.randn(pred.shape, device=x_world.device) * noise_std
+        return pred
+
+    def check_submap_intersection(self, src_id: int, dst_id: int, overlap_thresh=1e-2):
+        """True if more than overlap_thresh of src's finest-level voxel centres fall inside
+        dst's bound under the current poses (reference :405-420)."""
+        src, dst = self.get_submap(src_id), self.get_submap(dst_id)
+        pts = self._finest_vertices(src_id).to(self.device)
+        R_s, t_s = self.updated_submap_pose(src_id)
+        R_d, t_d = self.updated_submap_pose(dst_id)
+        world = utils_geometry.transform_points_to(pts, R_s, t_s)
+        local = utils_geometry.transfrom_points_from(world, R_d, t_d)
+        inside = utils_geometry.coords_in_bound(local, dst.bound)
+        return (torch.count_nonzero(inside) / pts.shape[0]) > overlap_thresh
+
+    def _finest_vertices(self, submap_id: int) -> Tensor:
+        """Voxel centres of the finest level, built once per submap (the reference rebuilds
+        the tensor on the host for every pair in every alignment iteration)."""
+        cache = self.__dict__.setdefault('_vertex_cache', {})
+        grid = self.get_submap(submap_id).features[-1]
+        key = (submap_id, tuple(grid.feature.shape))
+        if key not in cache:
+            cache[key] = grid.vertex_positions().to(self.device)
+        return cache[key]
+
+    # ---- parameter groups ---------------------------------------------------------------------------
+    def params_for_submap_pose(self, submap_id):
+        return [self.rotation_corrections[submap_id], self.translation_corrections[submap_id]]
+
+    def params_for_all_submap_poses(self):
+        return [*self.rotation_corrections, *self.translation_corrections]
+
+    def params_for_all_kf_poses(self):
+        return [p for s in self.submaps for p in s.params_for_poses()]
+
+    def params_for_all_features(self):
+        return [p for s in self.submaps for p in s.params_for_features()]
+
+    def params_at_level(self, level):
+        return [p for s in self.submaps for p in s.params_at_level(level)]
+
+    # ---- alignment coordinate cache -------------------------------------------------------------------
+    def precompute_coordinates_for_alignment(self, norm_thresh=1e-5):
+        """Per (submap, level): voxel centres whose multi-level feature norm exceeds the
+        threshold, cached detached (reference :565-579)."""
+        self._coords_for_alignment = dict()
+        for level in range(self.num_levels):
+            for s in range(self.num_submaps):
+                submap = self.get_submap(s)
+                coords = submap.features[level].vertex_positions().to(submap.device)
+                with torch.no_grad():
+                    norm = torch.linalg.norm(submap.query_feature(coords), dim=1)
+                self._coords_for_alignment[f"submap{s}_level{level}"] = coords[norm > norm_thresh].detach()
+
+    def coordinates_for_alignment(self, submap_id: int, level: int):
+        assert 0 <= submap_id < self.num_submaps
+        assert 0 <= level < self.num_levels
+        key = f"submap{submap_id}_level{level}"
+        if key not in self.__dict__.get('_coords_for_alignment', {}):
+            raise ValueError(f"Coordinates for alignment not found for submap {submap_id} and level {level}. "
+                             "Did you call precompute_coordinates_for_alignment()?")
+        return self._coords_for_alignment[key]

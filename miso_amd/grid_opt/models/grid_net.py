@@ -1,0 +1,256 @@
+"""One submap: L feature grids + L stability grids + decoder + per-keyframe pose
+corrections (reference: grid_opt/models/grid_net.py)."""
+import logging
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import miso_amd.grid_opt.utils.utils as utils
+import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
+from miso_amd import ops
+from .base_net import BaseNet
+from .grid_modules import FeatureGrid
+from .modules import MLPNet
+
+logger = logging.getLogger(__name__)
+
+
+class GridNet(BaseNet):
+    def __init__(self, cfg: dict, device='cuda:0', dtype=torch.float32, initial_features=dict()):
+        super().__init__(cfg, device, dtype)
+        self.initial_features = initial_features
+        self.init_grid(cfg)
+        self.init_decoder(cfg)
+        self.init_poses(cfg)
+
+    def save(self, ckpt_dir, ckpt_prefix):
+        self.decoder.save(os.path.join(ckpt_dir, f"{ckpt_prefix}_decoder.pt"))
+
+    # ---- construction ----------------------------------------------------------------
+    def init_grid(self, cfg):
+        g = cfg['grid']
+        self.num_levels = g['n_levels']
+        self.second_order_grid_sample = bool(g.get('second_order_grid_sample', False))
+        self.fdim = g['feature_dim']
+        self.grid_type = g['type']
+        if self.grid_type != 'regular':
+            raise ValueError(f"grid type {self.grid_type!r} is outside the MI355X hot path (regular grids only)")
+        self.features = nn.ModuleList()
+        self.feature_stability = nn.ModuleList()
+        self.bases = nn.ModuleList()
+        self.cell_sizes = []
+        for level in range(self.num_levels):
+            cell = g['base_cell_size'] / (g['per_level_scale'] ** level)
+            self.cell_sizes.append(cell)
+            common = dict(d=self.d, bound=self.bound, cell_size=cell, dtype=self.dtype,
+                          second_order_grid_sample=self.second_order_grid_sample)
+            self.features.append(FeatureGrid(fdim=self.fdim, name=f"feat-{level}",
+                                             initial_feature=self.initial_features.get(level),
+                                             init_stddev=g['init_stddev'], **common))
+            self.feature_stability.append(FeatureGrid(fdim=1, name=f"stab-{level}", initial_feature=None,
+                                                      init_stddev=0.0, **common))
+            self.bases.append(None)
+        self.ignore_level_ = np.zeros(self.num_levels).astype(bool)
+
+    def init_decoder(self, cfg):
+        d = cfg['decoder']
+        self.decoder_hidden_dim = d['hidden_dim']
+        self.decoder_hidden_layers = d['hidden_layers']
+        self.decoder_out_dim = d['out_dim']
+        self.pos_invariant = d['pos_invariant']
+        self.decoder_fixed = d['fix']
+        self.decoder_type = d['type']
+        in_dim = self.num_levels * self.fdim + (0 if self.pos_invariant else self.d)
+        if self.decoder_type == 'mlp':
+            self.decoder = MLPNet(input_dim=in_dim, output_dim=self.decoder_out_dim,
+                                  hidden_dim=self.decoder_hidden_dim, hidden_layers=self.decoder_hidden_layers,
+                                  bias=True, pretrained_path=d.get('pretrained_model'),
+                                  no_optimize=self.decoder_fixed)
+        elif self.decoder_type == 'none':
+            self.decoder = None
+        else:
+            raise ValueError(f"Unknown decoder type: {self.decoder_type}")
+
+    def init_poses(self, cfg):
+        self.num_poses = cfg['pose']['num_poses']
+        self.optimize_pose = cfg['pose']['optimize']
+        self.rotation_corrections = nn.Parameter(torch.zeros(self.num_poses, 3, device=self.device),
+                                                 requires_grad=self.optimize_pose)
+        self.translation_corrections = nn.Parameter(torch.zeros(self.num_poses, 3, 1, device=self.device),
+                                                    requires_grad=self.optimize_pose)
+        self.pose_estimates_known = [False] * self.num_poses
+        self.register_buffer('Rwk', utils_geometry.identity_rotations(self.num_poses).to(self.device))
+        self.register_buffer('twk', torch.zeros(self.num_poses, 3, 1, device=self.device))
+        self.locked_pose_indices = set()
+        self._pose_key_to_id = dict()
+
+    # ---- level / lock management -------------------------------------------------------
+    def ignore_level(self, l):
+        self.ignore_level_[l] = True
+
+    def include_level(self, l):
+        self.ignore_level_[l] = False
+
+    def lock_level(self, l):
+        self.features[l].lock()
+        self.feature_stability[l].lock()
+
+    def unlock_level(self, l):
+        self.features[l].unlock()
+        self.feature_stability[l].unlock()
+
+    def lock_feature(self):
+        for l in range(self.num_levels):
+            self.lock_level(l)
+
+    def unlock_feature(self):
+        for l in range(self.num_levels):
+            self.unlock_level(l)
+
+    def lock_pose(self):
+        self.rotation_corrections.requires_grad_(False)
+        self.translation_corrections.requires_grad_(False)
+        self.lock_all_pose_indices()
+
+    def unlock_pose(self):
+        self.rotation_corrections.requires_grad_(True)
+        self.translation_corrections.requires_grad_(True)
+        self.unlock_all_pose_indices()
+
+    def lock_pose_index(self, pose_index: int):
+        self.locked_pose_indices.add(pose_index)
+
+    def lock_all_pose_indices(self):
+        self.locked_pose_indices = set(range(self.num_poses))
+
+    def unlock_pose_index(self, pose_index: int):
+        self.locked_pose_indices.remove(pose_index)
+
+    def unlock_all_pose_indices(self):
+        self.locked_pose_indices.clear()
+
+    # ---- keyframe poses ------------------------------------------------------------------
+    def pose_correction(self, kf_id: int):
+        r = self.rotation_corrections[[kf_id], :]        # (1,3)
+        t = self.translation_corrections[kf_id, :, :]    # (3,1)
+        if kf_id in self.locked_pose_indices:
+            r, t = r.clone().detach(), t.clone().detach()
+        return r, t
+
+    def set_initial_kf_pose(self, kf_id: int, Rwk: torch.Tensor, twk: torch.Tensor, kf_key=None):
+        assert Rwk.shape == (3, 3) and twk.shape == (3, 1)
+        assert kf_id < self.num_poses, f"KF ID {kf_id} exceeds the number of poses {self.num_poses}!"
+        self.pose_estimates_known[kf_id] = True
+        self.Rwk[kf_id] = Rwk.to(self.Rwk)
+        self.twk[kf_id] = twk.to(self.twk)
+        with torch.no_grad():
+            self.rotation_corrections[kf_id].zero_()
+            self.translation_corrections[kf_id].zero_()
+        if kf_key is not None:
+            self._pose_key_to_id[kf_key] = kf_id
+
+    def pose_key_to_id(self, kf_key):
+        assert kf_key in self._pose_key_to_id, f"Key {kf_key} not found in pose key to ID mapping!"
+        return self._pose_key_to_id[kf_key]
+
+    def initial_kf_pose(self, kf_id: int):
+        assert self.pose_estimates_known[kf_id], f"Initial pose estimate for KF {kf_id} is not available!"
+        return self.Rwk[kf_id], self.twk[kf_id]
+
+    def initial_kf_pose_in_world(self, kf_id: int):
+        return self.initial_kf_pose(kf_id)
+
+    def initial_kf_pose_from_key(self, kf_key):
+        return self.initial_kf_pose(self.pose_key_to_id(kf_key))
+
+    def updated_kf_pose(self, kf_id: int):
+        R, t = self.initial_kf_pose_in_world(kf_id)
+        dr, dt = self.pose_correction(kf_id)
+        return utils_geometry.apply_pose_correction(R, t, dr, dt)
+
+    def updated_kf_pose_in_world(self, kf_id: int):
+        return self.updated_kf_pose(kf_id)
+
+    def updated_kf_pose_from_key(self, kf_key):
+        return self.updated_kf_pose(self.pose_key_to_id(kf_key))
+
+    def print_kf_pose_info(self):
+        rot = torch.linalg.norm(self.rotation_corrections, dim=1).max()
+        tran = torch.linalg.norm(self.translation_corrections.squeeze(2), dim=1).max()
+        logger.info(f"GridNet KF pose corrections: max_rot={math.degrees(rot):.3f}deg, max_tran={tran:.3f}m.")
+
+    def print_feature_info(self):
+        for l in range(self.num_levels):
+            logger.info(f"Level {l} norm: {self.features[l].norm():.2f}")
+
+    def zero_features(self):
+        for grid in self.features:
+            grid.zero_features()
+
+    def randn_features(self, std):
+        for grid in self.features:
+            grid.randn_features(std)
+
+    # ---- queries (the hot path) ----------------------------------------------------------
+    def _check_coords(self, x):
+        assert x.ndim == 2, f"Invalid input coords shape {x.shape}!"
+        assert x.shape[-1] == self.d
+
+    def query_feature(self, x: torch.Tensor):
+        self._check_coords(x)
+        return utils.grid_interp_regular(self.features, x, self.ignore_level_)
+
+    def query_stability(self, x: torch.Tensor):
+        self._check_coords(x)
+        return utils.grid_interp_regular(self.feature_stability, x, None)
+
+    def _fused_decoder(self):
+        """DecoderPack if encode+decode can run as one kernel for this model, else None."""
+        if self.decoder is None or not self.pos_invariant or not isinstance(self.decoder, MLPNet):
+            return None
+        pack = self.decoder.decoder_pack()
+        if pack is None:
+            return None
+        feats = [g.feature for g in self.features]
+        meta = self.features[0].grid_meta(self.ignore_level_)
+        return pack if ops.sdf_fused_supported(feats, meta, pack) else None
+
+    def forward(self, x: torch.Tensor, noise_std=0):
+        self._check_coords(x)
+        pack = self._fused_decoder() if x.is_cuda else None
+        if pack is not None:
+            meta = self.features[0].grid_meta(self.ignore_level_)
+            pred = ops.sdf_fused(x, [g.feature for g in self.features], meta, pack)
+        else:
+            feats = self.query_feature(x)
+            pred = utils.grid_decode(feats, x, self.decoder, self.pos_invariant)
+        if noise_std > 0:
+            pred = pred + torch.randn(pred.shape, device=x.device) * noise_std
+        return pred
+
+    # ---- parameter groups ------------------------------------------------------------------
+    def params_for_poses(self):
+        return [self.rotation_corrections, self.translation_corrections]
+
+    def params_for_features(self, stop_level=None):
+        stop_level = self.num_levels if stop_level is None else stop_level
+        assert stop_level <= self.num_levels
+        params = []
+        for l in range(stop_level):
+            params += list(self.features[l].parameters())
+        return params
+
+    def params_at_level(self, level):
+        params = []
+        levels = [level] if level < self.num_levels else range(self.num_levels)
+        for l in levels:
+            params += list(self.features[l].parameters())
+            params += list(self.feature_stability[l].parameters())
+        if not self.decoder_fixed:
+            params += list(self.decoder.parameters())
+        if self.optimize_pose:
+            params += self.params_for_poses()
+        return params

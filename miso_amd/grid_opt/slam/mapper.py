@@ -1,0 +1,45 @@
+"""Mapper: optimise one submap's grids on selected keyframes (reference: grid_opt/slam/mapper.py)."""
+import logging
+from copy import deepcopy
+
+import torch
+from torch.utils.data import DataLoader
+
+from miso_amd.grid_opt.loss import MisoLossMapping
+from miso_amd.grid_opt.models.grid_net import GridNet
+from miso_amd.grid_opt.trainer import GridTrainer
+
+logger = logging.getLogger(__name__)
+
+
+class Mapper:
+    def __init__(self, model: GridNet, dataset, cfg: dict):
+        assert isinstance(model, GridNet), f"Invalid model type {type(model)}."
+        self.grid = model
+        self.dataset = dataset
+        self.train_loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+        self.cfg = cfg
+        m = cfg['mapping']
+        self.lr = m['learning_rate']
+        self.verbose = m['verbose']
+        self.disable = bool(m.get('disable', False))
+        self.loss_fn = MisoLossMapping(weight_sdf=m['weight_sdf'], weight_eik=m['weight_eik'],
+                                       weight_fs=m['weight_fs'], loss_type=m['loss_type'],
+                                       trunc_dist=m['trunc_dist'], finite_diff_eps=m['finite_diff_eps'],
+                                       grad_method=m['grad_method'], eik_trunc_dist=m['eik_trunc_dist'])
+
+    def mapping(self, mapping_kfs, iterations=10, level_iterations=5):
+        if self.disable:
+            return
+        self.grid.unlock_feature()
+        self.grid.lock_pose()
+        self.dataset.select_keyframes(mapping_kfs)
+        cfg_train = deepcopy(self.cfg)['train']
+        cfg_train.update(max_epochs_in_level=level_iterations, epochs=iterations, learning_rate=self.lr,
+                         verbose=self.verbose)
+        trainer = GridTrainer(cfg_train, self.grid, self.loss_fn, self.train_loader, None, self.cfg['device'],
+                              torch.float32)
+        trainer.train()
+        if self.verbose:
+            self.grid.print_kf_pose_info()
+            self.grid.print_feature_info()

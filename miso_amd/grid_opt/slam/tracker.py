@@ -1,0 +1,130 @@
+"""Frame-to-submap tracking: Adam on the keyframe pose, or Gauss-Newton / LM with an
+explicit N x 6 pose Jacobian and Geman-McClure weights (reference: grid_opt/slam/tracker.py)."""
+import logging
+import math
+from copy import deepcopy
+from typing import List
+
+import torch
+from torch.utils.data import DataLoader
+
+import miso_amd.grid_opt.utils.utils as utils
+import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
+from miso_amd.grid_opt.diff import gradient3d
+from miso_amd.grid_opt.loss import MisoLossTracking
+from miso_amd.grid_opt.models.grid_net import GridNet
+from miso_amd.grid_opt.trainer import Trainer
+from miso_amd.so3 import hat
+
+logger = logging.getLogger(__name__)
+
+
+class Tracker:
+    def __init__(self, model: GridNet, dataset, cfg: dict):
+        assert isinstance(model, GridNet), "Model must be an instance of GridNet."
+        self.grid = model
+        self.dataset = dataset
+        self.train_loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+        self.cfg = cfg
+        t = cfg['tracking']
+        self.lr = t['learning_rate']
+        self.verbose = t['verbose']
+        self.gm_scale_sdf = t['gm_scale_sdf']
+        self.lm_lambda = t['lm_lambda']
+        self.lm_max_iter = t['lm_max_iter']
+        self.lm_tol_deg = t['lm_tol_deg']
+        self.lm_tol_m = t['lm_tol_m']
+        self.loss_type = t['loss_type']
+        self.trunc_dist = t['trunc_dist']
+        self.solver = t['solver']
+        if self.solver == 'adam':
+            self.loss_fn = MisoLossTracking(weight_sdf=1.0, loss_type=self.loss_type, trunc_dist=self.trunc_dist,
+                                            gm_scale_sdf=self.gm_scale_sdf)
+        self.disable = bool(t.get('disable', False))
+        self.latest_fov_overlap = 1.0
+
+    def initialize_window(self, head_kf, tail_kf):
+        """Propagate odometry to initialise the keyframe poses in [head_kf, tail_kf)."""
+        with torch.no_grad():
+            for dst in range(head_kf, tail_kf):
+                src = dst - 1
+                assert src >= 0
+                T_src = utils_geometry.pose_matrix(*self.grid.updated_kf_pose_in_world(src))
+                T_dst = T_src @ self.dataset.get_odometry_at_pose(src).to(T_src)
+                self.grid.set_initial_kf_pose(dst, T_dst[:3, :3], T_dst[:3, [3]])
+
+    def track_window(self, optimize_kfs: List[int], iterations=10):
+        self.grid.lock_feature()
+        self.grid.unlock_pose()
+        self.grid.lock_all_pose_indices()
+        for kf in optimize_kfs:
+            self.grid.unlock_pose_index(kf)
+        self.dataset.select_keyframes(optimize_kfs)
+        cfg_train = deepcopy(self.cfg)['train']
+        cfg_train.update(epochs=iterations, learning_rate=self.lr, verbose=self.verbose)
+        Trainer(cfg_train, self.grid, self.loss_fn, self.train_loader, None, self.cfg['device'],
+                torch.float32).train()
+
+    def track(self, optimize_kf: int):
+        if self.disable:
+            return
+        if self.solver == 'adam':
+            self.track_window([optimize_kf], iterations=15)
+        elif self.solver == 'lm':
+            self.track_lm(optimize_kf)
+        else:
+            raise ValueError(f"Unknown solver: {self.solver}.")
+
+    def track_lm(self, optimize_kf: int):
+        for _ in range(self.lm_max_iter):
+            info = self.lm_step(optimize_kf)
+            if info['delta_R_deg'] < self.lm_tol_deg and info['delta_t_norm'] < self.lm_tol_m:
+                break
+        self.latest_fov_overlap = info['fov_overlap']
+
+    def residual_weights(self, r: torch.Tensor):
+        if self.loss_type == 'L2':
+            return torch.ones_like(r)
+        if self.loss_type == 'GM':
+            return self.gm_scale_sdf / (self.gm_scale_sdf + r ** 2) ** 2
+        raise ValueError(f"Unknown loss type: {self.loss_type}.")
+
+    def lm_step(self, optimize_kf: int):
+        """One damped Gauss-Newton step on the keyframe pose (reference :148-212):
+        J_i = [ (hat(R x_i) grad_i)^T R , grad_i^T ], H = J^T W J + lambda I, g = J^T W r."""
+        self.dataset.select_keyframes([optimize_kf])
+        model_input, gt = utils.get_batch(self.train_loader, self.cfg['device'])
+        coords_frame = model_input['coords_frame'][0]
+        frame_ids = model_input['sample_frame_ids'][0]
+        gt_sdf, gt_valid = gt['sdf'][0], gt['sdf_valid'][0]
+        if self.trunc_dist is not None:
+            keep = torch.nonzero(torch.abs(gt_sdf[:, 0]) < self.trunc_dist, as_tuple=False).squeeze(1)
+            coords_frame, frame_ids = coords_frame[keep], frame_ids[keep]
+            gt_sdf, gt_valid = gt_sdf[keep], gt_valid[keep]
+        assert torch.all(frame_ids == optimize_kf)
+        assert torch.all(gt_valid == 1), "Only valid SDFs should be used for tracking."
+        R, t = self.grid.updated_kf_pose_from_key(f'KF{optimize_kf}')
+        R, t = R.detach(), t.detach()
+        coords_world = utils_geometry.transform_points_to(coords_frame, R, t)
+        in_bound = utils_geometry.coords_in_bound(coords_world, self.grid.bound)
+        fov_overlap = float(torch.count_nonzero(in_bound)) / in_bound.numel()
+        # SDF value and spatial gradient from ONE forward + coordinate backward
+        x = coords_world.clone().requires_grad_(True)
+        sdf_pred = self.grid(x)
+        grad_world = torch.autograd.grad(sdf_pred, x, torch.ones_like(sdf_pred))[0].detach()
+        Rx = utils_geometry.transform_points_to(coords_frame, R, torch.zeros_like(t))
+        cT = torch.bmm(hat(Rx), grad_world.unsqueeze(-1)).squeeze(-1)
+        J = torch.cat((cT @ R, grad_world), dim=1)                     # (N,6) = [J_R, J_t]
+        r = (sdf_pred - gt_sdf).detach()
+        w = self.residual_weights(r)
+        H = J.T @ (w * J) + self.lm_lambda * torch.eye(6, device=J.device)
+        g = J.T @ (w * r)
+        delta = torch.linalg.solve(H, -g)
+        delta_R, delta_t = delta[:3], delta[3:]
+        with torch.no_grad():
+            kf = self.grid.pose_key_to_id(f'KF{optimize_kf}')
+            self.grid.rotation_corrections[kf] += delta_R.squeeze()
+            self.grid.translation_corrections[kf] += delta_t
+        return {'delta_R_deg': math.degrees(torch.linalg.norm(delta_R).item()),
+                'delta_t_norm': torch.linalg.norm(delta_t).item(),
+                'grad_norm': torch.linalg.norm(g).item(), 'fov_overlap': fov_overlap}

@@ -1,0 +1,259 @@
+"""Epoch loop: batch -> loss dict -> sum -> backward -> Adam, with the coarse-to-fine
+level schedule of GridTrainer (reference: grid_opt/trainer.py).
+
+Differences from the reference that do not change results: the batch goes to the
+trainer's own device (the reference ignores it and uses 'cuda:0', trainer.py:204),
+TensorBoard is optional, and the NaN guard reads the loss once per step."""
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from miso_amd.optim import DenseAdam
+from .utils.utils import PerfTimer, cond_mkdir, prepare_batch
+
+logger = logging.getLogger(__name__)
+
+try:  # optional: only Trainer.eval writes scalars
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:  # pragma: no cover
+    SummaryWriter = None
+
+
+def _make_optimizer(name, params, lr):
+    if name == 'adam':
+        return DenseAdam(params, lr=lr)
+    if name == 'sgd':
+        return optim.SGD(params, lr=lr)
+    if name == 'lbfgs':
+        raise NotImplementedError("LBFGS optimizer not implemented yet.")
+    raise ValueError(f"Invalid optimizer: {name}.")
+
+
+class Trainer(object):
+    def __init__(self, cfg, model, loss_func, train_dataloader, val_dataloader=None, device='cuda:0',
+                 dtype=torch.float32):
+        self.cfg = cfg
+        self.verbose = cfg['verbose']
+        self.model = model
+        self.loss_func = loss_func
+        self.use_cuda = torch.cuda.is_available()
+        self.device = device
+        self.train_dataloader = train_dataloader
+        self.val_dataloader = val_dataloader
+        self.model.to(self.device)
+        self.set_optimizer()
+        self.set_logging()
+
+    # ---- setup -----------------------------------------------------------------------------
+    def _load_pretrained(self):
+        if self.cfg.get('pretrained_model') is not None:
+            ckpt = torch.load(self.cfg['pretrained_model'])
+            self.model.load_state_dict(ckpt['model_state_dict'])
+
+    def set_optimizer(self):
+        self._load_pretrained()
+        self.optimizer = _make_optimizer(self.cfg['optimizer'], self.model.parameters(), self.cfg['learning_rate'])
+
+    def set_external_optimizer(self, optimizer):
+        self.optimizer = optimizer
+
+    def set_logging(self):
+        self.eval_metric = self.cfg.get('eval_metric')
+        self.eval_best_loss = None
+        self.eval_every = self.cfg['eval_every']
+        self.ckpt_every = self.cfg['ckpt_every']
+        self.log_dir = self.cfg['log_dir']
+        self.ckpt_dir = os.path.join(self.log_dir, 'ckpt')
+        self.tb_dir = os.path.join(self.log_dir, 'tensorboard')
+        for d in (self.log_dir, self.ckpt_dir, self.tb_dir):
+            cond_mkdir(d)
+        self.train_dict = {'epochs': [], 'elapsed_time': [], 'epoch_time': [], 'total_loss': []}
+        self.val_dict = {'epochs': [], 'total_loss': []}
+        self.custom_eval_dict = {'epochs': []}
+        self.custom_eval_funcs = dict()
+        self.writer = SummaryWriter(self.tb_dir) if (SummaryWriter is not None and self.eval_every > 0) else None
+        self.timer = PerfTimer(activate=True)
+
+    def get_last_epoch(self):
+        return self.train_dict['epochs'][-1] if self.train_dict['epochs'] else 0
+
+    # ---- loop ---------------------------------------------------------------------------------
+    def pre_epoch(self, epoch):
+        if self.eval_every > 0 and epoch % self.eval_every == 0:
+            self.run_eval(epoch)
+
+    def post_epoch(self, epoch):
+        if self.ckpt_every > 0 and epoch % self.ckpt_every == 0:
+            self.save_model(epoch, f"ckpt_{epoch}")
+
+    def train(self):
+        self.total_steps = 0
+        self.train_start_time = time.process_time()
+        self.total_epoch_time = 0
+        epoch = 0
+        while epoch < self.cfg['epochs']:
+            self.pre_epoch(epoch)
+            self.train_epoch(epoch)
+            self.post_epoch(epoch)
+            epoch += 1
+        if self.eval_every > 0:
+            self.run_eval(epoch)
+        if self.ckpt_every > 0:
+            self.save_model(epoch, "final")
+
+    def train_step(self, model_input, gt):
+        """zero_grad -> loss dict -> sum of means -> NaN guard -> backward -> step.
+        Returns the total loss (device scalar)."""
+        self.optimizer.zero_grad()
+        loss_dict = self.loss_func.compute(self.model, model_input, gt)
+        total = 0.
+        for value in loss_dict.values():
+            total = total + value.mean()
+        if not torch.isnan(total):
+            total.backward(retain_graph=False)
+            self.optimizer.step()
+        else:
+            logger.warning("Loss is nan! Skip backward step.")
+        return total
+
+    def train_epoch(self, epoch):
+        self.model.train()
+        gpu_time = 0
+        for step, (model_input, gt) in enumerate(self.train_dataloader):
+            self.timer.reset()
+            model_input, gt = prepare_batch(model_input, gt, self.device)
+            total = self.train_step(model_input, gt)
+            self.total_steps += 1
+            if self.verbose and step % 10 == 0:
+                logger.info(f"Train epoch {epoch} step {step} | train_loss={float(total):.2e}.")
+            gpu_time += self.timer.check()[1]
+        self.total_epoch_time += gpu_time
+
+    def relative_param_change(self, epoch, params_list):
+        self.params_curr = [p.clone().detach() for p in params_list]
+        if self.params_prev is None:
+            self.params_prev = self.params_curr
+            return np.inf
+        num = sum(torch.sum((c - p) ** 2) for c, p in zip(self.params_curr, self.params_prev))
+        den = sum(torch.sum(p ** 2) for p in self.params_prev)
+        self.params_prev = self.params_curr
+        return torch.sqrt(num / den)
+
+    # ---- eval / checkpoints ------------------------------------------------------------------------
+    def register_eval_func(self, name, func):
+        self.custom_eval_funcs[name] = func
+        self.custom_eval_dict[name] = []
+
+    def run_eval(self, epoch):
+        self.eval(epoch, 'train')
+        self.eval(epoch, 'val')
+        self.custom_eval_dict['epochs'].append(epoch)
+        for name, func in self.custom_eval_funcs.items():
+            self.custom_eval_dict[name].append(
+                func(epoch, self.cfg, self.model, self.loss_func, self.train_dataloader, self.val_dataloader))
+
+    def eval(self, epoch, mode='train'):
+        self.model.eval()
+        if mode == 'train':
+            loader, target = self.train_dataloader, self.train_dict
+        elif mode == 'val':
+            loader, target = self.val_dataloader, self.val_dict
+        else:
+            raise ValueError(f"Invalid eval mode: {mode}!")
+        if loader is None:
+            return
+        sums = {}
+        for model_input, gt in loader:
+            model_input, gt = self.prepare_batch(model_input, gt)
+            for name, value in self.loss_func.compute(self.model, model_input, gt).items():
+                sums.setdefault(name, []).append(value.mean().item())
+        target['epochs'].append(epoch)
+        total = 0.0
+        for name, vals in sums.items():
+            avg = float(np.mean(np.asarray(vals)))
+            target.setdefault(name, []).append(avg)
+            total += avg
+            if self.writer is not None:
+                self.writer.add_scalar(f"{mode}/{name}", avg, epoch)
+        target['total_loss'].append(total)
+        if mode == 'train':
+            target['elapsed_time'].append(time.process_time() - self.train_start_time)
+            target['epoch_time'].append(self.total_epoch_time)
+        if mode == 'val' and self.eval_metric is not None:
+            cur = target[self.eval_metric][-1]
+            if self.eval_best_loss is None or self.eval_best_loss > cur:
+                self.eval_best_loss = cur
+                self.save_model(epoch, 'best_model')
+
+    def save_model(self, epoch, ckpt_name):
+        """Same checkpoint dict as the reference (trainer.py:319-332)."""
+        torch.save({'epoch': epoch, 'model_state_dict': self.model.state_dict(),
+                    'optimizer_state_dict': self.optimizer.state_dict(), 'train_dict': self.train_dict,
+                    'val_dict': self.val_dict}, os.path.join(self.ckpt_dir, f"{ckpt_name}.pt"))
+        if callable(getattr(self.model, 'save', None)):
+            self.model.save(self.ckpt_dir, ckpt_name)
+
+    def prepare_batch(self, model_input, gt):
+        model_input = {k: v.to(self.device) for k, v in model_input.items()}
+        if 'coords' in model_input:
+            model_input['coords'].requires_grad_(True)
+        gt = {k: v.to(self.device) for k, v in gt.items()}
+        return model_input, gt
+
+
+class GridTrainer(Trainer):
+    """Per-level Adam optimisers switched every ``max_epochs_in_level`` epochs (or on
+    convergence), then an optional joint optimiser (reference trainer.py:370-480)."""
+
+    def reset_convergence_check(self):
+        self.params_prev = None
+        self.params_curr = None
+        self.relchange = np.inf
+        self.epochs_in_level = 0
+
+    def set_optimizer(self):
+        self.relchange_tol = self.cfg['relchange_tol']
+        self.max_epochs_in_level = self.cfg['max_epochs_in_level']
+        self.grid_training_mode = self.cfg['grid_training_mode']
+        self._load_pretrained()
+        name, lr = self.cfg['optimizer'], self.cfg['learning_rate']
+        if name not in ('adam', 'sgd'):
+            raise ValueError(f"Invalid optimizer: {name}.")
+        self.level_optimizers = []
+        if self.grid_training_mode != 'joint':
+            for level in range(self.model.num_levels):
+                self.level_optimizers.append(_make_optimizer(name, self.model.params_at_level(level), lr))
+        self.joint_optimizer = _make_optimizer(name, self.model.parameters(), lr)
+        self.reset_convergence_check()
+        if self.grid_training_mode in ('coordinate', 'coordinate+joint'):
+            self.active_level = 0
+            self.optimizer = self.level_optimizers[0]
+        elif self.grid_training_mode == 'joint':
+            self.active_level = self.model.num_levels
+            self.optimizer = self.joint_optimizer
+        else:
+            raise ValueError(f"Invalid grid training mode: {self.grid_training_mode}")
+
+    def pre_epoch(self, epoch):
+        super().pre_epoch(epoch)
+        done = self.relchange < self.relchange_tol or self.epochs_in_level >= self.max_epochs_in_level
+        if done and self.active_level < self.model.num_levels:
+            self.train_dict[f'level{self.active_level}_last_epoch'] = epoch
+            self.active_level += 1
+            if self.active_level >= self.model.num_levels:
+                if self.grid_training_mode == 'coordinate+joint':
+                    self.optimizer = self.joint_optimizer
+            else:
+                self.optimizer = self.level_optimizers[self.active_level]
+            self.reset_convergence_check()
+        self.epochs_in_level += 1
+
+    def eval(self, epoch, mode='train'):
+        super().eval(epoch, mode)
+        if mode == 'train':
+            self.relchange = self.relative_param_change(epoch, self.model.params_at_level(self.active_level))
+            self.train_dict.setdefault('relchange', []).append(self.relchange)

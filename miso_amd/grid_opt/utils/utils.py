@@ -1,0 +1,193 @@
+"""Coordinate helpers, the multi-level lookup and small training utilities
+(reference: grid_opt/utils/utils.py)."""
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from miso_amd import ops
+
+logger = logging.getLogger(__name__)
+
+
+def _bounds_for(queries: torch.Tensor, bounds: torch.Tensor):
+    d = bounds.shape[0]
+    assert queries.shape[-1] == d
+    if queries.dim() not in (2, 3):
+        raise ValueError("queries tensor must be either 2D or 3D")
+    shape = (1,) * (queries.dim() - 1) + (d,)
+    return bounds[:, 0].view(shape), bounds[:, 1].view(shape)
+
+
+def normalize_coordinates(queries: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
+    """Metres -> [-1, 1] per axis (reference utils.py:22-51)."""
+    lo, hi = _bounds_for(queries, bounds)
+    return 2 * (queries - lo) / (hi - lo) - 1
+
+
+def denormalize_coordinates(normalized_queries: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
+    """[-1, 1] -> metres (reference utils.py:53-82)."""
+    lo, hi = _bounds_for(normalized_queries, bounds)
+    return (normalized_queries + 1) / 2 * (hi - lo) + lo
+
+
+# --------------------------------------------------------------------------- #
+# grid lookups
+# --------------------------------------------------------------------------- #
+def _ignore_mask(num_levels, ignore_level):
+    if ignore_level is None:
+        return None
+    assert len(ignore_level) == num_levels
+    return [bool(v) for v in ignore_level]
+
+
+def interp_3d(features, x, ignore_level=None, second_order_grid_sample=False):
+    """Reference utils.py:114-140: ``features`` is a list of (1,C,Z,Y,X) tensors and ``x``
+    holds NORMALISED coordinates (N,3).  One fused multi-level lookup; the op is
+    second-order capable regardless of ``second_order_grid_sample``."""
+    feats = list(features)
+    ig = _ignore_mask(len(feats), ignore_level)
+    meta = ops.GridMeta((-1.0,) * 3, (1.0,) * 3,
+                        sum(1 << l for l, v in enumerate(ig or []) if v), ops._lib.F_COORDS_NORMALIZED)
+    return ops.encode(x, feats, meta)
+
+
+def grid_interp_regular(reg_grids, x, ignore_level=None):
+    """Reference utils.py:143-164: ``reg_grids`` are FeatureGrid modules sharing one
+    bound, ``x`` metres (N,3) -> (N, sum fdim).  Ignored levels contribute zeros.
+    All levels are sampled by ONE kernel launch (no per-level launch, no cat)."""
+    grids = list(reg_grids)
+    meta = grids[0].grid_meta(_ignore_mask(len(grids), ignore_level))
+    return ops.encode(x, [g.feature for g in grids], meta)
+
+
+def grid_decode(feats, x, decoder=None, pos_invariant=True):
+    """Reference utils.py:194-208."""
+    assert feats.ndim == 2
+    if decoder is None:
+        return feats
+    inputs = feats if pos_invariant else torch.cat((feats, x), dim=1)
+    return decoder(inputs)
+
+
+def all_grid_positions(features: torch.Tensor) -> torch.Tensor:
+    """Normalised centres of every voxel of a (1,C,Z,Y,X) grid as (1,Z,Y,X,3) with the
+    last axis ordered (x,y,z) (reference utils.py:294-307)."""
+    _, _, nz, ny, nx = features.shape
+
+    def centres(n):
+        return 2 * torch.linspace(0.5 / n, 1 - 0.5 / n, n) - 1.
+
+    zz, yy, xx = torch.meshgrid(centres(nz), centres(ny), centres(nx), indexing="ij")
+    return torch.stack((xx, yy, zz), dim=-1).unsqueeze(0)
+
+
+def grid_pool_3d_avg(coords, features, grid_bound, cell_size):
+    """Average the features of the points falling into every cell of a regular grid
+    (reference utils.py:239-291).  Returns (nx, ny, nz, d)."""
+    assert coords.ndim == 2 and features.ndim == 2 and coords.shape == (features.shape[0], 3)
+    n, d = features.shape
+    extent = (grid_bound[:, 1] - grid_bound[:, 0]).cpu().numpy()
+    nx, ny, nz = (int(v) for v in np.ceil(extent / cell_size).astype(int))
+    idx = []
+    for axis, size in ((0, nx), (1, ny), (2, nz)):
+        idx.append(((coords[:, axis] - grid_bound[axis, 0]) / cell_size).long().clamp(0, size - 1))
+    lin = (idx[0] * ny + idx[1]) * nz + idx[2]
+    acc = torch.zeros(nx * ny * nz, d, device=features.device)
+    cnt = torch.zeros(nx * ny * nz, dtype=torch.int32, device=features.device)
+    acc.index_add_(0, lin, features)
+    cnt.index_add_(0, lin, torch.ones(n, dtype=torch.int32, device=features.device))
+    acc /= cnt.clamp(min=1).unsqueeze(-1)
+    return acc.view(nx, ny, nz, d)
+
+
+# --------------------------------------------------------------------------- #
+# batches, bookkeeping
+# --------------------------------------------------------------------------- #
+def cond_mkdir(path):
+    if not os.path.exists(path):
+        os.makedirs(path)
+
+
+def check_tensor(tensor):
+    if torch.isnan(tensor).any():
+        raise ValueError(f"Tensor has {int(torch.isnan(tensor).sum())} nan values!")
+    if torch.isinf(tensor).any():
+        raise ValueError(f"Tensor has {int(torch.isinf(tensor).sum())} inf values!")
+
+
+def sanitize_tensor_dict(input_dict):
+    """NaN -> 0 on every entry (reference utils.py:487-493), without a host sync per key."""
+    return {k: (torch.nan_to_num(v) if v.is_floating_point() else v) for k, v in input_dict.items()}
+
+
+def prepare_batch(model_input, gt, device='cuda:0'):
+    model_input = sanitize_tensor_dict({k: v.to(device) for k, v in model_input.items()})
+    gt = sanitize_tensor_dict({k: v.to(device) for k, v in gt.items()})
+    return model_input, gt
+
+
+def get_batch(data_loader, device='cuda:0'):
+    for model_input, gt in data_loader:
+        return prepare_batch(model_input, gt, device)
+
+
+def relative_param_change(params_curr, params_prev=None):
+    if params_prev is None:
+        return np.inf
+    num = sum(torch.sum((c - p) ** 2) for c, p in zip(params_curr, params_prev))
+    den = sum(torch.sum(p ** 2) for p in params_prev)
+    return torch.sqrt(num / den).item()
+
+
+class PerfTimer:
+    """CPU process time + device time between reset() and check() (reference
+    utils.py:518-552).  Uses HIP events when a device is present, wall clock otherwise
+    (the reference cannot be constructed without a GPU)."""
+
+    def __init__(self, activate=False):
+        self.activate = activate
+        self.counter = 0
+        self.reset()
+
+    def reset(self):
+        self.counter = 0
+        self.prev_time = time.process_time()
+        self._gpu = torch.cuda.is_available()
+        if self._gpu:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        else:
+            self._wall = time.perf_counter()
+
+    def check(self, name=None):
+        if not self.activate:
+            return None
+        cpu_time = time.process_time() - self.prev_time
+        if self._gpu:
+            self.end.record()
+            torch.cuda.synchronize()
+            gpu_time = self.start.elapsed_time(self.end) / 1e3
+            self.start.record()
+        else:
+            now = time.perf_counter()
+            gpu_time, self._wall = now - self._wall, now
+        self.prev_time = time.process_time()
+        self.counter += 1
+        return cpu_time, gpu_time
+
+
+class InfoNCE(torch.nn.Module):
+    """Reference utils.py:555-589."""
+
+    def __init__(self, temperature=0.07, reduction='mean'):
+        super().__init__()
+        self.temperature = temperature
+        self.criterion = torch.nn.CrossEntropyLoss(reduction=reduction)
+
+    def forward(self, query, key):
+        logits = query @ key.T / self.temperature
+        return self.criterion(logits, torch.arange(query.shape[0], device=query.device))

@@ -454,7 +454,7 @@ _LOSS_TYPES = {"L1": 1, "L2": 2}
 
 
 def mapping_loss_raw(pred, target, valid, sign, weight, loss_type: str, weight_sdf: float,
-                     weight_fs: float, trunc_dist: float, grad_pred=None, loss_out=None):
+                     weight_fs: float, trunc_dist: float, grad_pred=None, loss_out=None, grad_pred_fs=None):
     """miso_loss_regression + miso_loss_free_space (grid_opt/loss.py:594-635, :668-700) and
     d/d pred in one launch.  Returns (loss_out[2] = weighted terms, grad_pred (N,1))."""
     _require_hip(pred, target, valid, sign, weight)
@@ -464,36 +464,38 @@ def mapping_loss_raw(pred, target, valid, sign, weight, loss_type: str, weight_s
         grad_pred = torch.empty_like(pred)
     if loss_out is None:
         loss_out = torch.empty(2, device=pred.device, dtype=torch.float32)
-    cont = lambda t: None if t is None else t.contiguous()
+    cont = lambda t: None if t is None else t.to(torch.float32).contiguous()
     target, valid, sign, weight = cont(target), cont(valid), cont(sign), cont(weight)
     _lib.check(_lib.load().miso_mapping_loss(_LOSS_TYPES[loss_type], weight_sdf, weight_fs,
                                              0.0 if trunc_dist is None else trunc_dist, _ptr(pred),
                                              _ptr(target), _ptr(valid), _ptr(sign), _ptr(weight), n,
-                                             _ptr(grad_pred), _ptr(loss_out), _stream(pred)),
-               "miso_mapping_loss")
+                                             _ptr(grad_pred), _ptr(grad_pred_fs), _ptr(loss_out),
+                                             _stream(pred)), "miso_mapping_loss")
     return loss_out, grad_pred
 
 
 class _MappingLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, valid, sign, weight, loss_type, w_sdf, w_fs, trunc):
-        loss, gpred = mapping_loss_raw(pred, target, valid, sign, weight, loss_type, w_sdf, w_fs, trunc)
-        ctx.save_for_backward(gpred)
+        gfs = torch.empty_like(pred) if w_fs > 0 else None
+        loss, gpred = mapping_loss_raw(pred, target, valid, sign, weight, loss_type, w_sdf, w_fs, trunc,
+                                       grad_pred_fs=gfs)
+        ctx.save_for_backward(gpred, gfs)
         return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gl):
-        (gpred,) = ctx.saved_tensors
-        # both terms share d/d pred up to their weights, already folded into gpred; the
-        # cotangents of the two outputs are equal (the caller sums them) in MISO's use
-        return (gpred * gl[0], None, None, None, None, None, None, None, None)
+        gpred, gfs = ctx.saved_tensors
+        if gfs is None:
+            g = gpred * gl[0]
+        else:
+            g = (gpred - gfs) * gl[0] + gfs * gl[1]
+        return (g, None, None, None, None, None, None, None, None)
 
 
 def mapping_loss(pred, target, valid, sign, weight, loss_type="L1", weight_sdf=1.0, weight_fs=0.0,
                  trunc_dist=0.0):
-    """-> tensor([weight_sdf * sdf_term, weight_fs * free_space_term]); differentiable w.r.t.
-    pred provided both entries receive the same cotangent (they are summed by the trainer,
-    grid_opt/trainer.py:208-212)."""
+    """-> tensor([weight_sdf * sdf_term, weight_fs * free_space_term]), differentiable w.r.t. pred."""
     return _MappingLoss.apply(pred, target, valid, sign, weight, loss_type, weight_sdf, weight_fs,
                               trunc_dist)

@@ -21,3 +21,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=["oracle-cpu", pytest.param("hip", marks=pytest.mark.gpu)])
+def device_backend(request, monkeypatch):
+    """Device string for tests of the host-side mirror: on CPU the HIP operators are replaced
+    by the oracle (test-only stand-ins, tests/oracle_backend.py); on the GPU box the real
+    library runs."""
+    if request.param == "oracle-cpu":
+        import oracle_backend
+        oracle_backend.install(monkeypatch)
+        return "cpu"
+    return "cuda:0"
