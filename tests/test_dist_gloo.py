@@ -1,0 +1,127 @@
+"""world_size-2 tests of the submap-parallel layer on CPU (gloo).  The HIP operators are
+replaced by the oracle stand-ins (tests/oracle_backend.py) inside every worker: what is
+tested here is the sharding / collective logic, not the kernels."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Patch:
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import oracle_backend
+    oracle_backend.install(_Patch())
+    import golden_cases as gc
+    from test_grid_opt_mirror import make_atlas
+    from miso_amd import dist as mdist
+    import miso_amd.grid_opt.align.miso as AM
+    r, w = mdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    c = gc.ATLAS
+    atlas = make_atlas("cpu")
+    # --- mapping shard: every rank perturbs ONLY its own submaps, then sync ----------------
+    assert mdist.owned_submaps(3) == ([0, 2] if rank == 0 else [1])
+
+    def map_one(s):
+        with torch.no_grad():
+            for g in atlas.get_submap(s).features:
+                g.feature.add_(0.01 * (s + 1))
+    before = [[g.feature.detach().clone() for g in atlas.get_submap(s).features] for s in range(3)]
+    mdist.map_submaps_parallel(atlas, map_one, sync=True)
+    for s in range(3):
+        for g, b in zip(atlas.get_submap(s).features, before[s]):
+            torch.testing.assert_close(g.feature.detach(), b + 0.01 * (s + 1))
+            assert g.feature.is_contiguous(memory_format=torch.channels_last_3d)
+    with torch.no_grad():   # undo, so that the alignment below matches the golden atlas
+        for s in range(3):
+            for g, b in zip(atlas.get_submap(s).features, before[s]):
+                g.feature.copy_(b)
+    # --- alignment: pairs sharded, one all-reduce per iteration ------------------------------
+    atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+    assert mdist.partition_pairs([(0, 1), (0, 2), (1, 2)]) == ([(0, 1), (1, 2)] if rank == 0 else [(0, 2)])
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return 0
+
+    res = {}
+    for l in range(c["n_levels"]):
+        tup = (f"latent{l}", lambda at, ld, a, b, _l=l: AM.pairwise_loss_latent(
+            at, ld, a, b, level=_l, fdim=c["fdim"], align_loss="L2", device="cpu"))
+        mdist.align_multiple_submaps_distributed(atlas, DS(), tup, num_iters=3, lr=1e-2,
+                                                 pose_reg_weight=1.0, pose_thresh_rad=1e-3, pose_thresh_m=1e-3)
+        res[f"dr{l}"] = torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy()
+        res[f"dt{l}"] = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_submap_parallel_world2_matches_single_process(tmp_path, monkeypatch):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "rank0.npz")
+    b = np.load(tmp_path / "rank1.npz")
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k])     # replicas stay bit-identical
+    # single-process reference run of the same loop (with the same regulariser)
+    sys.path.insert(0, HERE)
+    import oracle_backend
+    oracle_backend.install(monkeypatch)
+    import golden_cases as gc
+    from test_grid_opt_mirror import make_atlas
+    import miso_amd.grid_opt.align.base as AB
+    import miso_amd.grid_opt.align.miso as AM
+    c = gc.ATLAS
+    atlas = make_atlas("cpu")
+    atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return 0
+
+    for l in range(c["n_levels"]):
+        tup = (f"latent{l}", lambda at, ld, x, y, _l=l: AM.pairwise_loss_latent(
+            at, ld, x, y, level=_l, fdim=c["fdim"], align_loss="L2", device="cpu"))
+        AB.generic_align_multiple_submaps(atlas, DS(), tup, num_iters=3, lr=1e-2, verbose=False,
+                                          pose_reg_weight=1.0, pose_thresh_rad=1e-3, pose_thresh_m=1e-3)
+        dr = torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy()
+        dt = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
+        np.testing.assert_allclose(a[f"dr{l}"], dr, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(a[f"dt{l}"], dt, rtol=0, atol=2e-5)
+
+
+def test_shard_helpers():
+    from miso_amd import dist as mdist
+    assert mdist.owned_submaps(8, rank=3, world=8) == [3]
+    assert mdist.owned_submaps(8, rank=1, world=4) == [1, 5]
+    assert mdist.owned_submaps(3, rank=0, world=1) == [0, 1, 2]
+    pairs = [(a, b) for a in range(8) for b in range(a + 1, 8)]
+    parts = [mdist.partition_pairs(pairs, r, 8) for r in range(8)]
+    assert sorted(sum(parts, [])) == pairs and max(map(len, parts)) - min(map(len, parts)) <= 1

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/profile_bench.sh into the committed summaries:
+profiles/<tag>_kernel_stats.csv (verbatim --stats table) and
+profiles/<tag>_pmc_summary.json (per kernel: FETCH_SIZE / WRITE_SIZE averages and HBM bytes
+per launch).  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters
+are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes actually fetched, so
+hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(f"{src}/trace/bench_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+
+
+def short(name):
+    m = re.search(r"(?:miso::)?(\w+)(?:<|\()", name.replace("void ", ""))
+    return m.group(1) if m else name[:40]
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for kind in ("fetch", "write"):
+    path = f"{src}/pmc_{kind}/bench_counter_collection.csv"
+    for r in csv.DictReader(open(path)):
+        if "miso::" not in r["Kernel_Name"]:
+            continue
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, d in acc.items():
+    f = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1) if d.get("FETCH_SIZE") else 0.0
+    w = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1) if d.get("WRITE_SIZE") else 0.0
+    out[k] = {"FETCH_SIZE_KiB_avg": f, "WRITE_SIZE_KiB_avg": w, "launches_sampled": len(d.get("FETCH_SIZE", [])),
+              "hbm_bytes_per_launch": (2 * f + w) * 1024,
+              "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halving, KiB units)"}
+json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))
