@@ -150,9 +150,13 @@ int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t
 int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, float* sdf, uint32_t* relu_mask,
                         void* stream);
+/* workspace (16-B aligned, miso_sdf_bwd_workspace_floats floats, may be NULL): with it the
+ * coarse levels' gradient is pre-reduced per tile on chip (tile_reduce.hip) instead of one
+ * atomic request per point and corner row. */
+int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n);
 int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,
-                        const uint32_t* relu_mask, float* grad_x, void* stream);
+                        const uint32_t* relu_mask, float* grad_x, float* workspace, void* stream);
 
 /* --- mapping loss (value + d/d pred) --------------------------------------
  * loss_type 1 = L1, 2 = L2.  pred/target (N); valid/sign/weight (N) or NULL

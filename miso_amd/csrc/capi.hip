@@ -14,8 +14,20 @@ bool fused_shape_supported(int C, int L, int H, int NH);
 hipError_t launch_sdf_fwd(int, int, int, int, const GridK&, const float*, const float*, int64_t, float*,
                           uint32_t*, const int*, hipStream_t);
 hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const float*, int64_t,
-                          const float*, const uint32_t*, float*, bool, const int*, const int*, int,
+                          const float*, const uint32_t*, float*, bool, const int*, float*, uint32_t,
                           hipStream_t);
+struct TileRed {
+  int T;
+  const int* tile_off;
+  uint32_t level_mask;
+  int nd;
+  int lev[MISO_MAX_LEVELS];
+  int W[MISO_MAX_LEVELS][3];
+  int acc_off[MISO_MAX_LEVELS];
+  int acc_total;
+};
+uint32_t plan_tile_reduce(const GridK&, int, TileRed*, int);
+hipError_t launch_tile_reduce(const GridK&, TileRed, const int*, const float*, const float*, int, hipStream_t);
 int64_t sort_workspace_bytes(int64_t n, int T);
 hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, int*, int*, hipStream_t);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
@@ -186,9 +198,14 @@ static int sdf_fwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, perm, (hipStream_t)stream);
 }
 
+// per-wave LDS budget (floats) of the tile reduction: 8 waves per CU in 160 KiB with the
+// staging buffers next to the accumulators
+static const int kTileBudgetFloats = 3584;
+
 static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
-                        float* grad_x, const int* perm, const int* tile_off, int T, void* stream) {
+                        float* grad_x, const int* perm, const int* tile_off, int T, float* workspace,
+                        void* stream) {
   if (n < 0 || !packed || (n > 0 && (!x || !grad_sdf || !relu_mask))) return MISO_E_BADARG;
   if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
   GridK g; bool v4;
@@ -200,8 +217,14 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   bool want_grid = false;
   for (int l = 0; l < g.n_levels; ++l) want_grid = want_grid || (g.lv[l].grad != nullptr);
   if (!want_grid && !grad_x) return MISO_OK;
-  return (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
-                             tile_off, T, (hipStream_t)stream);
+  TileRed tr;
+  uint32_t defer = 0;
+  const bool binned = perm && tile_off && workspace && want_grid && ((uintptr_t)workspace & 15u) == 0;
+  if (binned) defer = plan_tile_reduce(g, T, &tr, kTileBudgetFloats);
+  rc = (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
+                           defer ? workspace : nullptr, defer, (hipStream_t)stream);
+  if (rc || !defer) return rc;
+  return (int)launch_tile_reduce(g, tr, tile_off, x, workspace, C, (hipStream_t)stream);
 }
 
 int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
@@ -212,7 +235,8 @@ int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
 int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
                  int64_t n, const float* grad_sdf, const uint32_t* relu_mask, float* grad_x,
                  void* stream) {
-  return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, 0, stream);
+  return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, 0, nullptr,
+                      stream);
 }
 
 static int check_sorted(const miso_sorted_t* s) {
@@ -246,13 +270,19 @@ int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   return sdf_fwd_impl(grid, mlp, packed, sorted->x_sorted, n, sdf, relu_mask, sorted->perm, stream);
 }
 
+int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n) {
+  GridK g;
+  if (n < 0 || convert_grid(grid, &g, false, nullptr)) return 0;
+  return n * g.F;
+}
+
 int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,
-                        const uint32_t* relu_mask, float* grad_x, void* stream) {
+                        const uint32_t* relu_mask, float* grad_x, float* workspace, void* stream) {
   int rc = check_sorted(sorted);
   if (rc) return rc;
   return sdf_bwd_impl(grid, mlp, packed, sorted->x_sorted, n, grad_sdf, relu_mask, grad_x, sorted->perm,
-                      sorted->tile_offsets, sorted->tiles_per_axis, stream);
+                      sorted->tile_offsets, sorted->tiles_per_axis, workspace, stream);
 }
 
 int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,

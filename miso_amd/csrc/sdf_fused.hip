@@ -303,8 +303,12 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
                                                         const float* __restrict__ gsdf,
                                                         const uint32_t* __restrict__ mask,
                                                         float* __restrict__ gx,
-                                                        const int* __restrict__ perm, int debug) {
+                                                        const int* __restrict__ perm, int debug,
+                                                        float* __restrict__ dfeat_out,
+                                                        uint32_t defer_mask) {
   // perm != nullptr: x and mask are in tile-sorted order, gsdf / gx in the caller's.
+  // dfeat_out != nullptr: rows of d(feats) (N,F, sorted order) are written out and the levels in
+  // defer_mask are NOT scattered here: tile_reduce_kernel pre-reduces them per spatial tile.
   // debug: ablation switches (MISO_DEBUG_BWD, dev only): 1 = no atomics, 8 = no scatter.
   constexpr int F = C * L, RT = H / 32, KS1 = H / 2;
   constexpr int MW = (NH + 1) * RT;
@@ -436,6 +440,16 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (dfeat_out) {
+        // the chunk's 64 rows are contiguous in the (N,F) buffer: coalesced 16-B stores
+        float* dst = dfeat_out + chunk * 64 * F;
+        const int64_t rows_left = n - chunk * 64;
+        for (int i = lane; i < 64 * F / 4; i += 64) {
+          const int row = (i * 4) / F, col = (i * 4) % F;
+          if (row < rows_left)
+            *reinterpret_cast<float4*>(dst + row * F + col) = *reinterpret_cast<const float4*>(dF + row * FP + col);
+        }
+      }
       constexpr int LPR = 2 * C, SLOTS = 64 / LPR;
       const int slot = lane / LPR, dx = (lane / C) & 1, ch = lane % C;
 #pragma unroll 1
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
 #pragma unroll
         for (int l = 0; l < L; ++l) {
           const LevelK& lv = g.lv[l];
-          if (!lv.grad || ((g.ignore_mask >> l) & 1u)) continue;
+          if (!lv.grad || ((g.ignore_mask >> l) & 1u) || ((defer_mask >> l) & 1u)) continue;
           const int* r = rec + (pt * L + l) * REC;
           const int4 r0 = *reinterpret_cast<const int4*>(r);
           const int4 r1 = *reinterpret_cast<const int4*>(r + 4);
@@ -550,7 +564,7 @@ static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float*
 template <int C, int L, int H, int NH>
 static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
                                const float* gsdf, const uint32_t* mask, float* gx, bool want_grid,
-                               const int* perm, hipStream_t s) {
+                               const int* perm, float* dfeat_out, uint32_t defer_mask, hipStream_t s) {
   PackLayout pl(C * L, H, NH);
   constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4, WAVE_LDS = 64 * FP + 64 * L * 8;
   size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * WAVE_LDS : 0)) * sizeof(float);
@@ -559,13 +573,14 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   if (blocks > 512u) blocks = 512u;
   int debug = 0;
   if (const char* d = getenv("MISO_DEBUG_BWD")) debug = atoi(d);
-  void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*, const int*, int) =
+  void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*, const int*, int,
+            float*, uint32_t) =
       (want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true>
       : want_grid       ? sdf_bwd_kernel<C, L, H, NH, true, false>
                         : sdf_bwd_kernel<C, L, H, NH, false, true>;
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
-  k<<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx, perm, debug);
+  k<<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx, perm, debug, dfeat_out, defer_mask);
   return hipGetLastError();
 }
 
@@ -594,13 +609,12 @@ hipError_t launch_sdf_fwd(int C, int L, int H, int NH, const GridK& g, const flo
 
 hipError_t launch_sdf_bwd(int C, int L, int H, int NH, const GridK& g, const float* packed,
                           const float* x, int64_t n, const float* gsdf, const uint32_t* mask,
-                          float* gx, bool want_grid, const int* perm, const int* tile_off, int T,
-                          hipStream_t s) {
-  (void)tile_off; (void)T;
+                          float* gx, bool want_grid, const int* perm, float* dfeat_out,
+                          uint32_t defer_mask, hipStream_t s) {
   if (n == 0) return hipSuccess;
 #define X(c, l, h, nh) \
   if (C == c && L == l && H == h && NH == nh) \
-    return launch_bwd_t<c, l, h, nh>(g, packed, x, n, gsdf, mask, gx, want_grid, perm, s);
+    return launch_bwd_t<c, l, h, nh>(g, packed, x, n, gsdf, mask, gx, want_grid, perm, dfeat_out, defer_mask, s);
   MISO_FUSED_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;

@@ -320,6 +320,14 @@ class SortedBatch:
         self.struct.perm = self.perm.data_ptr()
         self.struct.tile_offsets = self.tile_offsets.data_ptr()
 
+    def bwd_workspace(self, floats: int) -> torch.Tensor:
+        """(N,F) d-feat rows handed from the MFMA backward to the per-tile reduction."""
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < floats:
+            ws = torch.empty(max(floats, 4), device=self.x_sorted.device, dtype=torch.float32)
+            self._ws = ws
+        return ws
+
     def sort(self, x: torch.Tensor, meta: GridMeta):
         _require_hip(x)
         x = x.contiguous()
@@ -377,9 +385,10 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
     gx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
     g = _fill_grid(features, meta, grads)
     if sorted_batch is not None:
+        ws = sorted_batch.bwd_workspace(n * _feature_dim(features)) if any(gr is not None for gr in grads) else None
         _lib.check(_lib.load().miso_sdf_bwd_sorted(C.byref(g), C.byref(m), _ptr(packed),
                                                    C.byref(sorted_batch.struct), n, _ptr(gsdf), _ptr(mask),
-                                                   _ptr(gx), _stream(x)), "miso_sdf_bwd_sorted")
+                                                   _ptr(gx), _ptr(ws), _stream(x)), "miso_sdf_bwd_sorted")
     else:
         _lib.check(_lib.load().miso_sdf_bwd(C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _ptr(gsdf),
                                             _ptr(mask), _ptr(gx), _stream(x)), "miso_sdf_bwd")
