@@ -6,8 +6,9 @@ Workload (BASELINE.json configs[1], "cfg-2"): one submap per GPU, 3-level
 (seeded random weights stand in for the unavailable decoder_indoor.pt), one
 batch of 262 144 uniform-in-bbox points per GPU per step, L1 regression loss,
 gradients to every grid level (decoder frozen, configs/rgbd/scannet.yaml:16).
-A step = clear grads -> fused forward -> loss -> fused backward, exactly K times
-inside the timed region (inputs resident in HBM).  Submaps are independent, so
+A step = bin the batch by spatial tile -> fused forward -> loss -> fused backward
+(MFMA pass + owner-computes gradient pull, which needs no zero-fill), exactly K
+times inside the timed region (inputs resident in HBM).  Submaps are independent, so
 N GPUs run N submaps with no data-path collective (weak scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -155,14 +156,33 @@ def main():
     # ---- per-kernel durations (HIP events on the launch stream) and roofline --------------------
     L = len(LEVELS)
     feats, meta, pack = step.features, step.meta, step.pack
-    mask = step._mask
-    t_fwd = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, True, out=step.sdf, mask=mask))
+    mask, sb = step._mask, step.sorted
+    t_sort = time_kernel(lambda: sb.sort(step.x, meta)) if sb is not None else 0.0
+    t_fwd = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, True, out=step.sdf, mask=mask,
+                                                sorted_batch=sb))
+    t_loss = time_kernel(lambda: ops.mapping_loss_raw(step.sdf, step.target, step.valid, step.sign, step.weight,
+                                                      "L1", 1.0, 0.0, 0.0, step.gpred, step.loss))
     t_bwd = time_kernel(lambda: ops.sdf_bwd_raw(step.x, feats, meta, pack, step.gpred, mask, False,
-                                                [True] * L, step.grads))
-    t_zero = time_kernel(lambda: [g.zero_() for g in step.grads])
+                                                [True] * L, step.grads, sorted_batch=sb, overwrite=True))
+    t_zero = time_kernel(lambda: [g.zero_() for g in step.grads]) if sb is None else 0.0
+    kernels_us = {"sort_points(3 launches)": t_sort, "sdf_fwd_kernel": t_fwd, "mapping_loss_kernel": t_loss,
+                  "backward(sdf_bwd_kernel + grad_pull_kernel)" if sb is not None else "sdf_bwd_kernel": t_bwd,
+                  "zero_grads": t_zero}
     b_fwd = 12 + 32 * L * C + 4        # xyz + 8 corners x C x 4 B per level + sdf
     b_bwd = 4 + 32 * L * C             # dL/dsdf + grad scatter counted once as a write
-    dom = ("sdf_bwd_kernel", t_bwd, b_bwd) if t_bwd >= t_fwd else ("sdf_fwd_kernel", t_fwd, b_fwd)
+    dom = ("sdf_bwd_kernel", t_bwd, b_bwd)
+    if sb is not None:
+        # the backward is two launches: the MFMA pass that leaves the d-feat rows in the workspace,
+        # and the owner-computes pull that forms the grid gradient from them; time the pull alone
+        ws = sb.bwd_workspace(N_POINTS * L * C)
+        t_pull = time_kernel(lambda: ops.grad_pull_raw(feats, meta, sb, ws, step.grads, overwrite=True))
+        kernels_us["grad_pull_kernel"] = t_pull
+        kernels_us["sdf_bwd_kernel(MFMA pass)"] = t_bwd - t_pull
+        # algorithmic bytes of the pull: the gradient of 8 corners x C channels per level, counted
+        # once as a write (SURVEY 8d backward figure without the 4 B of dL/dsdf the MFMA pass reads)
+        dom = ("grad_pull_kernel", t_pull, 32 * L * C)
+    if t_fwd > dom[1]:
+        dom = ("sdf_fwd_kernel", t_fwd, b_fwd)
     achieved = N_POINTS * dom[2] / (dom[1] * 1e-6) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
@@ -171,8 +191,7 @@ def main():
             traffic = json.load(open(pmc)).get(dom[0], {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic,
+    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes_per_point": dom[2], "kernel_us": dom[1]}
 
     out = {
@@ -187,7 +206,8 @@ def main():
                    "decoder": [C * L, HIDDEN, HIDDEN, 1], "parallelism": f"submap-parallel x{world}"},
         "roofline": roofline,
         "step_fraction_of_hbm_roofline": value / world * (20 + 64 * L * C) / 8e12,
-        "kernels_us": {"sdf_fwd_kernel": t_fwd, "sdf_bwd_kernel": t_bwd, "zero_grads": t_zero},
+        "kernels_us": kernels_us,
+        "binned": sb is not None,
     }
     if world == 1 and not args.no_cpu_baseline:
         cb, pred_cpu = cpu_baseline(data)

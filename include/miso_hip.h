@@ -58,6 +58,8 @@ extern "C" {
 #define MISO_F_ALIGN_CORNERS 1u    /* grid_sample align_corners=True (MISO uses False) */
 #define MISO_F_PAD_BORDER 2u       /* padding_mode='border' (MISO uses 'zeros') */
 #define MISO_F_COORDS_NORMALIZED 4u /* x is already in [-1,1]: skip normalize_coordinates */
+#define MISO_F_GRAD_OVERWRITE 8u    /* miso_sdf_bwd_sorted: level[l].grad = sum instead of += (the library
+                                       clears what it still scatters; the caller never zero-fills) */
 
 /* One feature-grid level: logical tensor (1,C,Z,Y,X) (grid_modules.py:54-57)
  * with arbitrary element strides, so both the reference's NCDHW layout and the
@@ -139,20 +141,32 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
 typedef struct {
   int32_t tiles_per_axis;      /* 1..16 */
   const float* x_sorted;       /* (N,3) points grouped by tile                   */
+  const float* xn_sorted;      /* (N,4) the same normalised to [-1,1] as {x,y,z,0}, 16-B aligned; NULL = absent */
   const int32_t* perm;         /* (N) sorted position -> original index          */
   const int32_t* tile_offsets; /* (tiles^3 + 1) start of every tile in x_sorted  */
 } miso_sorted_t;
 
 int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis);
 int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,
-                     void* workspace, float* x_sorted, int32_t* perm, int32_t* tile_offsets,
-                     void* stream);
+                     void* workspace, float* x_sorted, float* xn_sorted /* may be NULL */,
+                     int32_t* perm, int32_t* tile_offsets, void* stream);
 int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, float* sdf, uint32_t* relu_mask,
                         void* stream);
-/* workspace (16-B aligned, miso_sdf_bwd_workspace_floats floats, may be NULL): with it the
- * coarse levels' gradient is pre-reduced per tile on chip (tile_reduce.hip) instead of one
- * atomic request per point and corner row. */
+/* The owner-computes gradient on its own: dfeat (N,F) = rows of d loss / d feats in the
+ * binned order (what miso_sdf_bwd_sorted leaves in its workspace) -> level[l].grad for every
+ * level with a non-NULL grad (all of them must be pullable: <= 8 vertices per tile and axis,
+ * default sampling flags, C in {4,8}), written (MISO_F_GRAD_OVERWRITE) or accumulated.
+ * Replaces the grad_input half of aten::grid_sampler_3d_backward
+ * (third_party/cuda_gridsample_grad2/cuda_gridsample.py:102-105) without atomics. */
+int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
+                   void* stream);
+
+/* workspace (16-B aligned, miso_sdf_bwd_workspace_floats floats, may be NULL): with it and
+ * sorted->xn_sorted the grid gradient is formed owner-computes (grad_pull.hip): every tile
+ * gathers the contributions to the vertices it owns and writes them once, without atomics.
+ * Levels the pull cannot own (more than 8 vertices per tile and axis, non-default sampling
+ * flags) keep the atomic scatter. */
 int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n);
 int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,

@@ -22,6 +22,7 @@ MAX_LINEAR = 4
 F_ALIGN_CORNERS = 1
 F_PAD_BORDER = 2
 F_COORDS_NORMALIZED = 4
+F_GRAD_OVERWRITE = 8
 
 E_UNSUPPORTED = 2002
 
@@ -45,8 +46,8 @@ class Mlp(C.Structure):
 
 
 class Sorted(C.Structure):
-    _fields_ = [("tiles_per_axis", C.c_int32), ("x_sorted", C.c_void_p), ("perm", C.c_void_p),
-                ("tile_offsets", C.c_void_p)]
+    _fields_ = [("tiles_per_axis", C.c_int32), ("x_sorted", C.c_void_p), ("xn_sorted", C.c_void_p),
+                ("perm", C.c_void_p), ("tile_offsets", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/miso_hip.h declares
@@ -70,9 +71,10 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_sort_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "miso_sort_points": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_sdf_fwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted),
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_grad_pull": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_void_p]),
     "miso_sdf_bwd_workspace_floats": (C.c_int64, [C.POINTER(Grid), C.c_int64]),
     "miso_sdf_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted),
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

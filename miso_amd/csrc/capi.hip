@@ -16,20 +16,12 @@ hipError_t launch_sdf_fwd(int, int, int, int, const GridK&, const float*, const 
 hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const float*, int64_t,
                           const float*, const uint32_t*, float*, bool, const int*, float*, uint32_t,
                           hipStream_t);
-struct TileRed {
-  int T;
-  const int* tile_off;
-  uint32_t level_mask;
-  int nd;
-  int lev[MISO_MAX_LEVELS];
-  int W[MISO_MAX_LEVELS][3];
-  int acc_off[MISO_MAX_LEVELS];
-  int acc_total;
-};
-uint32_t plan_tile_reduce(const GridK&, int, TileRed*, int);
-hipError_t launch_tile_reduce(const GridK&, TileRed, const int*, const float*, const float*, int, hipStream_t);
 int64_t sort_workspace_bytes(int64_t n, int T);
-hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, int*, int*, hipStream_t);
+hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, float*, int*, int*,
+                       hipStream_t);
+uint32_t plan_grad_pull(const GridK&, int);
+hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, uint32_t, int,
+                            hipStream_t);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
 int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
@@ -47,12 +39,12 @@ enum Need { NEED_DATA = 1, NEED_GRAD_OPT = 2 };
 
 int convert_grid(const miso_grid_t* in, GridK* out, bool need_data, bool* vec4) {
   if (!in || in->n_levels < 1 || in->n_levels > MISO_MAX_LEVELS) return MISO_E_BADARG;
-  if (in->flags & ~(MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER | MISO_F_COORDS_NORMALIZED))
+  if (in->flags & ~(MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER | MISO_F_COORDS_NORMALIZED | MISO_F_GRAD_OVERWRITE))
     return MISO_E_BADARG;
   memset(out, 0, sizeof(*out));
   out->n_levels = in->n_levels;
   out->ignore_mask = in->ignore_mask;
-  out->flags = in->flags;
+  out->flags = in->flags & ~MISO_F_GRAD_OVERWRITE;   // host-side flag
   for (int a = 0; a < 3; ++a) { out->bmin[a] = in->bound_min[a]; out->bmax[a] = in->bound_max[a]; }
   bool v4 = true;
   int foff = 0;
@@ -198,14 +190,9 @@ static int sdf_fwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, perm, (hipStream_t)stream);
 }
 
-// per-wave LDS budget (floats) of the tile reduction: 8 waves per CU in 160 KiB with the
-// staging buffers next to the accumulators
-static const int kTileBudgetFloats = 3584;
-
 static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
-                        float* grad_x, const int* perm, const int* tile_off, int T, float* workspace,
-                        void* stream) {
+                        float* grad_x, const miso_sorted_t* sorted, float* workspace, void* stream) {
   if (n < 0 || !packed || (n > 0 && (!x || !grad_sdf || !relu_mask))) return MISO_E_BADARG;
   if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
   GridK g; bool v4;
@@ -217,14 +204,32 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   bool want_grid = false;
   for (int l = 0; l < g.n_levels; ++l) want_grid = want_grid || (g.lv[l].grad != nullptr);
   if (!want_grid && !grad_x) return MISO_OK;
-  TileRed tr;
-  uint32_t defer = 0;
-  const bool binned = perm && tile_off && workspace && want_grid && ((uintptr_t)workspace & 15u) == 0;
-  if (binned) defer = plan_tile_reduce(g, T, &tr, kTileBudgetFloats);
-  rc = (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
-                           defer ? workspace : nullptr, defer, (hipStream_t)stream);
-  if (rc || !defer) return rc;
-  return (int)launch_tile_reduce(g, tr, tile_off, x, workspace, C, (hipStream_t)stream);
+  const bool overwrite = (grid->flags & MISO_F_GRAD_OVERWRITE) != 0;
+  const int* perm = sorted ? sorted->perm : nullptr;
+  uint32_t pull = 0;
+  if (sorted && sorted->xn_sorted && workspace && want_grid && ((uintptr_t)workspace & 15u) == 0)
+    pull = plan_grad_pull(g, sorted->tiles_per_axis);
+  hipStream_t st = (hipStream_t)stream;
+  if (overwrite) {
+    // levels that are still scattered with atomics start from zero; pulled levels need no fill
+    for (int l = 0; l < g.n_levels; ++l) {
+      const LevelK& lv = g.lv[l];
+      if (!lv.grad || ((pull >> l) & 1u)) continue;
+      size_t span = (size_t)(lv.C - 1) * lv.sC + (size_t)(lv.X - 1) * lv.sX + (size_t)(lv.Y - 1) * lv.sY +
+                    (size_t)(lv.Z - 1) * lv.sZ + 1;
+      hipError_t e = hipMemsetAsync(lv.grad, 0, span * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  if (n == 0 && !pull) return MISO_OK;
+  if (n > 0) {
+    rc = (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
+                             pull ? workspace : nullptr, pull, st);
+    if (rc) return rc;
+  }
+  if (!pull) return MISO_OK;
+  return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace,
+                               pull, overwrite ? 1 : 0, st);
 }
 
 int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
@@ -235,8 +240,7 @@ int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
 int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
                  int64_t n, const float* grad_sdf, const uint32_t* relu_mask, float* grad_x,
                  void* stream) {
-  return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, 0, nullptr,
-                      stream);
+  return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, stream);
 }
 
 static int check_sorted(const miso_sorted_t* s) {
@@ -251,14 +255,14 @@ int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis) {
 }
 
 int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,
-                     void* workspace, float* x_sorted, int32_t* perm, int32_t* tile_offsets,
-                     void* stream) {
+                     void* workspace, float* x_sorted, float* xn_sorted, int32_t* perm,
+                     int32_t* tile_offsets, void* stream) {
   if (n < 0 || n >= ((int64_t)1 << 31) || tiles_per_axis < 1 || tiles_per_axis > 16) return MISO_E_BADARG;
   if (!workspace || !tile_offsets || (n > 0 && (!x || !x_sorted || !perm))) return MISO_E_BADARG;
   GridK g;
   int rc = convert_grid(grid, &g, false, nullptr);
   if (rc) return rc;
-  return (int)launch_sort(g, x, n, tiles_per_axis, workspace, x_sorted, perm, tile_offsets,
+  return (int)launch_sort(g, x, n, tiles_per_axis, workspace, x_sorted, xn_sorted, perm, tile_offsets,
                           (hipStream_t)stream);
 }
 
@@ -268,6 +272,26 @@ int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   int rc = check_sorted(sorted);
   if (rc) return rc;
   return sdf_fwd_impl(grid, mlp, packed, sorted->x_sorted, n, sdf, relu_mask, sorted->perm, stream);
+}
+
+int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
+                   void* stream) {
+  int rc = check_sorted(sorted);
+  if (rc) return rc;
+  if (n < 0 || !sorted->xn_sorted || !dfeat || ((uintptr_t)dfeat & 15u) != 0) return MISO_E_BADARG;
+  GridK g; bool v4;
+  rc = convert_grid(grid, &g, false, &v4);
+  if (rc) return rc;
+  if (!v4) return MISO_E_UNSUPPORTED;
+  const int C = g.lv[0].C;
+  for (int l = 0; l < g.n_levels; ++l)
+    if (g.lv[l].C != C) return MISO_E_UNSUPPORTED;
+  if (C != 4 && C != 8) return MISO_E_UNSUPPORTED;
+  const uint32_t pull = plan_grad_pull(g, sorted->tiles_per_axis);
+  for (int l = 0; l < g.n_levels; ++l)
+    if (g.lv[l].grad && !((pull >> l) & 1u)) return MISO_E_UNSUPPORTED;   // every requested level must be pullable
+  return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, dfeat, pull,
+                               (grid->flags & MISO_F_GRAD_OVERWRITE) ? 1 : 0, (hipStream_t)stream);
 }
 
 int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n) {
@@ -281,8 +305,8 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
                         const uint32_t* relu_mask, float* grad_x, float* workspace, void* stream) {
   int rc = check_sorted(sorted);
   if (rc) return rc;
-  return sdf_bwd_impl(grid, mlp, packed, sorted->x_sorted, n, grad_sdf, relu_mask, grad_x, sorted->perm,
-                      sorted->tile_offsets, sorted->tiles_per_axis, workspace, stream);
+  return sdf_bwd_impl(grid, mlp, packed, sorted->x_sorted, n, grad_sdf, relu_mask, grad_x, sorted, workspace,
+                      stream);
 }
 
 int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,

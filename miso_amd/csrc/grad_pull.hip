@@ -1,0 +1,401 @@
+// Owner-computes grid gradient ("pull"): the second half of the binned backward.
+//
+// The scatter formulation of the reference (one atomic per point, corner and channel,
+// third_party/cuda_gridsample_grad2/gridsample_cuda.cu:466-481; ATen does the same) is bound
+// on MI355X by the L2's fp32 atomic request rate (~21 G requests/s, tools/ubench/atomics.hip)
+// and ds_add_f32 in LDS serialises (tools/ubench/lds_atomics.hip).  With the batch binned
+// into T^3 spatial tiles (sort.hip) the sum can be turned around:
+//
+//   every tile OWNS the vertices of every level that lie inside it; one wavefront per tile
+//   (1) sweeps the points of its 3x3x3 tile neighbourhood and compacts those whose cell
+//       touches an owned vertex into a list (ballot + prefix popcount: deterministic order),
+//   (2) bins the list by cell with an LDS counting sort (integer LDS atomics are full rate),
+//       staging (frac_x, frac_y, frac_z) and the level's d-feat row next to each other,
+//   (3) lets every lane PULL: lane = owned vertex, loop over its 8 adjacent cells' short
+//       lists, accumulate w * d-feat in registers -- no atomics, no write conflicts,
+//   (4) writes each owned vertex exactly once with plain 16-B stores (dense, coalesced).
+//
+// So the gradient needs no zero-fill, no atomics, and is bit-reproducible for a given
+// sorted order.  d-feat rows come from sdf_bwd_kernel (dfeat_out); normalised coordinates
+// from sort_scatter_kernel (xn_sorted), so no division is repeated here.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace miso {
+
+constexpr int PULL_BMAX = 8;      // owned vertices per axis per tile
+constexpr int PULL_ARR = 736;     // (8+1)^3 = 729 cells, padded
+constexpr int PULL_LIST = 320;    // compacted candidate ids per level
+constexpr int PULL_CAP = 192;     // staged records per group (3 per lane)
+constexpr int PULL_MAXL = 4;      // levels swept together (the fused kernels cover <= 4 levels)
+
+struct PullK {
+  int T;
+  const int* tile_off;   // T^3 + 1
+  const float4* xn;      // (N) normalised coordinates {x,y,z,_}, tile-sorted
+  const float* dfeat;    // (N,F) d-feat rows, tile-sorted
+  int nl;                // number of pulled levels
+  int lev[PULL_MAXL];    // their indices
+  int overwrite;         // 1: grad = sum (no zero-fill needed), 0: grad += sum
+  int debug;             // ablation (MISO_DEBUG_PULL, dev only): 1 no pull loop, 2 no groups, 4 no sweep
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) {   // b > 0
+  int q = a / b;
+  return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+
+// continuous index from the normalised coordinate, op for op as common.hpp:axis_coord
+__device__ __forceinline__ void cell_of(float xn, int size, int& i0, float& frac) {
+  float pos = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(xn, 1.0f), (float)size), 1.0f), 0.5f);  // == /2 exactly
+  float f = fminf(fmaxf(floorf(pos), -2.0f), (float)size + 1.0f);
+  i0 = (pos == pos) ? (int)f : -2;
+  frac = __fsub_rn(pos, f);
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Owned brick of one (tile, level): wave-uniform scalars.
+struct Brick {
+  int v0[3], B[3];
+  int nverts;
+};
+
+__device__ __forceinline__ Brick make_brick(const LevelK& lv, int ta, int tb, int tc, int T) {
+  Brick b;
+  b.v0[0] = ta * lv.X / T; b.v0[1] = tb * lv.Y / T; b.v0[2] = tc * lv.Z / T;
+  b.B[0] = (ta + 1) * lv.X / T - b.v0[0]; b.B[1] = (tb + 1) * lv.Y / T - b.v0[1];
+  b.B[2] = (tc + 1) * lv.Z / T - b.v0[2];
+  b.nverts = b.B[0] * b.B[1] * b.B[2];
+  return b;
+}
+
+// Bin `n` listed candidates of one level by cell, pull them into the brick's vertices and store
+// the brick (steps 2-4 of the file comment).  `add`: accumulate onto what is already stored.
+template <int C>
+__device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, const LevelK& lv, const Brick& b,
+                                           float* smem, int o_list, int n, int o_arr, int o_rec, int o_df,
+                                           int lane, bool add) {
+  int* ismem = reinterpret_cast<int*>(smem);
+  const int vx0 = b.v0[0], vy0 = b.v0[1], vz0 = b.v0[2], Bx = b.B[0], By = b.B[1];
+  const int nverts = b.nverts;
+  const int ncx = Bx + 1, ncy = By + 1, ncz = b.B[2] + 1, ncells = ncx * ncy * ncz;
+  // lane roles.  Bricks of <= 8 vertices: 8 lanes per vertex, one adjacent cell each, reduced
+  // at the end; otherwise one lane per vertex in rounds of 64 vertices.
+  const bool lpv8 = nverts <= 8;
+  const int nrounds = lpv8 ? 1 : (nverts + 63) / 64;
+  // exact division of indices < 512 by B <= 8 through a 16-bit reciprocal
+  const int inv_bx = (65536 + Bx - 1) / Bx, inv_by = (65536 + By - 1) / By;
+  float acc[PULL_BMAX][C];
+#pragma unroll
+  for (int r = 0; r < PULL_BMAX; ++r)
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[r][c] = 0.0f;
+
+  for (int g0 = 0; g0 < n && !(pk.debug & 2); g0 += PULL_CAP) {
+    const int gn = min(PULL_CAP, n - g0);
+    for (int i = lane * 4; i < ncells; i += 256)
+      *reinterpret_cast<int4*>(ismem + o_arr + i) = make_int4(0, 0, 0, 0);
+    wave_sync_lds();
+    // (2a) exact cell of every listed candidate (the sweep's box test is conservative), count
+    // per cell; the records stay in registers (<= 3 per lane)
+    constexpr int RPL = PULL_CAP / 64;
+    int rc[RPL], rp[RPL]; float rfx[RPL], rfy[RPL], rfz[RPL];
+#pragma unroll
+    for (int u = 0; u < RPL; ++u) {
+      const int i = u * 64 + lane;
+      rc[u] = -1;
+      if (i < gn) {
+        const int p = ismem[o_list + g0 + i];
+        const float4 c4 = pk.xn[p];
+        int i0, j0, k0;
+        cell_of(c4.x, lv.X, i0, rfx[u]); cell_of(c4.y, lv.Y, j0, rfy[u]); cell_of(c4.z, lv.Z, k0, rfz[u]);
+        const int ci = i0 - (vx0 - 1), cj = j0 - (vy0 - 1), ck = k0 - (vz0 - 1);
+        if ((unsigned)ci < (unsigned)ncx && (unsigned)cj < (unsigned)ncy && (unsigned)ck < (unsigned)ncz) {
+          rc[u] = (ck * ncy + cj) * ncx + ci;
+          rp[u] = p;
+          atomicAdd(&ismem[o_arr + rc[u]], 1);
+        }
+      }
+    }
+    wave_sync_lds();
+    // (2b) exclusive scan of the counts in place, 4 cells per lane
+    int carry = 0;
+    for (int c0 = 0; c0 < ncells; c0 += 256) {
+      const int i = c0 + lane * 4;
+      int4 v = make_int4(0, 0, 0, 0);
+      if (i < ncells) v = *reinterpret_cast<const int4*>(ismem + o_arr + i);
+      const int tot = v.x + v.y + v.z + v.w;
+      int inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+      }
+      const int ex = carry + inc - tot;
+      if (i < ncells)
+        *reinterpret_cast<int4*>(ismem + o_arr + i) = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+      carry += __builtin_amdgcn_readlane(inc, 63);
+    }
+    wave_sync_lds();
+    // (2c) fill: afterwards arr[c] = end of cell c = start of cell c+1
+#pragma unroll
+    for (int u = 0; u < RPL; ++u) {
+      if (rc[u] >= 0) {
+        const int pos = atomicAdd(&ismem[o_arr + rc[u]], 1);
+        *reinterpret_cast<float4*>(smem + o_rec + pos * 4) = make_float4(rfx[u], rfy[u], rfz[u], 0.0f);
+        const float* src = pk.dfeat + (int64_t)rp[u] * g.F + lv.foff;
+#pragma unroll
+        for (int c = 0; c < C; c += 4)
+          *reinterpret_cast<float4*>(smem + o_df + pos * C + c) = *reinterpret_cast<const float4*>(src + c);
+      }
+    }
+    wave_sync_lds();
+    // (3) pull.  Cells c-1 and c (x-neighbours) are adjacent in the cell order, so their records
+    // form ONE contiguous range: 4 loops (dy,dz) per vertex instead of 8.
+    if (!(pk.debug & 1)) {
+#pragma unroll
+      for (int r = 0; r < PULL_BMAX; ++r) {
+        if (r >= nrounds) continue;
+        const int vidx = lpv8 ? (lane >> 3) : r * 64 + lane;
+        if (vidx >= nverts) continue;
+        const int t_ = (vidx * inv_bx) >> 16, lx = vidx - t_ * Bx;      // vidx / Bx, vidx % Bx
+        const int lz = (t_ * inv_by) >> 16, ly = t_ - lz * By;
+        const int c_hi = ((lz + 1) * ncy + (ly + 1)) * ncx + (lx + 1);   // cell whose corner (0,0,0) is this vertex
+        int b0[4], b1[4], b2[4];   // start of cell c-1, end of c-1 (= start of c), end of c
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int dy = k & 1, dz = k >> 1;
+          const int c = c_hi - (dz * ncy + dy) * ncx;        // corner (dx=0, dy, dz); (dx=1) is c-1
+          b0[k] = (c >= 2) ? ismem[o_arr + c - 2] : 0;
+          b1[k] = ismem[o_arr + c - 1];
+          b2[k] = ismem[o_arr + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int dy = k & 1, dz = k >> 1;
+          int q0 = b0[k], q1 = b2[k];
+          if (lpv8) {               // this lane handles exactly one of the 8 corners
+            const int kk = lane & 7;
+            if ((kk >> 1) != k) { q0 = 0; q1 = 0; }
+            else if (kk & 1) q1 = b1[k];   // dx = 1: cell c-1 only
+            else q0 = b1[k];               // dx = 0: cell c only
+          }
+          for (int q = q0; q < q1; ++q) {
+            const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * 4);
+            const float wx = (q < b1[k]) ? f.x : 1.0f - f.x;    // record of cell c-1 => corner dx = 1
+            const float w = (wx * (dy ? f.y : 1.0f - f.y)) * (dz ? f.z : 1.0f - f.z);
+#pragma unroll
+            for (int cc = 0; cc < C; cc += 4) {
+              const float4 dv = *reinterpret_cast<const float4*>(smem + o_df + q * C + cc);
+              acc[r][cc + 0] += w * dv.x; acc[r][cc + 1] += w * dv.y;
+              acc[r][cc + 2] += w * dv.z; acc[r][cc + 3] += w * dv.w;
+            }
+          }
+        }
+      }
+    }
+    wave_sync_lds();
+  }
+  // ---- (4) store: every owned vertex exactly once per call ---------------------------------------
+  if (!lv.grad) return;
+  if (lpv8) {   // reduce the 8 lanes of a vertex
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float v = acc[0][c];
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+      acc[0][c] = v;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < PULL_BMAX; ++r) {
+    if (r >= nrounds) continue;
+    const int vidx = lpv8 ? (lane >> 3) : r * 64 + lane;
+    if (vidx >= nverts || (lpv8 && (lane & 7) != 0)) continue;
+    const int t_ = (vidx * inv_bx) >> 16, lx = vidx - t_ * Bx;
+    const int lz = (t_ * inv_by) >> 16, ly = t_ - lz * By;
+    float* dst = lv.grad + (vz0 + lz) * lv.sZ + (vy0 + ly) * lv.sY + (vx0 + lx) * lv.sX;
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+      float4 v = make_float4(acc[r][c], acc[r][c + 1], acc[r][c + 2], acc[r][c + 3]);
+      if (add) {
+        const float4 o = *reinterpret_cast<const float4*>(dst + c);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(dst + c) = v;
+    }
+  }
+}
+
+// One wavefront per spatial tile.  The 3x3x3 tile neighbourhood is swept ONCE for all pulled
+// levels (a candidate's coordinates are loaded once and tested against every level's box).
+template <int C, int NLV>
+__global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
+  constexpr int PULL_NLV = NLV;   // levels swept together
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // the wave index is uniform, but derived from threadIdx the compiler treats everything that
+  // depends on it (tile, bricks, loop counters) as divergent: VGPRs, exec-mask juggling, no scalar
+  // loads.  readfirstlane pins it (and the list lengths below) to SGPRs.
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARR + PULL_CAP * 4 + PULL_CAP * C;
+  const int o_list = wave * PER_WAVE, o_arr = o_list + PULL_NLV * PULL_LIST, o_rec = o_arr + PULL_ARR,
+            o_df = o_rec + PULL_CAP * 4;
+  int* ismem = reinterpret_cast<int*>(smem);
+  const int T = pk.T, ntiles = T * T * T;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int ta = tile % T, tb = (tile / T) % T, tc = tile / (T * T);
+    const int tabc[3] = {ta, tb, tc};
+    // catchment box of every level's brick in normalised coordinates: base corner i0 in
+    // [v0-1, v1-1] <=> pos in [v0-1, v1) <=> xn in [(2 v0 - 1)/X - 1, (2 v1 + 1)/X - 1), widened by
+    // a few ulps; and the union of the tile ranges that can hold such points
+    float blo[PULL_NLV][3], bhi[PULL_NLV][3];
+    int t_lo[3] = {T, T, T}, t_hi[3] = {-1, -1, -1};
+#pragma unroll
+    for (int d = 0; d < PULL_NLV; ++d) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { blo[d][a] = 3e30f; bhi[d][a] = -3e30f; }   // empty box
+      if (d >= pk.nl) continue;
+      const int lvl = pk.lev[d];
+      const LevelK& lv = g.lv[lvl];
+      const Brick b = make_brick(lv, ta, tb, tc, T);
+      if (b.nverts == 0 || ((g.ignore_mask >> lvl) & 1u)) continue;
+      const int size[3] = {lv.X, lv.Y, lv.Z};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        blo[d][a] = (2.0f * b.v0[a] - 1.0f) / size[a] - 1.0f - 8e-6f;
+        bhi[d][a] = (2.0f * (b.v0[a] + b.B[a]) + 1.0f) / size[a] - 1.0f + 8e-6f;
+        t_lo[a] = min(t_lo[a], max(0, floor_div((b.v0[a] - 1) * T, size[a])));
+        t_hi[a] = max(t_hi[a], min(T - 1, floor_div((b.v0[a] + b.B[a] + 1) * T, size[a])));
+      }
+    }
+    int nlist[PULL_NLV];
+#pragma unroll
+    for (int d = 0; d < PULL_NLV; ++d) nlist[d] = 0;
+    unsigned stored = 0;    // bit d: level d's brick has been stored once already
+    bool sweeping = (t_hi[0] >= t_lo[0]) && !(pk.debug & 4);
+    int tz = t_lo[2], ty = t_lo[1];
+    int p_cur = 0, p_end = 0;
+    if (sweeping) {
+      p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
+      p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
+    }
+    bool more = true;
+    while (more) {
+      // ---- (1) sweep: compact the contributing candidates per level (deterministic order) ------
+      while (sweeping) {
+        int room = PULL_LIST;
+#pragma unroll
+        for (int d = 0; d < PULL_NLV; ++d) room = min(room, PULL_LIST - nlist[d]);
+        if (room < 64) break;                     // a list is nearly full: flush first
+        if (p_cur >= p_end) {                     // next (ty, tz) row of tiles
+          if (++ty > t_hi[1]) { ty = t_lo[1]; ++tz; }
+          if (tz > t_hi[2]) { sweeping = false; break; }
+          p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
+          p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
+          continue;
+        }
+        // up to 4 steps (256 candidates) per trip, fixed BEFORE the loads so that all coordinate
+        // loads are in flight together: a row of tiles costs one memory round trip
+        constexpr int UN = 4;
+        const int nstep = __builtin_amdgcn_readfirstlane(min(min(UN, (p_end - p_cur + 63) / 64), room / 64));
+        float4 c4[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int p = p_cur + u * 64 + lane;
+          c4[u] = make_float4(2e30f, 2e30f, 2e30f, 0.f);   // outside every box
+          if (u < nstep && p < p_end) c4[u] = pk.xn[p];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          if (u >= nstep) continue;    // wave-uniform
+#pragma unroll
+          for (int d = 0; d < PULL_NLV; ++d) {
+            const bool inside = c4[u].x >= blo[d][0] && c4[u].x < bhi[d][0] && c4[u].y >= blo[d][1] &&
+                                c4[u].y < bhi[d][1] && c4[u].z >= blo[d][2] && c4[u].z < bhi[d][2];
+            const unsigned long long m = __ballot(inside);
+            if (inside) ismem[o_list + d * PULL_LIST + nlist[d] + __popcll(m & lt_mask)] = p_cur + u * 64 + lane;
+            nlist[d] = __builtin_amdgcn_readfirstlane(nlist[d] + (int)__popcll(m));
+          }
+        }
+        p_cur += 64 * nstep;
+      }
+      wave_sync_lds();
+      // ---- (2-4) per level: bin, pull, store --------------------------------------------------------
+#pragma unroll 1
+      for (int d = 0; d < pk.nl; ++d) {
+        const int lvl = pk.lev[d];
+        const LevelK& lv = g.lv[lvl];
+        const Brick b = make_brick(lv, ta, tb, tc, T);
+        if (b.nverts == 0) continue;
+        int n = 0;
+#pragma unroll
+        for (int e = 0; e < PULL_NLV; ++e) n = (e == d) ? nlist[e] : n;
+        const bool first = !((stored >> d) & 1u);
+        if (n == 0 && !first) continue;
+        pull_level<C>(g, pk, lv, b, smem, o_list + d * PULL_LIST, n, o_arr, o_rec, o_df, lane,
+                      !(first && pk.overwrite));
+        stored |= 1u << d;
+      }
+#pragma unroll
+      for (int d = 0; d < PULL_NLV; ++d) nlist[d] = 0;
+      more = sweeping;
+    }
+    (void)tabc;
+  }
+}
+
+// Levels the pull kernel can own: default sampling convention, a brick of at most
+// PULL_BMAX^3 vertices per tile, a gradient requested; at most PULL_MAXL of them.
+uint32_t plan_grad_pull(const GridK& g, int T) {
+  if (g.flags & (MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER)) return 0;
+  uint32_t mask = 0;
+  int cnt = 0;
+  for (int l = 0; l < g.n_levels && cnt < PULL_MAXL; ++l) {
+    const LevelK& lv = g.lv[l];
+    if (!lv.grad) continue;
+    auto bmax = [&](int size) { return (size + T - 1) / T; };
+    if (bmax(lv.X) > PULL_BMAX || bmax(lv.Y) > PULL_BMAX || bmax(lv.Z) > PULL_BMAX) continue;
+    if ((int64_t)lv.X * T >= (1 << 30) || (int64_t)lv.Y * T >= (1 << 30) || (int64_t)lv.Z * T >= (1 << 30)) continue;
+    mask |= 1u << l;
+    ++cnt;
+  }
+  return mask;
+}
+
+hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, const float* xn,
+                            const float* dfeat, uint32_t level_mask, int overwrite, hipStream_t s) {
+  if (!level_mask) return hipSuccess;
+  PullK pk;
+  memset(&pk, 0, sizeof(pk));
+  pk.T = T; pk.tile_off = tile_off; pk.xn = reinterpret_cast<const float4*>(xn); pk.dfeat = dfeat;
+  for (int l = 0; l < g.n_levels; ++l)
+    if ((level_mask >> l) & 1u) pk.lev[pk.nl++] = l;
+  pk.overwrite = overwrite;
+  if (const char* d = getenv("MISO_DEBUG_PULL")) pk.debug = atoi(d);
+  const int per_wave = pk.nl * PULL_LIST + PULL_ARR + PULL_CAP * 4 + PULL_CAP * C;
+  const size_t lds = (size_t)per_wave * 4 * sizeof(float);
+  const int ntiles = T * T * T;
+  unsigned blocks = (unsigned)((ntiles + 3) / 4);
+  if (blocks > 2048u) blocks = 2048u;
+  void (*k)(GridK, PullK) = nullptr;
+#define PICK(c, n) if (C == c && pk.nl == n) k = grad_pull_kernel<c, n>;
+  PICK(8, 1) PICK(8, 2) PICK(8, 3) PICK(8, 4) PICK(4, 1) PICK(4, 2) PICK(4, 3) PICK(4, 4)
+#undef PICK
+  if (!k) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  k<<<blocks, 256, lds, s>>>(g, pk);
+  return hipGetLastError();
+}
+
+}  // namespace miso

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
   for (int i = threadIdx.x * 4; i < pl.fwd_end; i += blockDim.x * 4)
     *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + i);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hi = lane >> 5;
   const int64_t nchunks = (n + 63) / 64;
   const float* w0p = smem + pl.o_w0;
   const float* whp = smem + pl.o_wh;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
   const float* whT = smem;
   const float* w0T = smem + (pl.o_w0T - pl.o_whT);
   const float* wo = smem + nb;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hi = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hi = lane >> 5;
   constexpr int FP = ((F + 3) / 4) * 4 + 4;  // d-feat row pitch: 16-B aligned, conflict-free b128 writes
   constexpr int REC = 8;                     // ints per (point, level) cell record
   constexpr int WAVE_LDS = 64 * FP + 64 * L * REC;

@@ -81,11 +81,12 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(const int* __restrict__
   if (threadIdx.x == blockDim.x - 1) tile_off[nt] = sm[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const float* __restrict__ x, int64_t n, int nt,
-                                                          int64_t seg, const int* __restrict__ bh,
+__global__ __launch_bounds__(256) void sort_scatter_kernel(GridK g, const float* __restrict__ x, int64_t n,
+                                                          int nt, int64_t seg, const int* __restrict__ bh,
                                                           int* __restrict__ gcursor,
                                                           const uint16_t* __restrict__ tile_id,
-                                                          float* __restrict__ xs, int* __restrict__ perm) {
+                                                          float* __restrict__ xs, float* __restrict__ xn,
+                                                          int* __restrict__ perm) {
   extern __shared__ int cursor[];
   // reserve this block's run inside every tile with one returning atomic per (block, tile)
   for (int i = threadIdx.x; i < nt; i += blockDim.x) {
@@ -101,6 +102,18 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const float* __restri
     xs[(int64_t)pos * 3 + 0] = x[i * 3 + 0];
     xs[(int64_t)pos * 3 + 1] = x[i * 3 + 1];
     xs[(int64_t)pos * 3 + 2] = x[i * 3 + 2];
+    if (xn) {
+      // normalised coordinates exactly as common.hpp:axis_coord forms them, one float4 per
+      // point, so the pull backward (grad_pull.hip) lands on the same cells with one load
+      float v[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        v[a] = x[i * 3 + a];
+        if (!(g.flags & MISO_F_COORDS_NORMALIZED))
+          v[a] = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(v[a], g.bmin[a])), __fsub_rn(g.bmax[a], g.bmin[a])), 1.0f);
+      }
+      reinterpret_cast<float4*>(xn)[pos] = make_float4(v[0], v[1], v[2], 0.0f);
+    }
   }
 }
 
@@ -118,8 +131,8 @@ int64_t sort_workspace_bytes(int64_t n, int T) {
   return a256((int64_t)sort_blocks(n) * nt * sizeof(int)) + 2 * a256(nt * sizeof(int)) + a256(n * 2);
 }
 
-hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int T, void* ws, float* xs, int* perm,
-                       int* tile_off, hipStream_t s) {
+hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int T, void* ws, float* xs, float* xn,
+                       int* perm, int* tile_off, hipStream_t s) {
   const int nt = T * T * T;
   const int nb = sort_blocks(n);
   const int64_t seg = (n + nb - 1) / nb;
@@ -132,7 +145,7 @@ hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int T, void* w
   if (e != hipSuccess) return e;
   sort_hist_kernel<<<nb, 256, nt * sizeof(int), s>>>(g, x, n, T, seg, bh, count, tid);
   sort_scan_kernel<<<1, 1024, 1024 * sizeof(int), s>>>(count, nt, tile_off, cursor);
-  sort_scatter_kernel<<<nb, 256, nt * sizeof(int), s>>>(x, n, nt, seg, bh, cursor, tid, xs, perm);
+  sort_scatter_kernel<<<nb, 256, nt * sizeof(int), s>>>(g, x, n, nt, seg, bh, cursor, tid, xs, xn, perm);
   return hipGetLastError();
 }
 

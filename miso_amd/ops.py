@@ -300,16 +300,18 @@ class SortedBatch:
     reused across calls with the same n (graph-capture friendly)."""
 
     TILES = 16         # tiles per axis
-    # Batch size from which the autograd path bins automatically.  Measured on MI355X
-    # (cfg-2, 262144 points): binning costs 20-40 us and saves ~30 us of forward gather
-    # time, but the backward stays bound by the L2 atomic request rate, which locality
-    # does not change -- so it does not pay yet and is opt-in (None = never automatic).
-    AUTO_MIN_POINTS = None
+    # Batch size from which the autograd path bins automatically when grid gradients are wanted.
+    # Measured on MI355X (cfg-2, 262144 points): binning costs ~43 us, the forward gathers drop
+    # from 76 to 47 us, and the backward goes from 240 us (atomic scatter + 15 us zero-fill) to
+    # 157 us (MFMA pass + owner-computes pull, no zero-fill).  Below ~64 K points the tiles hold
+    # too few points for the sweep to pay.  None = never automatic.
+    AUTO_MIN_POINTS = 65536
 
     def __init__(self, n: int, device, tiles: int = TILES):
         self.n, self.tiles = int(n), int(tiles)
         i32 = dict(device=device, dtype=torch.int32)
         self.x_sorted = torch.empty((self.n, 3), device=device, dtype=torch.float32)
+        self.xn_sorted = torch.empty((self.n, 4), device=device, dtype=torch.float32)
         self.perm = torch.empty(self.n, **i32)
         self.tile_offsets = torch.empty(self.tiles ** 3 + 1, **i32)
         ws = _lib.load().miso_sort_workspace_bytes(self.n, self.tiles)
@@ -317,6 +319,7 @@ class SortedBatch:
         self.struct = _lib.Sorted()
         self.struct.tiles_per_axis = self.tiles
         self.struct.x_sorted = self.x_sorted.data_ptr()
+        self.struct.xn_sorted = self.xn_sorted.data_ptr()
         self.struct.perm = self.perm.data_ptr()
         self.struct.tile_offsets = self.tile_offsets.data_ptr()
 
@@ -342,7 +345,7 @@ class SortedBatch:
         lv.C = lv.X = lv.Y = lv.Z = 1
         lv.sC = lv.sX = lv.sY = lv.sZ = 1
         _lib.check(_lib.load().miso_sort_points(C.byref(g), _ptr(x), self.n, self.tiles, _ptr(self.workspace),
-                                                _ptr(self.x_sorted), _ptr(self.perm),
+                                                _ptr(self.x_sorted), _ptr(self.xn_sorted), _ptr(self.perm),
                                                 _ptr(self.tile_offsets), _stream(x)), "miso_sort_points")
         return self
 
@@ -374,16 +377,22 @@ def sdf_fwd_raw(x, features, meta, pack: DecoderPack, want_mask: bool, out=None,
 
 
 def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f, grads=None,
-                sorted_batch: Optional[SortedBatch] = None):
+                sorted_batch: Optional[SortedBatch] = None, overwrite: bool = False):
+    """overwrite (binned path only): the gradients are written, not accumulated -- ``grads``
+    need no zero-fill (MISO_F_GRAD_OVERWRITE)."""
     _require_hip(x, gsdf, *features)
     m, packed = pack.get()
     x = x.contiguous()
     gsdf = gsdf.contiguous()
     n = x.shape[0]
+    overwrite = overwrite and sorted_batch is not None
     if grads is None:
-        grads = [torch.zeros_like(f) if nf else None for f, nf in zip(features, need_f)]
+        alloc = torch.empty_like if overwrite else torch.zeros_like
+        grads = [alloc(f) if nf else None for f, nf in zip(features, need_f)]
     gx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
     g = _fill_grid(features, meta, grads)
+    if overwrite:
+        g.flags |= _lib.F_GRAD_OVERWRITE
     if sorted_batch is not None:
         ws = sorted_batch.bwd_workspace(n * _feature_dim(features)) if any(gr is not None for gr in grads) else None
         _lib.check(_lib.load().miso_sdf_bwd_sorted(C.byref(g), C.byref(m), _ptr(packed),
@@ -393,6 +402,18 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
         _lib.check(_lib.load().miso_sdf_bwd(C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _ptr(gsdf),
                                             _ptr(mask), _ptr(gx), _stream(x)), "miso_sdf_bwd")
     return gx, grads
+
+
+def grad_pull_raw(features, meta, sorted_batch: SortedBatch, dfeat, grads, overwrite: bool = True):
+    """Grid gradients from d-feat rows (N,F) in binned order, owner-computes (miso_grad_pull)."""
+    _require_hip(dfeat, *features)
+    g = _fill_grid(features, meta, grads, data=False)
+    if overwrite:
+        g.flags |= _lib.F_GRAD_OVERWRITE
+    n = sorted_batch.n
+    _lib.check(_lib.load().miso_grad_pull(C.byref(g), C.byref(sorted_batch.struct), n, _ptr(dfeat),
+                                          _stream(dfeat)), "miso_grad_pull")
+    return grads
 
 
 def _mlp_torch(feats, weights, biases):
@@ -409,7 +430,8 @@ class _SdfFused(torch.autograd.Function):
     def forward(ctx, x, meta, pack, *features):
         need = any(ctx.needs_input_grad)
         sb = None
-        if need and SortedBatch.AUTO_MIN_POINTS is not None and x.shape[0] >= SortedBatch.AUTO_MIN_POINTS:
+        if (any(ctx.needs_input_grad[3:]) and SortedBatch.AUTO_MIN_POINTS is not None
+                and x.shape[0] >= SortedBatch.AUTO_MIN_POINTS):
             # training-size batch: bin the points once, both passes use the binned order
             sb = SortedBatch(x.shape[0], x.device).sort(x, meta)
         sdf, mask = sdf_fwd_raw(x, features, meta, pack, want_mask=need, sorted_batch=sb)
@@ -433,7 +455,7 @@ class _SdfFused(torch.autograd.Function):
             gfs = [got.pop(0) if nf else None for nf in need_f]
             return (gx, None, None, *gfs)
         gx, grads = sdf_bwd_raw(x, features, ctx.meta, ctx.pack, gsdf, mask, need_x, need_f,
-                                sorted_batch=ctx.sb)
+                                sorted_batch=ctx.sb, overwrite=True)
         return (gx, None, None, *grads)
 
 

@@ -20,7 +20,7 @@ class MappingStep:
     def __init__(self, features: Sequence[torch.Tensor], meta: ops.GridMeta, pack: ops.DecoderPack,
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
                  trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
-                 sort: bool = False):
+                 sort: Optional[bool] = None):
         self.features = list(features)
         self.meta, self.pack = meta, pack
         self.n = int(n_points)
@@ -44,6 +44,8 @@ class MappingStep:
             self.exp_avg = [torch.zeros_like(f) for f in self.features]
             self.exp_avg_sq = [torch.zeros_like(f) for f in self.features]
             self.t = 0
+        if sort is None:   # default: bin when the batch is large enough for it to pay
+            sort = ops.SortedBatch.AUTO_MIN_POINTS is not None and self.n >= ops.SortedBatch.AUTO_MIN_POINTS
         self.sorted = ops.SortedBatch(self.n, dev) if sort else None
         self._graph = None
         self._use_graph = use_graph and adam is None  # the Adam step count changes per call
@@ -59,7 +61,8 @@ class MappingStep:
 
     def _launch(self):
         lt, ws, wf, td = self.loss_cfg
-        need_zero = self.adam is None or self.t == 0
+        # binned path: gradients are written owner-computes, nothing to clear
+        need_zero = self.sorted is None and (self.adam is None or self.t == 0)
         if need_zero:
             for g in self.grads:
                 g.zero_()
@@ -71,13 +74,13 @@ class MappingStep:
         ops.mapping_loss_raw(self.sdf, self.target, self.valid, self.sign, self.weight, lt, ws, wf, td,
                              self.gpred, self.loss)
         ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
-                        [True] * len(self.features), self.grads, sorted_batch=self.sorted)
+                        [True] * len(self.features), self.grads, sorted_batch=self.sorted, overwrite=True)
         if self.adam is not None:
             self.t += 1
             for p, g, m, v in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq):
                 # zero_grad=True: the gradient is cleared in the same pass, so the next
                 # iteration needs no memset
-                ops.adam_dense_(p.data, g, m, v, self.t, zero_grad=True, **self.adam)
+                ops.adam_dense_(p.data, g, m, v, self.t, zero_grad=self.sorted is None, **self.adam)
 
     def run(self):
         """Launch one iteration on the current stream (asynchronous)."""
