@@ -100,12 +100,62 @@ def cpu_baseline(data, budget_s=20.0):
                       f"the reference: F.grid_sample per level, cat, nn.Sequential, L1), {dt:.2f} s each"}, pred
 
 
+def extras(step, dev):
+    """Secondary figures SURVEY 8(d) asks for next to the headline: forward-only, the full trainer
+    step with dense Adam, and the alignment pair (pairwise_loss_latent forward+backward)."""
+    from miso_amd import ops
+    from miso_amd.step import MappingStep
+    import miso_amd.grid_opt.align.miso as AM
+    from miso_amd.grid_opt.models.grid_atlas import GridAtlas
+    ex = {}
+    feats, meta, pack = step.features, step.meta, step.pack
+    t = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, False, out=step.sdf))
+    ex["forward_only_point_samples_per_s"] = N_POINTS / (t * 1e-6)
+    # full trainer step: bin + forward + loss + backward + dense Adam over all 19.2 M grid floats
+    tr = MappingStep([f.clone() for f in feats], meta, pack, N_POINTS, "L1", 1.0, 0.0, 0.0, adam=dict(lr=1e-3),
+                     use_graph=False)
+    tr.set_batch(step.x, step.target)
+    t = time_kernel(tr.run, iters=20, warm=3)
+    ex["trainer_step_with_dense_adam"] = {"us": t, "point_samples_per_s": N_POINTS / (t * 1e-6),
+                                          "adam_bytes": 28 * sum(f.numel() for f in feats)}
+    del tr
+    # alignment pair, ScanNet-shaped submaps (bound 20x10x20 m, cells 0.5 / 0.1 m, C=4), level 1:
+    # 4.0 M cached voxel centres of src mapped into dst, loss + backward to both poses
+    cfg = {"name": "grid_net", "spatial_dim": 3,
+           "decoder": {"type": "mlp", "hidden_dim": 64, "hidden_layers": 1, "out_dim": 1, "pos_invariant": True,
+                       "fix": True, "pretrained_model": None},
+           "grid": {"type": "regular", "feature_dim": 4, "init_stddev": 1e-2, "bound": [[-10., 10.], [-5., 5.], [-10., 10.]],
+                    "base_cell_size": 0.5, "per_level_scale": 5, "n_levels": 2},
+           "pose": {"optimize": False, "num_poses": 1}}
+    torch.manual_seed(0)
+    atlas = GridAtlas(cfg, device=dev)
+    lb = torch.tensor(cfg["grid"]["bound"])
+    for s_, tx in enumerate((0.0, 9.0)):
+        atlas.add_submap(lb, torch.eye(3), torch.tensor([[tx], [0.3], [-0.4]]), num_poses=1)
+        atlas.add_kf(torch.eye(3), torch.zeros(3, 1))
+    atlas.to(dev)
+    atlas.set_submap_pose_correction(1, torch.tensor([[0.02, -0.03, 0.01]], device=dev),
+                                     torch.tensor([[0.1], [-0.05], [0.08]], device=dev))
+    atlas.precompute_coordinates_for_alignment()
+    nv = atlas.coordinates_for_alignment(0, 1).shape[0]
+
+    def pair():
+        atlas.zero_grad(set_to_none=True)
+        (v,) = AM.pairwise_loss_latent(atlas, None, 0, 1, level=1, fdim=4, align_loss="L2", device=dev).values()
+        v.backward()
+
+    t = time_kernel(pair, iters=10, warm=2)
+    ex["align_pair_latent_level1"] = {"vertices": nv, "us": t, "vertices_per_s": nv / (t * 1e-6)}
+    return ex
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,6 +259,8 @@ def main():
         "kernels_us": kernels_us,
         "binned": sb is not None,
     }
+    if world == 1 and not args.no_extras:
+        out["extras"] = extras(step, dev)
     if world == 1 and not args.no_cpu_baseline:
         cb, pred_cpu = cpu_baseline(data)
         out["cpu_baseline"] = cb

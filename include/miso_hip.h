@@ -27,9 +27,8 @@
  *                     (grid_opt/models/grid_net.py:288-325, grid_opt/utils/utils.py:194-208,
  *                     grid_opt/models/modules.py:11-32) and its autograd backward
  *                     with a frozen decoder (configs/rgbd/scannet.yaml:16).
- *   miso_pair_latent  pairwise_loss_latent, grid_opt/align/miso.py:116-211 (L2),
+ *   miso_pair_latent  pairwise_loss_latent, grid_opt/align/miso.py:116-211 (L2 / L1),
  *                     with the rigid maps of grid_opt/utils/utils_geometry.py:214-240.
- *   miso_lm_normal_eq Tracker.lm_step normal equations, grid_opt/slam/tracker.py:171-196.
  *   miso_mapping_loss miso_loss_regression + miso_loss_free_space and their gradient
  *                     w.r.t. the prediction, grid_opt/loss.py:594-635, :668-700, as
  *                     combined by MisoLossMappingBase.compute (loss.py:776-806).
@@ -171,6 +170,23 @@ int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n);
 int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,
                         const uint32_t* relu_mask, float* grad_x, float* workspace, void* stream);
+
+/* --- latent alignment residual of a submap pair (pose-Jacobian path) --------
+ * pairwise_loss_latent (grid_opt/align/miso.py:116-211) for the L2 / L1 variants.
+ * dst_grid: the destination submap's levels 0..level (data only) with its bound.
+ * pose (DEVICE pointer, 24 floats): R_src[9] t_src[3] R_dst[9] t_dst[3], row-major, the
+ *   updated submap poses of grid_opt/models/grid_atlas.py:250-268.
+ * coords_src (N,3): the source submap's cached voxel centres; feats_src (N, ld_feats >= F):
+ *   its features there.  loss_type 1 = L1 (row-wise 2-norm), 2 = L2.
+ * out (24 floats, device): [0] sum_i term_i over in-bound vertices, [1] their count,
+ *   [2..4] sum g_i (g_i = d term_i / d q_i, q_i the point in the dst frame),
+ *   [5..13] sum (w_i - t_dst) g_i^T, [14..22] sum (R_dst g_i) p_i^T  (row-major 3x3).
+ * The caller forms loss = weight * out[0] / (count * F) (L2) or / count (L1) and the pose
+ * cotangents dL/dt_dst = -R_dst sum g, dL/dR_dst = sum (w - t_dst) g^T, dL/dt_src = sum R_dst g,
+ * dL/dR_src = sum (R_dst g) p^T, scaled alike. */
+int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float* coords_src,
+                     const float* feats_src, int64_t ld_feats, int64_t n, int loss_type, float* out,
+                     void* stream);
 
 /* --- mapping loss (value + d/d pred) --------------------------------------
  * loss_type 1 = L1, 2 = L2.  pred/target (N); valid/sign/weight (N) or NULL

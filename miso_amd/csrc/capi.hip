@@ -19,6 +19,8 @@ hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const 
 int64_t sort_workspace_bytes(int64_t n, int T);
 hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, float*, int*, int*,
                        hipStream_t);
+hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, const float*, int64_t, int64_t, int,
+                              float*, hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, uint32_t, int,
                             hipStream_t);
@@ -307,6 +309,20 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   if (rc) return rc;
   return sdf_bwd_impl(grid, mlp, packed, sorted->x_sorted, n, grad_sdf, relu_mask, grad_x, sorted, workspace,
                       stream);
+}
+
+int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float* coords_src,
+                     const float* feats_src, int64_t ld_feats, int64_t n, int loss_type, float* out,
+                     void* stream) {
+  if (n < 0 || !pose || !out || (loss_type != 1 && loss_type != 2)) return MISO_E_BADARG;
+  if (n > 0 && (!coords_src || !feats_src)) return MISO_E_BADARG;
+  GridK g; bool v4;
+  int rc = convert_grid(dst_grid, &g, true, &v4);
+  if (rc) return rc;
+  if (g.flags & (MISO_F_COORDS_NORMALIZED | MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER)) return MISO_E_UNSUPPORTED;
+  if (ld_feats < g.F) return MISO_E_BADARG;
+  return (int)launch_pair_latent(g, v4, pose, coords_src, feats_src, ld_feats, n, loss_type, out,
+                                 (hipStream_t)stream);
 }
 
 int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,

@@ -1,0 +1,157 @@
+// Fused latent alignment residual of one submap pair: value and pose cotangents in one pass.
+//
+// Reference: pairwise_loss_latent, grid_opt/align/miso.py:116-211 -- per iteration and pair it
+// maps the source submap's cached voxel centres src -> world -> dst (two affine maps,
+// grid_opt/utils/utils_geometry.py:214-240), masks them with dst's bound (:11-27), compacts with
+// nonzero (host sync), samples ALL levels of both submaps, slices the channels, takes
+// mean(diff^2) (L2) or mean(|diff|_2) (L1), and lets autograd walk back through
+// grid_sampler_3d_backward (incl. an unused dense grad scatter into both grids), the affine
+// maps and so3_exp_map.  Here one kernel does, per source vertex i:
+//     w_i = R_s p_i + t_s ;  q_i = R_d^T (w_i - t_d) ;  m_i = q_i in bound(dst)
+//     r_i = f_src,i - encode_dst(q_i)              (levels 0..level only)
+//     term_i = sum_c r^2  (L2)  |  |r|_2  (L1)
+//     g_i = d term_i / d q_i                        (corner-derivative of the same gathers)
+// and reduces  sum term, sum m, sum g, sum (w - t_d) g^T, sum (R_d g) p^T  -- everything the
+// chain rule needs for d/dR_s, d/dt_s, d/dR_d, d/dt_d (SURVEY App. B "pose chain").  The source
+// features are read-only inputs (cached by the caller: they depend on no pose).
+#include "common.hpp"
+
+namespace miso {
+
+struct PairK {
+  const float* pose;   // device: R_s[9] t_s[3] R_d[9] t_d[3], row-major
+  const float* p;      // (N,3) source vertices in the source frame
+  const float* fsrc;   // (N, ld) source features
+  int64_t ld;
+  int64_t n;
+  int loss_type;       // 1 = L1 (vector norm), 2 = L2
+  float* out;          // 24 floats, zeroed by the launcher
+};
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void pair_latent_kernel(GridK g, PairK k) {
+  float Rs[9], ts[3], Rd[9], td[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Rs[i] = k.pose[i]; Rd[i] = k.pose[12 + i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { ts[i] = k.pose[9 + i]; td[i] = k.pose[21 + i]; }
+  float acc[23];
+#pragma unroll
+  for (int i = 0; i < 23; ++i) acc[i] = 0.0f;
+
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < k.n;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const float px = k.p[idx * 3 + 0], py = k.p[idx * 3 + 1], pz = k.p[idx * 3 + 2];
+    const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
+                        Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
+    const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
+    const float q[3] = {Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
+                        Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2]};
+    const bool inb = q[0] >= g.bmin[0] && q[0] <= g.bmax[0] && q[1] >= g.bmin[1] && q[1] <= g.bmax[1] &&
+                     q[2] >= g.bmin[2] && q[2] <= g.bmax[2];
+    if (!inb) continue;
+    const float* fs = k.fsrc + idx * k.ld;
+    // pass 1: residual norm (needed by L1 before the derivative weights are known)
+    float term = 0.0f, gq[3] = {0.f, 0.f, 0.f};
+    float inv_norm = 1.0f;
+    for (int pass = (k.loss_type == 1 ? 0 : 1); pass < 2; ++pass) {
+      float ss = 0.0f;
+      for (int l = 0; l < g.n_levels; ++l) {
+        const LevelK& lv = g.lv[l];
+        Axis ax = axis_coord(q[0], g.bmin[0], g.bmax[0], lv.X, g.flags);
+        Axis ay = axis_coord(q[1], g.bmin[1], g.bmax[1], lv.Y, g.flags);
+        Axis az = axis_coord(q[2], g.bmin[2], g.bmax[2], lv.Z, g.flags);
+        const bool ign = (g.ignore_mask >> l) & 1u;
+        Cell c = make_cell(ax, ay, az, lv);
+        int off[8]; float wt[8], dwx[8], dwy[8], dwz[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int dx = kk & 1, dy = (kk >> 1) & 1, dz = kk >> 2;
+          const bool in = c.inx[dx] && c.iny[dy] && c.inz[dz] && !ign;
+          const float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
+          wt[kk] = in ? (c.wx[dx] * c.wy[dy]) * c.wz[dz] : 0.0f;
+          dwx[kk] = in ? sx * c.wy[dy] * c.wz[dz] : 0.0f;
+          dwy[kk] = in ? sy * c.wx[dx] * c.wz[dz] : 0.0f;
+          dwz[kk] = in ? sz * c.wx[dx] * c.wy[dy] : 0.0f;
+          off[kk] = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+        }
+        float ax_ = 0.f, ay_ = 0.f, az_ = 0.f;
+        for (int ch = 0; ch < lv.C; ch += (VEC4 ? 4 : 1)) {
+          float v[8][4];
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) {
+            if (VEC4) {
+              const float4 t = *reinterpret_cast<const float4*>(lv.data + off[kk] + ch);
+              v[kk][0] = t.x; v[kk][1] = t.y; v[kk][2] = t.z; v[kk][3] = t.w;
+            } else {
+              v[kk][0] = lv.data[(int64_t)ch * lv.sC + off[kk]];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < (VEC4 ? 4 : 1); ++e) {
+            float fto = 0.f, gxs = 0.f, gys = 0.f, gzs = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+              fto += v[kk][e] * wt[kk];
+              gxs += v[kk][e] * dwx[kk]; gys += v[kk][e] * dwy[kk]; gzs += v[kk][e] * dwz[kk];
+            }
+            const float r = fs[lv.foff + ch + e] - fto;
+            ss += r * r;
+            if (pass == 1) {
+              // d term / d f_to: L2 -> -2 r ; L1 -> -r / |r|
+              const float gf = (k.loss_type == 2) ? -2.0f * r : -r * inv_norm;
+              ax_ += gf * gxs; ay_ += gf * gys; az_ += gf * gzs;
+            }
+          }
+        }
+        if (pass == 1) { gq[0] += ax_ * ax.mult; gq[1] += ay_ * ay.mult; gq[2] += az_ * az.mult; }
+      }
+      if (k.loss_type == 1) {
+        const float nrm = sqrtf(ss);
+        term = nrm;
+        inv_norm = nrm > 0.0f ? 1.0f / nrm : 0.0f;
+      } else {
+        term = ss;
+      }
+    }
+    // R_d g
+    const float h[3] = {Rd[0] * gq[0] + Rd[1] * gq[1] + Rd[2] * gq[2], Rd[3] * gq[0] + Rd[4] * gq[1] + Rd[5] * gq[2],
+                        Rd[6] * gq[0] + Rd[7] * gq[1] + Rd[8] * gq[2]};
+    const float pp[3] = {px, py, pz};
+    acc[0] += term; acc[1] += 1.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) acc[2 + a] += gq[a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) { acc[5 + a * 3 + b] += d[a] * gq[b]; acc[14 + a * 3 + b] += h[a] * pp[b]; }
+  }
+  // block reduction: wave shuffles, then one atomic per value per block
+  __shared__ float red[4][24];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 23; ++i) {
+    float v = acc[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 23) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (v != 0.0f) atomic_add_f32(k.out + threadIdx.x, v);
+  }
+}
+
+hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, const float* p, const float* fsrc,
+                              int64_t ld, int64_t n, int loss_type, float* out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(out, 0, 24 * sizeof(float), s);
+  if (e != hipSuccess || n == 0) return e;
+  PairK k{pose, p, fsrc, ld, n, loss_type, out};
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 2048u) blocks = 2048u;
+  if (vec4) pair_latent_kernel<true><<<blocks, 256, 0, s>>>(g, k);
+  else pair_latent_kernel<false><<<blocks, 256, 0, s>>>(g, k);
+  return hipGetLastError();
+}
+
+}  // namespace miso

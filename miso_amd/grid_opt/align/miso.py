@@ -21,14 +21,30 @@ from miso_amd.grid_opt.utils.utils_geometry import transform_points_to
 logger = logging.getLogger(__name__)
 
 
-def _frozen_features(submap):
-    return [g.feature.detach() for g in submap.features]
-
-
-def _query_feature_readonly(submap, x):
+def _query_feature_readonly(submap, x, n_levels):
+    """Features of levels 0..n_levels-1 only (the reference samples all levels and slices the
+    channels, miso.py:187-188), with the grids detached."""
     from miso_amd import ops
-    meta = submap.features[0].grid_meta(submap.ignore_level_)
-    return ops.encode(x, _frozen_features(submap), meta)
+    feats = [g.feature.detach() for g in submap.features[:n_levels]]
+    meta = submap.features[0].grid_meta(submap.ignore_level_[:n_levels])
+    return ops.encode(x, feats, meta)
+
+
+def _src_features(grid_atlas, src_id, level, coords_from, n_levels):
+    """Features of the source submap at its cached alignment coordinates.  They depend neither
+    on the poses nor on the iteration, so they are computed once per (submap, level) and reused
+    until a grid or the coordinate cache changes (the reference re-samples them every iteration)."""
+    sub = grid_atlas.get_submap(src_id)
+    key = (src_id, level, n_levels, coords_from.data_ptr(), coords_from.shape[0],
+           tuple((g.feature.data_ptr(), g.feature._version) for g in sub.features[:n_levels]),
+           tuple(bool(v) for v in sub.ignore_level_[:n_levels]))
+    cache = grid_atlas.__dict__.setdefault('_align_src_cache', {})
+    hit = cache.get((src_id, level))
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, _query_feature_readonly(sub, coords_from, n_levels))
+        cache[(src_id, level)] = hit
+    return hit[1]
 
 
 def pairwise_loss_latent(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id: int, level: int, fdim=4,
@@ -61,12 +77,26 @@ def pairwise_loss_latent(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id
         with torch.no_grad():
             near = torch.abs(sub_from(coords_from)) < trunc_factor * sub_from.cell_sizes[level]
         mask = mask & near
+    fused_ok = (align_loss in ('L2', 'L1') and use_bound and stability_thresh <= 0 and trunc_factor is None
+                and coords_from.is_cuda and fdim == sub_from.fdim)
+    if fused_ok:
+        # one kernel: both rigid maps, the bound mask, dst lookup, residual and the pose cotangents
+        from miso_amd import ops
+        nlv = min(level + 1, sub_from.num_levels)
+        f_from = (_src_features(grid_atlas, src_id, level, coords_from, nlv) if subsample_points is None
+                  else _query_feature_readonly(sub_from, coords_from, nlv))
+        feats_to = [g.feature.detach() for g in sub_to.features[:nlv]]
+        meta_to = sub_to.features[0].grid_meta(sub_to.ignore_level_[:nlv])
+        val = ops.pair_latent(R_from, t_from, R_to, t_to, coords_from, f_from, feats_to, meta_to, align_loss)
+        return {key: val * align_weight}
     if align_loss in ('L2', 'L1'):
         # sync-free: masked mean instead of nonzero-compaction (out-of-bound rows sample zeros)
         w = mask.to(coords_from.dtype)
         n_valid = w.sum().clamp(min=1.0)
-        diff = (_query_feature_readonly(sub_from, coords_from)[:, :end_ch]
-                - _query_feature_readonly(sub_to, coords_to)[:, :end_ch]) * w
+        nlv = min(level + 1, sub_from.num_levels) if fdim == sub_from.fdim else sub_from.num_levels
+        f_from = (_src_features(grid_atlas, src_id, level, coords_from, nlv) if subsample_points is None
+                  else _query_feature_readonly(sub_from, coords_from, nlv))
+        diff = (f_from[:, :end_ch] - _query_feature_readonly(sub_to, coords_to, nlv)[:, :end_ch]) * w
         if align_loss == 'L2':
             val = diff.pow(2).sum() / (n_valid * end_ch)
         else:
@@ -75,8 +105,9 @@ def pairwise_loss_latent(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id
     if torch.count_nonzero(mask) == 0:
         return {key: torch.tensor(0)}
     rows = torch.nonzero(mask, as_tuple=False)[:, 0]
-    out_from = _query_feature_readonly(sub_from, coords_from[rows])[:, :end_ch]
-    out_to = _query_feature_readonly(sub_to, coords_to[rows])[:, :end_ch]
+    nlv = sub_from.num_levels
+    out_from = _query_feature_readonly(sub_from, coords_from[rows], nlv)[:, :end_ch]
+    out_to = _query_feature_readonly(sub_to, coords_to[rows], nlv)[:, :end_ch]
     if align_loss == 'cos':
         val = torch.mean(1.0 - F.cosine_similarity(out_from, out_to, dim=1))
     elif align_loss == 'InfoNCE':

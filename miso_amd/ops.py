@@ -530,3 +530,45 @@ def mapping_loss(pred, target, valid, sign, weight, loss_type="L1", weight_sdf=1
     """-> tensor([weight_sdf * sdf_term, weight_fs * free_space_term]), differentiable w.r.t. pred."""
     return _MappingLoss.apply(pred, target, valid, sign, weight, loss_type, weight_sdf, weight_fs,
                               trunc_dist)
+
+
+# --------------------------------------------------------------------------- #
+# latent alignment residual of a submap pair (pose-Jacobian path)
+# --------------------------------------------------------------------------- #
+class _PairLatent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R_s, t_s, R_d, t_d, coords_src, feats_src, meta_dst, loss_type, *feats_dst):
+        _require_hip(R_s, t_s, R_d, t_d, coords_src, feats_src, *feats_dst)
+        n = coords_src.shape[0]
+        coords_src = coords_src.contiguous()
+        feats_src = _rows(feats_src)
+        n_ch = _feature_dim(feats_dst)
+        assert feats_src.shape[1] >= n_ch
+        pose = torch.cat((R_s.reshape(9), t_s.reshape(3), R_d.reshape(9), t_d.reshape(3))).contiguous()
+        out = torch.empty(24, device=coords_src.device, dtype=torch.float32)
+        g = _fill_grid(feats_dst, meta_dst)
+        _lib.check(_lib.load().miso_pair_latent(C.byref(g), _ptr(pose), _ptr(coords_src), _ptr(feats_src),
+                                                feats_src.stride(0) if n else n_ch, n, _LOSS_TYPES[loss_type],
+                                                _ptr(out), _stream(coords_src)), "miso_pair_latent")
+        denom = out[1].clamp(min=1.0) * (n_ch if loss_type == "L2" else 1)
+        ctx.save_for_backward(out, denom, R_d)
+        return out[0] / denom
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        out, denom, R_d = ctx.saved_tensors
+        s = gl / denom
+        h = R_d @ out[2:5]                      # sum_i R_dst g_i
+        g_Rs = out[14:23].view(3, 3) * s
+        g_ts = h.view(3, 1) * s
+        g_Rd = out[5:14].view(3, 3) * s
+        g_td = -h.view(3, 1) * s
+        return (g_Rs, g_ts, g_Rd, g_td) + (None,) * (4 + (len(ctx.needs_input_grad) - 8))
+
+
+def pair_latent(R_src, t_src, R_dst, t_dst, coords_src, feats_src, feats_dst, meta_dst, loss_type="L2"):
+    """mean over in-bound vertices (and channels, L2) of the latent residual between the source
+    features and the destination grid sampled at the mapped vertices; differentiable w.r.t. the four
+    pose tensors (R (3,3), t (3,1)).  One kernel forward, closed-form backward (miso_pair_latent)."""
+    return _PairLatent.apply(R_src, t_src, R_dst, t_dst, coords_src, feats_src, meta_dst, loss_type, *feats_dst)

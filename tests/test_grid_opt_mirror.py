@@ -306,3 +306,22 @@ def test_compat_aliases_and_pickle_roundtrip(device_backend, tmp_path):
     xw = T(gc.atlas_world_points()).to(dev)
     close(back(xw), atlas(xw), 0, 0)
     assert back.get_submap(1).features[1].feature.is_contiguous(memory_format=torch.channels_last_3d)
+
+
+def test_extract_fields_matches_pointwise_queries(device_backend):
+    """Slab-wise dense extraction == the reference's per-lattice-point values (utils_sdf.py:69-86)."""
+    from miso_amd.grid_opt.utils.utils_sdf import extract_fields
+    dev = device_backend
+    case = gc.CASES["small"]
+    net = make_gridnet(case, dev)
+    b = torch.tensor(case["bound"])
+    res = 21
+    u = extract_fields(b[:, 0], b[:, 1], res, lambda p: net(p), device=dev, max_points=res * res * 4)
+    assert u.shape == (res, res, res) and u.dtype == np.float32
+    ax = [torch.linspace(float(b[a, 0]), float(b[a, 1]), res) for a in range(3)]
+    xx, yy, zz = torch.meshgrid(*ax, indexing="ij")
+    pts = torch.stack((xx, yy, zz), -1).reshape(-1, 3)
+    from oracle import ref_torch as R
+    ws, bs = R.decoder_params({k: T(v) for k, v in gc.make_decoder(case).items()})
+    ref = R.sdf_stock([T(f) for f in gc.make_features(case)], b, pts, ws, bs).reshape(res, res, res)
+    close(T(u), ref, 0, 1e-5)

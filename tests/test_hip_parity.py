@@ -420,3 +420,49 @@ def test_mapping_step_matches_autograd_and_adam():
     gg = torch.autograd.grad(l, fd)
     for a, b_ in zip(s2.grads, gg):
         assert relerr(a, b_) < 2e-5
+
+
+@pytest.mark.parametrize("shape", ["scannet", "four_level", "tiny_grid"])
+def test_binned_backward_other_shapes(shape):
+    """Binned (pull) backward == plain atomic backward on shapes that exercise the fallbacks:
+    a level too fine for the pull (ScanNet's 200x100x200 at 16 tiles -> 13 vertices per tile:
+    stays on the atomic scatter, cleared by the library), C = 4 (two levels share the MFMA
+    register halves), four levels, grids smaller than the tile count (tiles owning no vertex)."""
+    from miso_amd import ops
+    torch.manual_seed(0)
+    if shape == "scannet":
+        bound, dims, C, H, n = [[-10.0, 10.0], [-5.0, 5.0], [-10.0, 10.0]], [(40, 20, 40), (200, 100, 200)], 4, 64, 70000
+    elif shape == "four_level":
+        bound, dims, C, H, n = [[-1.0, 1.0]] * 3, [(8, 8, 8), (16, 16, 16), (32, 32, 32), (64, 64, 64)], 8, 64, 70000
+    else:
+        bound, dims, C, H, n = [[0.0, 1.0], [0.0, 2.0], [-1.0, 0.0]], [(3, 5, 2), (7, 9, 5)], 4, 32, 66000
+    feats = [(torch.randn(1, C, z, y, x_, device=DEV) * 1e-2).contiguous(memory_format=torch.channels_last_3d)
+             for (x_, y, z) in dims]
+    F = C * len(dims)
+    lin = [torch.nn.Linear(F, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.detach().to(DEV) for l in lin], [l.bias.detach().to(DEV) for l in lin])
+    meta = ops.GridMeta.from_bound(bound)
+    assert ops.sdf_fused_supported(feats, meta, pack)
+    b = torch.tensor(bound)
+    x = (torch.rand(n, 3) * (b[:, 1] - b[:, 0]) * 1.04 + b[:, 0] - 0.02 * (b[:, 1] - b[:, 0])).to(DEV)
+    gs = torch.randn(n, 1, device=DEV)
+    L = len(feats)
+    sdf_a, mask_a = ops.sdf_fwd_raw(x, feats, meta, pack, True)
+    gx_a, gr_a = ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask_a, True, [True] * L)
+    sb = ops.SortedBatch(n, DEV).sort(x, meta)
+    sdf_b, mask_b = ops.sdf_fwd_raw(x, feats, meta, pack, True, sorted_batch=sb)
+    # poisoned gradient buffers: overwrite mode must not depend on their content
+    grads = [torch.full_like(f, float("nan")) for f in feats]
+    gx_b, gr_b = ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask_b, True, [True] * L, grads, sorted_batch=sb,
+                                 overwrite=True)
+    assert (sdf_a - sdf_b).abs().max().item() < 1e-7
+    assert relerr(gx_b, gx_a) < 1e-5
+    for a, b_ in zip(gr_a, gr_b):
+        assert torch.isfinite(b_).all()
+        assert relerr(b_, a) < 3e-5
+    # accumulate mode (+=) on top of an existing gradient
+    base = [torch.randn_like(f) for f in feats]
+    acc = [t.clone() for t in base]
+    ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask_b, False, [True] * L, acc, sorted_batch=sb, overwrite=False)
+    for a, b0, r in zip(acc, base, gr_a):
+        assert relerr(a - b0, r) < 3e-4
