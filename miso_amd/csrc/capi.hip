@@ -47,7 +47,8 @@ int convert_grid(const miso_grid_t* in, GridK* out, bool need_data, bool* vec4) 
   out->n_levels = in->n_levels;
   out->ignore_mask = in->ignore_mask;
   out->flags = in->flags & ~MISO_F_GRAD_OVERWRITE;   // host-side flag
-  for (int a = 0; a < 3; ++a) { out->bmin[a] = in->bound_min[a]; out->bmax[a] = in->bound_max[a]; }
+  for (int a = 0; a < 3; ++a) { out->bmin[a] = in->bound_min[a]; out->bmax[a] = in->bound_max[a]; out->gscale[a] = 1.0f; }
+  out->xstride = 3;
   bool v4 = true;
   int foff = 0;
   for (int l = 0; l < in->n_levels; ++l) {
@@ -178,10 +179,21 @@ int miso_sdf_supported(const miso_grid_t* grid, const miso_mlp_t* mlp) {
   return fused_shape(g, v4, mlp, &C, &L, &H, &NH) == MISO_OK ? 1 : 0;
 }
 
+// Sorted batches: read the pre-normalised float4 points instead of the metric ones.
+static const float* sorted_points(GridK* g, const miso_sorted_t* sorted) {
+  if (!sorted->xn_sorted) return sorted->x_sorted;
+  if (!(g->flags & MISO_F_COORDS_NORMALIZED)) {
+    for (int a = 0; a < 3; ++a) g->gscale[a] = 2.0f / (g->bmax[a] - g->bmin[a]);   // axis_coord's m
+    g->flags |= MISO_F_COORDS_NORMALIZED;
+  }
+  g->xstride = 4;
+  return sorted->xn_sorted;
+}
+
 static int sdf_fwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
-                        const float* x, int64_t n, float* sdf, uint32_t* relu_mask, const int* perm,
-                        void* stream) {
-  if (n < 0 || !packed || (n > 0 && (!x || !sdf))) return MISO_E_BADARG;
+                        const float* x, int64_t n, float* sdf, uint32_t* relu_mask,
+                        const miso_sorted_t* sorted, void* stream) {
+  if (n < 0 || !packed || (n > 0 && !sdf)) return MISO_E_BADARG;
   if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
   GridK g; bool v4;
   int rc = convert_grid(grid, &g, true, &v4);
@@ -189,17 +201,23 @@ static int sdf_fwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   int C, L, H, NH;
   rc = fused_shape(g, v4, mlp, &C, &L, &H, &NH);
   if (rc) return rc;
+  const int* perm = nullptr;
+  if (sorted) { x = sorted_points(&g, sorted); perm = sorted->perm; }
+  if (n > 0 && !x) return MISO_E_BADARG;
   return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, perm, (hipStream_t)stream);
 }
 
 static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
                         float* grad_x, const miso_sorted_t* sorted, float* workspace, void* stream) {
-  if (n < 0 || !packed || (n > 0 && (!x || !grad_sdf || !relu_mask))) return MISO_E_BADARG;
+  if (n < 0 || !packed || (n > 0 && (!grad_sdf || !relu_mask))) return MISO_E_BADARG;
   if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
   GridK g; bool v4;
   int rc = convert_grid(grid, &g, grad_x != nullptr, &v4);
   if (rc) return rc;
+  GridK gp = g;                                   // sample positions as the kernels read them
+  if (sorted) x = sorted_points(&gp, sorted);
+  if (n > 0 && !x) return MISO_E_BADARG;
   int C, L, H, NH;
   rc = fused_shape(g, v4, mlp, &C, &L, &H, &NH);
   if (rc) return rc;
@@ -225,7 +243,7 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   }
   if (n == 0 && !pull) return MISO_OK;
   if (n > 0) {
-    rc = (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
+    rc = (int)launch_sdf_bwd(C, L, H, NH, gp, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
                              pull ? workspace : nullptr, pull, st);
     if (rc) return rc;
   }
@@ -246,7 +264,8 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
 }
 
 static int check_sorted(const miso_sorted_t* s) {
-  if (!s || !s->x_sorted || !s->perm || !s->tile_offsets) return MISO_E_BADARG;
+  if (!s || (!s->x_sorted && !s->xn_sorted) || !s->perm || !s->tile_offsets) return MISO_E_BADARG;
+  if (((uintptr_t)s->xn_sorted & 15u) != 0) return MISO_E_BADARG;
   if (s->tiles_per_axis < 1 || s->tiles_per_axis > 16) return MISO_E_BADARG;
   return MISO_OK;
 }
@@ -260,7 +279,8 @@ int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t
                      void* workspace, float* x_sorted, float* xn_sorted, int32_t* perm,
                      int32_t* tile_offsets, void* stream) {
   if (n < 0 || n >= ((int64_t)1 << 31) || tiles_per_axis < 1 || tiles_per_axis > 16) return MISO_E_BADARG;
-  if (!workspace || !tile_offsets || (n > 0 && (!x || !x_sorted || !perm))) return MISO_E_BADARG;
+  if (!workspace || !tile_offsets || (n > 0 && (!x || (!x_sorted && !xn_sorted) || !perm))) return MISO_E_BADARG;
+  if (((uintptr_t)xn_sorted & 15u) != 0) return MISO_E_BADARG;
   GridK g;
   int rc = convert_grid(grid, &g, false, nullptr);
   if (rc) return rc;
@@ -273,7 +293,7 @@ int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
                         void* stream) {
   int rc = check_sorted(sorted);
   if (rc) return rc;
-  return sdf_fwd_impl(grid, mlp, packed, sorted->x_sorted, n, sdf, relu_mask, sorted->perm, stream);
+  return sdf_fwd_impl(grid, mlp, packed, nullptr, n, sdf, relu_mask, sorted, stream);
 }
 
 int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
@@ -307,7 +327,7 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
                         const uint32_t* relu_mask, float* grad_x, float* workspace, void* stream) {
   int rc = check_sorted(sorted);
   if (rc) return rc;
-  return sdf_bwd_impl(grid, mlp, packed, sorted->x_sorted, n, grad_sdf, relu_mask, grad_x, sorted, workspace,
+  return sdf_bwd_impl(grid, mlp, packed, nullptr, n, grad_sdf, relu_mask, grad_x, sorted, workspace,
                       stream);
 }
 

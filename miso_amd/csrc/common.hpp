@@ -23,8 +23,22 @@ struct GridK {
   uint32_t flags;
   int32_t F;
   float bmin[3], bmax[3];
+  // sorted batches hand the kernels pre-normalised float4 points (sort.hip): xstride = 4,
+  // flags carry COORDS_NORMALIZED and gscale = 2/len restores d xn / d x for the pose gradient
+  float gscale[3];
+  int32_t xstride;
   LevelK lv[MISO_MAX_LEVELS];
 };
+
+__device__ __forceinline__ void load_point(const GridK& g, const float* __restrict__ x, int64_t p, float& px,
+                                           float& py, float& pz) {
+  if (g.xstride == 4) {
+    const float4 v = reinterpret_cast<const float4*>(x)[p];
+    px = v.x; py = v.y; pz = v.z;
+  } else {
+    px = x[p * 3 + 0]; py = x[p * 3 + 1]; pz = x[p * 3 + 2];
+  }
+}
 
 struct MlpK {
   const float* w[MISO_MAX_LINEAR];

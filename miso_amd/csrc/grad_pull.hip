@@ -39,6 +39,8 @@ struct PullK {
   int nl;                // number of pulled levels
   int lev[PULL_MAXL];    // their indices
   int overwrite;         // 1: grad = sum (no zero-fill needed), 0: grad += sum
+  int bdiv[PULL_MAXL][3];   // size / T per pulled level and axis where T divides the size, else 0
+  float inv_size[PULL_MAXL][3];
   int debug;             // ablation (MISO_DEBUG_PULL, dev only): 1 no pull loop, 2 no groups, 4 no sweep
 };
 
@@ -67,8 +69,16 @@ struct Brick {
   int nverts;
 };
 
-__device__ __forceinline__ Brick make_brick(const LevelK& lv, int ta, int tb, int tc, int T) {
+// bd: PullK::bdiv of the level.  With T | size the brick is (t * size/T, size/T): no per-tile
+// integer divisions (they are emulated, ~25 instructions each, and every wave pays them per tile).
+__device__ __forceinline__ Brick make_brick(const LevelK& lv, int ta, int tb, int tc, int T, const int* bd) {
   Brick b;
+  if (bd[0] && bd[1] && bd[2]) {
+    b.v0[0] = ta * bd[0]; b.v0[1] = tb * bd[1]; b.v0[2] = tc * bd[2];
+    b.B[0] = bd[0]; b.B[1] = bd[1]; b.B[2] = bd[2];
+    b.nverts = bd[0] * bd[1] * bd[2];
+    return b;
+  }
   b.v0[0] = ta * lv.X / T; b.v0[1] = tb * lv.Y / T; b.v0[2] = tc * lv.Z / T;
   b.B[0] = (ta + 1) * lv.X / T - b.v0[0]; b.B[1] = (tb + 1) * lv.Y / T - b.v0[1];
   b.B[2] = (tc + 1) * lv.Z / T - b.v0[2];
@@ -265,15 +275,22 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
       if (d >= pk.nl) continue;
       const int lvl = pk.lev[d];
       const LevelK& lv = g.lv[lvl];
-      const Brick b = make_brick(lv, ta, tb, tc, T);
+      const Brick b = make_brick(lv, ta, tb, tc, T, pk.bdiv[d]);
       if (b.nverts == 0 || ((g.ignore_mask >> lvl) & 1u)) continue;
       const int size[3] = {lv.X, lv.Y, lv.Z};
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        blo[d][a] = (2.0f * b.v0[a] - 1.0f) / size[a] - 1.0f - 8e-6f;
-        bhi[d][a] = (2.0f * (b.v0[a] + b.B[a]) + 1.0f) / size[a] - 1.0f + 8e-6f;
-        t_lo[a] = min(t_lo[a], max(0, floor_div((b.v0[a] - 1) * T, size[a])));
-        t_hi[a] = max(t_hi[a], min(T - 1, floor_div((b.v0[a] + b.B[a] + 1) * T, size[a])));
+        // the reciprocal is within an ulp of the quotient; the box is widened by ~30 ulps
+        blo[d][a] = (2.0f * b.v0[a] - 1.0f) * pk.inv_size[d][a] - 1.0f - 8e-6f;
+        bhi[d][a] = (2.0f * (b.v0[a] + b.B[a]) + 1.0f) * pk.inv_size[d][a] - 1.0f + 8e-6f;
+        int lo, hi;
+        if (pk.bdiv[d][a]) {   // size = B T: floor((tB - 1) / B) = t - 1, floor((tB + B + 1) / B) = t + 1 (+1 if B = 1)
+          lo = tabc[a] - 1; hi = tabc[a] + (b.B[a] > 1 ? 1 : 2);
+        } else {
+          lo = floor_div((b.v0[a] - 1) * T, size[a]); hi = floor_div((b.v0[a] + b.B[a] + 1) * T, size[a]);
+        }
+        t_lo[a] = min(t_lo[a], max(0, lo));
+        t_hi[a] = max(t_hi[a], min(T - 1, hi));
       }
     }
     int nlist[PULL_NLV];
@@ -283,9 +300,25 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
     bool sweeping = (t_hi[0] >= t_lo[0]) && !(pk.debug & 4);
     int tz = t_lo[2], ty = t_lo[1];
     int p_cur = 0, p_end = 0;
+    // bounds of every row of tiles (fixed ty, tz), fetched lane-parallel up front: one memory
+    // round trip per tile instead of a dependent scalar load in front of every row's sweep
+    const int ny = t_hi[1] - t_lo[1] + 1;
+    const int nrows = sweeping ? ny * (t_hi[2] - t_lo[2] + 1) : 0;
+    const bool tabled = nrows <= 64;
+    int rs = 0, re = 0;
+    if (tabled && lane < nrows) {
+      const int ry = t_lo[1] + lane % ny, rz = t_lo[2] + lane / ny;
+      rs = pk.tile_off[(rz * T + ry) * T + t_lo[0]];
+      re = pk.tile_off[(rz * T + ry) * T + t_hi[0] + 1];
+    }
+    int ridx = 0;
     if (sweeping) {
-      p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
-      p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
+      if (tabled) {
+        p_cur = __builtin_amdgcn_readlane(rs, 0); p_end = __builtin_amdgcn_readlane(re, 0);
+      } else {
+        p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
+        p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
+      }
     }
     bool more = true;
     while (more) {
@@ -298,8 +331,13 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
         if (p_cur >= p_end) {                     // next (ty, tz) row of tiles
           if (++ty > t_hi[1]) { ty = t_lo[1]; ++tz; }
           if (tz > t_hi[2]) { sweeping = false; break; }
-          p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
-          p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
+          ++ridx;
+          if (tabled) {
+            p_cur = __builtin_amdgcn_readlane(rs, ridx); p_end = __builtin_amdgcn_readlane(re, ridx);
+          } else {
+            p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
+            p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
+          }
           continue;
         }
         // up to 4 steps (256 candidates) per trip, fixed BEFORE the loads so that all coordinate
@@ -333,19 +371,22 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
       for (int d = 0; d < pk.nl; ++d) {
         const int lvl = pk.lev[d];
         const LevelK& lv = g.lv[lvl];
-        const Brick b = make_brick(lv, ta, tb, tc, T);
+        const Brick b = make_brick(lv, ta, tb, tc, T, pk.bdiv[d]);
         if (b.nverts == 0) continue;
         int n = 0;
 #pragma unroll
         for (int e = 0; e < PULL_NLV; ++e) n = (e == d) ? nlist[e] : n;
+        // mid-sweep flush: only the level whose list is (nearly) full is processed; the others keep
+        // collecting, so a fine level's brick is normally pulled and stored once per tile
+        if (sweeping && PULL_LIST - n >= 64) continue;
         const bool first = !((stored >> d) & 1u);
         if (n == 0 && !first) continue;
         pull_level<C>(g, pk, lv, b, smem, o_list + d * PULL_LIST, n, o_arr, o_rec, o_df, lane,
                       !(first && pk.overwrite));
         stored |= 1u << d;
-      }
 #pragma unroll
-      for (int d = 0; d < PULL_NLV; ++d) nlist[d] = 0;
+        for (int e = 0; e < PULL_NLV; ++e) nlist[e] = (e == d) ? 0 : nlist[e];
+      }
       more = sweeping;
     }
     (void)tabc;
@@ -377,7 +418,14 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   memset(&pk, 0, sizeof(pk));
   pk.T = T; pk.tile_off = tile_off; pk.xn = reinterpret_cast<const float4*>(xn); pk.dfeat = dfeat;
   for (int l = 0; l < g.n_levels; ++l)
-    if ((level_mask >> l) & 1u) pk.lev[pk.nl++] = l;
+    if ((level_mask >> l) & 1u) {
+      const int size[3] = {g.lv[l].X, g.lv[l].Y, g.lv[l].Z};
+      for (int a = 0; a < 3; ++a) {
+        pk.bdiv[pk.nl][a] = (size[a] % T == 0) ? size[a] / T : 0;
+        pk.inv_size[pk.nl][a] = 1.0f / (float)size[a];
+      }
+      pk.lev[pk.nl++] = l;
+    }
   pk.overwrite = overwrite;
   if (const char* d = getenv("MISO_DEBUG_PULL")) pk.debug = atoi(d);
   const int per_wave = pk.nl * PULL_LIST + PULL_ARR + PULL_CAP * 4 + PULL_CAP * C;

@@ -14,6 +14,30 @@ struct MapLossK {
   float w_sdf, w_fs, trunc;
 };
 
+__device__ __forceinline__ void map_loss_one(const MapLossK& p, float s, float t, float w, bool v, bool fs,
+                                             float& g, float& gf, float& s_sdf, float& s_fs) {
+  g = 0.f; gf = 0.f;
+  const float d = s - t;
+  if (v) {
+    if (p.loss_type == 1) {
+      s_sdf += w * fabsf(d);
+      g = p.w_sdf * w * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+    } else {
+      s_sdf += w * d * d;
+      g = p.w_sdf * w * 2.f * d;
+    }
+  }
+  if (fs) {
+    const float up = fmaxf(d, 0.f), lo = fmaxf(p.trunc - s, 0.f);
+    s_fs += fmaxf(up, lo);
+    // d/ds max(relu(s-t), relu(trunc-s)); ties carry zero slope on both sides
+    if (up > lo) gf = p.w_fs;
+    else if (lo > up) gf = -p.w_fs;
+  }
+}
+
+// VEC: all arrays 16-B aligned and n % 4 == 0 -> one float4 per array per thread
+template <bool VEC>
 __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const float* __restrict__ pred,
                                                           const float* __restrict__ targ,
                                                           const float* __restrict__ valid,
@@ -24,31 +48,34 @@ __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const flo
                                                           float* __restrict__ loss_out) {
   const float inv_n = 1.0f / (float)n;
   float s_sdf = 0.f, s_fs = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const float s = pred[i], t = targ[i];
-    const float w = weight ? weight[i] : 1.0f;
-    const bool v = valid ? (valid[i] == 1.0f) : true;
-    float g = 0.f, gf = 0.f;
-    const float d = s - t;
-    if (v) {
-      if (p.loss_type == 1) {
-        s_sdf += w * fabsf(d);
-        g = p.w_sdf * w * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
-      } else {
-        s_sdf += w * d * d;
-        g = p.w_sdf * w * 2.f * d;
-      }
+  const bool want_fs = p.w_fs > 0.f && sign != nullptr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (VEC) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = i0; i < n4; i += stride) {
+      const float4 s4 = reinterpret_cast<const float4*>(pred)[i], t4 = reinterpret_cast<const float4*>(targ)[i];
+      const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 w4 = weight ? reinterpret_cast<const float4*>(weight)[i] : one;
+      const float4 v4 = valid ? reinterpret_cast<const float4*>(valid)[i] : one;
+      const float4 f4 = want_fs ? reinterpret_cast<const float4*>(sign)[i] : zero;
+      float g[4], gf[4];
+      map_loss_one(p, s4.x, t4.x, w4.x, v4.x == 1.f, f4.x == 1.f, g[0], gf[0], s_sdf, s_fs);
+      map_loss_one(p, s4.y, t4.y, w4.y, v4.y == 1.f, f4.y == 1.f, g[1], gf[1], s_sdf, s_fs);
+      map_loss_one(p, s4.z, t4.z, w4.z, v4.z == 1.f, f4.z == 1.f, g[2], gf[2], s_sdf, s_fs);
+      map_loss_one(p, s4.w, t4.w, w4.w, v4.w == 1.f, f4.w == 1.f, g[3], gf[3], s_sdf, s_fs);
+      reinterpret_cast<float4*>(gpred)[i] = make_float4((g[0] + gf[0]) * inv_n, (g[1] + gf[1]) * inv_n,
+                                                        (g[2] + gf[2]) * inv_n, (g[3] + gf[3]) * inv_n);
+      if (gpred_fs)   // free-space share, for callers weighting the terms apart
+        reinterpret_cast<float4*>(gpred_fs)[i] = make_float4(gf[0] * inv_n, gf[1] * inv_n, gf[2] * inv_n, gf[3] * inv_n);
     }
-    if (p.w_fs > 0.f && sign && sign[i] == 1.0f) {
-      const float up = fmaxf(d, 0.f), lo = fmaxf(p.trunc - s, 0.f);
-      s_fs += fmaxf(up, lo);
-      // d/ds max(relu(s-t), relu(trunc-s)); ties carry zero slope on both sides
-      if (up > lo) gf = p.w_fs;
-      else if (lo > up) gf = -p.w_fs;
+  } else {
+    for (int64_t i = i0; i < n; i += stride) {
+      float g, gf;
+      map_loss_one(p, pred[i], targ[i], weight ? weight[i] : 1.0f, valid ? (valid[i] == 1.0f) : true,
+                   want_fs && sign[i] == 1.0f, g, gf, s_sdf, s_fs);
+      gpred[i] = (g + gf) * inv_n;
+      if (gpred_fs) gpred_fs[i] = gf * inv_n;
     }
-    gpred[i] = (g + gf) * inv_n;
-    if (gpred_fs) gpred_fs[i] = gf * inv_n;  // free-space share, for callers weighting the terms apart
   }
   // wave reduction -> block reduction in LDS -> one atomic pair per block (same-address
   // atomics serialise at ~13 ns each: 8192 of them cost 106 us, 128 cost nothing)
@@ -72,9 +99,14 @@ hipError_t launch_mapping_loss(int loss_type, float w_sdf, float w_fs, float tru
   hipError_t e = hipMemsetAsync(loss_out, 0, 2 * sizeof(float), s);
   if (e != hipSuccess || n == 0) return e;
   MapLossK p{loss_type, w_sdf, w_fs, trunc};
-  unsigned blocks = (unsigned)((n + 1023) / 1024);
-  if (blocks > 256u) blocks = 256u;
-  mapping_loss_kernel<<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, gpred_fs, loss_out);
+  const uintptr_t al = (uintptr_t)pred | (uintptr_t)targ | (uintptr_t)valid | (uintptr_t)sign | (uintptr_t)weight |
+                       (uintptr_t)gpred | (uintptr_t)gpred_fs;
+  const bool vec = (al & 15u) == 0 && (n % 4) == 0;
+  const int64_t items = vec ? n / 4 : n;
+  unsigned blocks = (unsigned)((items + 255) / 256);
+  if (blocks > 1024u) blocks = 1024u;
+  if (vec) mapping_loss_kernel<true><<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, gpred_fs, loss_out);
+  else mapping_loss_kernel<false><<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, gpred_fs, loss_out);
   return hipGetLastError();
 }
 

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
 #pragma unroll
     for (int i = 0; i < 2 * KS0; ++i) f[i] = 0.0f;
     if (valid) {
-      float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
+      float px, py, pz;
+      load_point(g, x, p, px, py, pz);
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         const LevelK& lv = g.lv[l];
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
         const int64_t p = chunk * 64 + lane;
         const bool valid = p < n;
         float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) { px = x[p * 3 + 0]; py = x[p * 3 + 1]; pz = x[p * 3 + 2]; }
+        if (valid) load_point(g, x, p, px, py, pz);
 #pragma unroll
         for (int l = 0; l < L; ++l) {
           const LevelK& lv = g.lv[l];
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
       for (int t = 0; t < 2; ++t) {
         const bool valid = pt[t] < n;
         float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) { px = x[pt[t] * 3 + 0]; py = x[pt[t] * 3 + 1]; pz = x[pt[t] * 3 + 2]; }
+        if (valid) load_point(g, x, pt[t], px, py, pz);
         constexpr int NG = (C == 8) ? L : (L + 1) / 2;  // register groups of 4
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
@@ -520,7 +521,9 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
             sy_ += dot * sy * c.wx[dx] * c.wz[dz];
             sz_ += dot * sz * c.wx[dx] * c.wy[dy];
           }
-          gacc[t][0] += sx_ * ax.mult; gacc[t][1] += sy_ * ay.mult; gacc[t][2] += sz_ * az.mult;
+          gacc[t][0] += sx_ * (g.gscale[0] * ax.mult);
+          gacc[t][1] += sy_ * (g.gscale[1] * ay.mult);
+          gacc[t][2] += sz_ * (g.gscale[2] * az.mult);
         }
       }
 #pragma unroll

@@ -4,12 +4,17 @@
 // backward pre-reduce the coarse levels' gradient in LDS per tile before it
 // touches the L2 atomics (sdf_fused.hip, tiled variant).
 //
-// Three small launches (+ one memset):
-//   hist    per-block LDS histogram of tile ids -> bh[block][tile], tile_id[i], count[tile]
-//   scan    exclusive prefix of count -> tile_off (and the scatter cursors)
-//   scatter every block reserves its run per tile (one returning atomic per (block,
-//           tile)), then perm[pos] = i, xs[pos] = x[i].  The order inside a tile is
-//           not deterministic; only fp32 summation order depends on it.
+// Three small launches, no global atomics and nothing to zero:
+//   hist    <= 64 blocks of 1024 threads: LDS histogram of the block's slice of the
+//           batch -> bh[block][tile], tile_id[i]
+//   prefix  one thread per tile: exclusive prefix over blocks written back into bh,
+//           total -> count[tile]
+//   scatter every block re-derives the exclusive scan of count in LDS (block 0
+//           publishes it as tile_offsets), seeds its cursors with tile_off + its bh
+//           prefix, then perm[pos] = i, xn[pos] = normalised x[i] (and xs[pos] = x[i]
+//           when asked).  Blocks own disjoint runs, so only the order inside one
+//           (block, tile) run depends on LDS atomic timing; that order touches the
+//           fp32 summation order of the pull backward and nothing else.
 // The reference has no counterpart (it samples every level with independent
 // random gathers, grid_opt/models/grid_modules.py:86-94).
 #include "common.hpp"
@@ -31,10 +36,12 @@ __device__ __forceinline__ int tile_of(float px, float py, float pz, const GridK
   return (t[2] * T + t[1]) * T + t[0];
 }
 
-__global__ __launch_bounds__(256) void sort_hist_kernel(GridK g, const float* __restrict__ x, int64_t n,
-                                                       int T, int64_t seg, int* __restrict__ bh,
-                                                       int* __restrict__ count,
-                                                       uint16_t* __restrict__ tile_id) {
+constexpr int SORT_THREADS = 1024;
+constexpr int SORT_MAX_BLOCKS = 256;
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(GridK g, const float* __restrict__ x, int64_t n,
+                                                                int T, int64_t seg, int* __restrict__ bh,
+                                                                uint16_t* __restrict__ tile_id) {
   extern __shared__ int hist[];
   const int nt = T * T * T;
   for (int i = threadIdx.x; i < nt; i += blockDim.x) hist[i] = 0;
@@ -46,80 +53,82 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(GridK g, const float* __
     atomicAdd(&hist[t], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nt; i += blockDim.x) {
-    int v = hist[i];
-    bh[(int64_t)blockIdx.x * nt + i] = v;
-    if (v) atomicAdd(&count[i], v);
-  }
+  for (int i = threadIdx.x; i < nt; i += blockDim.x) bh[(int64_t)blockIdx.x * nt + i] = hist[i];
 }
 
-// one block: exclusive scan of the per-tile counts -> tile_off; cursor = tile_off
-__global__ __launch_bounds__(1024) void sort_scan_kernel(const int* __restrict__ count, int nt,
-                                                        int* __restrict__ tile_off,
-                                                        int* __restrict__ cursor) {
-  extern __shared__ int sm[];  // nt
-  // per-thread serial chunk + block scan of the chunk sums
-  const int per = (nt + blockDim.x - 1) / blockDim.x;
+// thread per tile: bh[b][t] <- sum_{b' < b} bh[b'][t]; count[t] <- column total
+__global__ __launch_bounds__(256) void sort_prefix_kernel(int* __restrict__ bh, int nb, int nt,
+                                                         int* __restrict__ count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  int run = 0;
+  int b = 0;
+  for (; b + 8 <= nb; b += 8) {
+    int v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = bh[(int64_t)(b + k) * nt + t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { bh[(int64_t)(b + k) * nt + t] = run; run += v[k]; }
+  }
+  for (; b < nb; ++b) { int v = bh[(int64_t)b * nt + t]; bh[(int64_t)b * nt + t] = run; run += v; }
+  count[t] = run;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, const float* __restrict__ x, int64_t n,
+                                                                   int nt, int64_t seg, const int* __restrict__ bh,
+                                                                   const int* __restrict__ count,
+                                                                   const uint16_t* __restrict__ tile_id,
+                                                                   float* __restrict__ xs, float* __restrict__ xn,
+                                                                   int* __restrict__ perm,
+                                                                   int* __restrict__ tile_off) {
+  extern __shared__ int cursor[];      // nt cursors, then 16 wave sums
+  int* wsum = cursor + nt;
+  // exclusive scan of count: contiguous chunk per thread, wave scan, scan of the wave sums
+  const int per = (nt + SORT_THREADS - 1) / SORT_THREADS;
   const int b0 = threadIdx.x * per;
   int sum = 0;
   for (int i = 0; i < per; ++i) if (b0 + i < nt) sum += count[b0 + i];
-  sm[threadIdx.x] = sum;
+  int inc = sum;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+  if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  for (int o = 1; o < (int)blockDim.x; o <<= 1) {
-    int v = (threadIdx.x >= (unsigned)o) ? sm[threadIdx.x - o] : 0;
-    __syncthreads();
-    sm[threadIdx.x] += v;
-    __syncthreads();
-  }
-  int run = sm[threadIdx.x] - sum;  // exclusive prefix of this thread's chunk
+  int wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wsum[w];
+  int run = wbase + inc - sum;
   for (int i = 0; i < per; ++i)
     if (b0 + i < nt) {
-      tile_off[b0 + i] = run;
-      cursor[b0 + i] = run;
+      cursor[b0 + i] = run + bh[(int64_t)blockIdx.x * nt + b0 + i];
+      if (blockIdx.x == 0) tile_off[b0 + i] = run;
       run += count[b0 + i];
     }
-  if (threadIdx.x == blockDim.x - 1) tile_off[nt] = sm[threadIdx.x];
-}
-
-__global__ __launch_bounds__(256) void sort_scatter_kernel(GridK g, const float* __restrict__ x, int64_t n,
-                                                          int nt, int64_t seg, const int* __restrict__ bh,
-                                                          int* __restrict__ gcursor,
-                                                          const uint16_t* __restrict__ tile_id,
-                                                          float* __restrict__ xs, float* __restrict__ xn,
-                                                          int* __restrict__ perm) {
-  extern __shared__ int cursor[];
-  // reserve this block's run inside every tile with one returning atomic per (block, tile)
-  for (int i = threadIdx.x; i < nt; i += blockDim.x) {
-    int v = bh[(int64_t)blockIdx.x * nt + i];
-    cursor[i] = v ? atomicAdd(&gcursor[i], v) : 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == SORT_THREADS - 1) tile_off[nt] = run;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * seg, hi = min(n, lo + seg);
   for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int t = tile_id[i];
     int pos = atomicAdd(&cursor[t], 1);
     perm[pos] = (int)i;
-    xs[(int64_t)pos * 3 + 0] = x[i * 3 + 0];
-    xs[(int64_t)pos * 3 + 1] = x[i * 3 + 1];
-    xs[(int64_t)pos * 3 + 2] = x[i * 3 + 2];
+    float v[3] = {x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2]};
+    if (xs) {
+      xs[(int64_t)pos * 3 + 0] = v[0]; xs[(int64_t)pos * 3 + 1] = v[1]; xs[(int64_t)pos * 3 + 2] = v[2];
+    }
     if (xn) {
       // normalised coordinates exactly as common.hpp:axis_coord forms them, one float4 per
-      // point, so the pull backward (grad_pull.hip) lands on the same cells with one load
-      float v[3];
+      // point: the sorted kernels read these and never repeat the division
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        v[a] = x[i * 3 + a];
+      for (int a = 0; a < 3; ++a)
         if (!(g.flags & MISO_F_COORDS_NORMALIZED))
           v[a] = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(v[a], g.bmin[a])), __fsub_rn(g.bmax[a], g.bmin[a])), 1.0f);
-      }
       reinterpret_cast<float4*>(xn)[pos] = make_float4(v[0], v[1], v[2], 0.0f);
     }
   }
 }
 
 static inline int sort_blocks(int64_t n) {
-  int64_t b = (n + 1023) / 1024;
-  if (b > 256) b = 256;
+  int64_t b = (n + 4095) / 4096;
+  if (b > SORT_MAX_BLOCKS) b = SORT_MAX_BLOCKS;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -128,7 +137,7 @@ static inline int64_t a256(int64_t v) { return (v + 255) / 256 * 256; }
 
 int64_t sort_workspace_bytes(int64_t n, int T) {
   int64_t nt = (int64_t)T * T * T;
-  return a256((int64_t)sort_blocks(n) * nt * sizeof(int)) + 2 * a256(nt * sizeof(int)) + a256(n * 2);
+  return a256((int64_t)sort_blocks(n) * nt * sizeof(int)) + a256(nt * sizeof(int)) + a256(n * 2);
 }
 
 hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int T, void* ws, float* xs, float* xn,
@@ -139,13 +148,11 @@ hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int T, void* w
   char* w = reinterpret_cast<char*>(ws);
   int* bh = reinterpret_cast<int*>(w);            w += a256((int64_t)nb * nt * sizeof(int));
   int* count = reinterpret_cast<int*>(w);         w += a256(nt * sizeof(int));
-  int* cursor = reinterpret_cast<int*>(w);        w += a256(nt * sizeof(int));
   uint16_t* tid = reinterpret_cast<uint16_t*>(w);
-  hipError_t e = hipMemsetAsync(count, 0, nt * sizeof(int), s);
-  if (e != hipSuccess) return e;
-  sort_hist_kernel<<<nb, 256, nt * sizeof(int), s>>>(g, x, n, T, seg, bh, count, tid);
-  sort_scan_kernel<<<1, 1024, 1024 * sizeof(int), s>>>(count, nt, tile_off, cursor);
-  sort_scatter_kernel<<<nb, 256, nt * sizeof(int), s>>>(g, x, n, nt, seg, bh, cursor, tid, xs, xn, perm);
+  sort_hist_kernel<<<nb, SORT_THREADS, nt * sizeof(int), s>>>(g, x, n, T, seg, bh, tid);
+  sort_prefix_kernel<<<(nt + 255) / 256, 256, 0, s>>>(bh, nb, nt, count);
+  sort_scatter_kernel<<<nb, SORT_THREADS, (nt + 16) * sizeof(int), s>>>(g, x, n, nt, seg, bh, count, tid, xs, xn,
+                                                                        perm, tile_off);
   return hipGetLastError();
 }
 

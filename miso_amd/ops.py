@@ -301,16 +301,17 @@ class SortedBatch:
 
     TILES = 16         # tiles per axis
     # Batch size from which the autograd path bins automatically when grid gradients are wanted.
-    # Measured on MI355X (cfg-2, 262144 points): binning costs ~43 us, the forward gathers drop
+    # Measured on MI355X (cfg-2, 262144 points): binning costs ~43 us (first version), the forward gathers drop
     # from 76 to 47 us, and the backward goes from 240 us (atomic scatter + 15 us zero-fill) to
     # 157 us (MFMA pass + owner-computes pull, no zero-fill).  Below ~64 K points the tiles hold
     # too few points for the sweep to pay.  None = never automatic.
     AUTO_MIN_POINTS = 65536
 
-    def __init__(self, n: int, device, tiles: int = TILES):
+    def __init__(self, n: int, device, tiles: int = TILES, keep_metric: bool = False):
         self.n, self.tiles = int(n), int(tiles)
         i32 = dict(device=device, dtype=torch.int32)
-        self.x_sorted = torch.empty((self.n, 3), device=device, dtype=torch.float32)
+        # the kernels read the normalised float4 copy; the metric copy is optional
+        self.x_sorted = torch.empty((self.n, 3), device=device, dtype=torch.float32) if keep_metric else None
         self.xn_sorted = torch.empty((self.n, 4), device=device, dtype=torch.float32)
         self.perm = torch.empty(self.n, **i32)
         self.tile_offsets = torch.empty(self.tiles ** 3 + 1, **i32)
@@ -318,7 +319,7 @@ class SortedBatch:
         self.workspace = torch.empty(max(ws, 1), device=device, dtype=torch.uint8)
         self.struct = _lib.Sorted()
         self.struct.tiles_per_axis = self.tiles
-        self.struct.x_sorted = self.x_sorted.data_ptr()
+        self.struct.x_sorted = self.x_sorted.data_ptr() if keep_metric else None
         self.struct.xn_sorted = self.xn_sorted.data_ptr()
         self.struct.perm = self.perm.data_ptr()
         self.struct.tile_offsets = self.tile_offsets.data_ptr()
@@ -327,7 +328,7 @@ class SortedBatch:
         """(N,F) d-feat rows handed from the MFMA backward to the per-tile reduction."""
         ws = getattr(self, "_ws", None)
         if ws is None or ws.numel() < floats:
-            ws = torch.empty(max(floats, 4), device=self.x_sorted.device, dtype=torch.float32)
+            ws = torch.empty(max(floats, 4), device=self.xn_sorted.device, dtype=torch.float32)
             self._ws = ws
         return ws
 

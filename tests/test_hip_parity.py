@@ -306,7 +306,7 @@ def test_native_library_is_loaded():
 # --------------------------------------------------------------------------- #
 # spatially binned (sorted) path
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("n", [1, 777, 40000])
+@pytest.mark.parametrize("n", [1, 777, 40000, 300001])
 def test_sort_points_is_a_tile_grouped_permutation(n):
     from miso_amd import ops
     bound = [[-1.0, 1.3], [-0.7, 0.9], [0.0, 2.1]]
@@ -314,11 +314,19 @@ def test_sort_points_is_a_tile_grouped_permutation(n):
     g = torch.Generator().manual_seed(n)
     x = torch.rand(n, 3, generator=g) * torch.tensor([2.5, 1.8, 2.3]) + torch.tensor([-1.1, -0.8, -0.1])
     x[0] = float("nan")
-    sb = ops.SortedBatch(n, DEV).sort(x.to(DEV), meta)
+    sb = ops.SortedBatch(n, DEV, keep_metric=True).sort(x.to(DEV), meta)
     perm = sb.perm.cpu().long()
-    assert sorted(perm.tolist()) == list(range(n))
+    assert torch.equal(torch.sort(perm).values, torch.arange(n))
     xs = sb.x_sorted.cpu()
     assert torch.equal(torch.nan_to_num(xs, nan=7.0), torch.nan_to_num(x[perm], nan=7.0))
+    # the normalised float4 copy the kernels read: 2 (x - min) / len - 1, op for op
+    b_ = torch.tensor(bound)
+    xn = (2.0 * (xs - b_[:, 0])) / (b_[:, 1] - b_[:, 0]) - 1.0
+    assert torch.equal(torch.nan_to_num(sb.xn_sorted.cpu()[:, :3], nan=7.0), torch.nan_to_num(xn, nan=7.0))
+    # metric copy is optional: same permutation class without it
+    sb2 = ops.SortedBatch(n, DEV).sort(x.to(DEV), meta)
+    assert torch.equal(sb2.tile_offsets.cpu(), sb.tile_offsets.cpu())
+    assert torch.equal(torch.sort(sb2.perm.cpu().long()).values, torch.arange(n))
     off = sb.tile_offsets.cpu().long()
     assert off[0] == 0 and off[-1] == n and torch.all(off[1:] >= off[:-1])
     b = torch.tensor(bound)
