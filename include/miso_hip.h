@@ -152,14 +152,19 @@ int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t
 int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, float* sdf, uint32_t* relu_mask,
                         void* stream);
-/* The owner-computes gradient on its own: dfeat (N,F) = rows of d loss / d feats in the
- * binned order (what miso_sdf_bwd_sorted leaves in its workspace) -> level[l].grad for every
- * level with a non-NULL grad (all of them must be pullable: <= 8 vertices per tile and axis,
- * default sampling flags, C in {4,8}), written (MISO_F_GRAD_OVERWRITE) or accumulated.
- * Replaces the grad_input half of aten::grid_sampler_3d_backward
- * (third_party/cuda_gridsample_grad2/cuda_gridsample.py:102-105) without atomics. */
+/* The owner-computes gradient on its own: rows of d loss / d feats (row pitch ld_d floats,
+ * a multiple of 4; 16-B aligned base) -> level[l].grad for every level with a non-NULL grad,
+ * written (MISO_F_GRAD_OVERWRITE) or accumulated, without atomics.  Rows are in the binned
+ * order (rows_in_caller_order = 0: what miso_sdf_bwd_sorted leaves in its workspace) or in the
+ * caller's order (1: row perm[p] belongs to sorted point p -- the grad_output of
+ * F.grid_sample as autograd hands it over).  Every level with a grad must be pullable:
+ * miso_grad_pull_levels returns that set as a bit mask (<= 8 vertices per tile and axis,
+ * default sampling flags, channels-last C in {4,8}, at most 4 levels); the others go through
+ * miso_encode_bwd.  Replaces the grad_input half of aten::grid_sampler_3d_backward
+ * (third_party/cuda_gridsample_grad2/cuda_gridsample.py:102-105). */
+uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis);
 int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
-                   void* stream);
+                   int64_t ld_d, int32_t rows_in_caller_order, void* stream);
 
 /* workspace (16-B aligned, miso_sdf_bwd_workspace_floats floats, may be NULL): with it and
  * sorted->xn_sorted the grid gradient is formed owner-computes (grad_pull.hip): every tile

@@ -1,5 +1,6 @@
 // extern "C" entry points of libmiso_hip.so (see include/miso_hip.h).
 // Argument validation + conversion to kernel-side structs + dispatch.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.hpp"
@@ -22,8 +23,8 @@ hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, 
 hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, const float*, int64_t, int64_t, int,
                               float*, hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
-hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, uint32_t, int,
-                            hipStream_t);
+hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
+                            uint32_t, int, hipStream_t);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
 int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
@@ -49,6 +50,8 @@ int convert_grid(const miso_grid_t* in, GridK* out, bool need_data, bool* vec4) 
   out->flags = in->flags & ~MISO_F_GRAD_OVERWRITE;   // host-side flag
   for (int a = 0; a < 3; ++a) { out->bmin[a] = in->bound_min[a]; out->bmax[a] = in->bound_max[a]; out->gscale[a] = 1.0f; }
   out->xstride = 3;
+  static const uint32_t tune = [] { const char* e = getenv("MISO_TUNE"); return e ? (uint32_t)atoi(e) : 0u; }();
+  out->tune = tune;
   bool v4 = true;
   int foff = 0;
   for (int l = 0; l < in->n_levels; ++l) {
@@ -249,7 +252,7 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   }
   if (!pull) return MISO_OK;
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace,
-                               pull, overwrite ? 1 : 0, st);
+                               g.F, nullptr, pull, overwrite ? 1 : 0, st);
 }
 
 int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
@@ -296,23 +299,41 @@ int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   return sdf_fwd_impl(grid, mlp, packed, nullptr, n, sdf, relu_mask, sorted, stream);
 }
 
+// levels (with a gradient requested) the owner-computes pull covers for this grid
+static int pull_plan(const miso_grid_t* grid, int32_t tiles_per_axis, GridK* g, int* C, uint32_t* mask) {
+  bool v4;
+  int rc = convert_grid(grid, g, false, &v4);
+  if (rc) return rc;
+  *mask = 0;
+  *C = g->lv[0].C;
+  if (tiles_per_axis < 1 || tiles_per_axis > 16) return MISO_E_BADARG;
+  if (!v4 || (*C != 4 && *C != 8)) return MISO_OK;
+  for (int l = 0; l < g->n_levels; ++l)
+    if (g->lv[l].C != *C) return MISO_OK;
+  *mask = plan_grad_pull(*g, tiles_per_axis);
+  return MISO_OK;
+}
+
+uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis) {
+  GridK g; int C; uint32_t mask;
+  if (pull_plan(grid, tiles_per_axis, &g, &C, &mask)) return 0;
+  return mask;
+}
+
 int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
-                   void* stream) {
+                   int64_t ld_d, int32_t rows_in_caller_order, void* stream) {
   int rc = check_sorted(sorted);
   if (rc) return rc;
-  if (n < 0 || !sorted->xn_sorted || !dfeat || ((uintptr_t)dfeat & 15u) != 0) return MISO_E_BADARG;
-  GridK g; bool v4;
-  rc = convert_grid(grid, &g, false, &v4);
+  if (n < 0 || !sorted->xn_sorted || !dfeat || ((uintptr_t)dfeat & 15u) != 0 || (ld_d & 3) != 0)
+    return MISO_E_BADARG;
+  GridK g; int C; uint32_t pull;
+  rc = pull_plan(grid, sorted->tiles_per_axis, &g, &C, &pull);
   if (rc) return rc;
-  if (!v4) return MISO_E_UNSUPPORTED;
-  const int C = g.lv[0].C;
-  for (int l = 0; l < g.n_levels; ++l)
-    if (g.lv[l].C != C) return MISO_E_UNSUPPORTED;
-  if (C != 4 && C != 8) return MISO_E_UNSUPPORTED;
-  const uint32_t pull = plan_grad_pull(g, sorted->tiles_per_axis);
+  if (ld_d < g.F) return MISO_E_BADARG;
   for (int l = 0; l < g.n_levels; ++l)
     if (g.lv[l].grad && !((pull >> l) & 1u)) return MISO_E_UNSUPPORTED;   // every requested level must be pullable
-  return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, dfeat, pull,
+  return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, dfeat, ld_d,
+                               rows_in_caller_order ? sorted->perm : nullptr, pull,
                                (grid->flags & MISO_F_GRAD_OVERWRITE) ? 1 : 0, (hipStream_t)stream);
 }
 

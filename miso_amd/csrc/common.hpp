@@ -27,6 +27,7 @@ struct GridK {
   // flags carry COORDS_NORMALIZED and gscale = 2/len restores d xn / d x for the pose gradient
   float gscale[3];
   int32_t xstride;
+  uint32_t tune;   // dev-only ablation bits from $MISO_TUNE (0 in production)
   LevelK lv[MISO_MAX_LEVELS];
 };
 

@@ -35,7 +35,9 @@ struct PullK {
   int T;
   const int* tile_off;   // T^3 + 1
   const float4* xn;      // (N) normalised coordinates {x,y,z,_}, tile-sorted
-  const float* dfeat;    // (N,F) d-feat rows, tile-sorted
+  const float* dfeat;    // d-feat rows: row p (tile-sorted order) or, with perm, row perm[p]
+  const int* perm;       // NULL: rows are in tile-sorted order
+  int64_t ld;            // row pitch in floats (multiple of 4)
   int nl;                // number of pulled levels
   int lev[PULL_MAXL];    // their indices
   int overwrite;         // 1: grad = sum (no zero-fill needed), 0: grad += sum
@@ -160,7 +162,8 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
       if (rc[u] >= 0) {
         const int pos = atomicAdd(&ismem[o_arr + rc[u]], 1);
         *reinterpret_cast<float4*>(smem + o_rec + pos * 4) = make_float4(rfx[u], rfy[u], rfz[u], 0.0f);
-        const float* src = pk.dfeat + (int64_t)rp[u] * g.F + lv.foff;
+        const int row = pk.perm ? pk.perm[rp[u]] : rp[u];
+        const float* src = pk.dfeat + (int64_t)row * pk.ld + lv.foff;
 #pragma unroll
         for (int c = 0; c < C; c += 4)
           *reinterpret_cast<float4*>(smem + o_df + pos * C + c) = *reinterpret_cast<const float4*>(src + c);
@@ -412,11 +415,13 @@ uint32_t plan_grad_pull(const GridK& g, int T) {
 }
 
 hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, const float* xn,
-                            const float* dfeat, uint32_t level_mask, int overwrite, hipStream_t s) {
+                            const float* dfeat, int64_t ld, const int* perm, uint32_t level_mask,
+                            int overwrite, hipStream_t s) {
   if (!level_mask) return hipSuccess;
   PullK pk;
   memset(&pk, 0, sizeof(pk));
   pk.T = T; pk.tile_off = tile_off; pk.xn = reinterpret_cast<const float4*>(xn); pk.dfeat = dfeat;
+  pk.ld = ld; pk.perm = perm;
   for (int l = 0; l < g.n_levels; ++l)
     if ((level_mask >> l) & 1u) {
       const int size[3] = {g.lv[l].X, g.lv[l].Y, g.lv[l].Z};

@@ -37,6 +37,22 @@ __device__ __forceinline__ int row_of(int j, int hi) { return (j & 3) + 8 * (j >
 // lines they gather from and scatter into: on MI355X an fp32 atomic that misses L2
 // costs ~50 ns of request slot (21 G requests/s chip-wide, tools/ubench/atomics.hip),
 // and a line bouncing between XCD L2s is the worst case.
+// Two wavefronts share a SIMD (and its MFMA pipe).  Left alone they run in lockstep -- both
+// gather, then both queue MFMAs -- and the matrix pipe idles during every gather phase.  Giving
+// the odd wave slot a higher issue priority lets it finish its MFMA phase first, after which the
+// two waves alternate: one gathers while the other multiplies.
+__device__ __forceinline__ void desync_wave_slots() {
+  // HW_REG_HW_ID (4), bits [3:0] = wave slot on the SIMD
+  const unsigned slot = __builtin_amdgcn_s_getreg((4u) | (0u << 6) | ((4u - 1u) << 11));
+  if (slot & 1u) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void delay_odd_slots(int reps) {
+  const unsigned slot = __builtin_amdgcn_s_getreg((4u) | (0u << 6) | ((4u - 1u) << 11));
+  if (slot & 1u)
+    for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 struct ChunkSched {
   int64_t cur, end, step;
   __device__ __forceinline__ ChunkSched(int64_t nchunks, int wave, int nw, bool xcd_local) {
@@ -174,6 +190,8 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
   const float* wo = smem + pl.o_wo;
   const float bo = smem[pl.o_bo];
 
+  if (!(g.tune & 1u)) desync_wave_slots();
+  if (g.tune & 0xf00u) delay_odd_slots((g.tune >> 8) & 15);
   ChunkSched sched(nchunks, wave, 4, perm != nullptr);
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     // keep the (chunk-invariant) LDS reads of biases / weights inside the loop:
@@ -184,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
     float f[2 * KS0];
 #pragma unroll
     for (int i = 0; i < 2 * KS0; ++i) f[i] = 0.0f;
-    if (valid) {
+    if (valid && !(g.tune & 2u)) {
       float px, py, pz;
       load_point(g, x, p, px, py, pz);
 #pragma unroll
@@ -197,6 +215,13 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
         Cell c = make_cell(ax, ay, az, lv);
         gather_level<C>(lv, c, &f[l * C]);
       }
+    }
+    if (g.tune & 4u) {   // dev ablation: gather only
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * KS0; ++i) sum += f[i];
+      if (valid) sdf[perm ? (int64_t)perm[p] : p] = sum;
+      continue;
     }
     // ---- layer 0: buf[0][r][t] = b0 + W0 * feats -------------------------------
     // Two accumulator sets ping-pong between layers (ReLU is applied in place, so
@@ -331,6 +356,8 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
   float* wave_lds = smem + ((nb + H + 3) / 4) * 4 + wave * WAVE_LDS;
   const int64_t nchunks = (n + 63) / 64;
 
+  if (!(g.tune & 1u)) desync_wave_slots();
+  if (g.tune & 0xf00u) delay_odd_slots((g.tune >> 8) & 15);
   ChunkSched sched(nchunks, wave, 4, perm != nullptr);
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     asm volatile("" ::: "memory");  // see sdf_fwd_kernel
