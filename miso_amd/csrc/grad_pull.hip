@@ -26,9 +26,10 @@
 namespace miso {
 
 constexpr int PULL_BMAX = 8;      // owned vertices per axis per tile
-constexpr int PULL_ARR = 736;     // (8+1)^3 = 729 cells, padded
-constexpr int PULL_LIST = 320;    // compacted candidate ids per level
-constexpr int PULL_CAP = 192;     // staged records per group (3 per lane)
+constexpr int PULL_ARRW = 192;    // words of byte counters: (8+1)^3 = 729 cells, 3 words per lane
+constexpr int PULL_LIST = 272;    // compacted candidate ids per level
+constexpr int PULL_CAP = 128;     // staged records per group (2 per lane); < 256: counters are bytes
+constexpr int PULL_RB = 4;        // rounds of 64 vertices pulled per pass over the staged records
 constexpr int PULL_MAXL = 4;      // levels swept together (the fused kernels cover <= 4 levels)
 
 struct PullK {
@@ -90,11 +91,20 @@ __device__ __forceinline__ Brick make_brick(const LevelK& lv, int ta, int tb, in
 
 // Bin `n` listed candidates of one level by cell, pull them into the brick's vertices and store
 // the brick (steps 2-4 of the file comment).  `add`: accumulate onto what is already stored.
+//
+// Per-cell counters are BYTES (a group stages at most PULL_CAP < 256 records, so counts, prefixes
+// and cursors all fit): 4 cells per LDS word, atomics on the containing word, plain ds_read_u8 for
+// lookups.  Vertices are pulled in blocks of PULL_RB rounds of 64 so that only PULL_RB accumulator
+// rows are live.  Both keep a wavefront at <= 128 VGPRs and 10 KB of LDS: 4 blocks per CU, i.e. all
+// 4096 tiles of a 16^3 binning resident at once -- the kernel is bound by the serial latency of one
+// tile (~55 us whatever the occupancy), so throughput is the number of resident wavefronts.
 template <int C>
 __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, const LevelK& lv, const Brick& b,
                                            float* smem, int o_list, int n, int o_arr, int o_rec, int o_df,
                                            int lane, bool add) {
   int* ismem = reinterpret_cast<int*>(smem);
+  unsigned* arrw = reinterpret_cast<unsigned*>(smem) + o_arr;
+  const unsigned char* arrb = reinterpret_cast<const unsigned char*>(arrw);
   const int vx0 = b.v0[0], vy0 = b.v0[1], vz0 = b.v0[2], Bx = b.B[0], By = b.B[1];
   const int nverts = b.nverts;
   const int ncx = Bx + 1, ncy = By + 1, ncz = b.B[2] + 1, ncells = ncx * ncy * ncz;
@@ -104,146 +114,171 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
   const int nrounds = lpv8 ? 1 : (nverts + 63) / 64;
   // exact division of indices < 512 by B <= 8 through a 16-bit reciprocal
   const int inv_bx = (65536 + Bx - 1) / Bx, inv_by = (65536 + By - 1) / By;
-  float acc[PULL_BMAX][C];
-#pragma unroll
-  for (int r = 0; r < PULL_BMAX; ++r)
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[r][c] = 0.0f;
+  // Loop nest.  Levels whose brick fits one block of rounds (the coarse ones): accumulate over all
+  // groups, store once.  Otherwise (the finest level): groups outside, round blocks inside, every
+  // (group, block) stored -- overflow groups add onto the first one's store, nothing is restaged.
+  const int ngroups = (pk.debug & 2) ? 1 : max(1, (n + PULL_CAP - 1) / PULL_CAP);
+  const int nrb = (nrounds + PULL_RB - 1) / PULL_RB;
+  const bool single_rb = nrb == 1;
+  const int npass = single_rb ? ngroups : ngroups * nrb;
+  float acc[PULL_RB][C];
 
-  for (int g0 = 0; g0 < n && !(pk.debug & 2); g0 += PULL_CAP) {
-    const int gn = min(PULL_CAP, n - g0);
-    for (int i = lane * 4; i < ncells; i += 256)
-      *reinterpret_cast<int4*>(ismem + o_arr + i) = make_int4(0, 0, 0, 0);
-    wave_sync_lds();
-    // (2a) exact cell of every listed candidate (the sweep's box test is conservative), count
-    // per cell; the records stay in registers (<= 3 per lane)
-    constexpr int RPL = PULL_CAP / 64;
-    int rc[RPL], rp[RPL]; float rfx[RPL], rfy[RPL], rfz[RPL];
+  for (int pass = 0; pass < npass; ++pass) {
+    const int gi = single_rb ? pass : pass / nrb;
+    const int rb0 = single_rb ? 0 : (pass - gi * nrb) * PULL_RB;
+    if (!single_rb || pass == 0) {
 #pragma unroll
-    for (int u = 0; u < RPL; ++u) {
-      const int i = u * 64 + lane;
-      rc[u] = -1;
-      if (i < gn) {
-        const int p = ismem[o_list + g0 + i];
-        const float4 c4 = pk.xn[p];
-        int i0, j0, k0;
-        cell_of(c4.x, lv.X, i0, rfx[u]); cell_of(c4.y, lv.Y, j0, rfy[u]); cell_of(c4.z, lv.Z, k0, rfz[u]);
-        const int ci = i0 - (vx0 - 1), cj = j0 - (vy0 - 1), ck = k0 - (vz0 - 1);
-        if ((unsigned)ci < (unsigned)ncx && (unsigned)cj < (unsigned)ncy && (unsigned)ck < (unsigned)ncz) {
-          rc[u] = (ck * ncy + cj) * ncx + ci;
-          rp[u] = p;
-          atomicAdd(&ismem[o_arr + rc[u]], 1);
-        }
-      }
+      for (int r = 0; r < PULL_RB; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[r][c] = 0.0f;
     }
-    wave_sync_lds();
-    // (2b) exclusive scan of the counts in place, 4 cells per lane
-    int carry = 0;
-    for (int c0 = 0; c0 < ncells; c0 += 256) {
-      const int i = c0 + lane * 4;
-      int4 v = make_int4(0, 0, 0, 0);
-      if (i < ncells) v = *reinterpret_cast<const int4*>(ismem + o_arr + i);
-      const int tot = v.x + v.y + v.z + v.w;
-      int inc = tot;
+    {
+      const int g0 = gi * PULL_CAP;
+      const int gn = (pk.debug & 2) ? 0 : max(0, min(PULL_CAP, n - g0));
+      if (single_rb || rb0 == 0) {
+        // ---- stage group gi: count, scan, fill ---------------------------------------------------
+        if (pass > 0) wave_sync_lds();     // the previous pass is done reading the staging area
+        for (int i = lane; i < PULL_ARRW; i += 64) arrw[i] = 0u;
+        wave_sync_lds();
+        // (2a) exact cell of every listed candidate (the sweep's box test is conservative), count
+        // per cell; the records stay in registers (<= 3 per lane)
+        constexpr int RPL = PULL_CAP / 64;
+        int rc[RPL], rp[RPL]; float rfx[RPL], rfy[RPL], rfz[RPL];
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-      }
-      const int ex = carry + inc - tot;
-      if (i < ncells)
-        *reinterpret_cast<int4*>(ismem + o_arr + i) = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
-      carry += __builtin_amdgcn_readlane(inc, 63);
-    }
-    wave_sync_lds();
-    // (2c) fill: afterwards arr[c] = end of cell c = start of cell c+1
-#pragma unroll
-    for (int u = 0; u < RPL; ++u) {
-      if (rc[u] >= 0) {
-        const int pos = atomicAdd(&ismem[o_arr + rc[u]], 1);
-        *reinterpret_cast<float4*>(smem + o_rec + pos * 4) = make_float4(rfx[u], rfy[u], rfz[u], 0.0f);
-        const int row = pk.perm ? pk.perm[rp[u]] : rp[u];
-        const float* src = pk.dfeat + (int64_t)row * pk.ld + lv.foff;
-#pragma unroll
-        for (int c = 0; c < C; c += 4)
-          *reinterpret_cast<float4*>(smem + o_df + pos * C + c) = *reinterpret_cast<const float4*>(src + c);
-      }
-    }
-    wave_sync_lds();
-    // (3) pull.  Cells c-1 and c (x-neighbours) are adjacent in the cell order, so their records
-    // form ONE contiguous range: 4 loops (dy,dz) per vertex instead of 8.
-    if (!(pk.debug & 1)) {
-#pragma unroll
-      for (int r = 0; r < PULL_BMAX; ++r) {
-        if (r >= nrounds) continue;
-        const int vidx = lpv8 ? (lane >> 3) : r * 64 + lane;
-        if (vidx >= nverts) continue;
-        const int t_ = (vidx * inv_bx) >> 16, lx = vidx - t_ * Bx;      // vidx / Bx, vidx % Bx
-        const int lz = (t_ * inv_by) >> 16, ly = t_ - lz * By;
-        const int c_hi = ((lz + 1) * ncy + (ly + 1)) * ncx + (lx + 1);   // cell whose corner (0,0,0) is this vertex
-        int b0[4], b1[4], b2[4];   // start of cell c-1, end of c-1 (= start of c), end of c
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int dy = k & 1, dz = k >> 1;
-          const int c = c_hi - (dz * ncy + dy) * ncx;        // corner (dx=0, dy, dz); (dx=1) is c-1
-          b0[k] = (c >= 2) ? ismem[o_arr + c - 2] : 0;
-          b1[k] = ismem[o_arr + c - 1];
-          b2[k] = ismem[o_arr + c];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int dy = k & 1, dz = k >> 1;
-          int q0 = b0[k], q1 = b2[k];
-          if (lpv8) {               // this lane handles exactly one of the 8 corners
-            const int kk = lane & 7;
-            if ((kk >> 1) != k) { q0 = 0; q1 = 0; }
-            else if (kk & 1) q1 = b1[k];   // dx = 1: cell c-1 only
-            else q0 = b1[k];               // dx = 0: cell c only
+        for (int u = 0; u < RPL; ++u) {
+          const int i = u * 64 + lane;
+          rc[u] = -1;
+          if (i < gn) {
+            const int p = ismem[o_list + g0 + i];
+            const float4 c4 = pk.xn[p];
+            int i0, j0, k0;
+            cell_of(c4.x, lv.X, i0, rfx[u]); cell_of(c4.y, lv.Y, j0, rfy[u]); cell_of(c4.z, lv.Z, k0, rfz[u]);
+            const int ci = i0 - (vx0 - 1), cj = j0 - (vy0 - 1), ck = k0 - (vz0 - 1);
+            if ((unsigned)ci < (unsigned)ncx && (unsigned)cj < (unsigned)ncy && (unsigned)ck < (unsigned)ncz) {
+              rc[u] = (ck * ncy + cj) * ncx + ci;
+              rp[u] = p;
+              atomicAdd(&arrw[rc[u] >> 2], 1u << (8 * (rc[u] & 3)));
+            }
           }
-          for (int q = q0; q < q1; ++q) {
-            const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * 4);
-            const float wx = (q < b1[k]) ? f.x : 1.0f - f.x;    // record of cell c-1 => corner dx = 1
-            const float w = (wx * (dy ? f.y : 1.0f - f.y)) * (dz ? f.z : 1.0f - f.z);
+        }
+        wave_sync_lds();
+        // (2b) exclusive scan of the byte counters in place: 3 words = 12 cells per lane, one wave scan
+        {
+          unsigned w[3];
+          int tot = 0;
 #pragma unroll
-            for (int cc = 0; cc < C; cc += 4) {
-              const float4 dv = *reinterpret_cast<const float4*>(smem + o_df + q * C + cc);
-              acc[r][cc + 0] += w * dv.x; acc[r][cc + 1] += w * dv.y;
-              acc[r][cc + 2] += w * dv.z; acc[r][cc + 3] += w * dv.w;
+          for (int k = 0; k < 3; ++k) {
+            w[k] = arrw[lane * 3 + k];
+            tot += (int)((w[k] & 255u) + ((w[k] >> 8) & 255u) + ((w[k] >> 16) & 255u) + (w[k] >> 24));
+          }
+          int inc = tot;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+          }
+          unsigned run = (unsigned)(inc - tot);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const unsigned c0 = w[k] & 255u, c1 = (w[k] >> 8) & 255u, c2 = (w[k] >> 16) & 255u, c3 = w[k] >> 24;
+            const unsigned e0 = run, e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
+            arrw[lane * 3 + k] = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+            run = e3 + c3;
+          }
+        }
+        wave_sync_lds();
+        // (2c) fill: afterwards arr[c] = end of cell c = start of cell c+1
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+          if (rc[u] >= 0) {
+            const int sh = 8 * (rc[u] & 3);
+            const int pos = (int)((atomicAdd(&arrw[rc[u] >> 2], 1u << sh) >> sh) & 255u);
+            *reinterpret_cast<float4*>(smem + o_rec + pos * 4) = make_float4(rfx[u], rfy[u], rfz[u], 0.0f);
+            const int row = pk.perm ? pk.perm[rp[u]] : rp[u];
+            const float* src = pk.dfeat + (int64_t)row * pk.ld + lv.foff;
+#pragma unroll
+            for (int c = 0; c < C; c += 4)
+              *reinterpret_cast<float4*>(smem + o_df + pos * C + c) = *reinterpret_cast<const float4*>(src + c);
+          }
+        }
+        wave_sync_lds();
+      }
+      // (3) pull.  Cells c-1 and c (x-neighbours) are adjacent in the cell order, so their records
+      // form ONE contiguous range: 4 loops (dy,dz) per vertex instead of 8.
+      if (!(pk.debug & 1)) {
+#pragma unroll
+        for (int r = 0; r < PULL_RB; ++r) {
+          if (rb0 + r >= nrounds) continue;
+          const int vidx = lpv8 ? (lane >> 3) : (rb0 + r) * 64 + lane;
+          if (vidx >= nverts) continue;
+          const int t_ = (vidx * inv_bx) >> 16, lx = vidx - t_ * Bx;      // vidx / Bx, vidx % Bx
+          const int lz = (t_ * inv_by) >> 16, ly = t_ - lz * By;
+          const int c_hi = ((lz + 1) * ncy + (ly + 1)) * ncx + (lx + 1);   // cell whose corner (0,0,0) is this vertex
+          int b0[4], b1[4], b2[4];   // start of cell c-1, end of c-1 (= start of c), end of c
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int dy = k & 1, dz = k >> 1;
+            const int c = c_hi - (dz * ncy + dy) * ncx;        // corner (dx=0, dy, dz); (dx=1) is c-1
+            b0[k] = (c >= 2) ? (int)arrb[c - 2] : 0;
+            b1[k] = (int)arrb[c - 1];
+            b2[k] = (int)arrb[c];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int dy = k & 1, dz = k >> 1;
+            int q0 = b0[k], q1 = b2[k];
+            if (lpv8) {               // this lane handles exactly one of the 8 corners
+              const int kk = lane & 7;
+              if ((kk >> 1) != k) { q0 = 0; q1 = 0; }
+              else if (kk & 1) q1 = b1[k];   // dx = 1: cell c-1 only
+              else q0 = b1[k];               // dx = 0: cell c only
+            }
+            for (int q = q0; q < q1; ++q) {
+              const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * 4);
+              const float wx = (q < b1[k]) ? f.x : 1.0f - f.x;    // record of cell c-1 => corner dx = 1
+              const float w = (wx * (dy ? f.y : 1.0f - f.y)) * (dz ? f.z : 1.0f - f.z);
+#pragma unroll
+              for (int cc = 0; cc < C; cc += 4) {
+                const float4 dv = *reinterpret_cast<const float4*>(smem + o_df + q * C + cc);
+                acc[r][cc + 0] += w * dv.x; acc[r][cc + 1] += w * dv.y;
+                acc[r][cc + 2] += w * dv.z; acc[r][cc + 3] += w * dv.w;
+              }
             }
           }
         }
       }
     }
-    wave_sync_lds();
-  }
-  // ---- (4) store: every owned vertex exactly once per call ---------------------------------------
-  if (!lv.grad) return;
-  if (lpv8) {   // reduce the 8 lanes of a vertex
+    // ---- (4) store ---------------------------------------------------------------------------------
+    if (!lv.grad || (single_rb && pass != npass - 1)) continue;
+    const bool add_eff = add || (!single_rb && gi > 0);
+    if (lpv8) {   // reduce the 8 lanes of a vertex
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      float v = acc[0][c];
-      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-      acc[0][c] = v;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < PULL_BMAX; ++r) {
-    if (r >= nrounds) continue;
-    const int vidx = lpv8 ? (lane >> 3) : r * 64 + lane;
-    if (vidx >= nverts || (lpv8 && (lane & 7) != 0)) continue;
-    const int t_ = (vidx * inv_bx) >> 16, lx = vidx - t_ * Bx;
-    const int lz = (t_ * inv_by) >> 16, ly = t_ - lz * By;
-    float* dst = lv.grad + (vz0 + lz) * lv.sZ + (vy0 + ly) * lv.sY + (vx0 + lx) * lv.sX;
-#pragma unroll
-    for (int c = 0; c < C; c += 4) {
-      float4 v = make_float4(acc[r][c], acc[r][c + 1], acc[r][c + 2], acc[r][c + 3]);
-      if (add) {
-        const float4 o = *reinterpret_cast<const float4*>(dst + c);
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      for (int c = 0; c < C; ++c) {
+        float v = acc[0][c];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        acc[0][c] = v;
       }
-      *reinterpret_cast<float4*>(dst + c) = v;
+    }
+#pragma unroll
+    for (int r = 0; r < PULL_RB; ++r) {
+      if (rb0 + r >= nrounds) continue;
+      const int vidx = lpv8 ? (lane >> 3) : (rb0 + r) * 64 + lane;
+      if (vidx >= nverts || (lpv8 && (lane & 7) != 0)) continue;
+      const int t_ = (vidx * inv_bx) >> 16, lx = vidx - t_ * Bx;
+      const int lz = (t_ * inv_by) >> 16, ly = t_ - lz * By;
+      float* dst = lv.grad + (vz0 + lz) * lv.sZ + (vy0 + ly) * lv.sY + (vx0 + lx) * lv.sX;
+#pragma unroll
+      for (int c = 0; c < C; c += 4) {
+        float4 v = make_float4(acc[r][c], acc[r][c + 1], acc[r][c + 2], acc[r][c + 3]);
+        if (add_eff) {
+          const float4 o = *reinterpret_cast<const float4*>(dst + c);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(dst + c) = v;
+      }
     }
   }
+  wave_sync_lds();   // the caller reuses the list and the staging area
 }
 
 // One wavefront per spatial tile.  The 3x3x3 tile neighbourhood is swept ONCE for all pulled
@@ -256,8 +291,8 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   // depends on it (tile, bricks, loop counters) as divergent: VGPRs, exec-mask juggling, no scalar
   // loads.  readfirstlane pins it (and the list lengths below) to SGPRs.
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARR + PULL_CAP * 4 + PULL_CAP * C;
-  const int o_list = wave * PER_WAVE, o_arr = o_list + PULL_NLV * PULL_LIST, o_rec = o_arr + PULL_ARR,
+  constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARRW + PULL_CAP * 4 + PULL_CAP * C;
+  const int o_list = wave * PER_WAVE, o_arr = o_list + PULL_NLV * PULL_LIST, o_rec = o_arr + PULL_ARRW,
             o_df = o_rec + PULL_CAP * 4;
   int* ismem = reinterpret_cast<int*>(smem);
   const int T = pk.T, ntiles = T * T * T;
@@ -433,8 +468,9 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
     }
   pk.overwrite = overwrite;
   if (const char* d = getenv("MISO_DEBUG_PULL")) pk.debug = atoi(d);
-  const int per_wave = pk.nl * PULL_LIST + PULL_ARR + PULL_CAP * 4 + PULL_CAP * C;
-  const size_t lds = (size_t)per_wave * 4 * sizeof(float);
+  const int per_wave = pk.nl * PULL_LIST + PULL_ARRW + PULL_CAP * 4 + PULL_CAP * C;
+  size_t lds = (size_t)per_wave * 4 * sizeof(float);
+  if (const char* d = getenv("MISO_PULL_LDS_PAD")) lds += (size_t)atoi(d);   // dev: force a lower occupancy
   const int ntiles = T * T * T;
   unsigned blocks = (unsigned)((ntiles + 3) / 4);
   if (blocks > 2048u) blocks = 2048u;
