@@ -214,6 +214,25 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
           const int t_ = (vidx * inv_bx) >> 16, lx = vidx - t_ * Bx;      // vidx / Bx, vidx % Bx
           const int lz = (t_ * inv_by) >> 16, ly = t_ - lz * By;
           const int c_hi = ((lz + 1) * ncy + (ly + 1)) * ncx + (lx + 1);   // cell whose corner (0,0,0) is this vertex
+          if (lpv8) {
+            // 8 lanes per vertex, one adjacent cell each: ONE loop per lane over its own cell's
+            // records (the general path below would run its four (dy,dz) loops back to back with a
+            // quarter of the lanes active in each)
+            const int kk = lane & 7, dx = kk & 1, dy = (kk >> 1) & 1, dz = kk >> 2;
+            const int cc_ = c_hi - (dz * ncy + dy) * ncx - dx;
+            const int q0 = (cc_ >= 1) ? (int)arrb[cc_ - 1] : 0, q1 = (int)arrb[cc_];
+            for (int q = q0; q < q1; ++q) {
+              const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * 4);
+              const float w = ((dx ? f.x : 1.0f - f.x) * (dy ? f.y : 1.0f - f.y)) * (dz ? f.z : 1.0f - f.z);
+#pragma unroll
+              for (int cc = 0; cc < C; cc += 4) {
+                const float4 dv = *reinterpret_cast<const float4*>(smem + o_df + q * C + cc);
+                acc[r][cc + 0] += w * dv.x; acc[r][cc + 1] += w * dv.y;
+                acc[r][cc + 2] += w * dv.z; acc[r][cc + 3] += w * dv.w;
+              }
+            }
+            continue;
+          }
           int b0[4], b1[4], b2[4];   // start of cell c-1, end of c-1 (= start of c), end of c
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -226,13 +245,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int dy = k & 1, dz = k >> 1;
-            int q0 = b0[k], q1 = b2[k];
-            if (lpv8) {               // this lane handles exactly one of the 8 corners
-              const int kk = lane & 7;
-              if ((kk >> 1) != k) { q0 = 0; q1 = 0; }
-              else if (kk & 1) q1 = b1[k];   // dx = 1: cell c-1 only
-              else q0 = b1[k];               // dx = 0: cell c only
-            }
+            const int q0 = b0[k], q1 = b2[k];
             for (int q = q0; q < q1; ++q) {
               const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * 4);
               const float wx = (q < b1[k]) ? f.x : 1.0f - f.x;    // record of cell c-1 => corner dx = 1
