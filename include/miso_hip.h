@@ -29,6 +29,8 @@
  *                     with a frozen decoder (configs/rgbd/scannet.yaml:16).
  *   miso_pair_latent  pairwise_loss_latent, grid_opt/align/miso.py:116-211 (L2 / L1),
  *                     with the rigid maps of grid_opt/utils/utils_geometry.py:214-240.
+ *   miso_lm_normal_eq Tracker.lm_step, grid_opt/slam/tracker.py:148-212 (J, H = J^T W J,
+ *                     g = J^T W r with the L2 / Geman-McClure weights of :139-146).
  *   miso_mapping_loss miso_loss_regression + miso_loss_free_space and their gradient
  *                     w.r.t. the prediction, grid_opt/loss.py:594-635, :668-700, as
  *                     combined by MisoLossMappingBase.compute (loss.py:776-806).
@@ -192,6 +194,18 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
 int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float* coords_src,
                      const float* feats_src, int64_t ld_feats, int64_t n, int loss_type, float* out,
                      void* stream);
+
+/* --- tracker: Gauss-Newton normal equations ------------------------------
+ * coords_frame (N,3): samples in the keyframe frame; R_frame (9 floats, DEVICE, row-major):
+ * rotation keyframe -> submap; grad_sdf_x (N,3): d sdf / d x in the submap frame (what
+ * miso_sdf_bwd returns as grad_x for grad_sdf = 1); sdf / target (N).
+ * loss_type 2 = L2 (w = 1), 3 = Geman-McClure (w = c / (c + r^2)^2, c = gm_scale).
+ * out (32 floats, device): [0,21) upper triangle of H = sum w J^T J, row-major (H00..H05,
+ * H11..H15, ..., H55), [21,27) g = sum w J^T r, [27] sum w r^2, [28] N; J = [c^T R, grad^T],
+ * c = (R x) x grad.  The caller adds lambda I and solves the 6x6 system. */
+int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const float* grad_sdf_x,
+                      const float* sdf, const float* target, int64_t n, int loss_type, float gm_scale,
+                      float* out, void* stream);
 
 /* --- mapping loss (value + d/d pred) --------------------------------------
  * loss_type 1 = L1, 2 = L2.  pred/target (N); valid/sign/weight (N) or NULL

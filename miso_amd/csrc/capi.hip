@@ -25,6 +25,8 @@ hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, co
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
                             uint32_t, int, hipStream_t);
+hipError_t launch_lm_normal_eq(const float*, const float*, const float*, const float*, const float*, int64_t, int,
+                               float, float*, hipStream_t);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
 int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
@@ -364,6 +366,17 @@ int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float
   if (ld_feats < g.F) return MISO_E_BADARG;
   return (int)launch_pair_latent(g, v4, pose, coords_src, feats_src, ld_feats, n, loss_type, out,
                                  (hipStream_t)stream);
+}
+
+int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const float* grad_sdf_x,
+                      const float* sdf, const float* target, int64_t n, int loss_type, float gm_scale,
+                      float* out, void* stream) {
+  if (n < 0 || !out || !R_frame) return MISO_E_BADARG;
+  if (n > 0 && (!coords_frame || !grad_sdf_x || !sdf || !target)) return MISO_E_BADARG;
+  if (loss_type != 2 && loss_type != 3) return MISO_E_UNSUPPORTED;
+  if (loss_type == 3 && !(gm_scale > 0.0f)) return MISO_E_BADARG;
+  return (int)launch_lm_normal_eq(coords_frame, R_frame, grad_sdf_x, sdf, target, n, loss_type, gm_scale, out,
+                                  (hipStream_t)stream);
 }
 
 int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,

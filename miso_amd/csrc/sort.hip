@@ -17,6 +17,8 @@
 //           fp32 summation order of the pull backward and nothing else.
 // The reference has no counterpart (it samples every level with independent
 // random gathers, grid_opt/models/grid_modules.py:86-94).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace miso {
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, con
 }
 
 static inline int sort_blocks(int64_t n) {
-  int64_t b = (n + 4095) / 4096;
+  static const int per = [] { const char* e = getenv("MISO_SORT_PER_BLOCK"); return e ? atoi(e) : 4096; }();
+  int64_t b = (n + per - 1) / per;
   if (b > SORT_MAX_BLOCKS) b = SORT_MAX_BLOCKS;
   if (b < 1) b = 1;
   return (int)b;

@@ -112,13 +112,20 @@ class Tracker:
         x = coords_world.clone().requires_grad_(True)
         sdf_pred = self.grid(x)
         grad_world = torch.autograd.grad(sdf_pred, x, torch.ones_like(sdf_pred))[0].detach()
-        Rx = utils_geometry.transform_points_to(coords_frame, R, torch.zeros_like(t))
-        cT = torch.bmm(hat(Rx), grad_world.unsqueeze(-1)).squeeze(-1)
-        J = torch.cat((cT @ R, grad_world), dim=1)                     # (N,6) = [J_R, J_t]
-        r = (sdf_pred - gt_sdf).detach()
-        w = self.residual_weights(r)
-        H = J.T @ (w * J) + self.lm_lambda * torch.eye(6, device=J.device)
-        g = J.T @ (w * r)
+        if coords_frame.is_cuda:
+            # J, H = J^T W J and g = J^T W r in one launch
+            from miso_amd import ops
+            H, g, _ = ops.lm_normal_eq(coords_frame, R, grad_world, sdf_pred, gt_sdf, self.loss_type,
+                                       self.gm_scale_sdf)
+            H = H + self.lm_lambda * torch.eye(6, device=H.device)
+        else:
+            Rx = utils_geometry.transform_points_to(coords_frame, R, torch.zeros_like(t))
+            cT = torch.bmm(hat(Rx), grad_world.unsqueeze(-1)).squeeze(-1)
+            J = torch.cat((cT @ R, grad_world), dim=1)                     # (N,6) = [J_R, J_t]
+            r = (sdf_pred - gt_sdf).detach()
+            w = self.residual_weights(r)
+            H = J.T @ (w * J) + self.lm_lambda * torch.eye(6, device=J.device)
+            g = J.T @ (w * r)
         delta = torch.linalg.solve(H, -g)
         delta_R, delta_t = delta[:3], delta[3:]
         with torch.no_grad():

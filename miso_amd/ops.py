@@ -601,3 +601,28 @@ def pair_latent(R_src, t_src, R_dst, t_dst, coords_src, feats_src, feats_dst, me
     features and the destination grid sampled at the mapped vertices; differentiable w.r.t. the four
     pose tensors (R (3,3), t (3,1)).  One kernel forward, closed-form backward (miso_pair_latent)."""
     return _PairLatent.apply(R_src, t_src, R_dst, t_dst, coords_src, feats_src, meta_dst, loss_type, *feats_dst)
+
+
+# --------------------------------------------------------------------------- #
+# tracker: Gauss-Newton normal equations
+# --------------------------------------------------------------------------- #
+def lm_normal_eq(coords_frame, R_frame, grad_world, sdf_pred, sdf_gt, loss_type="L2", gm_scale=0.1):
+    """H = J^T W J (6,6), g = J^T W r (6,1), sum w r^2, for J_i = [((R x_i) x grad_i)^T R, grad_i^T]
+    (Tracker.lm_step, grid_opt/slam/tracker.py:148-212) in one launch (miso_lm_normal_eq)."""
+    _require_hip(coords_frame, R_frame, grad_world, sdf_pred, sdf_gt)
+    x = coords_frame.detach().contiguous()
+    gw = grad_world.detach().contiguous()
+    Rm = R_frame.detach().contiguous()
+    s = sdf_pred.detach().reshape(-1).contiguous()
+    t = sdf_gt.detach().reshape(-1).contiguous()
+    n = x.shape[0]
+    assert x.shape == (n, 3) and gw.shape == (n, 3) and Rm.shape == (3, 3) and s.numel() == n and t.numel() == n
+    lt = {"L2": 2, "GM": 3}[loss_type]
+    out = torch.empty(32, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().miso_lm_normal_eq(_ptr(x), _ptr(Rm), _ptr(gw), _ptr(s), _ptr(t), n, lt, float(gm_scale),
+                                             _ptr(out), _stream(x)), "miso_lm_normal_eq")
+    iu = torch.triu_indices(6, 6, device=x.device)
+    H = torch.zeros(6, 6, device=x.device, dtype=torch.float32)
+    H[iu[0], iu[1]] = out[:21]
+    H = H + H.triu(1).T
+    return H, out[21:27].reshape(6, 1), out[27]

@@ -278,3 +278,19 @@ def pairwise_latent_loss(feats_src, bound_src, feats_dst, bound_dst, coords_from
     if align_loss == "L1":
         return torch.mean(torch.linalg.vector_norm(diff, dim=1)) * align_weight
     raise ValueError(align_loss)
+
+
+def lm_normal_equations(coords_frame, R, grad_world, sdf_pred, sdf_gt, loss_type="L2", gm_scale=0.1):
+    """J (N,6), H = J^T W J, g = J^T W r of Tracker.lm_step (grid_opt/slam/tracker.py:176-196;
+    weights :139-146; hat = pytorch3d.transforms.so3.hat, restated in `hat` above)."""
+    Rx = coords_frame @ R.T
+    cT = torch.bmm(hat(Rx), grad_world.unsqueeze(-1)).squeeze(-1)
+    J = torch.cat((cT @ R, grad_world), dim=1)
+    r = (sdf_pred - sdf_gt).reshape(-1, 1)
+    if loss_type == "L2":
+        w = torch.ones_like(r)
+    elif loss_type == "GM":
+        w = gm_scale / (gm_scale + r ** 2) ** 2
+    else:
+        raise ValueError(loss_type)
+    return J, J.T @ (w * J), J.T @ (w * r)

@@ -513,3 +513,22 @@ def test_encode_backward_pull_path_vs_oracle(name, n, monkeypatch):
     assert gi[L - 1] is None or float(gi[L - 1].abs().max()) == 0.0
     if L > 1:
         assert relerr(gi[0], got[0]) < 2e-5
+
+
+@pytest.mark.parametrize("lt", ["L2", "GM"])
+@pytest.mark.parametrize("n", [1, 1000, 16384])
+def test_lm_normal_equations_vs_oracle(lt, n):
+    """miso_lm_normal_eq == the tracker's J^T W J / J^T W r built op by op (tracker.py:176-196)."""
+    from miso_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 3, generator=g)
+    gw = torch.randn(n, 3, generator=g)
+    s = torch.randn(n, 1, generator=g) * 0.2
+    t = torch.randn(n, 1, generator=g) * 0.2
+    Rm = torch.tensor(gc.rodrigues(np.array([0.3, -0.2, 0.5])), dtype=torch.float32)
+    _, H_ref, g_ref = R.lm_normal_equations(x.double(), Rm.double(), gw.double(), s.double(), t.double(), lt, 0.1)
+    H, gv, wr2 = ops.lm_normal_eq(x.to(DEV), Rm.to(DEV), gw.to(DEV), s.to(DEV), t.to(DEV), lt, 0.1)
+    scale = max(H_ref.abs().max().item(), 1e-30)
+    assert (H.cpu().double() - H_ref).abs().max().item() < 2e-5 * scale
+    assert (gv.cpu().double() - g_ref).abs().max().item() < 2e-5 * max(g_ref.abs().max().item(), 1e-30)
+    assert torch.equal(H, H.T)
