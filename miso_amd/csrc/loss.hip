@@ -103,8 +103,10 @@ hipError_t launch_mapping_loss(int loss_type, float w_sdf, float w_fs, float tru
                        (uintptr_t)gpred | (uintptr_t)gpred_fs;
   const bool vec = (al & 15u) == 0 && (n % 4) == 0;
   const int64_t items = vec ? n / 4 : n;
+  // every block ends with one atomic pair on the same two addresses (~13 ns each, serialised):
+  // 64 blocks keep that tail under 2 us while 16 K threads still cover the 6 MB of streams
   unsigned blocks = (unsigned)((items + 255) / 256);
-  if (blocks > 1024u) blocks = 1024u;
+  if (blocks > 64u) blocks = 64u;
   if (vec) mapping_loss_kernel<true><<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, gpred_fs, loss_out);
   else mapping_loss_kernel<false><<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, gpred_fs, loss_out);
   return hipGetLastError();

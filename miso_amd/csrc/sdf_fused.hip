@@ -583,7 +583,8 @@ static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float*
   size_t lds = (size_t)((pl.fwd_end + 3) / 4 * 4) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
-  if (blocks > 512u) blocks = 512u;
+  static const unsigned cap = [] { const char* e = getenv("MISO_FWD_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
+  if (blocks > cap) blocks = cap;
   auto k = sdf_fwd_kernel<C, L, H, NH>;
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
@@ -600,7 +601,8 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * WAVE_LDS : 0)) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
-  if (blocks > 512u) blocks = 512u;
+  static const unsigned cap = [] { const char* e = getenv("MISO_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
+  if (blocks > cap) blocks = cap;
   int debug = 0;
   if (const char* d = getenv("MISO_DEBUG_BWD")) debug = atoi(d);
   void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*, const int*, int,

@@ -5,7 +5,7 @@ tag=${1:-r01}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $out/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/pmc_write.log 2>&1
 find $out -name "*.csv" | head -20
