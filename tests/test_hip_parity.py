@@ -497,8 +497,10 @@ def test_encode_backward_pull_path_vs_oracle(name, n, monkeypatch):
         return torch.autograd.grad(out, fd + [xd], go)
 
     got = run()
+    out_binned = ops.encode(x.to(DEV), fd, meta).detach()       # binned forward (features need grad)
     monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", None)
     atomic = run()
+    assert torch.equal(out_binned, ops.encode(x.to(DEV), fd, meta).detach())   # same op order per point
     for a, c in zip(got, atomic):
         assert relerr(a, c) < 2e-5
     fc = [f.clone().requires_grad_(True) for f in feats]
