@@ -208,14 +208,25 @@ def main():
     feats, meta, pack = step.features, step.meta, step.pack
     mask, sb = step._mask, step.sorted
     t_sort = time_kernel(lambda: sb.sort(step.x, meta)) if sb is not None else 0.0
-    t_fwd = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, True, out=step.sdf, mask=mask,
-                                                sorted_batch=sb))
-    t_loss = time_kernel(lambda: ops.mapping_loss_raw(step.sdf, step.target, step.valid, step.sign, step.weight,
-                                                      "L1", 1.0, 0.0, 0.0, step.gpred, step.loss))
-    t_bwd = time_kernel(lambda: ops.sdf_bwd_raw(step.x, feats, meta, pack, step.gpred, mask, False,
-                                                [True] * L, step.grads, sorted_batch=sb, overwrite=True))
+    if sb is not None:
+        # binned step: the mapping loss is folded into the forward launch, the backward reads
+        # d loss / d sdf in binned order
+        t_fwd = time_kernel(lambda: ops.sdf_fwd_loss_raw(feats, meta, pack, sb, step.aux, mask, step.gpred,
+                                                         step.loss_slots, "L1", 1.0, 0.0, 0.0, sdf_out=step.sdf))
+        t_loss = 0.0
+        t_bwd = time_kernel(lambda: ops.sdf_bwd_raw(step.x, feats, meta, pack, step.gpred, mask, False,
+                                                    [True] * L, step.grads, sorted_batch=sb, overwrite=True,
+                                                    gsdf_sorted=True))
+    else:
+        t_fwd = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, True, out=step.sdf, mask=mask))
+        cols = [c.contiguous() for c in (step.target, step.valid, step.sign, step.weight)]
+        t_loss = time_kernel(lambda: ops.mapping_loss_raw(step.sdf, *cols, "L1", 1.0, 0.0, 0.0, step.gpred, step._loss))
+        t_bwd = time_kernel(lambda: ops.sdf_bwd_raw(step.x, feats, meta, pack, step.gpred, mask, False,
+                                                    [True] * L, step.grads))
     t_zero = time_kernel(lambda: [g.zero_() for g in step.grads]) if sb is None else 0.0
-    kernels_us = {"sort_points(3 launches)": t_sort, "sdf_fwd_kernel": t_fwd, "mapping_loss_kernel": t_loss,
+    kernels_us = {"sort_points(3 launches)": t_sort,
+                  "sdf_fwd_kernel(+mapping loss)" if sb is not None else "sdf_fwd_kernel": t_fwd,
+                  "mapping_loss_kernel": t_loss,
                   "backward(sdf_bwd_kernel + grad_pull_kernel)" if sb is not None else "sdf_bwd_kernel": t_bwd,
                   "zero_grads": t_zero}
     b_fwd = 12 + 32 * L * C + 4        # xyz + 8 corners x C x 4 B per level + sdf

@@ -59,6 +59,8 @@ extern "C" {
 #define MISO_F_ALIGN_CORNERS 1u    /* grid_sample align_corners=True (MISO uses False) */
 #define MISO_F_PAD_BORDER 2u       /* padding_mode='border' (MISO uses 'zeros') */
 #define MISO_F_COORDS_NORMALIZED 4u /* x is already in [-1,1]: skip normalize_coordinates */
+#define MISO_F_GRAD_SDF_SORTED 16u  /* miso_sdf_bwd_sorted: grad_sdf is in the binned order (what
+                                       miso_sdf_fwd_sorted_loss writes), not the caller's */
 #define MISO_F_GRAD_OVERWRITE 8u    /* miso_sdf_bwd_sorted: level[l].grad = sum instead of += (the library
                                        clears what it still scatters; the caller never zero-fills) */
 
@@ -149,7 +151,7 @@ typedef struct {
 
 int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis);
 int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,
-                     void* workspace, float* x_sorted, float* xn_sorted /* may be NULL */,
+                     void* workspace, float* x_sorted /* may be NULL */, float* xn_sorted /* may be NULL */,
                      int32_t* perm, int32_t* tile_offsets, void* stream);
 /* miso_encode_fwd over a binned batch: the gathers of neighbouring lanes share cache lines
  * (105 -> 39 us at 262144 points); feats rows are written in the caller's order. */
@@ -158,6 +160,24 @@ int miso_encode_fwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted,
 int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, float* sdf, uint32_t* relu_mask,
                         void* stream);
+/* miso_sdf_fwd_sorted with the mapping loss folded in (the trainer step of
+ * grid_opt/trainer.py:196-228 with MisoLossMapping): right after a point's SDF the kernel
+ * evaluates the loss terms of miso_mapping_loss for it and writes d loss / d sdf to
+ * grad_sdf_sorted[p] (binned order: pass it to miso_sdf_bwd_sorted with
+ * MISO_F_GRAD_SDF_SORTED).
+ * loss_inputs (N,4), 16-B aligned, caller order: {target, valid, sign, weight} per point
+ * (valid / sign compare against 1.0 as in miso_mapping_loss; use valid = weight = 1, sign = 0
+ * for absent masks).
+ * loss_slots (MISO_LOSS_SLOTS, 2) floats, device: per-workgroup partial sums, ALL written by the
+ * launch (nothing to zero, no atomics: same-address atomics serialise at ~13 ns each and every
+ * workgroup ends at about the same time).  The loss is the column sum: [.,0] weight_sdf * sdf
+ * term, [.,1] weight_fs * free-space term.
+ * sdf (caller order) may be NULL. */
+#define MISO_LOSS_SLOTS 512
+int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                             const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf,
+                             float weight_fs, float trunc_dist, const float* loss_inputs, float* sdf,
+                             uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots, void* stream);
 /* The owner-computes gradient on its own: rows of d loss / d feats (row pitch ld_d floats,
  * a multiple of 4; 16-B aligned base) -> level[l].grad for every level with a non-NULL grad,
  * written (MISO_F_GRAD_OVERWRITE) or accumulated, without atomics.  Rows are in the binned

@@ -23,6 +23,8 @@ F_ALIGN_CORNERS = 1
 F_PAD_BORDER = 2
 F_COORDS_NORMALIZED = 4
 F_GRAD_OVERWRITE = 8
+F_GRAD_SDF_SORTED = 16
+LOSS_SLOTS = 512
 
 E_UNSUPPORTED = 2002
 
@@ -80,6 +82,9 @@ SIGNATURES = {
                                     C.c_float, C.c_void_p, C.c_void_p]),
     "miso_encode_fwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p]),
+    "miso_sdf_fwd_sorted_loss": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted), C.c_int64,
+                                           C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_grad_pull_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32]),
     "miso_sdf_bwd_workspace_floats": (C.c_int64, [C.POINTER(Grid), C.c_int64]),
     "miso_sdf_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted),

@@ -13,9 +13,9 @@ hipError_t launch_encode_bwd2(const GridK&, const float*, int64_t, const float*,
                               float*, int64_t, float*, hipStream_t);
 bool fused_shape_supported(int C, int L, int H, int NH);
 hipError_t launch_sdf_fwd(int, int, int, int, const GridK&, const float*, const float*, int64_t, float*,
-                          uint32_t*, const int*, hipStream_t);
+                          uint32_t*, const int*, const LossInK&, hipStream_t);
 hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const float*, int64_t,
-                          const float*, const uint32_t*, float*, bool, const int*, float*, uint32_t,
+                          const float*, const uint32_t*, float*, bool, const int*, float*, uint32_t, bool,
                           hipStream_t);
 int64_t sort_workspace_bytes(int64_t n, int T);
 hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, float*, int*, int*,
@@ -44,12 +44,13 @@ enum Need { NEED_DATA = 1, NEED_GRAD_OPT = 2 };
 
 int convert_grid(const miso_grid_t* in, GridK* out, bool need_data, bool* vec4) {
   if (!in || in->n_levels < 1 || in->n_levels > MISO_MAX_LEVELS) return MISO_E_BADARG;
-  if (in->flags & ~(MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER | MISO_F_COORDS_NORMALIZED | MISO_F_GRAD_OVERWRITE))
+  if (in->flags & ~(MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER | MISO_F_COORDS_NORMALIZED | MISO_F_GRAD_OVERWRITE |
+                    MISO_F_GRAD_SDF_SORTED))
     return MISO_E_BADARG;
   memset(out, 0, sizeof(*out));
   out->n_levels = in->n_levels;
   out->ignore_mask = in->ignore_mask;
-  out->flags = in->flags & ~MISO_F_GRAD_OVERWRITE;   // host-side flag
+  out->flags = in->flags & ~(MISO_F_GRAD_OVERWRITE | MISO_F_GRAD_SDF_SORTED);   // host-side flags
   for (int a = 0; a < 3; ++a) { out->bmin[a] = in->bound_min[a]; out->bmax[a] = in->bound_max[a]; out->gscale[a] = 1.0f; }
   out->xstride = 3;
   static const uint32_t tune = [] { const char* e = getenv("MISO_TUNE"); return e ? (uint32_t)atoi(e) : 0u; }();
@@ -197,8 +198,11 @@ static const float* sorted_points(GridK* g, const miso_sorted_t* sorted) {
 
 static int sdf_fwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const float* x, int64_t n, float* sdf, uint32_t* relu_mask,
-                        const miso_sorted_t* sorted, void* stream) {
-  if (n < 0 || !packed || (n > 0 && !sdf)) return MISO_E_BADARG;
+                        const miso_sorted_t* sorted, void* stream, const LossInK* loss = nullptr) {
+  LossInK lin;
+  memset(&lin, 0, sizeof(lin));
+  if (loss) lin = *loss;
+  if (n < 0 || !packed || (n > 0 && !sdf && !loss)) return MISO_E_BADARG;
   if (((uintptr_t)packed & 15u) != 0) return MISO_E_BADARG;
   GridK g; bool v4;
   int rc = convert_grid(grid, &g, true, &v4);
@@ -209,7 +213,7 @@ static int sdf_fwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   const int* perm = nullptr;
   if (sorted) { x = sorted_points(&g, sorted); perm = sorted->perm; }
   if (n > 0 && !x) return MISO_E_BADARG;
-  return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, perm, (hipStream_t)stream);
+  return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, perm, lin, (hipStream_t)stream);
 }
 
 static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
@@ -249,7 +253,8 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   if (n == 0 && !pull) return MISO_OK;
   if (n > 0) {
     rc = (int)launch_sdf_bwd(C, L, H, NH, gp, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
-                             pull ? workspace : nullptr, pull, st);
+                             pull ? workspace : nullptr, pull,
+                             sorted && (grid->flags & MISO_F_GRAD_SDF_SORTED), st);
     if (rc) return rc;
   }
   if (!pull) return MISO_OK;
@@ -312,6 +317,25 @@ int miso_encode_fwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted,
   if (ld_out < g.F) return MISO_E_BADARG;
   const float* x = sorted_points(&g, sorted);
   return (int)launch_encode_fwd(g, v4, x, n, feats, ld_out, sorted->perm, (hipStream_t)stream);
+}
+
+int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                             const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf,
+                             float weight_fs, float trunc_dist, const float* loss_inputs, float* sdf,
+                             uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots, void* stream) {
+  int rc = check_sorted(sorted);
+  if (rc) return rc;
+  if ((loss_type != 1 && loss_type != 2) || !loss_slots || (n > 0 && (!loss_inputs || !grad_sdf_sorted)))
+    return MISO_E_BADARG;
+  if (((uintptr_t)loss_inputs & 15u) != 0) return MISO_E_BADARG;
+  if (n == 0) return (int)hipMemsetAsync(loss_slots, 0, MISO_LOSS_SLOTS * 2 * sizeof(float), (hipStream_t)stream);
+  LossInK lin;
+  memset(&lin, 0, sizeof(lin));
+  lin.p.loss_type = loss_type; lin.p.w_sdf = weight_sdf; lin.p.w_fs = weight_fs; lin.p.trunc = trunc_dist;
+  lin.aux = reinterpret_cast<const float4*>(loss_inputs);
+  lin.gsdf_sorted = grad_sdf_sorted; lin.loss_out = loss_slots;
+  lin.inv_n = n > 0 ? 1.0f / (float)n : 0.0f;
+  return sdf_fwd_impl(grid, mlp, packed, nullptr, n, sdf, relu_mask, sorted, stream, &lin);
 }
 
 // levels (with a gradient requested) the owner-computes pull covers for this grid

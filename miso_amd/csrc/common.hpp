@@ -117,4 +117,45 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Pointwise mapping loss (grid_opt/loss.py:594-635, :668-700) shared by loss.hip and the fused
+// backward.  g / gf: d(w_sdf * sdf term) / ds and d(w_fs * free-space term) / ds BEFORE the 1/N of
+// the mean; s_sdf / s_fs accumulate the unweighted term sums.
+struct MapLossK {
+  int loss_type;  // 1 = L1, 2 = L2
+  float w_sdf, w_fs, trunc;
+};
+
+__device__ __forceinline__ void map_loss_one(const MapLossK& p, float s, float t, float w, bool v, bool fs,
+                                             float& g, float& gf, float& s_sdf, float& s_fs) {
+  g = 0.f; gf = 0.f;
+  const float d = s - t;
+  if (v) {
+    if (p.loss_type == 1) {
+      s_sdf += w * fabsf(d);
+      g = p.w_sdf * w * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+    } else {
+      s_sdf += w * d * d;
+      g = p.w_sdf * w * 2.f * d;
+    }
+  }
+  if (fs) {
+    const float up = fmaxf(d, 0.f), lo = fmaxf(p.trunc - s, 0.f);
+    s_fs += fmaxf(up, lo);
+    // d/ds max(relu(s-t), relu(trunc-s)); ties carry zero slope on both sides
+    if (up > lo) gf = p.w_fs;
+    else if (lo > up) gf = -p.w_fs;
+  }
+}
+
+
+// The mapping loss folded into the fused forward (sdf_fwd_kernel): with loss_type != 0 the kernel
+// forms d loss / d sdf for every point right after its SDF and writes it in the binned order.
+struct LossInK {
+  MapLossK p;          // p.loss_type 0 = not fused
+  const float4* aux;   // (N) {target, valid, sign, weight} per point, caller order
+  float* gsdf_sorted;  // (N) out: d loss / d sdf, binned order
+  float* loss_out;     // (MISO_LOSS_SLOTS, 2): every slot written by the launch
+  float inv_n;
+};
+
 }  // namespace miso

@@ -9,33 +9,6 @@
 
 namespace miso {
 
-struct MapLossK {
-  int loss_type;  // 1 = L1, 2 = L2
-  float w_sdf, w_fs, trunc;
-};
-
-__device__ __forceinline__ void map_loss_one(const MapLossK& p, float s, float t, float w, bool v, bool fs,
-                                             float& g, float& gf, float& s_sdf, float& s_fs) {
-  g = 0.f; gf = 0.f;
-  const float d = s - t;
-  if (v) {
-    if (p.loss_type == 1) {
-      s_sdf += w * fabsf(d);
-      g = p.w_sdf * w * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
-    } else {
-      s_sdf += w * d * d;
-      g = p.w_sdf * w * 2.f * d;
-    }
-  }
-  if (fs) {
-    const float up = fmaxf(d, 0.f), lo = fmaxf(p.trunc - s, 0.f);
-    s_fs += fmaxf(up, lo);
-    // d/ds max(relu(s-t), relu(trunc-s)); ties carry zero slope on both sides
-    if (up > lo) gf = p.w_fs;
-    else if (lo > up) gf = -p.w_fs;
-  }
-}
-
 // VEC: all arrays 16-B aligned and n % 4 == 0 -> one float4 per array per thread
 template <bool VEC>
 __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const float* __restrict__ pred,

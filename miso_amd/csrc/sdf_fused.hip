@@ -170,9 +170,12 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
                                                         const float* __restrict__ x, int64_t n,
                                                         float* __restrict__ sdf,
                                                         uint32_t* __restrict__ mask,
-                                                        const int* __restrict__ perm) {
+                                                        const int* __restrict__ perm, LossInK lin) {
   // perm != nullptr: x is the tile-sorted copy of the batch (sort.hip) and the
   // result is written back in the caller's order, sdf[perm[p]].
+  // lin.p.loss_type != 0 (binned batches only): the mapping loss of loss.hip is evaluated on the
+  // spot -- d loss / d sdf goes to lin.gsdf_sorted[p] (binned order: the backward reads it
+  // coalesced), the two loss sums are accumulated into lin.loss_out; sdf may then be NULL.
   constexpr int F = C * L, RT = H / 32, KS0 = (F + 1) / 2, KS1 = H / 2;
   constexpr int MW = (NH + 1) * RT;  // mask words per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
   const float* wo = smem + pl.o_wo;
   const float bo = smem[pl.o_bo];
 
+  float loss_sdf = 0.0f, loss_fs = 0.0f;
   ChunkSched sched(nchunks, wave, 4, perm != nullptr);
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     // keep the (chunk-invariant) LDS reads of biases / weights inside the loop:
@@ -196,6 +200,11 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
     asm volatile("" ::: "memory");
     const int64_t p = chunk * 64 + lane;
     const bool valid = p < n;
+    // loss inputs of this lane's point ({target, valid, sign, weight}, one 16-B row in the
+    // caller's order): issued now, consumed after the MLP
+    const int64_t po = (valid && perm) ? (int64_t)perm[p] : p;
+    float4 l_in = make_float4(0.f, 1.f, 0.f, 1.f);
+    if (lin.p.loss_type && valid) l_in = lin.aux[po];
     float f[2 * KS0];
 #pragma unroll
     for (int i = 0; i < 2 * KS0; ++i) f[i] = 0.0f;
@@ -346,11 +355,33 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
     }
     p0 += __shfl_xor(p0, 32);
     p1 += __shfl_xor(p1, 32);
-    if (valid) sdf[perm ? (int64_t)perm[p] : p] = (hi ? p1 : p0) + bo;
+    const float sdf_v = (hi ? p1 : p0) + bo;
+    if (valid && sdf) sdf[po] = sdf_v;
+    if (lin.p.loss_type && valid) {
+      float gsd, gfs;
+      map_loss_one(lin.p, sdf_v, l_in.x, l_in.w, l_in.y == 1.0f, lin.p.w_fs > 0.f && l_in.z == 1.0f, gsd, gfs,
+                   loss_sdf, loss_fs);
+      lin.gsdf_sorted[p] = (gsd + gfs) * lin.inv_n;
+    }
     if (mask) {
       uint32_t* mo = mask + (chunk * 64 + lane) * MW;
 #pragma unroll
       for (int i = 0; i < MW; ++i) mo[i] = mw[i];
+    }
+  }
+  if (lin.p.loss_type) {
+    // block reduction through LDS (the weights are dead by now), then every block STORES its pair
+    // into its own slot (and clears the slots no block owns): no atomics -- 1024 of them on two
+    // addresses would be a 13 us serialised tail -- and nothing for the caller to zero.
+    for (int o = 32; o > 0; o >>= 1) { loss_sdf += __shfl_down(loss_sdf, o); loss_fs += __shfl_down(loss_fs, o); }
+    __syncthreads();
+    if (lane == 0) { smem[2 * wave] = loss_sdf; smem[2 * wave + 1] = loss_fs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float a = (smem[0] + smem[2]) + (smem[4] + smem[6]), b = (smem[1] + smem[3]) + (smem[5] + smem[7]);
+      float2* slots = reinterpret_cast<float2*>(lin.loss_out);
+      slots[blockIdx.x] = make_float2(lin.p.w_sdf * a * lin.inv_n, lin.p.w_fs * b * lin.inv_n);
+      for (int sl = blockIdx.x + gridDim.x; sl < MISO_LOSS_SLOTS; sl += gridDim.x) slots[sl] = make_float2(0.f, 0.f);
     }
   }
 }
@@ -373,7 +404,8 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
   // perm != nullptr: x and mask are in tile-sorted order, gsdf / gx in the caller's.
   // dfeat_out != nullptr: rows of d(feats) (N,F, sorted order) are written out and the levels in
   // defer_mask are NOT scattered here: tile_reduce_kernel pre-reduces them per spatial tile.
-  // debug: ablation switches (MISO_DEBUG_BWD, dev only): 1 = no atomics, 8 = no scatter.
+  // debug: ablation switches (MISO_DEBUG_BWD, dev only): 1 = no atomics, 8 = no scatter; bit 16 (set by the
+  // launcher for MISO_F_GRAD_SDF_SORTED): gsdf is already in the binned order.
   constexpr int F = C * L, RT = H / 32, KS1 = H / 2;
   constexpr int MW = (NH + 1) * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -400,7 +432,8 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
     const int64_t pt[2] = {chunk * 64 + (lane & 31), chunk * 64 + 32 + (lane & 31)};
     float ds[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) ds[t] = (pt[t] < n) ? gsdf[perm ? (int64_t)perm[pt[t]] : pt[t]] : 0.0f;
+    for (int t = 0; t < 2; ++t)
+      ds[t] = (pt[t] < n) ? gsdf[(perm && !(debug & 16)) ? (int64_t)perm[pt[t]] : pt[t]] : 0.0f;   // 16: gsdf is binned
     uint32_t mw[MW];
     {
       const uint32_t* mi = mask + (chunk * 64 + lane) * MW;
@@ -616,24 +649,26 @@ static hipError_t allow_lds(const void* k, size_t lds) {
 
 template <int C, int L, int H, int NH>
 static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
-                               float* sdf, uint32_t* mask, const int* perm, hipStream_t s) {
+                               float* sdf, uint32_t* mask, const int* perm, const LossInK& lin, hipStream_t s) {
   PackLayout pl(C * L, H, NH);
   size_t lds = (size_t)((pl.fwd_end + 3) / 4 * 4) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   static const unsigned cap = [] { const char* e = getenv("MISO_FWD_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
   if (blocks > cap) blocks = cap;
+  if (lin.p.loss_type && blocks > MISO_LOSS_SLOTS) blocks = MISO_LOSS_SLOTS;   // one loss slot per block
   auto k = sdf_fwd_kernel<C, L, H, NH>;
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
-  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, mask, perm);
+  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, mask, perm, lin);
   return hipGetLastError();
 }
 
 template <int C, int L, int H, int NH>
 static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
                                const float* gsdf, const uint32_t* mask, float* gx, bool want_grid,
-                               const int* perm, float* dfeat_out, uint32_t defer_mask, hipStream_t s) {
+                               const int* perm, float* dfeat_out, uint32_t defer_mask, bool gsdf_sorted,
+                               hipStream_t s) {
   PackLayout pl(C * L, H, NH);
   constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4, WAVE_LDS = 64 * FP + 64 * L * 8;
   size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * WAVE_LDS : 0)) * sizeof(float);
@@ -642,7 +677,8 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   static const unsigned cap = [] { const char* e = getenv("MISO_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
   if (blocks > cap) blocks = cap;
   int debug = 0;
-  if (const char* d = getenv("MISO_DEBUG_BWD")) debug = atoi(d);
+  if (const char* d = getenv("MISO_DEBUG_BWD")) debug = atoi(d) & ~16;
+  if (gsdf_sorted) debug |= 16;
   void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*, const int*, int,
             float*, uint32_t) =
       (want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true>
@@ -667,11 +703,11 @@ bool fused_shape_supported(int C, int L, int H, int NH) {
 
 hipError_t launch_sdf_fwd(int C, int L, int H, int NH, const GridK& g, const float* packed,
                           const float* x, int64_t n, float* sdf, uint32_t* mask, const int* perm,
-                          hipStream_t s) {
+                          const LossInK& lin, hipStream_t s) {
   if (n == 0) return hipSuccess;
 #define X(c, l, h, nh) \
   if (C == c && L == l && H == h && NH == nh) \
-    return launch_fwd_t<c, l, h, nh>(g, packed, x, n, sdf, mask, perm, s);
+    return launch_fwd_t<c, l, h, nh>(g, packed, x, n, sdf, mask, perm, lin, s);
   MISO_FUSED_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;
@@ -680,11 +716,11 @@ hipError_t launch_sdf_fwd(int C, int L, int H, int NH, const GridK& g, const flo
 hipError_t launch_sdf_bwd(int C, int L, int H, int NH, const GridK& g, const float* packed,
                           const float* x, int64_t n, const float* gsdf, const uint32_t* mask,
                           float* gx, bool want_grid, const int* perm, float* dfeat_out,
-                          uint32_t defer_mask, hipStream_t s) {
+                          uint32_t defer_mask, bool gsdf_sorted, hipStream_t s) {
   if (n == 0) return hipSuccess;
 #define X(c, l, h, nh) \
   if (C == c && L == l && H == h && NH == nh) \
-    return launch_bwd_t<c, l, h, nh>(g, packed, x, n, gsdf, mask, gx, want_grid, perm, dfeat_out, defer_mask, s);
+    return launch_bwd_t<c, l, h, nh>(g, packed, x, n, gsdf, mask, gx, want_grid, perm, dfeat_out, defer_mask, gsdf_sorted, s);
   MISO_FUSED_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;

@@ -426,9 +426,10 @@ def sdf_fwd_raw(x, features, meta, pack: DecoderPack, want_mask: bool, out=None,
 
 
 def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f, grads=None,
-                sorted_batch: Optional[SortedBatch] = None, overwrite: bool = False):
+                sorted_batch: Optional[SortedBatch] = None, overwrite: bool = False, gsdf_sorted: bool = False):
     """overwrite (binned path only): the gradients are written, not accumulated -- ``grads``
-    need no zero-fill (MISO_F_GRAD_OVERWRITE)."""
+    need no zero-fill (MISO_F_GRAD_OVERWRITE).  gsdf_sorted (binned path only): ``gsdf`` is in
+    the binned order (sdf_fwd_loss_raw), not the caller's."""
     _require_hip(x, gsdf, *features)
     m, packed = pack.get()
     x = x.contiguous()
@@ -442,6 +443,9 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
     g = _fill_grid(features, meta, grads)
     if overwrite:
         g.flags |= _lib.F_GRAD_OVERWRITE
+    if gsdf_sorted:
+        assert sorted_batch is not None
+        g.flags |= _lib.F_GRAD_SDF_SORTED
     if sorted_batch is not None:
         ws = sorted_batch.bwd_workspace(n * _feature_dim(features)) if any(gr is not None for gr in grads) else None
         _lib.check(_lib.load().miso_sdf_bwd_sorted(C.byref(g), C.byref(m), _ptr(packed),
@@ -451,6 +455,34 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
         _lib.check(_lib.load().miso_sdf_bwd(C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _ptr(gsdf),
                                             _ptr(mask), _ptr(gx), _stream(x)), "miso_sdf_bwd")
     return gx, grads
+
+
+def sdf_mask_words(pack: DecoderPack) -> int:
+    """32-bit words of ReLU sign bits per point slot (miso_sdf_mask_words)."""
+    m, _ = pack.get()
+    if m is None:
+        raise RuntimeError("decoder shape is not covered by the fused kernels")
+    return int(_lib.load().miso_sdf_mask_words(C.byref(m)))
+
+
+def sdf_fwd_loss_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatch, loss_inputs, mask, gsdf_sorted,
+                     loss_slots, loss_type="L1", weight_sdf=1.0, weight_fs=0.0, trunc_dist=0.0, sdf_out=None):
+    """Binned forward with the mapping loss folded in (miso_sdf_fwd_sorted_loss).  loss_inputs (N,4):
+    {target, valid, sign, weight} per point, caller order.  Writes d loss / d sdf in binned order to
+    ``gsdf_sorted`` (feed it to sdf_bwd_raw(..., gsdf_sorted=True)) and the per-workgroup loss sums to
+    ``loss_slots`` ((LOSS_SLOTS,2) floats, fully overwritten; the loss is loss_slots.sum(0)).
+    sdf_out (N,1), caller order, is optional."""
+    _require_hip(loss_inputs, gsdf_sorted, loss_slots, *features)
+    m, packed = pack.get()
+    n = sorted_batch.n
+    assert loss_inputs.shape == (n, 4) and loss_inputs.is_contiguous()
+    assert gsdf_sorted.is_contiguous() and gsdf_sorted.numel() == n
+    assert loss_slots.is_contiguous() and loss_slots.numel() == _lib.LOSS_SLOTS * 2
+    g = _fill_grid(features, meta)
+    _lib.check(_lib.load().miso_sdf_fwd_sorted_loss(
+        C.byref(g), C.byref(m), _ptr(packed), C.byref(sorted_batch.struct), n, _LOSS_TYPES[loss_type],
+        float(weight_sdf), float(weight_fs), float(trunc_dist), _ptr(loss_inputs), _ptr(sdf_out), _ptr(mask),
+        _ptr(gsdf_sorted), _ptr(loss_slots), _stream(gsdf_sorted)), "miso_sdf_fwd_sorted_loss")
 
 
 def grad_pull_raw(features, meta, sorted_batch: SortedBatch, dfeat, grads, overwrite: bool = True,

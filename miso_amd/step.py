@@ -1,6 +1,7 @@
 """One mapping iteration of a submap with a frozen decoder as a fixed launch
-sequence: clear grads -> fused encode+decode forward -> mapping loss (+ d/d pred)
--> fused backward scatter [-> dense Adam].
+sequence.  Large batches (binned): sort -> fused encode+decode forward -> fused backward with the
+mapping loss folded in -> owner-computes grid gradient [-> dense Adam].  Small batches: clear
+grads -> forward -> mapping loss (+ d/d pred) -> backward with atomic scatter [-> Adam].
 
 This is the trainer step of grid_opt/trainer.py:196-228 for MisoLossMapping
 (grid_opt/loss.py:754-813, pose variables locked as in Mapper.mapping,
@@ -31,13 +32,17 @@ class MappingStep:
         f32 = dict(device=dev, dtype=torch.float32)
         # static buffers (graph-safe): inputs are copied into these
         self.x = torch.zeros((self.n, 3), **f32)
-        self.target = torch.zeros((self.n, 1), **f32)
-        self.valid = torch.ones((self.n, 1), **f32)
-        self.sign = torch.zeros((self.n, 1), **f32)
-        self.weight = torch.ones((self.n, 1), **f32)
+        # loss inputs {target, valid, sign, weight}: one (N,4) row per point (the binned forward reads
+        # a point's loss inputs with one 16-B load); the four columns are views
+        self.aux = torch.zeros((self.n, 4), **f32)
+        self.aux[:, 1] = 1.0
+        self.aux[:, 3] = 1.0
+        self.target, self.valid = self.aux[:, 0:1], self.aux[:, 1:2]
+        self.sign, self.weight = self.aux[:, 2:3], self.aux[:, 3:4]
         self.sdf = torch.empty((self.n, 1), **f32)
         self.gpred = torch.empty((self.n, 1), **f32)
-        self.loss = torch.zeros(2, **f32)
+        self.loss_slots = torch.zeros((ops._lib.LOSS_SLOTS, 2), **f32)   # binned path: per-workgroup sums
+        self._loss = torch.zeros(2, **f32)
         self.grads = [torch.zeros_like(f) for f in self.features]
         self.adam = adam
         if adam is not None:
@@ -66,21 +71,40 @@ class MappingStep:
         if need_zero:
             for g in self.grads:
                 g.zero_()
+        L = len(self.features)
         if self.sorted is not None:
+            # binned path
             self.sorted.sort(self.x, self.meta)   # part of the step: a new batch arrives every iteration
-        _, mask = ops.sdf_fwd_raw(self.x, self.features, self.meta, self.pack, True, out=self.sdf,
-                                  mask=getattr(self, "_mask", None), sorted_batch=self.sorted)
-        self._mask = mask
-        ops.mapping_loss_raw(self.sdf, self.target, self.valid, self.sign, self.weight, lt, ws, wf, td,
-                             self.gpred, self.loss)
-        ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
-                        [True] * len(self.features), self.grads, sorted_batch=self.sorted, overwrite=True)
+            if getattr(self, "_mask", None) is None:
+                mw = ops.sdf_mask_words(self.pack)
+                self._mask = torch.empty(((self.n + 63) // 64) * 64 * mw, device=self.x.device, dtype=torch.int32)
+            # forward + mapping loss: sdf, ReLU bits, d loss / d sdf (binned order) in one launch
+            ops.sdf_fwd_loss_raw(self.features, self.meta, self.pack, self.sorted, self.aux, self._mask,
+                                 self.gpred, self.loss_slots, lt, ws, wf, td, sdf_out=self.sdf)
+            ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, self._mask, False,
+                            [True] * L, self.grads, sorted_batch=self.sorted, overwrite=True, gsdf_sorted=True)
+        else:
+            _, mask = ops.sdf_fwd_raw(self.x, self.features, self.meta, self.pack, True, out=self.sdf,
+                                      mask=getattr(self, "_mask", None))
+            self._mask = mask
+            if getattr(self, "_cols", None) is None:
+                self._cols = [torch.empty((self.n, 1), device=self.x.device) for _ in range(4)]
+            for c, src in zip(self._cols, (self.target, self.valid, self.sign, self.weight)):
+                c.copy_(src)          # mapping_loss_raw takes unit-stride columns
+            ops.mapping_loss_raw(self.sdf, *self._cols, lt, ws, wf, td, self.gpred, self._loss)
+            ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
+                            [True] * L, self.grads)
         if self.adam is not None:
             self.t += 1
             for p, g, m, v in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq):
                 # zero_grad=True: the gradient is cleared in the same pass, so the next
                 # iteration needs no memset
                 ops.adam_dense_(p.data, g, m, v, self.t, zero_grad=self.sorted is None, **self.adam)
+
+    @property
+    def loss(self) -> torch.Tensor:
+        """(2,) = [weight_sdf * sdf term, weight_fs * free-space term] of the last iteration."""
+        return self.loss_slots.sum(dim=0) if self.sorted is not None else self._loss
 
     def run(self):
         """Launch one iteration on the current stream (asynchronous)."""
