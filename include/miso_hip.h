@@ -29,6 +29,7 @@
  *                     with a frozen decoder (configs/rgbd/scannet.yaml:16).
  *   miso_pair_latent  pairwise_loss_latent, grid_opt/align/miso.py:116-211 (L2 / L1),
  *                     with the rigid maps of grid_opt/utils/utils_geometry.py:214-240.
+ *   miso_overlap_count GridAtlas.check_submap_intersection, grid_opt/models/grid_atlas.py:405-420.
  *   miso_lm_normal_eq Tracker.lm_step, grid_opt/slam/tracker.py:148-212 (J, H = J^T W J,
  *                     g = J^T W r with the L2 / Geman-McClure weights of :139-146).
  *   miso_mapping_loss miso_loss_regression + miso_loss_free_space and their gradient
@@ -218,6 +219,15 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
 int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float* coords_src,
                      const float* feats_src, int64_t ld_feats, int64_t n, int loss_type, float* out,
                      void* stream);
+
+/* --- submap overlap test ----------------------------------------------------
+ * GridAtlas.check_submap_intersection (grid_opt/models/grid_atlas.py:405-420): count_out[0]
+ * (device float) = number of coords_src (N,3; the source submap's finest-level voxel centres)
+ * that fall inside [bound_min, bound_max] (host floats[3], inclusive) of the destination after
+ * src -> world -> dst.  pose: as miso_pair_latent (24 floats, DEVICE).  No host sync: the
+ * caller compares count / N with its threshold on the device or reads it back. */
+int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, const float* bound_min,
+                       const float* bound_max, float* count_out, void* stream);
 
 /* --- tracker: Gauss-Newton normal equations ------------------------------
  * coords_frame (N,3): samples in the keyframe frame; R_frame (9 floats, DEVICE, row-major):

@@ -25,6 +25,7 @@ hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, co
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
                             uint32_t, int, hipStream_t);
+hipError_t launch_overlap_count(const float*, const float*, int64_t, const float*, const float*, float*, hipStream_t);
 hipError_t launch_lm_normal_eq(const float*, const float*, const float*, const float*, const float*, int64_t, int,
                                float, float*, hipStream_t);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
@@ -403,6 +404,13 @@ int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float
   if (ld_feats < g.F) return MISO_E_BADARG;
   return (int)launch_pair_latent(g, v4, pose, coords_src, feats_src, ld_feats, n, loss_type, out,
                                  (hipStream_t)stream);
+}
+
+int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, const float* bound_min,
+                       const float* bound_max, float* count_out, void* stream) {
+  if (n < 0 || !pose || !bound_min || !bound_max || !count_out || (n > 0 && !coords_src)) return MISO_E_BADARG;
+  if (n >= ((int64_t)1 << 24) * 128) return MISO_E_TOOLARGE;     // fp32 count stays exact
+  return (int)launch_overlap_count(pose, coords_src, n, bound_min, bound_max, count_out, (hipStream_t)stream);
 }
 
 int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const float* grad_sdf_x,

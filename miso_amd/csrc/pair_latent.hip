@@ -142,6 +142,51 @@ __global__ __launch_bounds__(256) void pair_latent_kernel(GridK g, PairK k) {
   }
 }
 
+// Overlap test of two submaps (GridAtlas.check_submap_intersection, grid_opt/models/grid_atlas.py:405-420):
+// how many of the source vertices land inside the destination bound after src -> world -> dst.
+// The reference materialises both (N,3) transforms and a bool mask for ~4e6 vertices per pair per
+// alignment iteration; here one pass, one float out.
+__global__ __launch_bounds__(256) void overlap_count_kernel(const float* __restrict__ pose,
+                                                           const float* __restrict__ p, int64_t n, float bmin0,
+                                                           float bmin1, float bmin2, float bmax0, float bmax1,
+                                                           float bmax2, float* __restrict__ out) {
+  float Rs[9], ts[3], Rd[9], td[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Rs[i] = pose[i]; Rd[i] = pose[12 + i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { ts[i] = pose[9 + i]; td[i] = pose[21 + i]; }
+  float cnt = 0.0f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const float px = p[idx * 3 + 0], py = p[idx * 3 + 1], pz = p[idx * 3 + 2];
+    // same operation order as pair_latent_kernel, so both agree on which vertices are inside
+    const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
+                        Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
+    const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
+    const float q0 = Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], q1 = Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
+                q2 = Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2];
+    if (q0 >= bmin0 && q0 <= bmax0 && q1 >= bmin1 && q1 <= bmax1 && q2 >= bmin2 && q2 <= bmax2) cnt += 1.0f;
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (red[0] + red[1]) + (red[2] + red[3]);
+    if (v != 0.0f) atomic_add_f32(out, v);      // <= 128 blocks: counts are integers < 2^24 per block, exact
+  }
+}
+
+hipError_t launch_overlap_count(const float* pose, const float* p, int64_t n, const float* bmin, const float* bmax,
+                                float* out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+  if (e != hipSuccess || n == 0) return e;
+  unsigned blocks = (unsigned)((n + 4095) / 4096);
+  if (blocks > 128u) blocks = 128u;
+  if (blocks < 1u) blocks = 1u;
+  overlap_count_kernel<<<blocks, 256, 0, s>>>(pose, p, n, bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2], out);
+  return hipGetLastError();
+}
+
 hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, const float* p, const float* fsrc,
                               int64_t ld, int64_t n, int loss_type, float* out, hipStream_t s) {
   hipError_t e = hipMemsetAsync(out, 0, 24 * sizeof(float), s);

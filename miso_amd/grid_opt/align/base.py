@@ -98,11 +98,22 @@ def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pair
             iteration_results[it] = iteration_results_helper(grid_atlas)
         optimizer.zero_grad()
         loss_dict = {}
-        for src_id, dst_id in submap_pairs:
-            if check_intersection and not bool(grid_atlas.check_submap_intersection(src_id, dst_id)):
-                continue
-            pair = loss_func(grid_atlas, loader, src_id, dst_id)
-            loss_dict.update({k: torch.nan_to_num(v) for k, v in pair.items()})
+        # one backward per iteration over the summed pair losses: the updated submap poses (and the
+        # graph through so3_exp_map) are shared by all pairs
+        with grid_atlas.pose_cache():
+            for src_id, dst_id in submap_pairs:
+                gate = None
+                if check_intersection:
+                    inter = grid_atlas.check_submap_intersection(src_id, dst_id)
+                    if getattr(loss_func, 'device_gate', False) and isinstance(inter, torch.Tensor) and inter.is_cuda:
+                        # cheap fused pair loss: evaluate it regardless and multiply by the 0/1 overlap
+                        # flag on the device instead of stalling the host on it for every pair
+                        gate = inter.to(torch.float32)
+                    elif not bool(inter):
+                        continue
+                pair = loss_func(grid_atlas, loader, src_id, dst_id)
+                loss_dict.update({k: torch.nan_to_num(v) * gate if gate is not None else torch.nan_to_num(v)
+                                  for k, v in pair.items()})
         if pose_reg_weight > 0:
             loss_dict.update(grid_atlas_pose_trust_region_loss(grid_atlas, thresh_rad=pose_thresh_rad,
                                                                thresh_m=pose_thresh_m, weight=pose_reg_weight))

@@ -64,6 +64,19 @@ def pairwise_loss_latent(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id
     if subsample_points is not None:
         k = min(subsample_points, coords_from.shape[0])
         coords_from = coords_from[np.random.choice(coords_from.shape[0], k, replace=False), :]
+    fused_ok = (align_loss in ('L2', 'L1') and use_bound and stability_thresh <= 0 and trunc_factor is None
+                and coords_from.is_cuda and fdim == sub_from.fdim)
+    if fused_ok:
+        # one kernel: both rigid maps, the bound mask, dst lookup, residual and the pose cotangents
+        # (nothing below -- the (N,3) transforms, the mask -- is materialised on this path)
+        from miso_amd import ops
+        nlv = min(level + 1, sub_from.num_levels)
+        f_from = (_src_features(grid_atlas, src_id, level, coords_from, nlv) if subsample_points is None
+                  else _query_feature_readonly(sub_from, coords_from, nlv))
+        feats_to = [g.feature.detach() for g in sub_to.features[:nlv]]
+        meta_to = sub_to.features[0].grid_meta(sub_to.ignore_level_[:nlv])
+        val = ops.pair_latent(R_from, t_from, R_to, t_to, coords_from, f_from, feats_to, meta_to, align_loss)
+        return {key: val * align_weight}
     coords_world = utils_geometry.transform_points_to(coords_from, R_from, t_from)
     coords_to = utils_geometry.transfrom_points_from(coords_world, R_to, t_to)
     mask = torch.ones((coords_from.shape[0], 1), dtype=torch.bool, device=coords_from.device)
@@ -77,18 +90,6 @@ def pairwise_loss_latent(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id
         with torch.no_grad():
             near = torch.abs(sub_from(coords_from)) < trunc_factor * sub_from.cell_sizes[level]
         mask = mask & near
-    fused_ok = (align_loss in ('L2', 'L1') and use_bound and stability_thresh <= 0 and trunc_factor is None
-                and coords_from.is_cuda and fdim == sub_from.fdim)
-    if fused_ok:
-        # one kernel: both rigid maps, the bound mask, dst lookup, residual and the pose cotangents
-        from miso_amd import ops
-        nlv = min(level + 1, sub_from.num_levels)
-        f_from = (_src_features(grid_atlas, src_id, level, coords_from, nlv) if subsample_points is None
-                  else _query_feature_readonly(sub_from, coords_from, nlv))
-        feats_to = [g.feature.detach() for g in sub_to.features[:nlv]]
-        meta_to = sub_to.features[0].grid_meta(sub_to.ignore_level_[:nlv])
-        val = ops.pair_latent(R_from, t_from, R_to, t_to, coords_from, f_from, feats_to, meta_to, align_loss)
-        return {key: val * align_weight}
     if align_loss in ('L2', 'L1'):
         # sync-free: masked mean instead of nonzero-compaction (out-of-bound rows sample zeros)
         w = mask.to(coords_from.dtype)
@@ -184,6 +185,10 @@ def align_multiple_submaps_hierarchical(grid_atlas: GridAtlas, dataset, level_it
                                         align_loss=align_loss, use_bound=use_bound,
                                         stability_thresh=stability_thresh, subsample_points=subsample_points,
                                         device=device)
+        # the fused pair kernel is cheap enough to run on non-overlapping pairs too: let the driver
+        # gate it on the device instead of synchronising on check_submap_intersection per pair
+        latent.device_gate = (align_loss in ('L2', 'L1') and use_bound and stability_thresh <= 0
+                              and subsample_points is None and str(device).startswith('cuda'))
         name = f'hier_latent_level{lvl}_{align_loss}'
         res = generic_align_multiple_submaps(grid_atlas, dataset, (name, latent), num_iters=level_iters,
                                              rel_change_thresh=level_thresh, **common)

@@ -5,6 +5,8 @@ import math
 from copy import deepcopy
 from typing import Tuple
 
+import contextlib
+
 import torch
 from torch import Tensor
 
@@ -165,12 +167,35 @@ class GridAtlas(BaseNet):
         return self.R_world_submap_list[submap_id], self.t_world_submap_list[submap_id]
 
     def updated_submap_pose(self, submap_id: int, device=None) -> Tuple[Tensor, Tensor]:
+        cache = self.__dict__.get('_pose_cache')
+        key = None
+        if cache is not None:
+            dr, dt = self.rotation_corrections[submap_id], self.translation_corrections[submap_id]
+            key = (submap_id, str(device), dr._version, dt._version, torch.is_grad_enabled())
+            hit = cache.get(submap_id)
+            if hit is not None and hit[0] == key:
+                return hit[1], hit[2]
         R0, t0 = self.initial_submap_pose(submap_id)
         R, t = utils_geometry.apply_pose_correction(R=R0, t=t0, R_delta=self.rotation_corrections[submap_id],
                                                     t_delta=self.translation_corrections[submap_id])
         if device is not None:
             R, t = R.to(device), t.to(device)
+        if cache is not None:
+            cache[submap_id] = (key, R, t)
         return R, t
+
+    @contextlib.contextmanager
+    def pose_cache(self):
+        """Within the block, updated_submap_pose(s) is evaluated once per submap and parameter version
+        and shared (graph included) by every pair that uses it.  For loops that sum the pair losses and
+        call backward ONCE per iteration, like generic_align_multiple_submaps: the exponential map and
+        its backward then run S times per iteration instead of 2 * pairs times."""
+        prev = self.__dict__.get('_pose_cache')
+        self.__dict__['_pose_cache'] = {}
+        try:
+            yield self
+        finally:
+            self.__dict__['_pose_cache'] = prev
 
     def _local_kf(self, kf_id: int, submap_id: int) -> int:
         expect = self.submap_id_for_kf(kf_id)
@@ -248,6 +273,12 @@ class GridAtlas(BaseNet):
         pts = self._finest_vertices(src_id).to(self.device)
         R_s, t_s = self.updated_submap_pose(src_id)
         R_d, t_d = self.updated_submap_pose(dst_id)
+        if pts.is_cuda:
+            # one pass over the vertices, no (N,3) temporaries; the result stays on the device
+            from miso_amd import ops
+            bound = dst.features[0].grid_meta()
+            cnt = ops.overlap_count(R_s, t_s, R_d, t_d, pts, [[bound.bound_min[a], bound.bound_max[a]] for a in range(3)])
+            return (cnt / pts.shape[0]) > overlap_thresh
         world = utils_geometry.transform_points_to(pts, R_s, t_s)
         local = utils_geometry.transfrom_points_from(world, R_d, t_d)
         inside = utils_geometry.coords_in_bound(local, dst.bound)

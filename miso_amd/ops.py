@@ -659,6 +659,24 @@ def pair_latent(R_src, t_src, R_dst, t_dst, coords_src, feats_src, feats_dst, me
     return _PairLatent.apply(R_src, t_src, R_dst, t_dst, coords_src, feats_src, meta_dst, loss_type, *feats_dst)
 
 
+def overlap_count(R_src, t_src, R_dst, t_dst, coords_src, bound_dst) -> torch.Tensor:
+    """0-d device tensor: how many of coords_src (N,3) fall inside bound_dst ((3,2) [min,max] rows,
+    inclusive) after src -> world -> dst (GridAtlas.check_submap_intersection,
+    grid_opt/models/grid_atlas.py:405-420).  One pass, no host sync (miso_overlap_count)."""
+    _require_hip(R_src, t_src, R_dst, t_dst, coords_src)
+    pts = coords_src.detach().contiguous()
+    n = pts.shape[0]
+    pose = torch.cat((R_src.detach().reshape(9), t_src.detach().reshape(3), R_dst.detach().reshape(9),
+                      t_dst.detach().reshape(3))).contiguous()
+    b = bound_dst.detach().cpu().tolist() if isinstance(bound_dst, torch.Tensor) else bound_dst
+    bmin = (C.c_float * 3)(*[float(b[a][0]) for a in range(3)])
+    bmax = (C.c_float * 3)(*[float(b[a][1]) for a in range(3)])
+    out = torch.empty(1, device=pts.device, dtype=torch.float32)
+    _lib.check(_lib.load().miso_overlap_count(_ptr(pose), _ptr(pts), n, bmin, bmax, _ptr(out), _stream(pts)),
+               "miso_overlap_count")
+    return out[0]
+
+
 # --------------------------------------------------------------------------- #
 # tracker: Gauss-Newton normal equations
 # --------------------------------------------------------------------------- #

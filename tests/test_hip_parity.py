@@ -537,3 +537,22 @@ def test_lm_normal_equations_vs_oracle(lt, n):
     assert (H.cpu().double() - H_ref).abs().max().item() < 2e-5 * scale
     assert (gv.cpu().double() - g_ref).abs().max().item() < 2e-5 * max(g_ref.abs().max().item(), 1e-30)
     assert torch.equal(H, H.T)
+
+
+@pytest.mark.parametrize("n", [0, 5, 100003])
+def test_overlap_count_vs_oracle(n):
+    """miso_overlap_count == the reference's transform -> transform -> coords_in_bound -> count
+    (grid_atlas.py:405-420) on the CPU oracle."""
+    from miso_amd import ops
+    g = torch.Generator().manual_seed(n + 1)
+    pts = torch.rand(n, 3, generator=g) * 6 - 3
+    R_s = torch.tensor(gc.rodrigues(np.array([0.2, -0.1, 0.4])), dtype=torch.float32)
+    R_d = torch.tensor(gc.rodrigues(np.array([-0.3, 0.25, 0.1])), dtype=torch.float32)
+    t_s, t_d = torch.tensor([[0.3], [-0.2], [0.1]]), torch.tensor([[-0.4], [0.5], [0.2]])
+    bound = torch.tensor([[-1.0, 1.5], [-2.0, 0.7], [-0.5, 2.2]])
+    world = R.transform_points_to(pts, R_s, t_s)
+    local = R.transfrom_points_from(world, R_d, t_d)
+    ref = int(torch.count_nonzero(R.coords_in_bound(local, bound)))
+    got = ops.overlap_count(R_s.to(DEV), t_s.to(DEV), R_d.to(DEV), t_d.to(DEV), pts.to(DEV), bound)
+    # a point within a few ulps of a face may fall on either side (different summation order)
+    assert abs(int(got.item()) - ref) <= max(2, n // 50000)
