@@ -146,6 +146,29 @@ def extras(step, dev):
 
     t = time_kernel(pair, iters=10, warm=2)
     ex["align_pair_latent_level1"] = {"vertices": nv, "us": t, "vertices_per_s": nv / (t * 1e-6)}
+
+    # the same pair through the alignment driver (Adam on the pose corrections, overlap gate,
+    # all pairs of an iteration behind one autograd node): wall time per iteration
+    class _DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return 0
+
+    def run(n_it):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        AM.align_multiple_submaps_hierarchical(atlas, _DS(), level_iters=n_it - 1, latent_levels=[1],
+                                               skip_finetune=True, device=dev, verbose=False)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(3)                                   # warm-up
+    # the driver re-derives the alignment coordinates once per call: difference two run lengths
+    t = (run(50) - run(10)) / 40 * 1e6
+    ex["align_iteration_level1_driver"] = {"pairs": 1, "vertices": nv, "us_per_iteration": t,
+                                           "vertices_per_s": nv / (t * 1e-6)}
     return ex
 
 

@@ -100,8 +100,11 @@ def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pair
         loss_dict = {}
         # one backward per iteration over the summed pair losses: the updated submap poses (and the
         # graph through so3_exp_map) are shared by all pairs
+        batched = getattr(loss_func, 'batched', None)
+        if batched is not None:
+            loss_dict.update(batched(grid_atlas, submap_pairs, check_intersection))
         with grid_atlas.pose_cache():
-            for src_id, dst_id in submap_pairs:
+            for src_id, dst_id in (submap_pairs if batched is None else ()):
                 gate = None
                 if check_intersection:
                     inter = grid_atlas.check_submap_intersection(src_id, dst_id)

@@ -118,6 +118,44 @@ def pairwise_loss_latent(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id
     return {key: val * align_weight}
 
 
+def pairwise_loss_latent_batched(grid_atlas: GridAtlas, pairs, level: int, fdim=4, align_weight=3000,
+                                 align_loss='L2', check_intersection=True, overlap_thresh=1e-2, device="cuda:0"):
+    """pairwise_loss_latent for every (src, dst) of ``pairs`` in one autograd node (ops.pair_latent_multi):
+    same values and pose gradients as the per-pair calls, including the overlap gate of
+    generic_align_multiple_submaps (base.py:134; decided on the device), for the default options
+    (L2 / L1, bound mask on, no stability / truncation pruning, no subsampling)."""
+    import ctypes as C
+    from miso_amd import ops
+    assert align_loss in ('L2', 'L1')
+    R_all, t_all = grid_atlas.updated_submap_poses_all(device)
+    cache = grid_atlas.__dict__.setdefault('_align_grid_cache', {})
+    plan = dict(pairs=list(pairs), loss_type=align_loss, coords=[], feats_src=[], grids=[], n_ch=[], keep=[],
+                gate_pts=[] if check_intersection else None, overlap_thresh=float(overlap_thresh))
+    for src_id, dst_id in pairs:
+        sub_from, sub_to = grid_atlas.get_submap(src_id), grid_atlas.get_submap(dst_id)
+        assert fdim == sub_from.fdim
+        nlv = min(level + 1, sub_from.num_levels)
+        coords = grid_atlas.coordinates_for_alignment(submap_id=src_id, level=level)
+        feats_to = [g.feature.detach() for g in sub_to.features[:nlv]]
+        gkey = (dst_id, nlv, tuple(f.data_ptr() for f in feats_to), tuple(bool(v) for v in sub_to.ignore_level_[:nlv]))
+        hit = cache.get((dst_id, nlv))
+        if hit is None or hit[0] != gkey:
+            meta_to = sub_to.features[0].grid_meta(sub_to.ignore_level_[:nlv])
+            bmin = (C.c_float * 3)(*meta_to.bound_min)
+            bmax = (C.c_float * 3)(*meta_to.bound_max)
+            hit = (gkey, ops._fill_grid(feats_to, meta_to), bmin, bmax)
+            cache[(dst_id, nlv)] = hit
+        plan["coords"].append(coords)
+        plan["feats_src"].append(ops._rows(_src_features(grid_atlas, src_id, level, coords, nlv)))
+        plan["grids"].append(hit[1])
+        plan["n_ch"].append(sum(int(f.shape[1]) for f in feats_to))
+        plan["keep"].append(feats_to)
+        if check_intersection:
+            plan["gate_pts"].append((grid_atlas._finest_vertices(src_id), hit[2], hit[3]))
+    losses = ops.pair_latent_multi(R_all, t_all, plan) * align_weight
+    return {f'align_latent_level{level}_{a}_{b}': losses[i] for i, (a, b) in enumerate(pairs)}
+
+
 def pairwise_loss_sdf(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id: int, align_weight=3000,
                       align_loss='L2', use_bound=True, stability_thresh=0, covariance_thresh=None,
                       subsample_points=None, gm_scale_sdf=0.1, device="cuda:0"):
@@ -189,6 +227,13 @@ def align_multiple_submaps_hierarchical(grid_atlas: GridAtlas, dataset, level_it
         # gate it on the device instead of synchronising on check_submap_intersection per pair
         latent.device_gate = (align_loss in ('L2', 'L1') and use_bound and stability_thresh <= 0
                               and subsample_points is None and str(device).startswith('cuda'))
+        if latent.device_gate and grid_atlas.get_submap(0).features[0].feature.is_cuda:
+            # all pairs of an iteration behind one autograd node
+            def latent_all(atlas, pairs, check_intersection, _l=lvl):
+                return pairwise_loss_latent_batched(atlas, pairs, level=_l, fdim=atlas.get_submap(0).fdim,
+                                                    align_weight=align_weight, align_loss=align_loss,
+                                                    check_intersection=check_intersection, device=device)
+            latent.batched = latent_all
         name = f'hier_latent_level{lvl}_{align_loss}'
         res = generic_align_multiple_submaps(grid_atlas, dataset, (name, latent), num_iters=level_iters,
                                              rel_change_thresh=level_thresh, **common)

@@ -184,6 +184,19 @@ class GridAtlas(BaseNet):
             cache[submap_id] = (key, R, t)
         return R, t
 
+    def updated_submap_poses_all(self, device=None) -> Tuple[Tensor, Tensor]:
+        """All updated submap poses at once, (S,3,3) and (S,3,1): one batched exponential map (and one
+        backward through it) instead of one per submap."""
+        from miso_amd.so3 import so3_exp_map
+        R0 = torch.stack(list(self.R_world_submap_list))
+        t0 = torch.stack(list(self.t_world_submap_list))
+        dr = torch.cat(list(self.rotation_corrections), dim=0)
+        dt = torch.stack(list(self.translation_corrections))
+        R, t = R0 @ so3_exp_map(dr), t0 + dt
+        if device is not None:
+            R, t = R.to(device), t.to(device)
+        return R, t
+
     @contextlib.contextmanager
     def pose_cache(self):
         """Within the block, updated_submap_pose(s) is evaluated once per submap and parameter version

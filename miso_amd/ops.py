@@ -659,6 +659,73 @@ def pair_latent(R_src, t_src, R_dst, t_dst, coords_src, feats_src, feats_dst, me
     return _PairLatent.apply(R_src, t_src, R_dst, t_dst, coords_src, feats_src, meta_dst, loss_type, *feats_dst)
 
 
+class _PairLatentMulti(torch.autograd.Function):
+    """All pairs of one alignment iteration behind ONE autograd node: P kernel launches, then the
+    loss normalisation and the pose cotangents as a handful of batched tensor ops (instead of ~25
+    small ops and an autograd node per pair -- the per-pair version is host-bound)."""
+
+    @staticmethod
+    def forward(ctx, R_all, t_all, plan):
+        lib = _lib.load()
+        dev = R_all.device
+        S = R_all.shape[0]
+        pairs = plan["pairs"]
+        P = len(pairs)
+        src = torch.tensor([a for a, _ in pairs], device=dev, dtype=torch.long)
+        dst = torch.tensor([b for _, b in pairs], device=dev, dtype=torch.long)
+        pose_all = torch.cat((R_all.reshape(S, 9), t_all.reshape(S, 3)), dim=1)            # (S,12)
+        pose_pairs = torch.cat((pose_all[src], pose_all[dst]), dim=1).contiguous()           # (P,24)
+        out = torch.empty((P, 24), device=dev, dtype=torch.float32)
+        cnt = torch.empty(P, device=dev, dtype=torch.float32) if plan["gate_pts"] is not None else None
+        stream = _stream(pose_pairs)
+        lt = _LOSS_TYPES[plan["loss_type"]]
+        for p in range(P):
+            coords, fsrc, grid, nch = plan["coords"][p], plan["feats_src"][p], plan["grids"][p], plan["n_ch"][p]
+            n = coords.shape[0]
+            _lib.check(lib.miso_pair_latent(C.byref(grid), C.c_void_p(pose_pairs.data_ptr() + 96 * p), _ptr(coords),
+                                            _ptr(fsrc), fsrc.stride(0) if n else nch, n, lt,
+                                            C.c_void_p(out.data_ptr() + 96 * p), stream), "miso_pair_latent")
+            if cnt is not None:
+                pts, bmin, bmax = plan["gate_pts"][p]
+                _lib.check(lib.miso_overlap_count(C.c_void_p(pose_pairs.data_ptr() + 96 * p), _ptr(pts), pts.shape[0],
+                                                  bmin, bmax, C.c_void_p(cnt.data_ptr() + 4 * p), stream),
+                           "miso_overlap_count")
+        nch_t = torch.tensor(plan["n_ch"], device=dev, dtype=torch.float32)
+        denom = out[:, 1].clamp(min=1.0) * (nch_t if plan["loss_type"] == "L2" else 1.0)
+        gate = torch.ones(P, device=dev)
+        if cnt is not None:
+            npts = torch.tensor([g_[0].shape[0] for g_ in plan["gate_pts"]], device=dev, dtype=torch.float32)
+            gate = ((cnt / npts) > plan["overlap_thresh"]).to(torch.float32)
+        ctx.save_for_backward(out, denom, gate, R_all, src, dst)
+        return torch.nan_to_num(out[:, 0] / denom) * gate
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        out, denom, gate, R_all, src, dst = ctx.saved_tensors
+        s = (gl * gate / denom).view(-1, 1, 1)
+        h = R_all[dst] @ out[:, 2:5].unsqueeze(-1)                  # sum_i R_dst g_i, (P,3,1)
+        gR = torch.zeros_like(R_all)
+        gt = torch.zeros((R_all.shape[0], 3, 1), device=R_all.device, dtype=R_all.dtype)
+        gR.index_add_(0, src, out[:, 14:23].reshape(-1, 3, 3) * s)
+        gR.index_add_(0, dst, out[:, 5:14].reshape(-1, 3, 3) * s)
+        gt.index_add_(0, src, h * s)
+        gt.index_add_(0, dst, -h * s)
+        return gR, gt, None
+
+
+def pair_latent_multi(R_all, t_all, plan) -> torch.Tensor:
+    """(P,) pair losses of one alignment iteration (pairwise_loss_latent for every pair of
+    ``plan['pairs']``), differentiable w.r.t. the stacked submap poses R_all (S,3,3), t_all (S,3,1).
+    plan: dict with per-pair lists ``coords`` (N_p,3), ``feats_src`` (N_p,>=n_ch), ``grids``
+    (_lib.Grid of the destination levels), ``n_ch``; ``loss_type``; ``gate_pts`` (per pair
+    (finest vertices, c_float[3] bound_min, c_float[3] bound_max)) or None and ``overlap_thresh``:
+    pairs whose overlap fraction is not above the threshold contribute exactly 0 -- decided on the
+    device (GridAtlas.check_submap_intersection without the host sync)."""
+    _require_hip(R_all, t_all)
+    return _PairLatentMulti.apply(R_all, t_all, plan)
+
+
 def overlap_count(R_src, t_src, R_dst, t_dst, coords_src, bound_dst) -> torch.Tensor:
     """0-d device tensor: how many of coords_src (N,3) fall inside bound_dst ((3,2) [min,max] rows,
     inclusive) after src -> world -> dst (GridAtlas.check_submap_intersection,

@@ -252,6 +252,39 @@ def test_atlas_queries_and_pairwise_alignment(device_backend):
         close(dt, T(g[f"align_l{l}_dt"]), 0, 2e-4)
 
 
+@pytest.mark.gpu
+def test_hierarchical_alignment_batched_path_matches_reference(monkeypatch):
+    """align_multiple_submaps_hierarchical on the GPU takes the batched path (all pairs of an
+    iteration behind one autograd node, overlap gate on the device) and reproduces the reference's
+    pose trajectory (3 (+1) Adam iterations per level, levels in sequence)."""
+    from miso_amd import ops
+    import miso_amd.grid_opt.align.miso as AM
+    dev = "cuda:0"
+    c = gc.ATLAS
+    g = G("atlas")
+    atlas = make_atlas(dev)
+    calls = []
+    real = ops.pair_latent_multi
+    monkeypatch.setattr(ops, "pair_latent_multi", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return 0
+
+    info = AM.align_multiple_submaps_hierarchical(atlas, DS(), level_iters=3, lr=1e-2, align_loss="L2",
+                                                  skip_finetune=True, device=dev, verbose=False)
+    assert len(calls) == c["n_levels"] * 4           # num_iters + 1 iterations per level, one node each
+    assert {f"hier_latent_level{l}_L2" for l in range(c["n_levels"])} <= set(info)
+    l = c["n_levels"] - 1
+    dr = torch.stack([p.detach().cpu() for p in atlas.rotation_corrections])
+    dt = torch.stack([p.detach().cpu() for p in atlas.translation_corrections])
+    close(dr, T(g[f"align_l{l}_dr"]), 0, 2e-4)
+    close(dt, T(g[f"align_l{l}_dt"]), 0, 2e-4)
+
+
 @pytest.mark.parametrize("lt", ["GM", "L2"])
 def test_tracker_lm_step_matches_reference(device_backend, lt):
     from miso_amd.grid_opt.slam.tracker import Tracker
