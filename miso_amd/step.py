@@ -115,6 +115,8 @@ class MappingStep:
             self._launch()                      # warm-up (allocates the mask buffer)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            # thread_local: another thread touching the runtime during capture (e.g. the RCCL
+            # watchdog of a multi-GPU job polling events) must not invalidate it
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self._launch()
         self._graph.replay()
