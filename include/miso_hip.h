@@ -192,6 +192,21 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
 uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis);
 int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
                    int64_t ld_d, int32_t rows_in_caller_order, void* stream);
+/* miso_encode_bwd over a binned batch: grad_x (and any level the pull cannot own) with
+ * tile-ordered gathers; grad_feats / grad_x rows stay in the caller's order. */
+int miso_encode_bwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n,
+                           const float* grad_feats, int64_t ld_g, float* grad_x, void* stream);
+/* miso_encode_bwd2 over a binned batch (tile-ordered gathers); all per-point rows (grad_feats,
+ * gg_x, gg_out, g_x) stay in the caller's order. */
+int miso_encode_bwd2_sorted(const miso_grid_t* grid, const miso_grid_t* gg_grid, const miso_sorted_t* sorted,
+                            int64_t n, const float* grad_feats, int64_t ld_g, const float* gg_x, float* gg_out,
+                            int64_t ld_gg, float* g_x, void* stream);
+/* The same for the SECOND backward: the g_input output of gridsample_grad2.grad2_3d
+ * (gridsample_cuda.cu:462-481), level[l].grad (+)= sum_i (sum_a gg_x[i,a] * d w_corner / d x_a) *
+ * grad_feats[i, channels of l] -- the scatter half of miso_encode_bwd2, which is then called with
+ * grad == NULL for these levels.  grad_feats (N, ld_g) and gg_x (N,3) in the caller's order. */
+int miso_grad_pull_dx(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* grad_feats,
+                      int64_t ld_g, const float* gg_x, void* stream);
 
 /* workspace (16-B aligned, miso_sdf_bwd_workspace_floats floats, may be NULL): with it and
  * sorted->xn_sorted the grid gradient is formed owner-computes (grad_pull.hip): every tile

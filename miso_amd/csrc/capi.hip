@@ -7,10 +7,10 @@
 
 namespace miso {
 hipError_t launch_encode_fwd(const GridK&, bool, const float*, int64_t, float*, int64_t, const int*, hipStream_t);
-hipError_t launch_encode_bwd(const GridK&, bool, const float*, int64_t, const float*, int64_t, float*,
+hipError_t launch_encode_bwd(const GridK&, bool, const float*, int64_t, const float*, int64_t, float*, const int*,
                              hipStream_t);
-hipError_t launch_encode_bwd2(const GridK&, const float*, int64_t, const float*, int64_t, const float*,
-                              float*, int64_t, float*, hipStream_t);
+hipError_t launch_encode_bwd2(const GridK&, bool, const float*, int64_t, const float*, int64_t, const float*, float*,
+                              int64_t, float*, const int*, hipStream_t);
 bool fused_shape_supported(int C, int L, int H, int NH);
 hipError_t launch_sdf_fwd(int, int, int, int, const GridK&, const float*, const float*, int64_t, float*,
                           uint32_t*, const int*, const LossInK&, hipStream_t);
@@ -24,7 +24,7 @@ hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, co
                               float*, hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
-                            uint32_t, int, hipStream_t);
+                            uint32_t, int, const float*, hipStream_t);
 hipError_t launch_overlap_count(const float*, const float*, int64_t, const float*, const float*, float*, hipStream_t);
 hipError_t launch_lm_normal_eq(const float*, const float*, const float*, const float*, const float*, int64_t, int,
                                float, float*, hipStream_t);
@@ -120,22 +120,40 @@ int miso_encode_fwd(const miso_grid_t* grid, const float* x, int64_t n, float* f
   return (int)launch_encode_fwd(g, v4, x, n, feats, ld_out, nullptr, (hipStream_t)stream);
 }
 
-int miso_encode_bwd(const miso_grid_t* grid, const float* x, int64_t n, const float* grad_feats,
-                    int64_t ld_g, float* grad_x, void* stream) {
-  if (n < 0 || (n > 0 && (!x || !grad_feats))) return MISO_E_BADARG;
+static const float* sorted_points(GridK* g, const miso_sorted_t* sorted);
+static int check_sorted(const miso_sorted_t* s);
+
+static int encode_bwd_impl(const miso_grid_t* grid, const float* x, int64_t n, const float* grad_feats,
+                           int64_t ld_g, float* grad_x, const miso_sorted_t* sorted, void* stream) {
+  if (n < 0 || (n > 0 && !grad_feats)) return MISO_E_BADARG;
   GridK g; bool v4;
   int rc = convert_grid(grid, &g, grad_x != nullptr, &v4);
   if (rc) return rc;
   if (ld_g < g.F) return MISO_E_BADARG;
-  return (int)launch_encode_bwd(g, v4, x, n, grad_feats, ld_g, grad_x, (hipStream_t)stream);
+  const int* perm = nullptr;
+  if (sorted) { x = sorted_points(&g, sorted); perm = sorted->perm; }
+  if (n > 0 && !x) return MISO_E_BADARG;
+  return (int)launch_encode_bwd(g, v4, x, n, grad_feats, ld_g, grad_x, perm, (hipStream_t)stream);
 }
 
-int miso_encode_bwd2(const miso_grid_t* grid, const miso_grid_t* gg_grid, const float* x, int64_t n,
-                     const float* grad_feats, int64_t ld_g, const float* gg_x, float* gg_out,
-                     int64_t ld_gg, float* g_x, void* stream) {
-  if (n < 0 || (n > 0 && (!x || !grad_feats || !gg_out))) return MISO_E_BADARG;
-  GridK g;
-  int rc = convert_grid(grid, &g, true, nullptr);
+int miso_encode_bwd(const miso_grid_t* grid, const float* x, int64_t n, const float* grad_feats,
+                    int64_t ld_g, float* grad_x, void* stream) {
+  return encode_bwd_impl(grid, x, n, grad_feats, ld_g, grad_x, nullptr, stream);
+}
+
+int miso_encode_bwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n,
+                           const float* grad_feats, int64_t ld_g, float* grad_x, void* stream) {
+  int rc = check_sorted(sorted);
+  if (rc) return rc;
+  return encode_bwd_impl(grid, nullptr, n, grad_feats, ld_g, grad_x, sorted, stream);
+}
+
+static int encode_bwd2_impl(const miso_grid_t* grid, const miso_grid_t* gg_grid, const float* x, int64_t n,
+                            const float* grad_feats, int64_t ld_g, const float* gg_x, float* gg_out,
+                            int64_t ld_gg, float* g_x, const miso_sorted_t* sorted, void* stream) {
+  if (n < 0 || (n > 0 && (!grad_feats || !gg_out))) return MISO_E_BADARG;
+  GridK g; bool v4;
+  int rc = convert_grid(grid, &g, true, &v4);
   if (rc) return rc;
   if (ld_g < g.F || ld_gg < g.F) return MISO_E_BADARG;
   if (gg_grid) {
@@ -147,11 +165,29 @@ int miso_encode_bwd2(const miso_grid_t* grid, const miso_grid_t* gg_grid, const 
       if (a.C != b.C || a.X != b.X || a.Y != b.Y || a.Z != b.Z || a.sC != b.sC || a.sX != b.sX ||
           a.sY != b.sY || a.sZ != b.sZ)
         return MISO_E_BADARG;  // cotangent must share the layout of the grid
+      if (((uintptr_t)b.data & 15u) != 0) v4 = false;
       g.lv[l].gg = b.data;
     }
   }
-  return (int)launch_encode_bwd2(g, x, n, grad_feats, ld_g, gg_x, gg_out, ld_gg, g_x,
+  const int* perm = nullptr;
+  if (sorted) { x = sorted_points(&g, sorted); perm = sorted->perm; }
+  if (n > 0 && !x) return MISO_E_BADARG;
+  return (int)launch_encode_bwd2(g, v4, x, n, grad_feats, ld_g, gg_x, gg_out, ld_gg, g_x, perm,
                                  (hipStream_t)stream);
+}
+
+int miso_encode_bwd2(const miso_grid_t* grid, const miso_grid_t* gg_grid, const float* x, int64_t n,
+                     const float* grad_feats, int64_t ld_g, const float* gg_x, float* gg_out,
+                     int64_t ld_gg, float* g_x, void* stream) {
+  return encode_bwd2_impl(grid, gg_grid, x, n, grad_feats, ld_g, gg_x, gg_out, ld_gg, g_x, nullptr, stream);
+}
+
+int miso_encode_bwd2_sorted(const miso_grid_t* grid, const miso_grid_t* gg_grid, const miso_sorted_t* sorted,
+                            int64_t n, const float* grad_feats, int64_t ld_g, const float* gg_x, float* gg_out,
+                            int64_t ld_gg, float* g_x, void* stream) {
+  int rc = check_sorted(sorted);
+  if (rc) return rc;
+  return encode_bwd2_impl(grid, gg_grid, nullptr, n, grad_feats, ld_g, gg_x, gg_out, ld_gg, g_x, sorted, stream);
 }
 
 int64_t miso_mlp_packed_floats(const miso_mlp_t* mlp) {
@@ -260,7 +296,7 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   }
   if (!pull) return MISO_OK;
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace,
-                               g.F, nullptr, pull, overwrite ? 1 : 0, st);
+                               g.F, nullptr, pull, overwrite ? 1 : 0, nullptr, st);
 }
 
 int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
@@ -360,8 +396,8 @@ uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis) 
   return mask;
 }
 
-int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
-                   int64_t ld_d, int32_t rows_in_caller_order, void* stream) {
+static int grad_pull_impl(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
+                          int64_t ld_d, int32_t rows_in_caller_order, const float* gg_x, void* stream) {
   int rc = check_sorted(sorted);
   if (rc) return rc;
   if (n < 0 || !sorted->xn_sorted || !dfeat || ((uintptr_t)dfeat & 15u) != 0 || (ld_d & 3) != 0)
@@ -372,9 +408,22 @@ int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t
   if (ld_d < g.F) return MISO_E_BADARG;
   for (int l = 0; l < g.n_levels; ++l)
     if (g.lv[l].grad && !((pull >> l) & 1u)) return MISO_E_UNSUPPORTED;   // every requested level must be pullable
+  if (gg_x && !(g.flags & MISO_F_COORDS_NORMALIZED))
+    for (int a = 0; a < 3; ++a) g.gscale[a] = 2.0f / (g.bmax[a] - g.bmin[a]);   // d xn / d x (axis_coord's m)
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, dfeat, ld_d,
                                rows_in_caller_order ? sorted->perm : nullptr, pull,
-                               (grid->flags & MISO_F_GRAD_OVERWRITE) ? 1 : 0, (hipStream_t)stream);
+                               (grid->flags & MISO_F_GRAD_OVERWRITE) ? 1 : 0, gg_x, (hipStream_t)stream);
+}
+
+int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
+                   int64_t ld_d, int32_t rows_in_caller_order, void* stream) {
+  return grad_pull_impl(grid, sorted, n, dfeat, ld_d, rows_in_caller_order, nullptr, stream);
+}
+
+int miso_grad_pull_dx(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* grad_feats,
+                      int64_t ld_g, const float* gg_x, void* stream) {
+  if (!gg_x) return MISO_E_BADARG;
+  return grad_pull_impl(grid, sorted, n, grad_feats, ld_g, 1, gg_x, stream);
 }
 
 int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n) {

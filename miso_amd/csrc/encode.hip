@@ -74,11 +74,15 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(GridK g, const float* _
 template <bool VEC4>
 __global__ __launch_bounds__(256) void encode_bwd_kernel(GridK g, const float* __restrict__ x,
                                                         int64_t n, const float* __restrict__ gf,
-                                                        int64_t ld, float* __restrict__ gx) {
+                                                        int64_t ld, float* __restrict__ gx,
+                                                        const int* __restrict__ perm) {
+  // perm != nullptr: x is the tile-sorted (pre-normalised) copy; gf / gx rows in the caller's order
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
-  const float* go = gf + p * ld;
+  float px, py, pz;
+  load_point(g, x, p, px, py, pz);
+  const int64_t po = perm ? (int64_t)perm[p] : p;
+  const float* go = gf + po * ld;
   float gpx = 0.f, gpy = 0.f, gpz = 0.f;
   for (int l = 0; l < g.n_levels; ++l) {
     const LevelK& lv = g.lv[l];
@@ -143,9 +147,9 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(GridK g, const float* _
         }
       }
     }
-    gpx += ax_ * ax.mult; gpy += ay_ * ay.mult; gpz += az_ * az.mult;
+    gpx += ax_ * (g.gscale[0] * ax.mult); gpy += ay_ * (g.gscale[1] * ay.mult); gpz += az_ * (g.gscale[2] * az.mult);
   }
-  if (gx) { gx[p * 3 + 0] = gpx; gx[p * 3 + 1] = gpy; gx[p * 3 + 2] = gpz; }
+  if (gx) { gx[po * 3 + 0] = gpx; gx[po * 3 + 1] = gpy; gx[po * 3 + 2] = gpz; }
 }
 
 // Second backward.  Inputs: ggG (= lv.gg, cotangent of grad_grid, may be null),
@@ -155,18 +159,24 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(GridK g, const float* _
 //   gG[c,k]    += inb * (grad w . d) * gF[c]
 //   gx_x        = mult_x * sum_c gF[c] * sum_k inb * ( dwx*ggG[c,k]
 //                          + G[c,k] * (d_y * dwxy + d_z * dwxz) )        (d2w/dx2 = 0)
+// VEC4: channels-last levels with C % 4 == 0 (one 16-B access per corner and channel quad).
+// perm != nullptr: x is the tile-sorted (pre-normalised) copy of the batch and every per-point row
+// (gf, ggx, ggo, gx) is addressed through perm, i.e. stays in the caller's order.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void encode_bwd2_kernel(GridK g, const float* __restrict__ x,
                                                          int64_t n, const float* __restrict__ gf,
                                                          int64_t ld, const float* __restrict__ ggx,
                                                          float* __restrict__ ggo, int64_t ldgg,
-                                                         float* __restrict__ gx) {
+                                                         float* __restrict__ gx, const int* __restrict__ perm) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  float px = x[p * 3 + 0], py = x[p * 3 + 1], pz = x[p * 3 + 2];
-  const float* go = gf + p * ld;
-  float* ggout = ggo + p * ldgg;
+  float px, py, pz;
+  load_point(g, x, p, px, py, pz);
+  const int64_t po = perm ? (int64_t)perm[p] : p;
+  const float* go = gf + po * ld;
+  float* ggout = ggo + po * ldgg;
   float ex = 0.f, ey = 0.f, ez = 0.f;
-  if (ggx) { ex = ggx[p * 3 + 0]; ey = ggx[p * 3 + 1]; ez = ggx[p * 3 + 2]; }
+  if (ggx) { ex = ggx[po * 3 + 0]; ey = ggx[po * 3 + 1]; ez = ggx[po * 3 + 2]; }
   float gpx = 0.f, gpy = 0.f, gpz = 0.f;
   for (int l = 0; l < g.n_levels; ++l) {
     const LevelK& lv = g.lv[l];
@@ -178,7 +188,9 @@ __global__ __launch_bounds__(256) void encode_bwd2_kernel(GridK g, const float* 
     Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
     Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
     Cell c = make_cell(ax, ay, az, lv);
-    float dxi = ex * ax.mult, dyi = ey * ay.mult, dzi = ez * az.mult;
+    // g.gscale restores d xn / d x when the points were pre-normalised (sorted batches)
+    const float mx = g.gscale[0] * ax.mult, my = g.gscale[1] * ay.mult, mz = g.gscale[2] * az.mult;
+    float dxi = ex * mx, dyi = ey * my, dzi = ez * mz;
     int off[8];
     float w[8], dwx[8], dwy[8], dwz[8], gwd[8], cx[8], cy[8], cz[8];
     bool inb[8];
@@ -203,25 +215,53 @@ __global__ __launch_bounds__(256) void encode_bwd2_kernel(GridK g, const float* 
       off[k] = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
     }
     float ax_ = 0.f, ay_ = 0.f, az_ = 0.f;
-    for (int ch = 0; ch < lv.C; ++ch) {
-      int64_t cb = (int64_t)ch * lv.sC;
-      float gv = go[lv.foff + ch];
-      float ggv = 0.0f;
+    if (VEC4) {
+      for (int ch = 0; ch < lv.C; ch += 4) {
+        const float gv[4] = {go[lv.foff + ch], go[lv.foff + ch + 1], go[lv.foff + ch + 2], go[lv.foff + ch + 3]};
+        float ggv[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 vv[8], g2v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float val = lv.data[cb + off[k]];
-        float g2 = lv.gg ? lv.gg[cb + off[k]] : 0.0f;
-        ggv += g2 * w[k] + val * gwd[k];
-        ax_ += gv * (g2 * dwx[k] + val * cx[k]);
-        ay_ += gv * (g2 * dwy[k] + val * cy[k]);
-        az_ += gv * (g2 * dwz[k] + val * cz[k]);
-        if (lv.grad && inb[k] && ggx) atomic_add_f32(lv.grad + cb + off[k], gwd[k] * gv);
+        for (int k = 0; k < 8; ++k) {
+          vv[k] = *reinterpret_cast<const float4*>(lv.data + off[k] + ch);
+          g2v[k] = lv.gg ? *reinterpret_cast<const float4*>(lv.gg + off[k] + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float val[4] = {vv[k].x, vv[k].y, vv[k].z, vv[k].w};
+          const float g2[4] = {g2v[k].x, g2v[k].y, g2v[k].z, g2v[k].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {     // same operation order per channel as the scalar path
+            ggv[e] += g2[e] * w[k] + val[e] * gwd[k];
+            ax_ += gv[e] * (g2[e] * dwx[k] + val[e] * cx[k]);
+            ay_ += gv[e] * (g2[e] * dwy[k] + val[e] * cy[k]);
+            az_ += gv[e] * (g2[e] * dwz[k] + val[e] * cz[k]);
+            if (lv.grad && inb[k] && ggx) atomic_add_f32(lv.grad + off[k] + ch + e, gwd[k] * gv[e]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ggout[lv.foff + ch + e] = ggv[e];
       }
-      ggout[lv.foff + ch] = ggv;
+    } else {
+      for (int ch = 0; ch < lv.C; ++ch) {
+        int64_t cb = (int64_t)ch * lv.sC;
+        float gv = go[lv.foff + ch];
+        float ggv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float val = lv.data[cb + off[k]];
+          float g2 = lv.gg ? lv.gg[cb + off[k]] : 0.0f;
+          ggv += g2 * w[k] + val * gwd[k];
+          ax_ += gv * (g2 * dwx[k] + val * cx[k]);
+          ay_ += gv * (g2 * dwy[k] + val * cy[k]);
+          az_ += gv * (g2 * dwz[k] + val * cz[k]);
+          if (lv.grad && inb[k] && ggx) atomic_add_f32(lv.grad + cb + off[k], gwd[k] * gv);
+        }
+        ggout[lv.foff + ch] = ggv;
+      }
     }
-    gpx += ax_ * ax.mult; gpy += ay_ * ay.mult; gpz += az_ * az.mult;
+    gpx += ax_ * mx; gpy += ay_ * my; gpz += az_ * mz;
   }
-  if (gx) { gx[p * 3 + 0] = gpx; gx[p * 3 + 1] = gpy; gx[p * 3 + 2] = gpz; }
+  if (gx) { gx[po * 3 + 0] = gpx; gx[po * 3 + 1] = gpy; gx[po * 3 + 2] = gpz; }
 }
 
 // ---- host-side launch helpers (called from capi.hip) -----------------------
@@ -236,17 +276,19 @@ hipError_t launch_encode_fwd(const GridK& g, bool vec4, const float* x, int64_t 
 }
 
 hipError_t launch_encode_bwd(const GridK& g, bool vec4, const float* x, int64_t n, const float* gf,
-                             int64_t ld, float* gx, hipStream_t s) {
+                             int64_t ld, float* gx, const int* perm, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  if (vec4) encode_bwd_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx);
-  else encode_bwd_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx);
+  if (vec4) encode_bwd_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx, perm);
+  else encode_bwd_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx, perm);
   return hipGetLastError();
 }
 
-hipError_t launch_encode_bwd2(const GridK& g, const float* x, int64_t n, const float* gf, int64_t ld,
-                              const float* ggx, float* ggo, int64_t ldgg, float* gx, hipStream_t s) {
+hipError_t launch_encode_bwd2(const GridK& g, bool vec4, const float* x, int64_t n, const float* gf, int64_t ld,
+                              const float* ggx, float* ggo, int64_t ldgg, float* gx, const int* perm,
+                              hipStream_t s) {
   if (n == 0) return hipSuccess;
-  encode_bwd2_kernel<<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx);
+  if (vec4) encode_bwd2_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx, perm);
+  else encode_bwd2_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx, perm);
   return hipGetLastError();
 }
 

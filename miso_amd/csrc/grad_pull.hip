@@ -38,6 +38,7 @@ struct PullK {
   const float4* xn;      // (N) normalised coordinates {x,y,z,_}, tile-sorted
   const float* dfeat;    // d-feat rows: row p (tile-sorted order) or, with perm, row perm[p]
   const int* perm;       // NULL: rows are in tile-sorted order
+  const float* ggx;      // MODE 1 only: (N,3) cotangent of the coordinate gradient, caller order (see below)
   int64_t ld;            // row pitch in floats (multiple of 4)
   int nl;                // number of pulled levels
   int lev[PULL_MAXL];    // their indices
@@ -98,7 +99,12 @@ __device__ __forceinline__ Brick make_brick(const LevelK& lv, int ta, int tb, in
 // rows are live.  Both keep a wavefront at <= 128 VGPRs and 10 KB of LDS: 4 blocks per CU, i.e. all
 // 4096 tiles of a 16^3 binning resident at once -- the kernel is bound by the serial latency of one
 // tile (~55 us whatever the occupancy), so throughput is the number of resident wavefronts.
-template <int C>
+//
+// MODE 0: vertex += w(corner) * row, w the trilinear weight -- the grid gradient of the first
+// backward.  MODE 1: vertex += (sum_a e_a * d w(corner) / d ix_a) * row with e = gg_x (.) d ix / d x per
+// point -- the grid gradient of the SECOND backward (g_input of gridsample_grad2.grad2_3d,
+// third_party/cuda_gridsample_grad2/gridsample_cuda.cu:462-481); records carry e next to the fracs.
+template <int C, int MODE>
 __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, const LevelK& lv, const Brick& b,
                                            float* smem, int o_list, int n, int o_arr, int o_rec, int o_df,
                                            int lane, bool add) {
@@ -144,6 +150,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
         // per cell; the records stay in registers (<= 3 per lane)
         constexpr int RPL = PULL_CAP / 64;
         int rc[RPL], rp[RPL]; float rfx[RPL], rfy[RPL], rfz[RPL];
+        constexpr int REC = MODE ? 8 : 4;
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
           const int i = u * 64 + lane;
@@ -193,8 +200,15 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
           if (rc[u] >= 0) {
             const int sh = 8 * (rc[u] & 3);
             const int pos = (int)((atomicAdd(&arrw[rc[u] >> 2], 1u << sh) >> sh) & 255u);
-            *reinterpret_cast<float4*>(smem + o_rec + pos * 4) = make_float4(rfx[u], rfy[u], rfz[u], 0.0f);
+            *reinterpret_cast<float4*>(smem + o_rec + pos * REC) = make_float4(rfx[u], rfy[u], rfz[u], 0.0f);
             const int row = pk.perm ? pk.perm[rp[u]] : rp[u];
+            if (MODE) {
+              // e_a = gg_x[a] * d ix_a / d x_a = gg_x[a] * (2 / len_a) * (size_a / 2)   (axis_coord's mult)
+              const float* e = pk.ggx + (int64_t)row * 3;
+              *reinterpret_cast<float4*>(smem + o_rec + pos * REC + 4) =
+                  make_float4(e[0] * (g.gscale[0] * (0.5f * (float)lv.X)), e[1] * (g.gscale[1] * (0.5f * (float)lv.Y)),
+                              e[2] * (g.gscale[2] * (0.5f * (float)lv.Z)), 0.0f);
+            }
             const float* src = pk.dfeat + (int64_t)row * pk.ld + lv.foff;
 #pragma unroll
             for (int c = 0; c < C; c += 4)
@@ -222,8 +236,15 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
             const int cc_ = c_hi - (dz * ncy + dy) * ncx - dx;
             const int q0 = (cc_ >= 1) ? (int)arrb[cc_ - 1] : 0, q1 = (int)arrb[cc_];
             for (int q = q0; q < q1; ++q) {
-              const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * 4);
-              const float w = ((dx ? f.x : 1.0f - f.x) * (dy ? f.y : 1.0f - f.y)) * (dz ? f.z : 1.0f - f.z);
+              constexpr int REC = MODE ? 8 : 4;
+              const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * REC);
+              const float ux = dx ? f.x : 1.0f - f.x, uy = dy ? f.y : 1.0f - f.y, uz = dz ? f.z : 1.0f - f.z;
+              float w = (ux * uy) * uz;
+              if (MODE) {
+                const float4 e = *reinterpret_cast<const float4*>(smem + o_rec + q * REC + 4);
+                w = e.x * ((dx ? 1.0f : -1.0f) * uy * uz) + e.y * ((dy ? 1.0f : -1.0f) * ux * uz) +
+                    e.z * ((dz ? 1.0f : -1.0f) * ux * uy);
+              }
 #pragma unroll
               for (int cc = 0; cc < C; cc += 4) {
                 const float4 dv = *reinterpret_cast<const float4*>(smem + o_df + q * C + cc);
@@ -247,9 +268,16 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
             const int dy = k & 1, dz = k >> 1;
             const int q0 = b0[k], q1 = b2[k];
             for (int q = q0; q < q1; ++q) {
-              const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * 4);
-              const float wx = (q < b1[k]) ? f.x : 1.0f - f.x;    // record of cell c-1 => corner dx = 1
-              const float w = (wx * (dy ? f.y : 1.0f - f.y)) * (dz ? f.z : 1.0f - f.z);
+              constexpr int REC = MODE ? 8 : 4;
+              const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * REC);
+              const bool dx1 = q < b1[k];                         // record of cell c-1 => corner dx = 1
+              const float ux = dx1 ? f.x : 1.0f - f.x, uy = dy ? f.y : 1.0f - f.y, uz = dz ? f.z : 1.0f - f.z;
+              float w = (ux * uy) * uz;
+              if (MODE) {
+                const float4 e = *reinterpret_cast<const float4*>(smem + o_rec + q * REC + 4);
+                w = e.x * ((dx1 ? 1.0f : -1.0f) * uy * uz) + e.y * ((dy ? 1.0f : -1.0f) * ux * uz) +
+                    e.z * ((dz ? 1.0f : -1.0f) * ux * uy);
+              }
 #pragma unroll
               for (int cc = 0; cc < C; cc += 4) {
                 const float4 dv = *reinterpret_cast<const float4*>(smem + o_df + q * C + cc);
@@ -296,7 +324,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
 
 // One wavefront per spatial tile.  The 3x3x3 tile neighbourhood is swept ONCE for all pulled
 // levels (a candidate's coordinates are loaded once and tested against every level's box).
-template <int C, int NLV>
+template <int C, int NLV, int MODE>
 __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   constexpr int PULL_NLV = NLV;   // levels swept together
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -304,9 +332,10 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   // depends on it (tile, bricks, loop counters) as divergent: VGPRs, exec-mask juggling, no scalar
   // loads.  readfirstlane pins it (and the list lengths below) to SGPRs.
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARRW + PULL_CAP * 4 + PULL_CAP * C;
+  constexpr int REC = MODE ? 8 : 4;
+  constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARRW + PULL_CAP * REC + PULL_CAP * C;
   const int o_list = wave * PER_WAVE, o_arr = o_list + PULL_NLV * PULL_LIST, o_rec = o_arr + PULL_ARRW,
-            o_df = o_rec + PULL_CAP * 4;
+            o_df = o_rec + PULL_CAP * REC;
   int* ismem = reinterpret_cast<int*>(smem);
   const int T = pk.T, ntiles = T * T * T;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -432,7 +461,7 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
         if (sweeping && PULL_LIST - n >= 64) continue;
         const bool first = !((stored >> d) & 1u);
         if (n == 0 && !first) continue;
-        pull_level<C>(g, pk, lv, b, smem, o_list + d * PULL_LIST, n, o_arr, o_rec, o_df, lane,
+        pull_level<C, MODE>(g, pk, lv, b, smem, o_list + d * PULL_LIST, n, o_arr, o_rec, o_df, lane,
                       !(first && pk.overwrite));
         stored |= 1u << d;
 #pragma unroll
@@ -464,12 +493,12 @@ uint32_t plan_grad_pull(const GridK& g, int T) {
 
 hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, const float* xn,
                             const float* dfeat, int64_t ld, const int* perm, uint32_t level_mask,
-                            int overwrite, hipStream_t s) {
+                            int overwrite, const float* ggx, hipStream_t s) {
   if (!level_mask) return hipSuccess;
   PullK pk;
   memset(&pk, 0, sizeof(pk));
   pk.T = T; pk.tile_off = tile_off; pk.xn = reinterpret_cast<const float4*>(xn); pk.dfeat = dfeat;
-  pk.ld = ld; pk.perm = perm;
+  pk.ld = ld; pk.perm = perm; pk.ggx = ggx;
   for (int l = 0; l < g.n_levels; ++l)
     if ((level_mask >> l) & 1u) {
       const int size[3] = {g.lv[l].X, g.lv[l].Y, g.lv[l].Z};
@@ -481,14 +510,14 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
     }
   pk.overwrite = overwrite;
   if (const char* d = getenv("MISO_DEBUG_PULL")) pk.debug = atoi(d);
-  const int per_wave = pk.nl * PULL_LIST + PULL_ARRW + PULL_CAP * 4 + PULL_CAP * C;
+  const int per_wave = pk.nl * PULL_LIST + PULL_ARRW + PULL_CAP * (ggx ? 8 : 4) + PULL_CAP * C;
   size_t lds = (size_t)per_wave * 4 * sizeof(float);
   if (const char* d = getenv("MISO_PULL_LDS_PAD")) lds += (size_t)atoi(d);   // dev: force a lower occupancy
   const int ntiles = T * T * T;
   unsigned blocks = (unsigned)((ntiles + 3) / 4);
   if (blocks > 2048u) blocks = 2048u;
   void (*k)(GridK, PullK) = nullptr;
-#define PICK(c, n) if (C == c && pk.nl == n) k = grad_pull_kernel<c, n>;
+#define PICK(c, n) if (C == c && pk.nl == n) k = ggx ? grad_pull_kernel<c, n, 1> : grad_pull_kernel<c, n, 0>;
   PICK(8, 1) PICK(8, 2) PICK(8, 3) PICK(8, 4) PICK(4, 1) PICK(4, 2) PICK(4, 3) PICK(4, 4)
 #undef PICK
   if (!k) return hipErrorInvalidValue;

@@ -152,9 +152,10 @@ def encode_bwd_raw(x, features, meta: GridMeta, gout, need_x: bool, need_f: Sequ
         pulled = int(lib.miso_grad_pull_levels(C.byref(_fill_grid(features, meta, want, data=False)),
                                                SortedBatch.TILES))
         if pulled:
-            sb = sorted_batch if sorted_batch is not None else SortedBatch(n, x.device).sort(x, meta)
+            if sorted_batch is None:
+                sorted_batch = SortedBatch(n, x.device).sort(x, meta)
             mine = [w if (pulled >> l) & 1 else None for l, w in enumerate(want)]
-            grad_pull_raw(features, meta, sb, gout, mine, overwrite=True, caller_order=True)
+            grad_pull_raw(features, meta, sorted_batch, gout, mine, overwrite=True, caller_order=True)
             grads = mine
     rest = [bool(nf) and not (pulled >> l) & 1 for l, nf in enumerate(need_f)]
     gx = None
@@ -165,19 +166,44 @@ def encode_bwd_raw(x, features, meta: GridMeta, gout, need_x: bool, need_f: Sequ
         gx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
         g = _fill_grid(features, meta, [gr if r else None for gr, r in zip(grads, rest)])
         ld = gout.stride(0) if n else _feature_dim(features)
-        _lib.check(lib.miso_encode_bwd(C.byref(g), _ptr(x), n, _ptr(gout), ld, _ptr(gx), _stream(x)),
-                   "miso_encode_bwd")
+        if sorted_batch is not None:      # the batch is binned already: gather in tile order
+            _lib.check(lib.miso_encode_bwd_sorted(C.byref(g), C.byref(sorted_batch.struct), n, _ptr(gout), ld, _ptr(gx),
+                                                  _stream(x)), "miso_encode_bwd_sorted")
+        else:
+            _lib.check(lib.miso_encode_bwd(C.byref(g), _ptr(x), n, _ptr(gout), ld, _ptr(gx), _stream(x)),
+                       "miso_encode_bwd")
     return gx, grads
 
 
-def encode_bwd2_raw(x, features, meta: GridMeta, gout, ggx, ggf, need_x: bool, need_f: Sequence[bool]):
+def encode_bwd2_raw(x, features, meta: GridMeta, gout, ggx, ggf, need_x: bool, need_f: Sequence[bool],
+                    sorted_batch: Optional["SortedBatch"] = None):
+    """Second backward (gridsample_grad2.grad2_3d).  Large batches: the grid-gradient output is
+    formed by the owner-computes pull (miso_grad_pull_dx) instead of float atomics -- they were
+    2.4 of the 2.5 ms of this op at 262144 points."""
     _require_hip(x, gout, ggx, *features)
     x = x.contiguous()
     gout = _rows(gout)
     n = x.shape[0]
     F = _feature_dim(features)
-    grads = [torch.zeros_like(f) if (nf and ggx is not None) else None for f, nf in zip(features, need_f)]
-    g = _fill_grid(features, meta, grads)
+    want = [bool(nf) and ggx is not None for nf in need_f]
+    grads: List[Optional[torch.Tensor]] = [None] * len(features)
+    pulled = 0
+    if (any(want) and encode_pull_applies(n, meta) and gout.stride(0) % 4 == 0 and gout.data_ptr() % 16 == 0):
+        cand = [torch.empty_like(f) if w else None for f, w in zip(features, want)]
+        pulled = int(_lib.load().miso_grad_pull_levels(C.byref(_fill_grid(features, meta, cand, data=False)),
+                                                       SortedBatch.TILES))
+        if pulled:
+            sorted_batch = sorted_batch if sorted_batch is not None else SortedBatch(n, x.device).sort(x, meta)
+            mine = [c if (pulled >> l) & 1 else None for l, c in enumerate(cand)]
+            gp = _fill_grid(features, meta, mine, data=False)
+            gp.flags |= _lib.F_GRAD_OVERWRITE
+            _lib.check(_lib.load().miso_grad_pull_dx(C.byref(gp), C.byref(sorted_batch.struct), n, _ptr(gout), gout.stride(0),
+                                                     _ptr(ggx.contiguous()), _stream(x)), "miso_grad_pull_dx")
+            grads = mine
+    for l, w in enumerate(want):
+        if w and not (pulled >> l) & 1:
+            grads[l] = torch.zeros_like(features[l])
+    g = _fill_grid(features, meta, [gr if not (pulled >> l) & 1 else None for l, gr in enumerate(grads)])
     gg = None
     keep = []
     if ggf is not None and any(t is not None for t in ggf):
@@ -194,9 +220,15 @@ def encode_bwd2_raw(x, features, meta: GridMeta, gout, ggx, ggf, need_x: bool, n
         ggx = ggx.contiguous()
     gg_out = torch.empty((n, F), device=x.device, dtype=torch.float32)
     g_x = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
-    _lib.check(_lib.load().miso_encode_bwd2(
-        C.byref(g), C.byref(gg) if gg is not None else None, _ptr(x), n, _ptr(gout),
-        gout.stride(0) if n else F, _ptr(ggx), _ptr(gg_out), F, _ptr(g_x), _stream(x)), "miso_encode_bwd2")
+    sb = sorted_batch if pulled else None      # the binned copy exists: gather in tile order as well
+    if sb is not None:
+        _lib.check(_lib.load().miso_encode_bwd2_sorted(
+            C.byref(g), C.byref(gg) if gg is not None else None, C.byref(sb.struct), n, _ptr(gout),
+            gout.stride(0) if n else F, _ptr(ggx), _ptr(gg_out), F, _ptr(g_x), _stream(x)), "miso_encode_bwd2_sorted")
+    else:
+        _lib.check(_lib.load().miso_encode_bwd2(
+            C.byref(g), C.byref(gg) if gg is not None else None, _ptr(x), n, _ptr(gout),
+            gout.stride(0) if n else F, _ptr(ggx), _ptr(gg_out), F, _ptr(g_x), _stream(x)), "miso_encode_bwd2")
     return gg_out, g_x, grads
 
 
@@ -215,6 +247,7 @@ class _EncodeBackward(torch.autograd.Function):
         gx, grads = encode_bwd_raw(x, features, meta, gout, need_x, need_f, sorted_batch=sb)
         ctx.save_for_backward(gout, x, *features)
         ctx.meta = meta
+        ctx.sorted = sb
         return (gx, *grads)
 
     @staticmethod
@@ -225,7 +258,8 @@ class _EncodeBackward(torch.autograd.Function):
         need_f = ctx.needs_input_grad[5:]
         if ggx is None and all(t is None for t in ggf):
             return (None,) * (5 + len(features))
-        gg_out, g_x, g_f = encode_bwd2_raw(x, features, ctx.meta, gout, ggx, ggf, need_x, need_f)
+        gg_out, g_x, g_f = encode_bwd2_raw(x, features, ctx.meta, gout, ggx, ggf, need_x, need_f,
+                                           sorted_batch=ctx.sorted)
         return (gg_out if need_gout else None, g_x, None, None, None, *g_f)
 
 

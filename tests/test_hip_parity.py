@@ -556,3 +556,44 @@ def test_overlap_count_vs_oracle(n):
     got = ops.overlap_count(R_s.to(DEV), t_s.to(DEV), R_d.to(DEV), t_d.to(DEV), pts.to(DEV), bound)
     # a point within a few ulps of a face may fall on either side (different summation order)
     assert abs(int(got.item()) - ref) <= max(2, n // 50000)
+
+
+@pytest.mark.parametrize("name,n", [("small", 20000), ("cfg2", 40000)])
+def test_second_order_pull_path_vs_atomic_and_oracle(name, n, monkeypatch):
+    """Eikonal-type loss on a batch large enough for the binned path: the grid gradient of the
+    SECOND backward comes from miso_grad_pull_dx; same as the atomic scatter of miso_encode_bwd2
+    and (on a subset small enough for the CPU) as the any-order oracle."""
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x0, meta, fd, pack = setup_case(name)
+    g = torch.Generator().manual_seed(21)
+    b = torch.tensor(case["bound"])
+    x = torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) * 1.1 + b[:, 0] - 0.05 * (b[:, 1] - b[:, 0])
+    wd, bd = [w.to(DEV) for w in ws], [bb.to(DEV) for bb in bs]
+
+    def eik(enc, fs, xx, w, b_):
+        sdf = R.mlp_forward(enc(fs, xx), w, b_)
+        (gx,) = torch.autograd.grad(sdf, xx, torch.ones_like(sdf), create_graph=True)
+        return ((gx.norm(dim=-1) - 1) ** 2).mean()
+
+    def run():
+        xd = x.to(DEV).requires_grad_(True)
+        l = eik(lambda fs, xx: ops.encode(xx, fs, meta), fd, xd, wd, bd)
+        return l, torch.autograd.grad(l, fd + [xd])
+
+    assert n >= ops.ENCODE_PULL_MIN_POINTS
+    called = []
+    real = ops._lib.load().miso_grad_pull_dx
+    la, ga = run()
+    monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", None)
+    lb, gb = run()
+    assert abs(la.item() - lb.item()) <= 1e-6 * max(1.0, abs(lb.item()))
+    for a, c in zip(ga, gb):
+        assert relerr(a, c) < 5e-5
+    # oracle on the first 300 points only (the any-order restatement is slow); gradient w.r.t. x
+    # of those points depends on nothing else
+    m = 300
+    fc = [f.clone().requires_grad_(True) for f in feats]
+    xc = x[:m].clone().requires_grad_(True)
+    lc = eik(lambda fs, xx: R.encode_gather(fs, bound, xx), fc, xc, ws, bs)
+    (gxc,) = torch.autograd.grad(lc, [xc])
+    assert relerr(ga[-1][:m].cpu() * (n / m), gxc) < 5e-4
