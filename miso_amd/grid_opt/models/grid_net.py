@@ -174,6 +174,37 @@ class GridNet(BaseNet):
     def updated_kf_pose_in_world(self, kf_id: int):
         return self.updated_kf_pose(kf_id)
 
+    def updated_kf_poses_all(self):
+        """All keyframe poses at once, (P,3,3) and (P,3,1): updated_kf_pose for every index with ONE
+        batched exponential map; locked indices are detached exactly as pose_correction does."""
+        from miso_amd.so3 import so3_exp_map
+        dr, dt = self.rotation_corrections, self.translation_corrections
+        if self.locked_pose_indices:
+            if len(self.locked_pose_indices) >= self.num_poses:
+                dr, dt = dr.detach(), dt.detach()
+            else:
+                locked = torch.zeros(self.num_poses, dtype=torch.bool, device=dr.device)
+                locked[list(self.locked_pose_indices)] = True
+                dr = torch.where(locked[:, None], dr.detach(), dr)
+                dt = torch.where(locked[:, None, None], dt.detach(), dt)
+        return self.Rwk @ so3_exp_map(dr), self.twk + dt
+
+    def kf_key_index_table(self, prefix='KF'):
+        """LongTensor t with t[k] = pose index of key f'{prefix}{k}' (-1: unknown), on the model's
+        device, rebuilt when the key set changes: maps a batch's frame ids to poses without a
+        host round trip."""
+        items = [(int(k[len(prefix):]), v) for k, v in self._pose_key_to_id.items()
+                 if isinstance(k, str) and k.startswith(prefix) and k[len(prefix):].isdigit()]
+        sig = (prefix, tuple(sorted(items)), str(self.Rwk.device))
+        hit = self.__dict__.get('_kf_table')
+        if hit is None or hit[0] != sig:
+            t = torch.full((max([k for k, _ in items], default=-1) + 2,), -1, dtype=torch.long)
+            for k, v in items:
+                t[k] = v
+            hit = (sig, t.to(self.Rwk.device))
+            self.__dict__['_kf_table'] = hit
+        return hit[1]
+
     def updated_kf_pose_from_key(self, kf_key):
         return self.updated_kf_pose(self.pose_key_to_id(kf_key))
 

@@ -105,9 +105,72 @@ class Trainer(object):
         if self.ckpt_every > 0:
             self.save_model(epoch, "final")
 
+    # ---- captured mapping step -----------------------------------------------------------------
+    def _captured_mapping_step(self, model_input, gt):
+        """The common mapping configuration -- MisoLossMapping with only its sdf / free-space terms, a
+        GridNet with a frozen MLP decoder, keyframe poses not optimised, dense Adam over feature
+        grids -- as ONE graph replay (miso_amd.step.MappingStep: sort, forward + loss, backward, pull)
+        followed by the usual optimizer.step().  Same arithmetic as the op-by-op path below; what
+        goes away is ~60 launches and the autograd bookkeeping per iteration, which cost several
+        times the 0.2 ms the GPU needs.  Returns the total loss, or None if the configuration
+        does not qualify (the op-by-op path then runs)."""
+        from miso_amd.grid_opt.loss import MisoLossMappingBase
+        from miso_amd.step import MappingStep
+        lf, model = self.loss_func, self.model
+        if not (isinstance(lf, MisoLossMappingBase) and type(lf).compute is MisoLossMappingBase.compute):
+            return None
+        if lf.loss_type not in ('L1', 'L2') or lf.weight_eik > 0 or lf.use_stability or lf.weight_clip > 0:
+            return None
+        if not isinstance(self.optimizer, DenseAdam) or not hasattr(model, '_fused_decoder'):
+            return None
+        coords_frame = model_input['coords_frame'][0]
+        if not coords_frame.is_cuda or coords_frame.shape[0] == 0:
+            return None
+        pack = model._fused_decoder()
+        if pack is None or any(p.requires_grad for p in model.decoder.parameters()):
+            return None
+        if any(p.requires_grad for p in model.params_for_poses()):
+            return None
+        feats = [g.feature for g in model.features]
+        opt_params = {id(p) for group in self.optimizer.param_groups for p in group['params']}
+        need = tuple(id(f) in opt_params and f.requires_grad for f in feats)
+        if not any(need) or any(f.requires_grad and not nd for f, nd in zip(feats, need)):
+            return None      # a feature grid would receive a gradient that no optimizer consumes: keep autograd's view
+        n = coords_frame.shape[0]
+        ignore = tuple(bool(v) for v in model.ignore_level_)
+        key = (n, need, ignore, lf.loss_type, float(lf.weight_sdf), float(lf.weight_fs), lf.trunc_dist,
+               tuple(f.data_ptr() for f in feats))
+        cache = self.__dict__.setdefault('_mapping_steps', {})
+        step = cache.get(key)
+        if step is None:
+            cache.clear()            # one live graph: batch sizes rarely alternate
+            meta = model.features[0].grid_meta(model.ignore_level_)
+            step = MappingStep([f.data for f in feats], meta, pack, n, lf.loss_type, float(lf.weight_sdf),
+                               float(lf.weight_fs) if lf.weight_fs > 0 else 0.0,
+                               0.0 if lf.trunc_dist is None else float(lf.trunc_dist), need_levels=need)
+            cache[key] = step
+        with torch.no_grad():
+            frame_ids = model_input['sample_frame_ids'][0, :, 0]
+            coords_world = lf.world_coords(model, coords_frame, frame_ids)
+            step.set_batch(coords_world, gt['sdf'][0], gt['sdf_valid'][0], gt['sdf_signs'][0],
+                           model_input['weights'][0])
+        step.run()
+        for f, g, nd in zip(feats, step.grads, need):
+            f.grad = g if nd else None
+        total = step.loss.sum()
+        if not torch.isnan(total):
+            self.optimizer.step()
+        else:
+            logger.warning("Loss is nan! Skip backward step.")
+        return total
+
     def train_step(self, model_input, gt):
         """zero_grad -> loss dict -> sum of means -> NaN guard -> backward -> step.
         Returns the total loss (device scalar)."""
+        if self.cfg.get('captured_step', True):
+            total = self._captured_mapping_step(model_input, gt)
+            if total is not None:
+                return total
         self.optimizer.zero_grad()
         loss_dict = self.loss_func.compute(self.model, model_input, gt)
         total = 0.

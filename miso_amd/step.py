@@ -21,7 +21,9 @@ class MappingStep:
     def __init__(self, features: Sequence[torch.Tensor], meta: ops.GridMeta, pack: ops.DecoderPack,
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
                  trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
-                 sort: Optional[bool] = None):
+                 sort: Optional[bool] = None, need_levels: Optional[Sequence[bool]] = None):
+        """need_levels: which levels get a gradient (default all) -- the coarse-to-fine schedule of
+        GridTrainer optimises one level at a time."""
         self.features = list(features)
         self.meta, self.pack = meta, pack
         self.n = int(n_points)
@@ -43,11 +45,14 @@ class MappingStep:
         self.gpred = torch.empty((self.n, 1), **f32)
         self.loss_slots = torch.zeros((ops._lib.LOSS_SLOTS, 2), **f32)   # binned path: per-workgroup sums
         self._loss = torch.zeros(2, **f32)
-        self.grads = [torch.zeros_like(f) for f in self.features]
+        need = [True] * len(self.features) if need_levels is None else [bool(v) for v in need_levels]
+        assert len(need) == len(self.features)
+        self.need_levels = need
+        self.grads = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
         self.adam = adam
         if adam is not None:
-            self.exp_avg = [torch.zeros_like(f) for f in self.features]
-            self.exp_avg_sq = [torch.zeros_like(f) for f in self.features]
+            self.exp_avg = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
+            self.exp_avg_sq = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
             self.t = 0
         if sort is None:   # default: bin when the batch is large enough for it to pay
             sort = ops.SortedBatch.AUTO_MIN_POINTS is not None and self.n >= ops.SortedBatch.AUTO_MIN_POINTS
@@ -70,7 +75,8 @@ class MappingStep:
         need_zero = self.sorted is None and (self.adam is None or self.t == 0)
         if need_zero:
             for g in self.grads:
-                g.zero_()
+                if g is not None:
+                    g.zero_()
         L = len(self.features)
         if self.sorted is not None:
             # binned path
@@ -82,7 +88,7 @@ class MappingStep:
             ops.sdf_fwd_loss_raw(self.features, self.meta, self.pack, self.sorted, self.aux, self._mask,
                                  self.gpred, self.loss_slots, lt, ws, wf, td, sdf_out=self.sdf)
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, self._mask, False,
-                            [True] * L, self.grads, sorted_batch=self.sorted, overwrite=True, gsdf_sorted=True)
+                            self.need_levels, self.grads, sorted_batch=self.sorted, overwrite=True, gsdf_sorted=True)
         else:
             _, mask = ops.sdf_fwd_raw(self.x, self.features, self.meta, self.pack, True, out=self.sdf,
                                       mask=getattr(self, "_mask", None))
@@ -93,10 +99,12 @@ class MappingStep:
                 c.copy_(src)          # mapping_loss_raw takes unit-stride columns
             ops.mapping_loss_raw(self.sdf, *self._cols, lt, ws, wf, td, self.gpred, self._loss)
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
-                            [True] * L, self.grads)
+                            self.need_levels, self.grads)
         if self.adam is not None:
             self.t += 1
             for p, g, m, v in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq):
+                if g is None:
+                    continue
                 # zero_grad=True: the gradient is cleared in the same pass, so the next
                 # iteration needs no memset
                 ops.adam_dense_(p.data, g, m, v, self.t, zero_grad=self.sorted is None, **self.adam)

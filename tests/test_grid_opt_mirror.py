@@ -142,10 +142,12 @@ def test_miso_losses_match_reference(device_backend):
         close(net.features[l].feature.grad, T(g[f"isdf_slam_gfeat{l}"]), 1e-4)
 
 
+@pytest.mark.parametrize("captured", [True, False])
 @pytest.mark.parametrize("mode", ["joint", "coordinate+joint"])
-def test_grid_trainer_matches_reference(device_backend, mode, tmp_path):
+def test_grid_trainer_matches_reference(device_backend, mode, captured, tmp_path):
     """GridTrainer, 6 epochs, level switch every 2 epochs -> features equal the reference's
-    (dense Adam semantics incl. untouched stability grids)."""
+    (dense Adam semantics incl. untouched stability grids).  captured: on the GPU the step runs
+    as one graph replay (Trainer._captured_mapping_step); False forces the op-by-op autograd path."""
     import miso_amd.grid_opt.loss as L
     from miso_amd.grid_opt.trainer import GridTrainer
     dev = device_backend
@@ -170,10 +172,13 @@ def test_grid_trainer_matches_reference(device_backend, mode, tmp_path):
     net.lock_pose()
     cfg_train = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 6, "ckpt_every": -1,
                  "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": str(tmp_path),
-                 "relchange_tol": 0, "max_epochs_in_level": 2, "grid_training_mode": mode}
+                 "relchange_tol": 0, "max_epochs_in_level": 2, "grid_training_mode": mode,
+                 "captured_step": captured}
     lossf = L.MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
     loader = torch.utils.data.DataLoader(DS(), batch_size=1, shuffle=False, num_workers=0)
-    GridTrainer(cfg_train, net, lossf, loader, None, dev, torch.float32).train()
+    tr = GridTrainer(cfg_train, net, lossf, loader, None, dev, torch.float32)
+    tr.train()
+    assert bool(tr.__dict__.get("_mapping_steps")) == (captured and str(dev).startswith("cuda"))
     tag = mode.replace("+", "_")
     for l in range(case["n_levels"]):
         close(net.features[l].feature, T(g[f"{tag}_feat{l}"]), 0, 3e-6)

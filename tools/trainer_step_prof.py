@@ -1,0 +1,35 @@
+import os, sys, tempfile, time, torch
+sys.path.insert(0, os.getcwd())
+import miso_amd.grid_opt.loss as L
+from miso_amd.grid_opt.models.grid_net import GridNet
+from miso_amd.grid_opt.trainer import GridTrainer
+dev="cuda:0"; n=262144
+cfg = {"name": "grid_net", "spatial_dim": 3,
+       "decoder": {"type": "mlp", "hidden_dim": 64, "hidden_layers": 1, "out_dim": 1, "pos_invariant": True, "fix": True, "pretrained_model": None},
+       "grid": {"type": "regular", "feature_dim": 8, "init_stddev": 1e-2, "bound": [[-1., 1.]] * 3, "base_cell_size": 2.0 / 32, "per_level_scale": 2, "n_levels": 3},
+       "pose": {"optimize": False, "num_poses": 1}}
+torch.manual_seed(0)
+x = torch.rand(n, 3) * 2 - 1
+mi = {"coords_frame": x[None].to(dev), "sample_frame_ids": torch.zeros(1, n, 1, dtype=torch.int64, device=dev), "weights": torch.ones(1, n, 1, device=dev)}
+gt = {"sdf": (torch.rand(1, n, 1) * 0.2 - 0.1).to(dev), "sdf_valid": torch.ones(1, n, 1, device=dev), "sdf_signs": torch.zeros(1, n, 1, device=dev)}
+net = GridNet(cfg, device=dev).to(dev)
+net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0"); net.unlock_feature(); net.lock_pose()
+tcfg = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 1, "ckpt_every": -1, "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": tempfile.mkdtemp(), "relchange_tol": 0, "max_epochs_in_level": 1000, "grid_training_mode": "joint"}
+lf = L.MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
+tr = GridTrainer(tcfg, net, lf, None, None, dev, torch.float32)
+for _ in range(5): tr.train_step(mi, gt)
+step = list(tr._mapping_steps.values())[0]
+def T(fn, it=20):
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    for _ in range(it): r = fn()
+    torch.cuda.synchronize(); return (time.perf_counter()-t0)/it*1e6
+cf = mi['coords_frame'][0]; fid = mi['sample_frame_ids'][0,:,0]
+print("world_coords", T(lambda: lf.world_coords(net, cf, fid)))
+cw = lf.world_coords(net, cf, fid)
+print("set_batch", T(lambda: step.set_batch(cw, gt['sdf'][0], gt['sdf_valid'][0], gt['sdf_signs'][0], mi['weights'][0])))
+print("run", T(step.run))
+print("loss.sum+isnan", T(lambda: bool(torch.isnan(step.loss.sum()))))
+print("optimizer.step", T(tr.optimizer.step))
+print("fused_decoder()", T(net._fused_decoder))
+print("full", T(lambda: tr.train_step(mi, gt)))
+print("n params in optimizer:", sum(len(g['params']) for g in tr.optimizer.param_groups), [tuple(p.shape) for g in tr.optimizer.param_groups for p in g['params']])
