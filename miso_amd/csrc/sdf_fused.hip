@@ -52,6 +52,21 @@ __device__ __forceinline__ void memory_phase(bool on, uint32_t tune) {
 #define MISO_FWD_OCC 2
 #endif
 
+// On gfx950 the fp32 MFMA shares the vector FMA datapath (tools/ubench/mfma_valu.hip): every VALU
+// instruction between two MFMAs costs matrix throughput, so the MLP phase is trimmed of them.
+// * ReLU on the raw bits: max_i32(bits, 0) is ONE instruction and exact (negative floats, -0 included,
+//   are negative integers); fmaxf(x, 0) costs two (a canonicalising v_max x,x first).
+// * Sign bit for the backward from the ReLU output: min_u32(bits, 1) then shift-or -- two instructions
+//   instead of compare + select + or.
+// * The bias enters as the C operand of the first MFMA of each chain (no accumulator init moves).
+// (Inline-asm variants were tried: the hazard recogniser does not see that the asm reads MFMA results,
+//  and the missing wait states returned stale accumulators.)
+#define MISO_FUSED_KERNEL_ATTR
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// y = relu1(x): bit <- (x > 0)
+__device__ __forceinline__ void push_gt0(uint32_t& m, float y, int bit) { m |= min(__float_as_uint(y), 1u) << bit; }
+__device__ __forceinline__ bool mask_bit(uint32_t m, int t, int j) { return (m >> (t * 16 + j)) & 1u; }
+
 struct ChunkSched {
   int64_t cur, end, step;
   __device__ __forceinline__ ChunkSched(int64_t nchunks, int wave, int nw, bool xcd_local) {
@@ -166,7 +181,7 @@ __device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, fl
 }
 
 template <int C, int L, int H, int NH>
-__global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
+__global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
                                                         const float* __restrict__ x, int64_t n,
                                                         float* __restrict__ sdf,
                                                         uint32_t* __restrict__ mask,
@@ -241,23 +256,25 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
     // Two accumulator sets ping-pong between layers (ReLU is applied in place, so
     // no third copy of the 64 activation registers is ever live).
     f32x16 buf[2][RT][2];
+    {
+      // the bias enters as the C operand of the first MFMA of each chain (one register block per
+      // row tile, shared by both point tiles): no accumulator initialisation moves
+      f32x16 bias[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float b = b0[32 * r + row_of(j, hi)];
-        buf[0][r][0][j] = b; buf[0][r][1][j] = b;
-      }
+        for (int j = 0; j < 16; ++j) bias[r][j] = b0[32 * r + row_of(j, hi)];
 #pragma unroll
-    for (int s = 0; s < KS0; ++s) {
-      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[2 * s]), __float_as_uint(f[2 * s + 1]),
-                                                 false, false);
-      float bt0 = __uint_as_float(sw[0]), bt1 = __uint_as_float(sw[1]);
+      for (int s = 0; s < KS0; ++s) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[2 * s]), __float_as_uint(f[2 * s + 1]),
+                                                   false, false);
+        float bt0 = __uint_as_float(sw[0]), bt1 = __uint_as_float(sw[1]);
 #pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        float a = w0p[(s * 64 + lane) * RT + r];
-        buf[0][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt0, buf[0][r][0], 0, 0, 0);
-        buf[0][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt1, buf[0][r][1], 0, 0, 0);
+        for (int r = 0; r < RT; ++r) {
+          float a = w0p[(s * 64 + lane) * RT + r];
+          buf[0][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt0, s == 0 ? bias[r] : buf[0][r][0], 0, 0, 0);
+          buf[0][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt1, s == 0 ? bias[r] : buf[0][r][1], 0, 0, 0);
+        }
       }
     }
     uint32_t mw[MW];
@@ -268,8 +285,8 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          m |= (buf[0][r][t][j] > 0.0f ? 1u : 0u) << (t * 16 + j);
-          buf[0][r][t][j] = fmaxf(buf[0][r][t][j], 0.0f);
+          buf[0][r][t][j] = relu1(buf[0][r][t][j]);
+          push_gt0(m, buf[0][r][t][j], t * 16 + j);
         }
       mw[r] = m;
     }
@@ -277,13 +294,11 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
 #pragma unroll
     for (int h = 0; h + 1 < NH; ++h) {
       const int ci = h & 1, ni = ci ^ 1;
+      f32x16 bias[RT];
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float b = bh[h * H + 32 * r + row_of(j, hi)];
-          buf[ni][r][0][j] = b; buf[ni][r][1][j] = b;
-        }
+        for (int j = 0; j < 16; ++j) bias[r][j] = bh[h * H + 32 * r + row_of(j, hi)];
 #pragma unroll
       for (int rp = 0; rp < RT; ++rp)
 #pragma unroll
@@ -292,8 +307,8 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
 #pragma unroll
           for (int r = 0; r < RT; ++r) {
             float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
-            buf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], buf[ni][r][0], 0, 0, 0);
-            buf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], buf[ni][r][1], 0, 0, 0);
+            buf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias[r] : buf[ni][r][0], 0, 0, 0);
+            buf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias[r] : buf[ni][r][1], 0, 0, 0);
           }
         }
 #pragma unroll
@@ -303,8 +318,8 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            m |= (buf[ni][r][t][j] > 0.0f ? 1u : 0u) << (t * 16 + j);
-            buf[ni][r][t][j] = fmaxf(buf[ni][r][t][j], 0.0f);
+            buf[ni][r][t][j] = relu1(buf[ni][r][t][j]);
+            push_gt0(m, buf[ni][r][t][j], t * 16 + j);
           }
         mw[(h + 1) * RT + r] = m;
       }
@@ -326,29 +341,27 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
       constexpr int h = NH > 0 ? NH - 1 : 0, ci = h & 1;
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
-        f32x16 a0, a1;
+        f32x16 a0, a1, bias;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float b = bh[h * H + 32 * r + row_of(j, hi)];
-          a0[j] = b; a1[j] = b;
-        }
+        for (int j = 0; j < 16; ++j) bias[j] = bh[h * H + 32 * r + row_of(j, hi)];
 #pragma unroll
         for (int rp = 0; rp < RT; ++rp)
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
             const int ks = rp * 16 + j;
             float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
-            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias : a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias : a1, 0, 0, 0);
           }
         uint32_t m = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          m |= (a0[j] > 0.0f ? 1u : 0u) << j;
-          m |= (a1[j] > 0.0f ? 1u : 0u) << (16 + j);
+          const float y0 = relu1(a0[j]), y1 = relu1(a1[j]);
+          push_gt0(m, y0, j);
+          push_gt0(m, y1, 16 + j);
           float wv = wo[32 * r + row_of(j, hi)];
-          p0 += wv * fmaxf(a0[j], 0.0f);
-          p1 += wv * fmaxf(a1[j], 0.0f);
+          p0 += wv * y0;
+          p1 += wv * y1;
         }
         mw[(h + 1) * RT + r] = m;
       }
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) void sdf_fwd_kernel(GridK g, con
 //   C == 8: channels 4hi..4hi+3 of level j>>2      (registers j = 4*level + c)
 //   C == 4: channels 0..3 of level 2*(j>>2) + hi   (registers j = 4*g + c)
 template <int C, int L, int H, int NH, bool WANT_GRID, bool WANT_X>
-__global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* __restrict__ packed,
+__global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(GridK g, const float* __restrict__ packed,
                                                         const float* __restrict__ x, int64_t n,
                                                         const float* __restrict__ gsdf,
                                                         const uint32_t* __restrict__ mask,
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
         float wv = wo[32 * r + row_of(j, hi)];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          dbuf[0][r][t][j] = ((mw[NH * RT + r] >> (t * 16 + j)) & 1u) ? wv * ds[t] : 0.0f;
+          dbuf[0][r][t][j] = mask_bit(mw[NH * RT + r], t, j) ? wv * ds[t] : 0.0f;
       }
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(GridK g, const float* _
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int j = 0; j < 16; ++j)
-            dbuf[ni][r][t][j] = ((mw[h * RT + r] >> (t * 16 + j)) & 1u) ? dbuf[ni][r][t][j] : 0.0f;
+            dbuf[ni][r][t][j] = mask_bit(mw[h * RT + r], t, j) ? dbuf[ni][r][t][j] : 0.0f;
     }
     f32x16 (&d)[RT][2] = dbuf[NH & 1];
     // d feats = W0^T d   (one 32-row tile; rows >= F are zero)
