@@ -24,17 +24,52 @@ class BaseLoss:
 # --------------------------------------------------------------------------- #
 # helpers
 # --------------------------------------------------------------------------- #
+class _RigidByIndex(torch.autograd.Function):
+    """y_i = R[idx_i] x_i + t[idx_i] for R (K,3,3), t (K,3), idx (N,) with few distinct, heavily repeated
+    values.  Autograd's own backward of R[idx] is an index_put with accumulation -- sort-based, 3.2 ms
+    for 16384 rows that all name the same keyframe.  Here the pose cotangents are two small products
+    with the one-hot selection matrix (chunked), the point cotangent one multiply-reduce."""
+
+    @staticmethod
+    def forward(ctx, R, t, idx, x):
+        ctx.save_for_backward(R, idx, x)
+        return (R[idx] * x.unsqueeze(1)).sum(dim=2) + t[idx]
+
+    @staticmethod
+    def backward(ctx, g):
+        R, idx, x = ctx.saved_tensors
+        K = R.shape[0]
+        gR = gt = gx = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gR = torch.zeros((K, 9), device=g.device, dtype=g.dtype)
+            gt = torch.zeros((K, 3), device=g.device, dtype=g.dtype)
+            step = max(1, (1 << 24) // max(K, 1))          # <= 16 M one-hot entries at a time
+            for lo in range(0, g.shape[0], step):
+                hi = min(g.shape[0], lo + step)
+                sel = torch.nn.functional.one_hot(idx[lo:hi], K).to(g.dtype)          # (n,K)
+                gR += sel.T @ (g[lo:hi].unsqueeze(2) * x[lo:hi].unsqueeze(1)).reshape(-1, 9)
+                gt += sel.T @ g[lo:hi]
+            gR = gR.view(K, 3, 3)
+        if ctx.needs_input_grad[3]:
+            gx = (R[idx] * g.unsqueeze(2)).sum(dim=1)                                 # R^T g
+        return gR, gt, None, gx
+
+
+def rigid_by_index(R, t, idx, x):
+    """R (K,3,3), t (K,3) or (K,3,1), idx (N,) long, x (N,3) -> R[idx] x + t[idx], differentiable."""
+    return _RigidByIndex.apply(R, t.reshape(-1, 3), idx, x)
+
+
 def transform_by_keyframe(coords_frame, frame_ids, pose_of):
     """coords_world[i] = R_k x_i + t_k with k = frame_ids[i].  ``pose_of(k) -> (R (3,3), t (3,1))``
     is evaluated once per keyframe present in the batch; the points are then mapped with one
-    gather + batched product, so pose gradients flow as in the reference's per-keyframe loop."""
+    gather + multiply-reduce, so pose gradients flow as in the reference's per-keyframe loop."""
     ids = torch.unique(frame_ids)
     Rs, ts = zip(*(pose_of(int(k)) for k in ids.tolist()))
     R = torch.stack(Rs)                       # (K,3,3)
     t = torch.stack(ts).squeeze(-1)           # (K,3)
     slot = torch.searchsorted(ids, frame_ids)
-    # (N,3,3) x (N,3) as multiply + reduce: einsum / bmm would launch N tiny GEMMs (3.5 ms at N = 262144)
-    return (R[slot] * coords_frame.unsqueeze(1)).sum(dim=2) + t[slot]
+    return rigid_by_index(R, t, slot, coords_frame)
 
 
 def miso_loss_regression(pred, targ, valid_mask=None, sample_weights=None, loss_type='L1'):
@@ -253,7 +288,7 @@ class MisoLossMapping(MisoLossMappingBase):
         if __debug__ and getattr(self, 'check_frame_ids', False):
             assert bool((idx >= 0).all()) and bool((frame_ids < table.numel() - 1).all()), "unknown keyframe id"
         R_all, t_all = model.updated_kf_poses_all()
-        return (R_all[idx] * coords_frame.unsqueeze(1)).sum(dim=2) + t_all[idx].squeeze(-1)
+        return rigid_by_index(R_all, t_all, idx, coords_frame)
 
 
 class MisoLossFusion(MisoLossMappingBase):

@@ -262,6 +262,25 @@ class GridNet(BaseNet):
             pred = pred + torch.randn(pred.shape, device=x.device) * noise_std
         return pred
 
+    def sdf_and_gradient(self, x: torch.Tensor):
+        """(sdf (N,1), d sdf / d x (N,3)), both detached: what the tracker's Gauss-Newton step needs
+        (reference tracker.py:176-181 runs a forward and an autograd backward for it).  With the fused
+        decoder this is two launches and no autograd graph -- in particular no gradient is formed
+        for the feature grids, which autograd would produce whenever they are unlocked."""
+        self._check_coords(x)
+        pack = self._fused_decoder() if x.is_cuda else None
+        if pack is not None:
+            feats = [g.feature.detach() for g in self.features]
+            meta = self.features[0].grid_meta(self.ignore_level_)
+            xd = x.detach().contiguous()
+            sdf, mask = ops.sdf_fwd_raw(xd, feats, meta, pack, True)
+            gx, _ = ops.sdf_bwd_raw(xd, feats, meta, pack, torch.ones_like(sdf), mask, True, [False] * len(feats))
+            return sdf, gx
+        xr = x.detach().clone().requires_grad_(True)
+        sdf = self(xr)
+        (gx,) = torch.autograd.grad(sdf, xr, torch.ones_like(sdf))
+        return sdf.detach(), gx.detach()
+
     # ---- parameter groups ------------------------------------------------------------------
     def params_for_poses(self):
         return [self.rotation_corrections, self.translation_corrections]

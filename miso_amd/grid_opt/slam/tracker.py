@@ -108,10 +108,8 @@ class Tracker:
         coords_world = utils_geometry.transform_points_to(coords_frame, R, t)
         in_bound = utils_geometry.coords_in_bound(coords_world, self.grid.bound)
         fov_overlap = float(torch.count_nonzero(in_bound)) / in_bound.numel()
-        # SDF value and spatial gradient from ONE forward + coordinate backward
-        x = coords_world.clone().requires_grad_(True)
-        sdf_pred = self.grid(x)
-        grad_world = torch.autograd.grad(sdf_pred, x, torch.ones_like(sdf_pred))[0].detach()
+        # SDF value and spatial gradient from ONE forward + coordinate backward (no autograd graph)
+        sdf_pred, grad_world = self.grid.sdf_and_gradient(coords_world)
         if coords_frame.is_cuda:
             # J, H = J^T W J and g = J^T W r in one launch
             from miso_amd import ops
