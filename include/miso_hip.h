@@ -139,9 +139,11 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
  * Counting sort of a point batch by coarse tile (tiles_per_axis^3 tiles over the
  * bound).  No reference counterpart: the reference gathers every level with
  * independent random accesses (grid_modules.py:86-94); binning is what lets the
- * backward pre-reduce coarse-level gradients on chip.  Results of the *_sorted
- * calls are identical to the unsorted ones up to fp32 summation order; sdf,
- * grad_sdf and grad_x stay in the caller's (original) point order. */
+ * gathers of neighbouring lanes share cache lines and the backward form the grid
+ * gradient owner-computes, without atomics (miso_grad_pull).  Results of the
+ * *_sorted calls are identical to the unsorted ones up to fp32 summation order;
+ * sdf, grad_sdf (unless MISO_F_GRAD_SDF_SORTED) and grad_x stay in the caller's
+ * (original) point order. */
 typedef struct {
   int32_t tiles_per_axis;      /* 1..16 */
   const float* x_sorted;       /* (N,3) points grouped by tile                   */

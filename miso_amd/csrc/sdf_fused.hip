@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
                                                         uint32_t defer_mask) {
   // perm != nullptr: x and mask are in tile-sorted order, gsdf / gx in the caller's.
   // dfeat_out != nullptr: rows of d(feats) (N,F, sorted order) are written out and the levels in
-  // defer_mask are NOT scattered here: tile_reduce_kernel pre-reduces them per spatial tile.
+  // defer_mask are NOT scattered here: grad_pull_kernel (grad_pull.hip) forms their gradient owner-computes.
   // debug: ablation switches (MISO_DEBUG_BWD, dev only): 1 = no atomics, 8 = no scatter; bit 16 (set by the
   // launcher for MISO_F_GRAD_SDF_SORTED): gsdf is already in the binned order.
   constexpr int F = C * L, RT = H / 32, KS1 = H / 2;

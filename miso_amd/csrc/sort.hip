@@ -1,8 +1,8 @@
 // Spatial binning of a point batch: counting sort by coarse tile (T^3 tiles over
 // the submap bound).  Points of a tile become contiguous, which (a) makes the
 // corner gathers of neighbouring lanes hit the same L2 lines and (b) lets the
-// backward pre-reduce the coarse levels' gradient in LDS per tile before it
-// touches the L2 atomics (sdf_fused.hip, tiled variant).
+// backward form the grid gradient owner-computes, one wavefront per tile
+// (grad_pull.hip), instead of scattering it with float atomics.
 //
 // Three small launches, no global atomics and nothing to zero:
 //   hist    <= 64 blocks of 1024 threads: LDS histogram of the block's slice of the
