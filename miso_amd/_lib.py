@@ -26,7 +26,9 @@ F_GRAD_OVERWRITE = 8
 F_GRAD_SDF_SORTED = 16
 LOSS_SLOTS = 512
 
+E_BADARG = 2001
 E_UNSUPPORTED = 2002
+E_TOOLARGE = 2003
 
 
 class Level(C.Structure):

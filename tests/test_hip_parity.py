@@ -597,3 +597,49 @@ def test_second_order_pull_path_vs_atomic_and_oracle(name, n, monkeypatch):
     lc = eik(lambda fs, xx: R.encode_gather(fs, bound, xx), fc, xc, ws, bs)
     (gxc,) = torch.autograd.grad(lc, [xc])
     assert relerr(ga[-1][:m].cpu() * (n / m), gxc) < 5e-4
+
+
+def test_capi_rejects_bad_arguments_before_launching():
+    """Return codes of the C ABI for malformed calls: nothing is launched,
+    nothing crashes, the error string is meaningful."""
+    import ctypes as C
+    from miso_amd import _lib, ops
+    lib = _lib.load()
+    case, feats, bound, ws, bs, x0, meta, fd, pack = setup_case("small")
+    fdd = [f.detach() for f in fd]
+    x = x0.to(DEV)
+    n = x.shape[0]
+    g = ops._fill_grid(fdd, meta)
+    out = torch.empty(n, sum(f.shape[1] for f in fdd), device=DEV)
+    st = ops._stream(x)
+    BAD, UNSUP = _lib.E_BADARG, _lib.E_UNSUPPORTED
+    assert lib.miso_encode_fwd(C.byref(g), ops._ptr(x), -1, ops._ptr(out), out.stride(0), st) == BAD
+    assert lib.miso_encode_fwd(C.byref(g), None, n, ops._ptr(out), out.stride(0), st) == BAD
+    assert lib.miso_encode_fwd(C.byref(g), ops._ptr(x), n, ops._ptr(out), 1, st) == BAD          # ld < F
+    g2 = ops._fill_grid(fdd, meta)
+    g2.flags = 1 << 20                                                                           # unknown flag
+    assert lib.miso_encode_fwd(C.byref(g2), ops._ptr(x), n, ops._ptr(out), out.stride(0), st) == BAD
+    g3 = ops._fill_grid(fdd, meta)
+    g3.n_levels = 0
+    assert lib.miso_encode_fwd(C.byref(g3), ops._ptr(x), n, ops._ptr(out), out.stride(0), st) == BAD
+    # sort: tiles out of range, misaligned normalised buffer
+    sb = ops.SortedBatch(n, DEV)
+    assert lib.miso_sort_points(C.byref(g), ops._ptr(x), n, 17, ops._ptr(sb.workspace), None, ops._ptr(sb.xn_sorted),
+                                ops._ptr(sb.perm), ops._ptr(sb.tile_offsets), st) == BAD
+    assert lib.miso_sort_points(C.byref(g), ops._ptr(x), n, 16, ops._ptr(sb.workspace), None,
+                                C.c_void_p(sb.xn_sorted.data_ptr() + 4), ops._ptr(sb.perm),
+                                ops._ptr(sb.tile_offsets), st) == BAD
+    # fused: decoder shape outside the table is "unsupported", not a crash
+    m, packed = pack.get()
+    m2 = _lib.Mlp()
+    C.memmove(C.byref(m2), C.byref(m), C.sizeof(m2))
+    m2.hidden_dim = 48
+    sdf = torch.empty(n, 1, device=DEV)
+    assert lib.miso_sdf_fwd(C.byref(g), C.byref(m2), ops._ptr(packed), ops._ptr(x), n, ops._ptr(sdf), None, st) == UNSUP
+    assert lib.miso_lm_normal_eq(ops._ptr(x), ops._ptr(x), ops._ptr(x), ops._ptr(sdf), ops._ptr(sdf), n, 7, 0.1,
+                                 ops._ptr(sdf), st) == UNSUP
+    assert b"argument" in lib.miso_error_string(BAD).lower() or len(lib.miso_error_string(BAD)) > 0
+    torch.cuda.synchronize()
+    # and a well-formed call still works afterwards
+    assert lib.miso_encode_fwd(C.byref(g), ops._ptr(x), n, ops._ptr(out), out.stride(0), st) == 0
+    torch.cuda.synchronize()
