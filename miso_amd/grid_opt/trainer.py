@@ -147,7 +147,8 @@ class Trainer(object):
             meta = model.features[0].grid_meta(model.ignore_level_)
             step = MappingStep([f.data for f in feats], meta, pack, n, lf.loss_type, float(lf.weight_sdf),
                                float(lf.weight_fs) if lf.weight_fs > 0 else 0.0,
-                               0.0 if lf.trunc_dist is None else float(lf.trunc_dist), need_levels=need)
+                               0.0 if lf.trunc_dist is None else float(lf.trunc_dist), need_levels=need,
+                               keep_sdf=False)
             cache[key] = step
         with torch.no_grad():
             frame_ids = model_input['sample_frame_ids'][0, :, 0]

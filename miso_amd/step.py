@@ -21,9 +21,13 @@ class MappingStep:
     def __init__(self, features: Sequence[torch.Tensor], meta: ops.GridMeta, pack: ops.DecoderPack,
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
                  trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
-                 sort: Optional[bool] = None, need_levels: Optional[Sequence[bool]] = None):
+                 sort: Optional[bool] = None, need_levels: Optional[Sequence[bool]] = None,
+                 keep_sdf: bool = True):
         """need_levels: which levels get a gradient (default all) -- the coarse-to-fine schedule of
-        GridTrainer optimises one level at a time."""
+        GridTrainer optimises one level at a time.  keep_sdf: also leave the predicted SDF of the batch
+        in ``self.sdf`` (caller order); a training loop only needs the loss and the gradients, and on
+        the binned path the scattered write costs 1.6 us."""
+        self.keep_sdf = bool(keep_sdf)
         self.features = list(features)
         self.meta, self.pack = meta, pack
         self.n = int(n_points)
@@ -86,7 +90,8 @@ class MappingStep:
                 self._mask = torch.empty(((self.n + 63) // 64) * 64 * mw, device=self.x.device, dtype=torch.int32)
             # forward + mapping loss: sdf, ReLU bits, d loss / d sdf (binned order) in one launch
             ops.sdf_fwd_loss_raw(self.features, self.meta, self.pack, self.sorted, self.aux, self._mask,
-                                 self.gpred, self.loss_slots, lt, ws, wf, td, sdf_out=self.sdf)
+                                 self.gpred, self.loss_slots, lt, ws, wf, td,
+                                 sdf_out=self.sdf if self.keep_sdf else None)
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, self._mask, False,
                             self.need_levels, self.grads, sorted_batch=self.sorted, overwrite=True, gsdf_sorted=True)
         else:
