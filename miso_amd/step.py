@@ -125,11 +125,12 @@ class MappingStep:
             self._launch()
             return
         if self._graph is None:
-            self._launch()                      # warm-up (allocates the mask buffer)
+            self._launch()                      # this call's iteration, eagerly (allocates the buffers)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             # thread_local: another thread touching the runtime during capture (e.g. the RCCL
             # watchdog of a multi-GPU job polling events) must not invalidate it
             with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                self._launch()
+                self._launch()                  # recorded, not executed
+            return
         self._graph.replay()
