@@ -179,6 +179,19 @@ class GridNet(BaseNet):
         batched exponential map; locked indices are detached exactly as pose_correction does."""
         from miso_amd.so3 import so3_exp_map
         dr, dt = self.rotation_corrections, self.translation_corrections
+        # without a graph to build (no_grad, or every index locked) the result only changes when a pose
+        # tensor is written: keep it (the exponential map is ~20 tiny launches per call)
+        static = (not torch.is_grad_enabled() or len(self.locked_pose_indices) >= self.num_poses
+                  or not (dr.requires_grad or dt.requires_grad))
+        if static:
+            key = (dr._version, dt._version, self.Rwk._version, self.twk._version, dr.data_ptr(), self.Rwk.data_ptr())
+            hit = self.__dict__.get('_kf_pose_cache')
+            if hit is not None and hit[0] == key:
+                return hit[1], hit[2]
+            with torch.no_grad():
+                R, t = self.Rwk @ so3_exp_map(dr.detach()), self.twk + dt.detach()
+            self.__dict__['_kf_pose_cache'] = (key, R, t)
+            return R, t
         if self.locked_pose_indices:
             if len(self.locked_pose_indices) >= self.num_poses:
                 dr, dt = dr.detach(), dt.detach()
