@@ -436,8 +436,16 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
   constexpr int FP = ((F + 3) / 4) * 4 + 4;  // d-feat row pitch: 16-B aligned, conflict-free b128 writes
   constexpr int REC = 8;                     // ints per (point, level) cell record
   constexpr int WAVE_LDS = 64 * FP + 64 * L * REC;
-  float* wave_lds = smem + ((nb + H + 3) / 4) * 4 + wave * WAVE_LDS;
+  // debug bit 32 (set by the launcher when nothing is scattered from here): only the d-feat tile is
+  // allocated per wave -- 50 KB per workgroup instead of 74, i.e. three workgroups per CU
+  float* wave_lds = smem + ((nb + H + 3) / 4) * 4 + wave * ((debug & 32) ? 64 * FP : WAVE_LDS);
   const int64_t nchunks = (n + 63) / 64;
+  // levels whose gradient is scattered from this kernel (binned training defers all of them to the
+  // pull: then no per-point cell records are formed at all)
+  uint32_t scatter_mask = 0;
+  if (WANT_GRID)
+    for (int l = 0; l < L; ++l)
+      if (g.lv[l].grad && !((g.ignore_mask >> l) & 1u) && !((defer_mask >> l) & 1u)) scatter_mask |= 1u << l;
 
   ChunkSched sched(nchunks, wave, 4, perm != nullptr);
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
             *reinterpret_cast<float4*>(dF + (32 * t + (lane & 31)) * FP + f0) =
                 make_float4(df[t][4 * gq], df[t][4 * gq + 1], df[t][4 * gq + 2], df[t][4 * gq + 3]);
         }
-      {
+      if (scatter_mask) {     // cell records only where a level is still scattered from here
         const int64_t p = chunk * 64 + lane;
         const bool valid = p < n;
         float px = 0.f, py = 0.f, pz = 0.f;
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
       constexpr int LPR = 2 * C, SLOTS = 64 / LPR;
       const int slot = lane / LPR, dx = (lane / C) & 1, ch = lane % C;
 #pragma unroll 1
-      for (int pg = 0; pg < 64 / SLOTS; ++pg) {
+      for (int pg = 0; pg < (scatter_mask ? 64 / SLOTS : 0); ++pg) {
         const int pt = pg * SLOTS + slot;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -684,14 +692,22 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
                                hipStream_t s) {
   PackLayout pl(C * L, H, NH);
   constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4, WAVE_LDS = 64 * FP + 64 * L * 8;
-  size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * WAVE_LDS : 0)) * sizeof(float);
+  bool lean = want_grid && !gx && dfeat_out != nullptr;      // every gradient level deferred to the pull?
+  for (int l = 0; l < L && lean; ++l)
+    if (g.lv[l].grad && !((g.ignore_mask >> l) & 1u) && !((defer_mask >> l) & 1u)) lean = false;
+  static const bool no_lean = getenv("MISO_BWD_NO_LEAN") != nullptr;      // dev
+  if (no_lean) lean = false;
+  size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * (lean ? 64 * FP : WAVE_LDS) : 0)) *
+               sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
-  static const unsigned cap = [] { const char* e = getenv("MISO_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
-  if (blocks > cap) blocks = cap;
+  static const unsigned cap = [] { const char* e = getenv("MISO_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 0u; }();
+  const unsigned use_cap = cap ? cap : (lean ? 768u : 512u);
+  if (blocks > use_cap) blocks = use_cap;
   int debug = 0;
-  if (const char* d = getenv("MISO_DEBUG_BWD")) debug = atoi(d) & ~16;
+  if (const char* d = getenv("MISO_DEBUG_BWD")) debug = atoi(d) & ~(16 | 32);
   if (gsdf_sorted) debug |= 16;
+  if (lean) debug |= 32;
   void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*, const int*, int,
             float*, uint32_t) =
       (want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true>
