@@ -458,7 +458,7 @@ int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float
 int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, const float* bound_min,
                        const float* bound_max, float* count_out, void* stream) {
   if (n < 0 || !pose || !bound_min || !bound_max || !count_out || (n > 0 && !coords_src)) return MISO_E_BADARG;
-  if (n >= ((int64_t)1 << 24) * 128) return MISO_E_TOOLARGE;     // fp32 count stays exact
+  if (n >= ((int64_t)1 << 24)) return MISO_E_TOOLARGE;     // the fp32 count stays exact
   return (int)launch_overlap_count(pose, coords_src, n, bound_min, bound_max, count_out, (hipStream_t)stream);
 }
 

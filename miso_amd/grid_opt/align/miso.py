@@ -152,7 +152,14 @@ def pairwise_loss_latent_batched(grid_atlas: GridAtlas, pairs, level: int, fdim=
         plan["keep"].append(feats_to)
         if check_intersection:
             plan["gate_pts"].append((grid_atlas._finest_vertices(src_id), hit[2], hit[3]))
+    # the index / count tensors of the plan depend only on the pair list: keep them across iterations
+    ckey = (tuple(pairs), level, bool(check_intersection), tuple(plan["n_ch"]),
+            tuple(c.shape[0] for c in plan["coords"]))
+    cc = grid_atlas.__dict__.setdefault('_align_plan_const', {})
+    if cc.get('key') == ckey:
+        plan["_const"] = cc['const']
     losses = ops.pair_latent_multi(R_all, t_all, plan) * align_weight
+    cc['key'], cc['const'] = ckey, plan.get("_const")
     return {f'align_latent_level{level}_{a}_{b}': losses[i] for i, (a, b) in enumerate(pairs)}
 
 

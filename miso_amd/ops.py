@@ -705,8 +705,16 @@ class _PairLatentMulti(torch.autograd.Function):
         S = R_all.shape[0]
         pairs = plan["pairs"]
         P = len(pairs)
-        src = torch.tensor([a for a, _ in pairs], device=dev, dtype=torch.long)
-        dst = torch.tensor([b for _, b in pairs], device=dev, dtype=torch.long)
+        const = plan.get("_const")          # index / count tensors of this pair list: built once, not per iteration
+        if const is None or const["dev"] != dev:
+            const = dict(dev=dev,
+                         src=torch.tensor([a for a, _ in pairs], device=dev, dtype=torch.long),
+                         dst=torch.tensor([b for _, b in pairs], device=dev, dtype=torch.long),
+                         nch=torch.tensor(plan["n_ch"], device=dev, dtype=torch.float32),
+                         npts=(torch.tensor([g_[0].shape[0] for g_ in plan["gate_pts"]], device=dev,
+                                            dtype=torch.float32) if plan["gate_pts"] is not None else None))
+            plan["_const"] = const
+        src, dst = const["src"], const["dst"]
         pose_all = torch.cat((R_all.reshape(S, 9), t_all.reshape(S, 3)), dim=1)            # (S,12)
         pose_pairs = torch.cat((pose_all[src], pose_all[dst]), dim=1).contiguous()           # (P,24)
         out = torch.empty((P, 24), device=dev, dtype=torch.float32)
@@ -724,12 +732,10 @@ class _PairLatentMulti(torch.autograd.Function):
                 _lib.check(lib.miso_overlap_count(C.c_void_p(pose_pairs.data_ptr() + 96 * p), _ptr(pts), pts.shape[0],
                                                   bmin, bmax, C.c_void_p(cnt.data_ptr() + 4 * p), stream),
                            "miso_overlap_count")
-        nch_t = torch.tensor(plan["n_ch"], device=dev, dtype=torch.float32)
-        denom = out[:, 1].clamp(min=1.0) * (nch_t if plan["loss_type"] == "L2" else 1.0)
+        denom = out[:, 1].clamp(min=1.0) * (const["nch"] if plan["loss_type"] == "L2" else 1.0)
         gate = torch.ones(P, device=dev)
         if cnt is not None:
-            npts = torch.tensor([g_[0].shape[0] for g_ in plan["gate_pts"]], device=dev, dtype=torch.float32)
-            gate = ((cnt / npts) > plan["overlap_thresh"]).to(torch.float32)
+            gate = ((cnt / const["npts"]) > plan["overlap_thresh"]).to(torch.float32)
         ctx.save_for_backward(out, denom, gate, R_all, src, dst)
         return torch.nan_to_num(out[:, 0] / denom) * gate
 
