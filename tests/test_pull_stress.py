@@ -61,3 +61,49 @@ def test_binned_encode_matches_atomic(seed, monkeypatch):
         a, c = torch.nan_to_num(a), torch.nan_to_num(c)
         assert a.shape == c.shape
         assert relerr(a, c) < 5e-5, (seed, l, dims, C, n)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MISO_STRESS_SEEDS", "10"))))
+def test_binned_fused_matches_plain(seed):
+    """Fused encode+decoder: binned forward / backward (incl. the loss-fused forward and grad_x) against
+    the plain kernels over the covered (C, L, H) table and irregular grid shapes."""
+    from miso_amd import ops
+    rs = np.random.RandomState(5000 + seed)
+    C, L, H = [(4, 1, 32), (4, 1, 64), (4, 2, 32), (4, 2, 64), (4, 3, 64), (4, 4, 64), (8, 1, 64), (8, 2, 64),
+               (8, 3, 64), (8, 4, 64), (8, 3, 32)][seed % 11]
+    dims = [tuple(int(v) for v in rs.choice([8, 16, 24, 32, 40, 64, 100, 128], size=3)) for _ in range(L)]
+    bmin = rs.uniform(-2, 0, size=3)
+    bmax = bmin + rs.uniform(1.0, 5.0, size=3)
+    bound = [[float(bmin[a]), float(bmax[a])] for a in range(3)]
+    n = int(rs.choice([1, 63, 4097, 70000]))
+    g = torch.Generator().manual_seed(seed)
+    feats = [(torch.randn(1, C, z, y, x, generator=g) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+             for (z, y, x) in dims]
+    lin = [torch.nn.Linear(C * L, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.data.to(DEV) for l in lin], [l.bias.data.to(DEV) for l in lin])
+    meta = ops.GridMeta.from_bound(bound)
+    assert ops.sdf_fused_supported(feats, meta, pack)
+    b = torch.tensor(bound)
+    x = (torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) * 1.1 + b[:, 0] - 0.05 * (b[:, 1] - b[:, 0])).to(DEV)
+    gs = (torch.randn(n, 1, generator=g) / max(n, 1)).to(DEV)
+    sdf_a, mask_a = ops.sdf_fwd_raw(x, feats, meta, pack, True)
+    gx_a, gr_a = ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask_a, True, [True] * L)
+    sb = ops.SortedBatch(n, DEV).sort(x, meta)
+    sdf_b, mask_b = ops.sdf_fwd_raw(x, feats, meta, pack, True, sorted_batch=sb)
+    gx_b, gr_b = ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask_b, True, [True] * L, sorted_batch=sb, overwrite=True)
+    assert torch.equal(sdf_a, sdf_b)
+    if n:
+        assert relerr(gx_b, gx_a) < 1e-5
+    for a, c in zip(gr_b, gr_a):
+        assert relerr(a, c) < 5e-5, (seed, C, L, H, dims, n)
+    # loss-fused forward: same d loss / d sdf (in binned order) and loss as the separate loss kernel
+    if n:
+        aux = torch.stack([torch.randn(n, generator=g) * 0.1, (torch.rand(n, generator=g) > 0.2).float(),
+                           (torch.rand(n, generator=g) > 0.7).float(), torch.rand(n, generator=g) + 0.5], dim=1).to(DEV)
+        gsort = torch.empty(n, device=DEV)
+        slots = torch.empty(ops._lib.LOSS_SLOTS, 2, device=DEV)
+        ops.sdf_fwd_loss_raw(feats, meta, pack, sb, aux.contiguous(), mask_b, gsort, slots, "L1", 1.0, 0.3, 0.2)
+        terms, gref = ops.mapping_loss_raw(sdf_a, aux[:, 0:1].contiguous(), aux[:, 1:2].contiguous(),
+                                           aux[:, 2:3].contiguous(), aux[:, 3:4].contiguous(), "L1", 1.0, 0.3, 0.2)
+        assert torch.allclose(slots.sum(0), terms, rtol=1e-5, atol=1e-7)
+        assert torch.equal(gsort, gref.reshape(-1)[sb.perm.long()])
