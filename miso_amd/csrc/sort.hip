@@ -49,31 +49,64 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(GridK g, const 
   for (int i = threadIdx.x; i < nt; i += blockDim.x) hist[i] = 0;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * seg, hi = min(n, lo + seg);
-  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    int t = tile_of(x[i * 3], x[i * 3 + 1], x[i * 3 + 2], g, T);
-    tile_id[i] = (uint16_t)t;
-    atomicAdd(&hist[t], 1);
+  constexpr int UP = 4;      // independent points per trip (loads in flight together)
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)UP * blockDim.x) {
+    float v[UP][3];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      if (i < hi) { v[u][0] = x[i * 3]; v[u][1] = x[i * 3 + 1]; v[u][2] = x[i * 3 + 2]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      if (i < hi) {
+        const int t = tile_of(v[u][0], v[u][1], v[u][2], g, T);
+        tile_id[i] = (uint16_t)t;
+        atomicAdd(&hist[t], 1);
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nt; i += blockDim.x) bh[(int64_t)blockIdx.x * nt + i] = hist[i];
 }
 
-// thread per tile: bh[b][t] <- sum_{b' < b} bh[b'][t]; count[t] <- column total
+// 64 tiles per workgroup, lane = tile; the blocks' histograms are split over the four waves:
+// bh[b][t] <- sum_{b' < b} bh[b'][t]; count[t] <- column total
 __global__ __launch_bounds__(256) void sort_prefix_kernel(int* __restrict__ bh, int nb, int nt,
                                                          int* __restrict__ count) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nt) return;
-  int run = 0;
-  int b = 0;
-  for (; b + 8 <= nb; b += 8) {
-    int v[8];
+  __shared__ int part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  const int per = (nb + 3) / 4, b0 = wave * per, b1 = min(nb, b0 + per);
+  int sum = 0;
+  if (t < nt) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      int v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = bh[(int64_t)(b + k) * nt + t];
+      for (int k = 0; k < 8; ++k) v[k] = bh[(int64_t)(b + k) * nt + t];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { bh[(int64_t)(b + k) * nt + t] = run; run += v[k]; }
+      for (int k = 0; k < 8; ++k) sum += v[k];
+    }
+    for (; b < b1; ++b) sum += bh[(int64_t)b * nt + t];
   }
-  for (; b < nb; ++b) { int v = bh[(int64_t)b * nt + t]; bh[(int64_t)b * nt + t] = run; run += v; }
-  count[t] = run;
+  part[wave][lane] = sum;
+  __syncthreads();
+  int run = 0;
+  for (int w = 0; w < wave; ++w) run += part[w][lane];
+  if (t < nt) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      int v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = bh[(int64_t)(b + k) * nt + t];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { bh[(int64_t)(b + k) * nt + t] = run; run += v[k]; }
+    }
+    for (; b < b1; ++b) { int v = bh[(int64_t)b * nt + t]; bh[(int64_t)b * nt + t] = run; run += v; }
+    if (wave == 3) count[t] = run;
+  }
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, const float* __restrict__ x, int64_t n,
@@ -108,22 +141,44 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, con
   if (blockIdx.x == 0 && threadIdx.x == SORT_THREADS - 1) tile_off[nt] = run;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * seg, hi = min(n, lo + seg);
-  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    int t = tile_id[i];
-    int pos = atomicAdd(&cursor[t], 1);
-    perm[pos] = (int)i;
-    float v[3] = {x[i * 3 + 0], x[i * 3 + 1], x[i * 3 + 2]};
-    if (xs) {
-      xs[(int64_t)pos * 3 + 0] = v[0]; xs[(int64_t)pos * 3 + 1] = v[1]; xs[(int64_t)pos * 3 + 2] = v[2];
-    }
-    if (xn) {
-      // normalised coordinates exactly as common.hpp:axis_coord forms them, one float4 per
-      // point: the sorted kernels read these and never repeat the division
+  // four points per thread per trip: their loads, LDS atomics and stores are independent, so they are
+  // issued together instead of as four dependent round trips
+  constexpr int UP = 4;
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)UP * blockDim.x) {
+    int t[UP];
+    float v[UP][3];
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
-        if (!(g.flags & MISO_F_COORDS_NORMALIZED))
-          v[a] = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(v[a], g.bmin[a])), __fsub_rn(g.bmax[a], g.bmin[a])), 1.0f);
-      reinterpret_cast<float4*>(xn)[pos] = make_float4(v[0], v[1], v[2], 0.0f);
+    for (int u = 0; u < UP; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      t[u] = -1;
+      if (i < hi) {
+        t[u] = tile_id[i];
+        v[u][0] = x[i * 3 + 0]; v[u][1] = x[i * 3 + 1]; v[u][2] = x[i * 3 + 2];
+      }
+    }
+    int pos[UP];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) pos[u] = (t[u] >= 0) ? atomicAdd(&cursor[t[u]], 1) : 0;
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      if (t[u] < 0) continue;
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      perm[pos[u]] = (int)i;
+      if (xs) {
+        xs[(int64_t)pos[u] * 3 + 0] = v[u][0]; xs[(int64_t)pos[u] * 3 + 1] = v[u][1];
+        xs[(int64_t)pos[u] * 3 + 2] = v[u][2];
+      }
+      if (xn) {
+        // normalised coordinates exactly as common.hpp:axis_coord forms them, one float4 per
+        // point: the sorted kernels read these and never repeat the division
+        float w[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+          w[a] = (g.flags & MISO_F_COORDS_NORMALIZED)
+                     ? v[u][a]
+                     : __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(v[u][a], g.bmin[a])), __fsub_rn(g.bmax[a], g.bmin[a])), 1.0f);
+        reinterpret_cast<float4*>(xn)[pos[u]] = make_float4(w[0], w[1], w[2], 0.0f);
+      }
     }
   }
 }
@@ -153,7 +208,7 @@ hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int T, void* w
   int* count = reinterpret_cast<int*>(w);         w += a256(nt * sizeof(int));
   uint16_t* tid = reinterpret_cast<uint16_t*>(w);
   sort_hist_kernel<<<nb, SORT_THREADS, nt * sizeof(int), s>>>(g, x, n, T, seg, bh, tid);
-  sort_prefix_kernel<<<(nt + 255) / 256, 256, 0, s>>>(bh, nb, nt, count);
+  sort_prefix_kernel<<<(nt + 63) / 64, 256, 0, s>>>(bh, nb, nt, count);
   sort_scatter_kernel<<<nb, SORT_THREADS, (nt + 16) * sizeof(int), s>>>(g, x, n, nt, seg, bh, count, tid, xs, xn,
                                                                         perm, tile_off);
   return hipGetLastError();
