@@ -687,3 +687,38 @@ def test_full_size_training_step_vs_cpu_oracle_cfg2():
         a = a.cpu()
         assert ((a - b).double().norm() / b.double().norm()).item() < 5e-4
         assert relerr(a, b) < 3e-2
+
+
+@pytest.mark.parametrize("lt", ["L2", "L1"])
+@pytest.mark.parametrize("level", [0, 1])
+def test_pair_latent_kernel_vs_oracle_large(lt, level):
+    """miso_pair_latent at an alignment-sized problem (200 000 source vertices, two ScanNet-shaped
+    levels) against the oracle's pairwise_latent_loss + autograd: loss and the gradient w.r.t. all
+    four pose tensors."""
+    from miso_amd import ops
+    g = torch.Generator().manual_seed(31 + level)
+    bound = torch.tensor([[-10.0, 10.0], [-5.0, 5.0], [-10.0, 10.0]])
+    shapes = [(1, 4, 20, 10, 20), (1, 4, 50, 25, 50)]       # (1,C,Z,Y,X): cells 1.0 / 0.4 m over 20x10x20 m
+    fs = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    fdst = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    n = 200000
+    coords = (torch.rand(n, 3, generator=g) - 0.5) * (bound[:, 1] - bound[:, 0])
+    R_s = torch.tensor(gc.rodrigues(np.array([0.02, -0.03, 0.05])), dtype=torch.float32)
+    R_d = torch.tensor(gc.rodrigues(np.array([-0.04, 0.01, 0.02])), dtype=torch.float32)
+    t_s, t_d = torch.tensor([[0.3], [-0.2], [0.1]]), torch.tensor([[6.0], [0.4], [-1.5]])
+    # oracle
+    ps = [p.clone().requires_grad_(True) for p in (R_s, t_s, R_d, t_d)]
+    ref = R.pairwise_latent_loss(fs, bound, fdst, bound, coords, *ps, level=level, fdim=4, align_weight=1.0,
+                                 align_loss=lt)
+    gref = torch.autograd.grad(ref, ps)
+    # HIP
+    nlv = level + 1
+    meta = ops.GridMeta.from_bound(bound)
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    f_src = ops.encode(coords.to(DEV), [cl(f) for f in fs[:nlv]], meta).detach()
+    pd = [p.detach().clone().to(DEV).requires_grad_(True) for p in (R_s, t_s, R_d, t_d)]
+    val = ops.pair_latent(pd[0], pd[1], pd[2], pd[3], coords.to(DEV), f_src, [cl(f) for f in fdst[:nlv]], meta, lt)
+    gg = torch.autograd.grad(val, pd)
+    assert abs(val.item() - ref.item()) <= 2e-5 * abs(ref.item())
+    for a, b in zip(gg, gref):
+        assert relerr(a.cpu(), b) < 2e-3
