@@ -121,7 +121,7 @@ int miso_encode_fwd(const miso_grid_t* grid, const float* x, int64_t n, float* f
 }
 
 static const float* sorted_points(GridK* g, const miso_sorted_t* sorted);
-static int check_sorted(const miso_sorted_t* s);
+static int check_sorted(const miso_sorted_t* s, int64_t n);
 
 static int encode_bwd_impl(const miso_grid_t* grid, const float* x, int64_t n, const float* grad_feats,
                            int64_t ld_g, float* grad_x, const miso_sorted_t* sorted, void* stream) {
@@ -143,7 +143,7 @@ int miso_encode_bwd(const miso_grid_t* grid, const float* x, int64_t n, const fl
 
 int miso_encode_bwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n,
                            const float* grad_feats, int64_t ld_g, float* grad_x, void* stream) {
-  int rc = check_sorted(sorted);
+  int rc = check_sorted(sorted, n);
   if (rc) return rc;
   return encode_bwd_impl(grid, nullptr, n, grad_feats, ld_g, grad_x, sorted, stream);
 }
@@ -185,7 +185,7 @@ int miso_encode_bwd2(const miso_grid_t* grid, const miso_grid_t* gg_grid, const 
 int miso_encode_bwd2_sorted(const miso_grid_t* grid, const miso_grid_t* gg_grid, const miso_sorted_t* sorted,
                             int64_t n, const float* grad_feats, int64_t ld_g, const float* gg_x, float* gg_out,
                             int64_t ld_gg, float* g_x, void* stream) {
-  int rc = check_sorted(sorted);
+  int rc = check_sorted(sorted, n);
   if (rc) return rc;
   return encode_bwd2_impl(grid, gg_grid, nullptr, n, grad_feats, ld_g, gg_x, gg_out, ld_gg, g_x, sorted, stream);
 }
@@ -310,8 +310,9 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
   return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, stream);
 }
 
-static int check_sorted(const miso_sorted_t* s) {
-  if (!s || (!s->x_sorted && !s->xn_sorted) || !s->perm || !s->tile_offsets) return MISO_E_BADARG;
+static int check_sorted(const miso_sorted_t* s, int64_t n) {
+  if (!s || !s->tile_offsets) return MISO_E_BADARG;
+  if (n > 0 && ((!s->x_sorted && !s->xn_sorted) || !s->perm)) return MISO_E_BADARG;   // an empty batch has no buffers
   if (((uintptr_t)s->xn_sorted & 15u) != 0) return MISO_E_BADARG;
   if (s->tiles_per_axis < 1 || s->tiles_per_axis > 16) return MISO_E_BADARG;
   return MISO_OK;
@@ -338,14 +339,14 @@ int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t
 int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, float* sdf, uint32_t* relu_mask,
                         void* stream) {
-  int rc = check_sorted(sorted);
+  int rc = check_sorted(sorted, n);
   if (rc) return rc;
   return sdf_fwd_impl(grid, mlp, packed, nullptr, n, sdf, relu_mask, sorted, stream);
 }
 
 int miso_encode_fwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, float* feats,
                            int64_t ld_out, void* stream) {
-  int rc = check_sorted(sorted);
+  int rc = check_sorted(sorted, n);
   if (rc) return rc;
   if (n < 0 || (n > 0 && !feats)) return MISO_E_BADARG;
   GridK g; bool v4;
@@ -360,7 +361,7 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
                              const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf,
                              float weight_fs, float trunc_dist, const float* loss_inputs, float* sdf,
                              uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots, void* stream) {
-  int rc = check_sorted(sorted);
+  int rc = check_sorted(sorted, n);
   if (rc) return rc;
   if ((loss_type != 1 && loss_type != 2) || !loss_slots || (n > 0 && (!loss_inputs || !grad_sdf_sorted)))
     return MISO_E_BADARG;
@@ -398,9 +399,9 @@ uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis) 
 
 static int grad_pull_impl(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
                           int64_t ld_d, int32_t rows_in_caller_order, const float* gg_x, void* stream) {
-  int rc = check_sorted(sorted);
+  int rc = check_sorted(sorted, n);
   if (rc) return rc;
-  if (n < 0 || !sorted->xn_sorted || !dfeat || ((uintptr_t)dfeat & 15u) != 0 || (ld_d & 3) != 0)
+  if (n < 0 || (n > 0 && (!sorted->xn_sorted || !dfeat)) || ((uintptr_t)dfeat & 15u) != 0 || (ld_d & 3) != 0)
     return MISO_E_BADARG;
   GridK g; int C; uint32_t pull;
   rc = pull_plan(grid, sorted->tiles_per_axis, &g, &C, &pull);
@@ -435,7 +436,7 @@ int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n) {
 int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,
                         const uint32_t* relu_mask, float* grad_x, float* workspace, void* stream) {
-  int rc = check_sorted(sorted);
+  int rc = check_sorted(sorted, n);
   if (rc) return rc;
   return sdf_bwd_impl(grid, mlp, packed, nullptr, n, grad_sdf, relu_mask, grad_x, sorted, workspace,
                       stream);

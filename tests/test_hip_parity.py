@@ -722,3 +722,32 @@ def test_pair_latent_kernel_vs_oracle_large(lt, level):
     assert abs(val.item() - ref.item()) <= 2e-5 * abs(ref.item())
     for a, b in zip(gg, gref):
         assert relerr(a.cpu(), b) < 2e-3
+
+
+@pytest.mark.parametrize("n", [0, 1, 64, 65])
+def test_binned_path_ragged_and_empty(n):
+    """Binned entry points at the edges: an empty batch (every gradient must come back exactly zero
+    -- MISO_F_GRAD_OVERWRITE promises no stale values), one point, one chunk, one chunk + 1."""
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x0, meta, fd, pack = setup_case("cfg2")
+    fdd = [f.detach() for f in fd]
+    L = len(fdd)
+    x = x0[:n].to(DEV)
+    sb = ops.SortedBatch(n, DEV).sort(x, meta)
+    off = sb.tile_offsets.cpu()
+    assert off[0] == 0 and off[-1] == n
+    sdf, mask = ops.sdf_fwd_raw(x, fdd, meta, pack, True, sorted_batch=sb)
+    assert sdf.shape == (n, 1)
+    grads = [torch.full_like(f, 7.0) for f in fdd]               # poison: must be overwritten
+    gs = torch.full((n, 1), 0.5, device=DEV)
+    ops.sdf_bwd_raw(x, fdd, meta, pack, gs, mask, False, [True] * L, grads, sorted_batch=sb, overwrite=True)
+    torch.cuda.synchronize()
+    if n == 0:
+        for gr in grads:
+            assert float(gr.abs().max()) == 0.0
+        return
+    ref_s, ref_m = ops.sdf_fwd_raw(x, fdd, meta, pack, True)
+    _, ref_g = ops.sdf_bwd_raw(x, fdd, meta, pack, gs, ref_m, False, [True] * L)
+    assert torch.equal(sdf, ref_s)
+    for a, b in zip(grads, ref_g):
+        assert relerr(a, b) < 2e-5
