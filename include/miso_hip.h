@@ -37,6 +37,10 @@
  *                     combined by MisoLossMappingBase.compute (loss.py:776-806).
  *   miso_adam_dense   torch.optim.Adam.step on one dense tensor as used by
  *                     grid_opt/trainer.py:196-228 / :410-452.
+ *   miso_sample_rays  PosedSdfRgbd.getitem_sdf, grid_opt/datasets/sdf_rgbd.py:381-483 (the step that
+ *                     feeds the path): get_batch_data / sample_along_rays
+ *                     (grid_opt/utils/utils_sample.py:142-302), bounds_ray (sdf_rgbd.py:525-534), the
+ *                     per-keyframe world -> keyframe loop (:436-445) and the truncation labels (:447-455).
  */
 #ifndef MISO_HIP_H
 #define MISO_HIP_H
@@ -277,6 +281,55 @@ int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float tr
 int miso_adam_dense(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                     int64_t numel, double lr, double beta1, double beta2, double eps,
                     int32_t step /* 1-based */, int zero_grad, void* stream);
+
+/* --- sample generation: posed depth frames -> SDF training rows ------------
+ * Frames: depth (B,H,W) metres, 0 = no return (DepthFilter, grid_opt/utils/utils_data.py:34-47);
+ * normals (B,H,W,3) or NULL -- only `isnan(normals[...,0])` is used, as a ray filter
+ * (utils_sample.py:164); T_WC (B,4,4) row-major camera -> world; R_wk (B,3,3), t_wk (B,3): the
+ * keyframe pose the samples are expressed in (the reference passes the same pose twice,
+ * sdf_rgbd.py:209-210,442); frame_ids (B) int64 written to sample_frame_ids, NULL = 0..B-1.
+ * Pin-hole intrinsics as ray_dirs_C(depth_type='z') (utils_sample.py:10-30). */
+#define MISO_RAY_MAX_BINS 64
+typedef struct {
+  const float* depth;
+  const float* normals;
+  const float* T_WC;
+  const float* R_wk;
+  const float* t_wk;
+  const int64_t* frame_ids;
+  int32_t n_frames, H, W;
+  float fx, fy, cx, cy;
+} miso_ray_frames_t;
+
+/* PosedSdfRgbd's sampling knobs (sdf_rgbd.py:33-40).  bin_edges: HOST array of n_strat+1 floats =
+ * torch.linspace(0,1,n_strat+1) (utils_sample.py:214-216), NULL = computed by the library.
+ * rays_per_frame: ray r belongs to frame r / rays_per_frame when pix_b is NULL
+ * (repeat_interleave, utils_sample.py:136-137). */
+typedef struct {
+  float min_depth, dist_behind_surf, trunc_dist;
+  int32_t n_strat, n_surf, rays_per_frame;
+  const float* bin_edges;
+} miso_ray_sampling_t;
+
+int64_t miso_sample_rays_workspace_bytes(int64_t n_rays, int32_t n_frames);
+
+/* One batch of rays.  pix_b (or NULL) / pix_h / pix_w (n_rays) int64: the sampled pixels
+ * (sample_pixels, utils_sample.py:129-139).  u (n_rays, n_strat) uniforms in [0,1) and
+ * g (n_rays, n_surf-1) near-surface depth offsets (the reference draws N(0, 0.1^2),
+ * utils_sample.py:284-286), both indexed by the ray's position AFTER the depth/normal filter, as
+ * the reference draws them for the surviving rays only.  S = n_surf + n_strat rows per ray, in the
+ * order [surface, near..., stratified...]; rays with depth 0, a NaN normal or a NaN sample are
+ * dropped and the remaining rays packed to the front, ray order kept.
+ * Outputs, capacity n_rays*S rows each: coords_frame (rows,3) in the keyframe frame,
+ * sample_frame_ids (rows) int64, aux (rows,4) = {sdf, valid, sign, weight} -- the row layout
+ * miso_sdf_fwd_sorted_loss reads -- with valid = |sdf| < trunc_dist, sign = -1 / 0 / +1 beyond the
+ * truncation band, weight = 1; optional pc_world (rows,3) and z_vals (rows) (NULL to skip).
+ * Rows past the packed ones are neutral padding (zeros: no loss, no gradient).
+ * counts (2 x int32, device) = {rays after the first filter, rays kept}; kept*S rows are live. */
+int miso_sample_rays(const miso_ray_frames_t* frames, const miso_ray_sampling_t* sampling, int64_t n_rays,
+                     const int64_t* pix_b, const int64_t* pix_h, const int64_t* pix_w, const float* u,
+                     const float* g, void* workspace, float* coords_frame, int64_t* sample_frame_ids,
+                     float* aux, float* pc_world, float* z_vals, int32_t* counts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libmiso_hip.so")
 
 MAX_LEVELS = 8
 MAX_LINEAR = 4
+RAY_MAX_BINS = 64
 
 F_ALIGN_CORNERS = 1
 F_PAD_BORDER = 2
@@ -52,6 +53,19 @@ class Mlp(C.Structure):
 class Sorted(C.Structure):
     _fields_ = [("tiles_per_axis", C.c_int32), ("x_sorted", C.c_void_p), ("xn_sorted", C.c_void_p),
                 ("perm", C.c_void_p), ("tile_offsets", C.c_void_p)]
+
+
+class RayFrames(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("normals", C.c_void_p), ("T_WC", C.c_void_p), ("R_wk", C.c_void_p),
+                ("t_wk", C.c_void_p), ("frame_ids", C.c_void_p),
+                ("n_frames", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
+class RaySampling(C.Structure):
+    _fields_ = [("min_depth", C.c_float), ("dist_behind_surf", C.c_float), ("trunc_dist", C.c_float),
+                ("n_strat", C.c_int32), ("n_surf", C.c_int32), ("rays_per_frame", C.c_int32),
+                ("bin_edges", C.POINTER(C.c_float))]
 
 
 # name -> (restype, argtypes); every symbol include/miso_hip.h declares
@@ -104,6 +118,10 @@ SIGNATURES = {
     "miso_mapping_loss": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "miso_sample_rays_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "miso_sample_rays": (C.c_int, [C.POINTER(RayFrames), C.POINTER(RaySampling), C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_adam_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int,
                                   C.c_void_p]),

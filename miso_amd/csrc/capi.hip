@@ -28,6 +28,10 @@ hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, co
 hipError_t launch_overlap_count(const float*, const float*, int64_t, const float*, const float*, float*, hipStream_t);
 hipError_t launch_lm_normal_eq(const float*, const float*, const float*, const float*, const float*, int64_t, int,
                                float, float*, hipStream_t);
+size_t sample_rays_workspace_bytes(int64_t, int32_t);
+hipError_t launch_sample_rays(const miso_ray_frames_t&, const miso_ray_sampling_t&, const float*, int64_t,
+                              const int64_t*, const int64_t*, const int64_t*, const float*, const float*, void*,
+                              float*, int64_t*, float*, float*, float*, int32_t*, hipStream_t);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
 int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
@@ -472,6 +476,39 @@ int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const flo
   if (loss_type == 3 && !(gm_scale > 0.0f)) return MISO_E_BADARG;
   return (int)launch_lm_normal_eq(coords_frame, R_frame, grad_sdf_x, sdf, target, n, loss_type, gm_scale, out,
                                   (hipStream_t)stream);
+}
+
+int64_t miso_sample_rays_workspace_bytes(int64_t n_rays, int32_t n_frames) {
+  if (n_rays < 0 || n_frames < 0) return 0;
+  return (int64_t)sample_rays_workspace_bytes(n_rays, n_frames);
+}
+
+int miso_sample_rays(const miso_ray_frames_t* f, const miso_ray_sampling_t* c, int64_t n_rays, const int64_t* pix_b,
+                     const int64_t* pix_h, const int64_t* pix_w, const float* u, const float* g, void* workspace,
+                     float* coords_frame, int64_t* sample_frame_ids, float* aux, float* pc_world, float* z_vals,
+                     int32_t* counts, void* stream) {
+  if (!f || !c || n_rays < 0 || !counts) return MISO_E_BADARG;
+  if (c->n_strat < 0 || c->n_surf < 0 || c->n_strat + c->n_surf < 1) return MISO_E_BADARG;
+  if (c->n_strat > MISO_RAY_MAX_BINS) return MISO_E_UNSUPPORTED;
+  const int64_t S = c->n_strat + c->n_surf;
+  if (n_rays * S >= (int64_t(1) << 31)) return MISO_E_TOOLARGE;
+  if (n_rays > 0) {
+    if (!f->depth || !f->T_WC || !f->R_wk || !f->t_wk || f->n_frames < 1 || f->H < 1 || f->W < 1) return MISO_E_BADARG;
+    if (!pix_h || !pix_w || !workspace || !coords_frame || !sample_frame_ids || !aux) return MISO_E_BADARG;
+    if (!pix_b && c->rays_per_frame < 1) return MISO_E_BADARG;
+    if ((c->n_strat > 0 && !u) || (c->n_surf > 1 && !g)) return MISO_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(aux) & 15u) return MISO_E_BADARG;
+  }
+  float lin[MISO_RAY_MAX_BINS + 1];
+  if (c->bin_edges) {
+    for (int i = 0; i <= c->n_strat; ++i) lin[i] = c->bin_edges[i];
+  } else {   // at::linspace's two-sided float formula
+    const int steps = c->n_strat + 1;
+    const float step = steps > 1 ? 1.0f / (float)(steps - 1) : 0.0f;
+    for (int i = 0; i < steps; ++i) lin[i] = i < steps / 2 ? step * (float)i : 1.0f - step * (float)(steps - 1 - i);
+  }
+  return (int)launch_sample_rays(*f, *c, lin, n_rays, pix_b, pix_h, pix_w, u, g, workspace, coords_frame,
+                                 sample_frame_ids, aux, pc_world, z_vals, counts, (hipStream_t)stream);
 }
 
 int miso_mapping_loss(int loss_type, float weight_sdf, float weight_fs, float trunc_dist,

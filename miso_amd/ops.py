@@ -807,3 +807,84 @@ def lm_normal_eq(coords_frame, R_frame, grad_world, sdf_pred, sdf_gt, loss_type=
     H[iu[0], iu[1]] = out[:21]
     H = H + H.triu(1).T
     return H, out[21:27].reshape(6, 1), out[27]
+
+
+# --------------------------------------------------------------------------- #
+# sample generation: posed depth frames -> SDF training rows
+# --------------------------------------------------------------------------- #
+class RayBatch:
+    """Device buffers of one ray batch (capacity n_rays * S rows) plus the two live counters.
+
+    ``aux`` columns are {sdf, valid, sign, weight}: the table MappingStep reads, so a trainer can hand
+    ``coords_frame`` / ``aux`` on without a copy.  ``rows()`` reads the live count back (one sync)."""
+
+    def __init__(self, n_rays: int, samples_per_ray: int, device, keep_world=False):
+        cap = n_rays * samples_per_ray
+        self.n_rays, self.S, self.capacity = n_rays, samples_per_ray, cap
+        self.coords_frame = torch.empty(cap, 3, device=device, dtype=torch.float32)
+        self.sample_frame_ids = torch.empty(cap, device=device, dtype=torch.int64)
+        self.aux = torch.empty(cap, 4, device=device, dtype=torch.float32)
+        self.pc_world = torch.empty(cap, 3, device=device, dtype=torch.float32) if keep_world else None
+        self.z_vals = torch.empty(cap, device=device, dtype=torch.float32) if keep_world else None
+        self.counts = torch.zeros(2, device=device, dtype=torch.int32)
+
+    def rows(self) -> int:
+        return int(self.counts[1].item()) * self.S
+
+
+def sample_rays(depth, T_WC, R_wk, t_wk, intrinsics, pix_h, pix_w, u, g, *, min_depth, dist_behind_surf,
+                trunc_dist, n_strat, n_surf, rays_per_frame=0, pix_b=None, normals=None, frame_ids=None,
+                out: Optional[RayBatch] = None, keep_world=False, workspace=None) -> RayBatch:
+    """PosedSdfRgbd.getitem_sdf (grid_opt/datasets/sdf_rgbd.py:381-483) for one batch of pixels, on the device:
+    miso_sample_rays.  ``intrinsics`` = (fx, fy, cx, cy); draws ``u`` (n_rays, n_strat) and ``g`` (n_rays, n_surf-1)
+    are consumed by the rays that pass the depth filter, in order."""
+    _require_hip(depth, T_WC, R_wk, t_wk, u, g, normals)
+    dev = depth.device
+    if not (pix_h.is_cuda and pix_w.is_cuda and (pix_b is None or pix_b.is_cuda)):
+        raise RuntimeError("miso_amd ops run on the HIP device only (no CPU fallback); pixel indices are on the host")
+    B, H, W = depth.shape
+    n_rays = pix_h.numel()
+    S = n_strat + n_surf
+
+    def f32(t, shape):
+        t = t.detach().to(torch.float32).contiguous()
+        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+        return t
+
+    def i64(t):
+        t = t.detach().reshape(-1).to(torch.int64).contiguous()
+        assert t.numel() == n_rays
+        return t
+
+    keep = [f32(depth, (B, H, W)), f32(T_WC, (B, 4, 4)), f32(R_wk, (B, 3, 3)), f32(t_wk.reshape(B, 3), (B, 3))]
+    fr = _lib.RayFrames()
+    fr.depth, fr.T_WC, fr.R_wk, fr.t_wk = (t.data_ptr() for t in keep)
+    if normals is not None:
+        keep.append(f32(normals, (B, H, W, 3)))
+        fr.normals = keep[-1].data_ptr()
+    if frame_ids is not None:
+        keep.append(frame_ids.detach().to(device=dev, dtype=torch.int64).contiguous())
+        assert keep[-1].numel() == B
+        fr.frame_ids = keep[-1].data_ptr()
+    fr.n_frames, fr.H, fr.W = B, H, W
+    fr.fx, fr.fy, fr.cx, fr.cy = (float(v) for v in intrinsics)
+    edges = torch.linspace(0, 1, n_strat + 1, dtype=torch.float32)        # utils_sample.py:214-216
+    edges_c = (C.c_float * (n_strat + 1))(*edges.tolist())
+    cfg = _lib.RaySampling(float(min_depth), float(dist_behind_surf), float(trunc_dist), int(n_strat), int(n_surf),
+                           int(rays_per_frame), C.cast(edges_c, C.POINTER(C.c_float)))
+    ph, pw = i64(pix_h), i64(pix_w)
+    pb = i64(pix_b) if pix_b is not None else None
+    uu = f32(u, (n_rays, n_strat)) if n_strat > 0 else None
+    gg = f32(g, (n_rays, n_surf - 1)) if n_surf > 1 else None
+    if out is None:
+        out = RayBatch(n_rays, S, dev, keep_world=keep_world)
+    assert out.n_rays == n_rays and out.S == S
+    lib = _lib.load()
+    if workspace is None:
+        workspace = torch.empty(max(int(lib.miso_sample_rays_workspace_bytes(n_rays, B)), 1), device=dev,
+                                dtype=torch.uint8)
+    _lib.check(lib.miso_sample_rays(C.byref(fr), C.byref(cfg), n_rays, _ptr(pb), _ptr(ph), _ptr(pw), _ptr(uu),
+                                    _ptr(gg), _ptr(workspace), _ptr(out.coords_frame), _ptr(out.sample_frame_ids),
+                                    _ptr(out.aux), _ptr(out.pc_world), _ptr(out.z_vals), _ptr(out.counts),
+                                    _stream(depth)), "miso_sample_rays")
+    return out

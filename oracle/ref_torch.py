@@ -294,3 +294,112 @@ def lm_normal_equations(coords_frame, R, grad_world, sdf_pred, sdf_gt, loss_type
     else:
         raise ValueError(loss_type)
     return J, J.T @ (w * J), J.T @ (w * r)
+
+
+# --------------------------------------------------------------------------- #
+# Sample generation (the step that feeds the path).  Random draws are inputs.
+# --------------------------------------------------------------------------- #
+def ray_dirs_camera(H: int, W: int, fx, fy, cx, cy) -> torch.Tensor:
+    """grid_opt/utils/utils_sample.py:10-30, depth_type 'z': (H,W,3) directions ((c-cx)/fx, (r-cy)/fy, 1)."""
+    cols = torch.arange(W, dtype=torch.float32)[None, :].expand(H, W)
+    rows = torch.arange(H, dtype=torch.float32)[:, None].expand(H, W)
+    return torch.stack(((cols - cx) / fx, (rows - cy) / fy, torch.ones(H, W)), dim=-1)
+
+
+def rgbd_sdf_samples(depth, T_WC, R_wk, t_wk, intrinsics, pix_b, pix_h, pix_w, u, g, *, min_depth,
+                     dist_behind_surf, trunc_dist, n_strat, n_surf, normals=None, frame_ids=None):
+    """PosedSdfRgbd.getitem_sdf, grid_opt/datasets/sdf_rgbd.py:381-483, with the random draws passed in.
+
+    ``u`` (>= n1, n_strat) and ``g`` (>= n1, n_surf-1) are consumed by the n1 rays that survive the first filter
+    (the reference draws them after that filter, utils_sample.py:241,284).  Returns the two dictionaries of
+    :472-481 plus ``pc_world``, ``z_vals`` and the two ray counts."""
+    B, H, W = depth.shape
+    dirs = ray_dirs_camera(H, W, *intrinsics)
+    d = depth[pix_b, pix_h, pix_w].reshape(-1)                      # utils_sample.py:156-157
+    keep = d != 0
+    if normals is not None:                                         # :160-166
+        keep = keep & ~torch.isnan(normals[pix_b, pix_h, pix_w, 0])
+    d, b, h, w = d[keep], pix_b[keep], pix_h[keep], pix_w[keep]
+    n1 = d.numel()
+    T = T_WC[b]
+    dc = dirs[h, w]
+    dw = (T[:, :3, :3] * dc[:, None, :]).sum(dim=-1)                # origin_dirs_W, :33-38
+    org = T[:, :3, 3]
+    far = d + dist_behind_surf                                      # sdf_rgbd.py:268
+    span = (far - min_depth)[:, None]                               # stratified_sample, utils_sample.py:212-222
+    edges = torch.linspace(0, 1, n_strat + 1)[None, :].repeat(n1, 1) * span + min_depth
+    z = edges[:, :-1] + u[:n1] * (span / n_strat)                   # :241-244
+    if n_surf == 1:                                                 # :278-281
+        z = torch.cat((d[:, None], z), dim=1)
+    elif n_surf > 1:                                                # :283-297
+        near = torch.clamp(d[:, None] + g[:n1], torch.full((n1, 1), float(min_depth)), far[:, None])
+        z = torch.cat((d[:, None], near, z), dim=1)
+    pc = org[:, None, :] + dw[:, None, :] * z[:, :, None]           # :300
+    sdf = dc.norm(dim=-1)[:, None] * (d[:, None] - z)               # bounds_ray, sdf_rgbd.py:525-528
+    ok = ~torch.isnan(pc).reshape(n1, -1).any(dim=1)                # :416-424
+    pc, sdf, b, z = pc[ok], sdf[ok], b[ok], z[ok]
+    S = z.shape[1]
+    ids = (b if frame_ids is None else frame_ids[b])[:, None].expand(-1, S).reshape(-1)   # :427-432
+    world = pc.reshape(-1, 3)
+    rb = b[:, None].expand(-1, S).reshape(-1)
+    Rk, tk = R_wk[rb], t_wk.reshape(-1, 3)[rb]
+    t_inv = -(Rk.transpose(1, 2) @ tk[:, :, None])[:, :, 0]         # transfrom_points_from, utils_geometry.py:227-240
+    coords = (world[:, None, :] @ Rk)[:, 0, :] + t_inv              # x R + t_inv^T   (:436-445)
+    sdf = sdf.reshape(-1, 1)
+    sign = torch.zeros_like(sdf)                                    # :452-455
+    sign[sdf < -trunc_dist] = -1
+    sign[sdf > trunc_dist] = 1
+    inputs = {"coords_frame": coords, "sample_frame_ids": ids[:, None].long(), "weights": torch.ones_like(sdf)}
+    gt = {"sdf": sdf, "sdf_valid": sdf.abs() < trunc_dist, "sdf_signs": sign}
+    return inputs, gt, {"pc_world": world, "z_vals": z, "n_first": n1, "n_kept": int(ok.sum())}
+
+
+def lidar_distance_weight(dists, max_range, scale=0.8):
+    """PosedSdf3DLidar.distance_weight_func, grid_opt/datasets/sdf_3d_lidar.py:205-211."""
+    return 1 + scale * 0.5 - (dists / max_range) * scale
+
+
+def lidar_frame_samples(pts_world, R_wf, t_wf, g_near, u_free, u_behind, *, near_surface_n, near_surface_std,
+                        free_space_n, behind_surface_n, trunc_dist, min_dist_ratio, max_range):
+    """One frame of PosedSdf3DLidar.sample_frames, grid_opt/datasets/sdf_3d_lidar.py:214-347 (after the
+    sub-sampling permutation :233-237), draws passed in: g_near (n*near_n,1) standard normals, u_free
+    (n*free_n,1) and u_behind (n*behind_n,1) uniforms.  fp64 like the reference's numpy, cast at :340-345."""
+    p = pts_world.double()
+    eye = t_wf.reshape(1, 3).double()
+    dist = (p - eye).norm(dim=1, keepdim=True)                       # :240
+    pts, sdfs, wts, sgn = [p], [torch.zeros_like(dist)], [lidar_distance_weight(dist, max_range)], [torch.zeros_like(dist)]
+
+    def along(rep, d_new):
+        rp = p.repeat_interleave(rep, dim=0)
+        direc = rp - eye
+        direc = direc / (direc.norm(dim=1, keepdim=True) + 1e-8)
+        return eye + direc * d_new
+
+    if near_surface_n > 0:                                           # :252-265
+        rd = dist.repeat_interleave(near_surface_n, dim=0)
+        dn = rd + g_near.double() * near_surface_std
+        pts.append(along(near_surface_n, dn))
+        sdfs.append((rd - dn).float().double())
+        wts.append(lidar_distance_weight(rd, max_range))
+        sgn.append(torch.zeros_like(rd))
+    if free_space_n > 0:                                             # :270-285
+        rd = dist.repeat_interleave(free_space_n, dim=0)
+        span = torch.clamp((1.0 - trunc_dist / rd) - min_dist_ratio, min=1e-2)
+        disp = ((min_dist_ratio + u_free.double() * span) - 1.0) * rd
+        pts.append(along(free_space_n, rd + disp))
+        sdfs.append((-disp.float()).double())
+        wts.append(torch.ones_like(rd))
+        sgn.append(torch.ones_like(rd))
+    if behind_surface_n > 0:                                         # :290-302
+        rd = dist.repeat_interleave(behind_surface_n, dim=0)
+        disp = near_surface_std + u_behind.double() * (4 * near_surface_std - 2 * near_surface_std)
+        pts.append(along(behind_surface_n, rd + disp))
+        sdfs.append((-disp.float()).double())
+        wts.append(torch.ones_like(rd))
+        sgn.append(-torch.ones_like(rd))
+    world = torch.cat(pts).float()                                   # :307-323
+    sdf = torch.cat(sdfs).float()
+    frame = transfrom_points_from(world, R_wf.float(), t_wf.reshape(3, 1).float())
+    return {"points_frame": frame, "points_world_gt": world, "sdfs": sdf,
+            "sdfs_valid": (sdf.abs() < trunc_dist).float(), "signs": torch.cat(sgn).float(),
+            "weights": torch.cat(wts).float()}

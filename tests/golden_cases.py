@@ -176,3 +176,46 @@ def atlas_world_points():
     lo = np.array([-2.5, -1.5, -2.8], dtype=np.float32)
     hi = np.array([6.0, 1.5, 2.5], dtype=np.float32)
     return (rs.uniform(0, 1, (c["n_points"], 3)).astype(np.float32) * (hi - lo) + lo)
+
+
+# --- sample generation (depth frames / lidar frames -> SDF rows) --------------
+RGBD = dict(seed=31, n_frames=4, H=24, W=32, fx=30.0, fy=28.0, cx=15.5, cy=11.5, n_rays=48, n_strat=5, n_surf=4,
+            min_depth=0.07, dist_behind_surf=0.1, trunc_dist=0.15, selected=[2, 0, 3])
+
+
+def rgbd_inputs(case=None):
+    """Depth frames with holes (0 = no return), one NaN depth, normals with NaNs, random keyframe poses."""
+    c = case or RGBD
+    rs = np.random.RandomState(c["seed"])
+    B, H, W = c["n_frames"], c["H"], c["W"]
+    depth = rs.uniform(0.4, 4.0, (B, H, W)).astype(np.float32)
+    depth[rs.uniform(0, 1, (B, H, W)) < 0.2] = 0.0
+    depth[min(2, B - 1), 3, 5] = np.nan
+    normals = rs.standard_normal((B, H, W, 3)).astype(np.float32)
+    normals[rs.uniform(0, 1, (B, H, W)) < 0.1] = np.nan
+    R = np.stack([rodrigues(rs.uniform(-0.8, 0.8, 3)) for _ in range(B)]).astype(np.float32)
+    t = rs.uniform(-3.0, 3.0, (B, 3, 1)).astype(np.float32)
+    T = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    T[:, :3, :3] = R
+    T[:, :3, 3:] = t
+    return dict(depth=depth, normals=normals, R=R, t=t, T_WC=T)
+
+
+LIDAR = dict(seed=41, n_frames=3, n_points=[96, 64, 80], frame_samples=72, frame_batchsize=200, near_surface_n=4,
+             near_surface_std=0.1, free_space_n=2, behind_surface_n=1, trunc_dist=0.5, min_dist_ratio=0.3,
+             max_range=60.0)
+
+
+def lidar_inputs(case=None):
+    """World-frame surface points per frame (ranges 2..30 m around the sensor) and sensor poses."""
+    c = case or LIDAR
+    rs = np.random.RandomState(c["seed"])
+    frames = []
+    for f in range(c["n_frames"]):
+        R = rodrigues(rs.uniform(-0.5, 0.5, 3)).astype(np.float32)
+        t = rs.uniform(-5.0, 5.0, (3, 1)).astype(np.float32)
+        d = rs.standard_normal((c["n_points"][f], 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        pts = t.reshape(1, 3).astype(np.float64) + d * rs.uniform(2.0, 30.0, (c["n_points"][f], 1))
+        frames.append(dict(R=R, t=t, points_global=pts))
+    return frames

@@ -150,3 +150,64 @@ def test_pairwise_latent_matches_reference():
                 for which, s in (("src", a), ("dst", b)):
                     torch.testing.assert_close(prm[s][0].grad, T(g[key + f"_gR_{which}"]), rtol=2e-3, atol=2e-3)
                     torch.testing.assert_close(prm[s][1].grad, T(g[key + f"_gt_{which}"]), rtol=2e-3, atol=2e-3)
+
+
+def _rgbd_case(tag):
+    c = gc.RGBD
+    inp = gc.rgbd_inputs()
+    g = _load("samples")
+    sel = list(range(c["n_frames"])) if tag == "all" else c["selected"]
+    nf = len(sel)
+    pb = torch.arange(nf).repeat_interleave(c["n_rays"])
+    args = dict(depth=T(inp["depth"])[sel], T_WC=T(inp["T_WC"])[sel], R_wk=T(inp["R"])[sel], t_wk=T(inp["t"])[sel],
+                intrinsics=(c["fx"], c["fy"], c["cx"], c["cy"]), pix_b=pb, pix_h=T(g[f"rgbd_{tag}_pix_h"]),
+                pix_w=T(g[f"rgbd_{tag}_pix_w"]), u=T(g[f"rgbd_{tag}_u"]), g=T(g[f"rgbd_{tag}_g"]),
+                normals=T(inp["normals"])[sel], frame_ids=torch.tensor(sel))
+    knobs = {k: c[k] for k in ("min_depth", "dist_behind_surf", "trunc_dist", "n_strat", "n_surf")}
+    return args, knobs, g
+
+
+@pytest.mark.parametrize("tag", ["all", "sel"])
+def test_rgbd_samples_match_reference(tag):
+    """oracle.rgbd_sdf_samples vs the reference's PosedSdfRgbd.getitem_sdf on the same frames and draws."""
+    args, knobs, g = _rgbd_case(tag)
+    inputs, gt, extra = R.rgbd_sdf_samples(**args, **knobs)
+    assert extra["n_first"] == g[f"rgbd_{tag}_u"].shape[0]
+    assert inputs["coords_frame"].shape == g[f"rgbd_{tag}_coords"].shape
+    # the frame change cancels two ~3 m terms: a few ulp of 3 m
+    torch.testing.assert_close(inputs["coords_frame"], T(g[f"rgbd_{tag}_coords"]), rtol=0, atol=2e-6)
+    assert torch.equal(inputs["sample_frame_ids"], T(g[f"rgbd_{tag}_ids"]))
+    assert torch.equal(inputs["weights"], T(g[f"rgbd_{tag}_weights"]))
+    torch.testing.assert_close(gt["sdf"], T(g[f"rgbd_{tag}_sdf"]), rtol=0, atol=1e-7)
+    assert torch.equal(gt["sdf_valid"], T(g[f"rgbd_{tag}_valid"]))
+    assert torch.equal(gt["sdf_signs"], T(g[f"rgbd_{tag}_signs"]))
+
+
+def test_lidar_samples_match_reference():
+    """oracle.lidar_frame_samples vs PosedSdf3DLidar.sample_frames, then the per-frame choice of getitem_world."""
+    c = gc.LIDAR
+    g = _load("samples")
+    knobs = {k: c[k] for k in ("near_surface_n", "near_surface_std", "free_space_n", "behind_surface_n",
+                               "trunc_dist", "min_dist_ratio", "max_range")}
+    batch = {k: [] for k in ("points_frame", "sdfs", "sdfs_valid", "signs", "weights", "ids")}
+    for f, fr in enumerate(gc.lidar_inputs()):
+        pts = T(fr["points_global"])[T(g[f"lidar_perm_{f}"])]
+        out = R.lidar_frame_samples(pts, T(fr["R"]), T(fr["t"]), T(g[f"lidar_g_near_{f}"]), T(g[f"lidar_u_free_{f}"]),
+                                    T(g[f"lidar_u_behind_{f}"]), **knobs)
+        for k, v in out.items():
+            ref = T(g[f"lidar_{k}_{f}"])
+            if k in ("sdfs_valid", "signs"):
+                assert torch.equal(v, ref), k
+            else:
+                torch.testing.assert_close(v, ref, rtol=0, atol=4e-6, msg=k)
+        pick = T(g[f"lidar_choice_{f}"])
+        for k in ("points_frame", "sdfs", "sdfs_valid", "signs", "weights"):
+            batch[k].append(out[k][pick])
+        batch["ids"].append(torch.full((pick.numel(), 1), f, dtype=torch.int64))
+    cat = {k: torch.cat(v) for k, v in batch.items()}
+    torch.testing.assert_close(cat["points_frame"], T(g["lidar_batch_coords"]), rtol=0, atol=4e-6)
+    torch.testing.assert_close(cat["sdfs"], T(g["lidar_batch_sdf"]), rtol=0, atol=4e-6)
+    assert torch.equal(cat["ids"], T(g["lidar_batch_ids"]))
+    assert torch.equal(cat["sdfs_valid"], T(g["lidar_batch_valid"]))
+    assert torch.equal(cat["signs"], T(g["lidar_batch_signs"]))
+    torch.testing.assert_close(cat["weights"], T(g["lidar_batch_weights"]), rtol=0, atol=1e-6)

@@ -419,6 +419,95 @@ def gen_so3(rgeom, gc):
     print("[so3] ok")
 
 
+def gen_samples(gc):
+    """Sample generation: the reference's own PosedSdfRgbd.getitem_sdf and PosedSdf3DLidar.sample_frames /
+    getitem_world, driven on in-memory frames (the constructors only add file IO).  The random draws the
+    reference makes are recorded by replaying its RNG calls from the same seed."""
+    import grid_opt.datasets.sdf_rgbd as rr
+    import grid_opt.datasets.sdf_3d_lidar as rl
+    import grid_opt.utils.utils_data as rdata
+    out = {}
+    c = gc.RGBD
+    inp = gc.rgbd_inputs()
+    ds = object.__new__(rr.PosedSdfRgbd)
+    ds._cam_params = rdata.CameraParameters(fx=c["fx"], fy=c["fy"], cx=c["cx"], cy=c["cy"], H=c["H"], W=c["W"])
+    ds.device = "cpu"
+    ds.dirs_C = rr.ray_dirs_C(1, c["H"], c["W"], c["fx"], c["fy"], c["cx"], c["cy"], "cpu", depth_type="z")
+    ds.min_depth, ds.max_depth, ds.voxel_size = c["min_depth"], 12.0, None
+    ds.n_rays, ds.dist_behind_surf = c["n_rays"], c["dist_behind_surf"]
+    ds.n_strat_samples, ds.n_surf_samples, ds.trunc_dist = c["n_strat"], c["n_surf"], c["trunc_dist"]
+    ds.bounds_method, ds.normal_trunc_dist, ds.use_clip = "ray", 0.30, False
+    ds._num_frames = c["n_frames"]
+    ds._depth_batch, ds._T_WC_batch, ds._norm_batch = T(inp["depth"]), T(inp["T_WC"]), T(inp["normals"])
+    ds.R_world_frame_gt, ds.t_world_frame_gt = T(inp["R"]), T(inp["t"])
+    for tag, sel in (("all", None), ("sel", c["selected"])):
+        ds._selected_kfs = sel
+        nf = c["n_frames"] if sel is None else len(sel)
+        # replay of the reference's RNG calls: sample_pixels (utils_sample.py:133-134), stratified_sample (:241),
+        # sample_along_rays (:284-286)
+        torch.manual_seed(100 + nf)
+        total = c["n_rays"] * nf
+        ph = torch.randint(0, c["H"], (total,))
+        pw = torch.randint(0, c["W"], (total,))
+        pb = torch.arange(nf).repeat_interleave(c["n_rays"])
+        idx = list(range(c["n_frames"])) if sel is None else sel
+        d = ds._depth_batch[idx][pb, ph, pw]
+        ok = (d != 0) & ~torch.isnan(ds._norm_batch[idx][pb, ph, pw, 0])
+        n1 = int(ok.sum())
+        u = torch.rand(n1, c["n_strat"])
+        g = torch.normal(torch.zeros(n1, c["n_surf"] - 1), 0.1)
+        torch.manual_seed(100 + nf)
+        inputs, gt = ds.getitem_sdf(0)
+        out.update({f"rgbd_{tag}_pix_h": ph.numpy(), f"rgbd_{tag}_pix_w": pw.numpy(), f"rgbd_{tag}_u": u.numpy(),
+                    f"rgbd_{tag}_g": g.numpy(), f"rgbd_{tag}_coords": inputs["coords_frame"].numpy(),
+                    f"rgbd_{tag}_ids": inputs["sample_frame_ids"].numpy(),
+                    f"rgbd_{tag}_weights": inputs["weights"].numpy(), f"rgbd_{tag}_sdf": gt["sdf"].numpy(),
+                    f"rgbd_{tag}_valid": gt["sdf_valid"].numpy(), f"rgbd_{tag}_signs": gt["sdf_signs"].numpy()})
+        print(f"[samples] rgbd {tag}: rays {total} -> first filter {n1} -> rows {tuple(gt['sdf'].shape)}")
+
+    lc = gc.LIDAR
+    frames = gc.lidar_inputs()
+    dl = object.__new__(rl.PosedSdf3DLidar)
+    for k in ("frame_batchsize", "frame_samples", "near_surface_n", "near_surface_std", "free_space_n",
+              "behind_surface_n", "trunc_dist", "min_dist_ratio", "max_range"):
+        setattr(dl, k, lc[k])
+    dl.max_range_hehind_surface = 4 * lc["near_surface_std"]
+    dl.distance_std = 0.0
+    dl._num_frames = lc["n_frames"]
+    dl.R_world_frame_gt = torch.stack([T(f["R"]) for f in frames])
+    dl.t_world_frame_gt = torch.stack([T(f["t"]) for f in frames])
+    dl.frames_lidar = [{"points_global": f["points_global"]} for f in frames]
+    dl.frames_data = []
+    rl.tqdm = lambda it, **k: it
+    # replay of the numpy RNG calls of sample_frames (:235,:257,:277,:295) per frame
+    np.random.seed(77)
+    for f, fr in enumerate(frames):
+        n = fr["points_global"].shape[0]
+        keep = min(lc["frame_samples"], n)
+        out[f"lidar_perm_{f}"] = np.random.permutation(n)[:keep]
+        out[f"lidar_g_near_{f}"] = np.random.randn(keep * lc["near_surface_n"], 1)
+        out[f"lidar_u_free_{f}"] = np.random.rand(keep * lc["free_space_n"], 1)
+        out[f"lidar_u_behind_{f}"] = np.random.rand(keep * lc["behind_surface_n"], 1)
+    np.random.seed(77)
+    dl.sample_frames()
+    for f, fd in enumerate(dl.frames_data):
+        for k, v in fd.items():
+            out[f"lidar_{k}_{f}"] = v.numpy()
+    dl._selected_kfs = None
+    np.random.seed(78)
+    sel = [np.random.choice(fd["points_frame"].shape[0], size=min(lc["frame_batchsize"], fd["points_frame"].shape[0]),
+                            replace=False) for fd in dl.frames_data]
+    np.random.seed(78)
+    inputs, gt = dl.getitem_world(0)
+    for f, sidx in enumerate(sel):
+        out[f"lidar_choice_{f}"] = sidx
+    out.update({"lidar_batch_coords": inputs["coords_frame"].numpy(), "lidar_batch_ids": inputs["sample_frame_ids"].numpy(),
+                "lidar_batch_weights": inputs["weights"].numpy(), "lidar_batch_sdf": gt["sdf"].numpy(),
+                "lidar_batch_valid": gt["sdf_valid"].numpy(), "lidar_batch_signs": gt["sdf_signs"].numpy()})
+    print("[samples] lidar batch", tuple(gt["sdf"].shape))
+    np.savez_compressed(gc.golden_path("samples"), **out)
+
+
 def main():
     import_reference()
     import golden_cases as gc
@@ -435,7 +524,7 @@ def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
-    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3"]
+    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples"]
     for name in which:
         if name in gc.CASES:
             gen_encode_decode(name, GridNet, rloss, gc)
@@ -449,6 +538,8 @@ def main():
             gen_tracker(GridNet, rtracker, gc)
         elif name == "so3":
             gen_so3(rgeom, gc)
+        elif name == "samples":
+            gen_samples(gc)
 
 
 if __name__ == "__main__":
