@@ -646,7 +646,10 @@ class _MappingLoss(torch.autograd.Function):
 
 def mapping_loss(pred, target, valid, sign, weight, loss_type="L1", weight_sdf=1.0, weight_fs=0.0,
                  trunc_dist=0.0):
-    """-> tensor([weight_sdf * sdf_term, weight_fs * free_space_term]), differentiable w.r.t. pred."""
+    """-> tensor([weight_sdf * sdf_term, weight_fs * free_space_term]), differentiable w.r.t. pred.
+    The row labels may arrive as bool / integer tensors (the RGB-D dataset's ``sdf_valid`` is bool, sdf_rgbd.py:452)."""
+    f32 = lambda t: t if t is None or t.dtype == torch.float32 else t.to(torch.float32)
+    valid, sign, weight = f32(valid), f32(sign), f32(weight)
     return _MappingLoss.apply(pred, target, valid, sign, weight, loss_type, weight_sdf, weight_fs,
                               trunc_dist)
 

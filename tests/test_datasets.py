@@ -1,0 +1,271 @@
+"""The dataset mirrors (miso_amd.grid_opt.datasets) against the rows the reference's own datasets produced
+(tests/golden/samples.npz, written by tools/make_goldens.py::gen_samples).  Host logic runs on the CPU; everything
+that goes through the HIP sampler is marked gpu."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def G():
+    return np.load(gc.golden_path("samples"))
+
+
+def cam():
+    from miso_amd.grid_opt.utils.utils_data import CameraParameters
+    c = gc.RGBD
+    return CameraParameters(fx=c["fx"], fy=c["fy"], cx=c["cx"], cy=c["cy"], H=c["H"], W=c["W"])
+
+
+# --------------------------------------------------------------------------- host logic (CPU)
+def test_backprojection_and_normals_match_reference():
+    from miso_amd.grid_opt.utils.utils_sample import estimate_pointcloud_normals, pointcloud_from_depth_torch
+    c, g, inp = gc.RGBD, G(), gc.rgbd_inputs()
+    for f in range(c["n_frames"]):
+        pc = pointcloud_from_depth_torch(T(inp["depth"][f]), c["fx"], c["fy"], c["cx"], c["cy"])
+        torch.testing.assert_close(pc, T(g[f"rgbd_pc_{f}"]), rtol=0, atol=0, equal_nan=True)
+        n = estimate_pointcloud_normals(pc)
+        ref = T(g[f"rgbd_est_normals_{f}"])
+        assert torch.equal(torch.isnan(n), torch.isnan(ref))          # the NaN pattern is what filters rays
+        torch.testing.assert_close(n, ref, rtol=1e-5, atol=1e-6, equal_nan=True)
+
+
+def test_ray_dirs_match_reference_layout():
+    from miso_amd.grid_opt.utils.utils_sample import origin_dirs_W, ray_dirs_C
+    from oracle import ref_torch as R
+    d = ray_dirs_C(2, 5, 7, 30.0, 28.0, 3.0, 2.0, "cpu")
+    assert d.shape == (2, 5, 7, 3)
+    assert torch.equal(d[1], R.ray_dirs_camera(5, 7, 30.0, 28.0, 3.0, 2.0))
+    e = ray_dirs_C(1, 5, 7, 30.0, 28.0, 3.0, 2.0, "cpu", depth_type="euclidean")
+    torch.testing.assert_close(e.norm(dim=-1), torch.ones(1, 5, 7))
+    Tm = torch.eye(4).repeat(3, 1, 1)
+    Tm[:, :3, 3] = torch.arange(9.0).reshape(3, 3)
+    o, dw = origin_dirs_W(Tm, d[0, 0, :3])
+    assert torch.equal(o, Tm[:, :3, 3]) and torch.equal(dw, d[0, 0, :3])
+
+
+def lidar_dataset(device, with_draws=True):
+    from miso_amd.grid_opt.datasets.sdf_3d_lidar import PosedSdf3DLidar
+    c, g = gc.LIDAR, G()
+    frames = gc.lidar_inputs()
+    poses = np.tile(np.eye(4), (len(frames), 1, 1))
+    local = []
+    for f, fr in enumerate(frames):
+        poses[f, :3, :3], poses[f, :3, 3:] = fr["R"], fr["t"]
+        local.append((fr["points_global"] - fr["t"].reshape(1, 3)) @ fr["R"].astype(np.float64))
+    draws = None
+    if with_draws:
+        draws = [{"perm": g[f"lidar_perm_{f}"], "g_near": g[f"lidar_g_near_{f}"], "u_free": g[f"lidar_u_free_{f}"],
+                  "u_behind": g[f"lidar_u_behind_{f}"]} for f in range(len(frames))]
+    knobs = {k: c[k] for k in ("frame_batchsize", "frame_samples", "near_surface_n", "near_surface_std", "free_space_n",
+                               "behind_surface_n", "trunc_dist", "min_dist_ratio", "max_range")}
+    return PosedSdf3DLidar.from_frames(local, poses, crop=False, device=device, draws=draws, **knobs), g
+
+
+def check_lidar_against_reference(ds, g):
+    # local = R^T (global - t) is rebuilt in fp32 here, so allow its rounding at ranges up to 30 m
+    for f, fd in enumerate(ds.frames_data):
+        torch.testing.assert_close(fd["points_frame"].cpu(), T(g[f"lidar_points_frame_{f}"]), rtol=0, atol=3e-5)
+        torch.testing.assert_close(fd["sdfs"].cpu(), T(g[f"lidar_sdfs_{f}"]), rtol=0, atol=1e-5)
+        assert torch.equal(fd["signs"].cpu(), T(g[f"lidar_signs_{f}"]))
+        torch.testing.assert_close(fd["weights"].cpu(), T(g[f"lidar_weights_{f}"]), rtol=0, atol=1e-5)
+        band = (T(g[f"lidar_sdfs_{f}"]).abs() - ds.trunc_dist).abs() > 1e-4
+        assert torch.equal(fd["sdfs_valid"].cpu()[band], T(g[f"lidar_sdfs_valid_{f}"])[band])
+    inputs, gt = ds.getitem_world(0, choice=[g[f"lidar_choice_{f}"] for f in range(ds.num_kfs)])
+    torch.testing.assert_close(inputs["coords_frame"].cpu(), T(g["lidar_batch_coords"]), rtol=0, atol=3e-5)
+    assert torch.equal(inputs["sample_frame_ids"].cpu(), T(g["lidar_batch_ids"]))
+    torch.testing.assert_close(gt["sdf"].cpu(), T(g["lidar_batch_sdf"]), rtol=0, atol=1e-5)
+    assert torch.equal(gt["sdf_signs"].cpu(), T(g["lidar_batch_signs"]))
+
+
+def test_lidar_dataset_matches_reference_cpu():
+    ds, g = lidar_dataset("cpu")
+    check_lidar_against_reference(ds, g)
+
+
+def check_lidar_random_batches(ds):
+    c = gc.LIDAR
+    sizes = [fd["points_frame"].shape[0] for fd in ds.frames_data]
+    assert sizes == [min(c["frame_samples"], n) * (1 + c["near_surface_n"] + c["free_space_n"] + c["behind_surface_n"])
+                     for n in c["n_points"]]
+    seen = set()
+    for _ in range(3):
+        inputs, gt = ds[0]
+        ids = inputs["sample_frame_ids"][:, 0].cpu()
+        assert inputs["coords_frame"].shape == (sum(min(c["frame_batchsize"], s) for s in sizes), 3)
+        for f in range(ds.num_kfs):
+            rows = inputs["coords_frame"][ids == f].cpu()
+            assert rows.shape[0] == min(c["frame_batchsize"], sizes[f])
+            table = ds.frames_data[f]["points_frame"].cpu()
+            # every row comes from its own frame's table, without replacement
+            match = (rows[:, None, :] == table[None, :, :]).all(-1)
+            assert match.any(1).all()
+            assert torch.unique(match.float().argmax(1)).numel() == rows.shape[0]
+        seen.add(float(inputs["coords_frame"].sum()))
+    assert len(seen) == 3                                                  # a fresh draw every call
+    ds.select_keyframes([2, 0])
+    inputs, _ = ds[0]
+    assert sorted(inputs["sample_frame_ids"][:, 0].unique().tolist()) == [0, 2]
+    ds.unselect_keyframes()
+    assert ds.sampled_points_at_kf(1).shape == (sizes[1], 3)
+    assert ds.get_odometry_at_pose(0).shape == (4, 4)
+
+
+def test_lidar_dataset_random_batches_cpu():
+    ds, _ = lidar_dataset("cpu", with_draws=False)
+    check_lidar_random_batches(ds)
+
+
+def test_pgm_and_pose_files_roundtrip(tmp_path):
+    """The constructor's file formats: frames/pose/*.pose.txt, frames/depth/*.depth.pgm (16-bit), ICP poses in
+    KITTI rows -- same frames as from_frames."""
+    from miso_amd.grid_opt.datasets import sdf_rgbd
+    c, inp = gc.RGBD, gc.rgbd_inputs()
+    root = tmp_path / "scene"
+    (root / "frames" / "pose").mkdir(parents=True)
+    (root / "frames" / "depth").mkdir(parents=True)
+    depth_mm = np.nan_to_num(inp["depth"] * 1000.0).round().astype(np.uint16)
+    for f in range(c["n_frames"]):
+        with open(root / "frames" / "depth" / f"{f}.depth.pgm", "wb") as fh:
+            fh.write(f"P5\n# made by a test\n{c['W']} {c['H']}\n65535\n".encode() + depth_mm[f].astype(">u2").tobytes())
+        np.savetxt(root / "frames" / "pose" / f"{f}.pose.txt", inp["T_WC"][f])
+    np.savetxt(root / "poses_color_icp.txt", inp["T_WC"][:, :3, :].reshape(c["n_frames"], 12))
+    assert np.array_equal(sdf_rgbd.read_pgm16(root / "frames" / "depth" / "1.depth.pgm"), depth_mm[1])
+    ds = sdf_rgbd.PosedSdfRgbd(str(root), c["n_frames"], cam(), n_rays=c["n_rays"], device="cpu", max_depth=3.0)
+    assert ds.num_kfs == c["n_frames"]
+    want = depth_mm.astype(np.float32) * np.float32(1.0 / 1000.0)
+    want[want > 3.0] = 0.0
+    assert torch.equal(ds._depth_batch, T(want))
+    torch.testing.assert_close(ds.R_world_frame_gt, T(inp["R"]))
+    torch.testing.assert_close(ds.t_world_frame, T(inp["t"]))
+    (root / "poses_color_icp.txt").unlink()           # without ICP poses the ground truth stands in (reference :174-178)
+    ds2 = sdf_rgbd.PosedSdfRgbd(str(root), c["n_frames"], cam(), frame_downsample=2, device="cpu")
+    assert torch.equal(ds2.R_world_frame, ds2.R_world_frame_gt)
+    assert ds2.num_kfs == 2 and torch.equal(ds2.R_world_frame_gt[1], ds.R_world_frame_gt[2])
+    with pytest.raises(NotImplementedError):
+        sdf_rgbd.PosedSdfRgbd(str(root), c["n_frames"], cam(), voxel_size=0.05, device="cpu")
+
+
+# --------------------------------------------------------------------------- through the HIP sampler
+DEV = "cuda:0"
+
+
+def rgbd_dataset(normals=True):
+    from miso_amd.grid_opt.datasets.sdf_rgbd import PosedSdfRgbd
+    c, inp = gc.RGBD, gc.rgbd_inputs()
+    return PosedSdfRgbd.from_frames(T(inp["depth"]), T(inp["R"]), T(inp["t"]), cam(), n_rays=c["n_rays"],
+                                    min_depth=c["min_depth"], dist_behind_surf=c["dist_behind_surf"],
+                                    n_strat_samples=c["n_strat"], n_surf_samples=c["n_surf"],
+                                    trunc_dist=c["trunc_dist"], device=DEV,
+                                    normals=T(inp["normals"]) if normals else None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["all", "sel"])
+def test_rgbd_dataset_matches_reference(tag):
+    """PosedSdfRgbd.__getitem__ on the reference's pixel / depth draws == the reference's getitem_sdf rows."""
+    c, g = gc.RGBD, G()
+    ds = rgbd_dataset()
+    if tag == "sel":
+        ds.select_keyframes(c["selected"])
+    nf = c["n_frames"] if tag == "all" else len(c["selected"])
+    total, n1 = nf * c["n_rays"], g[f"rgbd_{tag}_u"].shape[0]
+    u = torch.zeros(total, c["n_strat"])
+    u[:n1] = T(g[f"rgbd_{tag}_u"])
+    gg = torch.zeros(total, c["n_surf"] - 1)
+    gg[:n1] = T(g[f"rgbd_{tag}_g"])
+    draws = (T(g[f"rgbd_{tag}_pix_h"]).to(DEV), T(g[f"rgbd_{tag}_pix_w"]).to(DEV), u.to(DEV), gg.to(DEV))
+    inputs, gt = ds.getitem_sdf(0, draws=draws)
+    torch.testing.assert_close(inputs["coords_frame"].cpu(), T(g[f"rgbd_{tag}_coords"]), rtol=0, atol=4e-6)
+    assert torch.equal(inputs["sample_frame_ids"].cpu(), T(g[f"rgbd_{tag}_ids"]))
+    assert torch.equal(inputs["weights"].cpu(), T(g[f"rgbd_{tag}_weights"]))
+    torch.testing.assert_close(gt["sdf"].cpu(), T(g[f"rgbd_{tag}_sdf"]), rtol=1e-6, atol=1e-6)
+    edge = ((T(g[f"rgbd_{tag}_sdf"]).abs() - c["trunc_dist"]).abs() < 1e-6)
+    assert gt["sdf_valid"].dtype == torch.bool
+    assert torch.equal(gt["sdf_valid"].cpu()[~edge], T(g[f"rgbd_{tag}_valid"])[~edge])
+    assert torch.equal(gt["sdf_signs"].cpu()[~edge], T(g[f"rgbd_{tag}_signs"])[~edge])
+
+
+@pytest.mark.gpu
+def test_rgbd_dataset_random_draws_and_loader():
+    """Own draws: shapes, invariants of the rows, a fresh batch per call, DataLoader collation."""
+    c = gc.RGBD
+    ds = rgbd_dataset(normals=False)            # normals estimated from the depth, as load_rgbd does
+    S = c["n_strat"] + c["n_surf"]
+    sums = set()
+    for _ in range(3):
+        inputs, gt = ds[0]
+        n = gt["sdf"].shape[0]
+        assert n % S == 0 and 0 < n <= c["n_frames"] * c["n_rays"] * S
+        assert inputs["coords_frame"].shape == (n, 3) and inputs["sample_frame_ids"].shape == (n, 1)
+        sdf = gt["sdf"]
+        assert torch.equal(gt["sdf_valid"], sdf.abs() < c["trunc_dist"])
+        assert torch.equal(gt["sdf_signs"], torch.sign(sdf) * (sdf.abs() > c["trunc_dist"]))
+        assert bool((sdf.reshape(-1, S)[:, 0] == 0).all())              # first row of a ray sits on the surface
+        assert bool((sdf >= -c["dist_behind_surf"] * 2.0).all())        # nothing deeper than dist_behind (x |dir|)
+        assert not torch.isnan(inputs["coords_frame"]).any()
+        sums.add(float(inputs["coords_frame"].sum()))
+    assert len(sums) == 3
+    pts = ds.sampled_points_at_kf(1)
+    assert pts.shape[1] == 3 and ds._selected_kfs is None
+    loader = torch.utils.data.DataLoader(ds, shuffle=True, batch_size=1, num_workers=0)
+    for model_input, gt in loader:
+        assert model_input["coords_frame"].shape[0] == 1 and model_input["coords_frame"].is_cuda
+        assert gt["sdf"].dim() == 3
+    sp = ds.sample_points()
+    assert sp["pc"].shape[1:] == (S, 3) and sp["z_vals"].shape[1] == S
+
+
+@pytest.mark.gpu
+def test_lidar_dataset_on_device():
+    ds, g = lidar_dataset(DEV)
+    check_lidar_against_reference(ds, g)
+    ds, _ = lidar_dataset(DEV, with_draws=False)
+    check_lidar_random_batches(ds)
+
+
+@pytest.mark.gpu
+def test_mapper_trains_from_rgbd_dataset(tmp_path):
+    """End to end: depth frames -> HIP sampler -> Mapper / GridTrainer -> fused encode+decode step.  A planar
+    scene (a wall 2 m in front of two cameras): the mapping loss on held-out draws must fall."""
+    from miso_amd.grid_opt.datasets.sdf_rgbd import PosedSdfRgbd
+    from miso_amd.grid_opt.loss import MisoLossMapping
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    from miso_amd.grid_opt.slam.mapper import Mapper
+    from miso_amd.grid_opt.utils.utils import get_batch
+    from miso_amd.grid_opt.utils.utils_data import CameraParameters
+    H, W = 48, 64
+    cp = CameraParameters(fx=50.0, fy=50.0, cx=31.5, cy=23.5, H=H, W=W)
+    R = torch.eye(3).repeat(2, 1, 1)
+    t = torch.tensor([[[0.0], [0.0], [0.0]], [[0.3], [0.1], [0.0]]])
+    ds = PosedSdfRgbd.from_frames(torch.full((2, H, W), 2.0), R, t, cp, n_rays=512, n_strat_samples=5,
+                                  n_surf_samples=4, trunc_dist=0.15, device=DEV)
+    cfg_model = gc.model_cfg([[-2.0, 2.5], [-2.0, 2.0], [-0.5, 3.0]], 0.4, 4, 2, 4, 32, num_poses=2,
+                             init_stddev=1e-2)
+    torch.manual_seed(0)
+    net = GridNet(cfg_model, device=DEV).to(DEV)
+    for k in range(2):
+        net.set_initial_kf_pose(k, R[k], t[k], kf_key=f"KF{k}")
+    mapping = dict(learning_rate=1e-1, verbose=False, weight_sdf=1.0, weight_eik=0.0, weight_fs=1.0, loss_type="L1",
+                   trunc_dist=0.15, finite_diff_eps=1e-3, grad_method="autograd", eik_trunc_dist=0.1)
+    cfg = {"device": DEV, "mapping": mapping,
+           "train": {"verbose": False, "optimizer": "adam", "learning_rate": 1e-1, "epochs": 1, "ckpt_every": -1,
+                     "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": str(tmp_path),
+                     "relchange_tol": 0, "max_epochs_in_level": 1, "grid_training_mode": "joint"}}
+    lf = MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=1.0, trunc_dist=0.15)
+
+    def loss_now():
+        torch.manual_seed(5)
+        mi, gt = get_batch(torch.utils.data.DataLoader(ds, batch_size=1), DEV)
+        with torch.no_grad():
+            return float(sum(v.mean() for v in lf.compute(net, mi, gt).values()))
+
+    before = loss_now()
+    Mapper(net, ds, cfg).mapping([0, 1], iterations=200, level_iterations=100)
+    after = loss_now()
+    assert after < 0.1 * before, (before, after)      # measured: 0.318 -> 0.0008

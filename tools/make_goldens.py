@@ -465,6 +465,12 @@ def gen_samples(gc):
                     f"rgbd_{tag}_valid": gt["sdf_valid"].numpy(), f"rgbd_{tag}_signs": gt["sdf_signs"].numpy()})
         print(f"[samples] rgbd {tag}: rays {total} -> first filter {n1} -> rows {tuple(gt['sdf'].shape)}")
 
+    # normals as load_rgbd estimates them (sdf_rgbd.py:205-207)
+    for f in range(c["n_frames"]):
+        pc = rr.pointcloud_from_depth_torch(T(inp["depth"][f]), c["fx"], c["fy"], c["cx"], c["cy"])
+        out[f"rgbd_pc_{f}"] = pc.numpy()
+        out[f"rgbd_est_normals_{f}"] = rr.estimate_pointcloud_normals(pc).numpy()
+
     lc = gc.LIDAR
     frames = gc.lidar_inputs()
     dl = object.__new__(rl.PosedSdf3DLidar)
