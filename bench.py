@@ -171,7 +171,62 @@ def extras(step, dev):
     t = (run(50) - run(10)) / 40 * 1e6
     ex["align_iteration_level1_driver"] = {"pairs": 1, "vertices": nv, "us_per_iteration": t,
                                            "vertices_per_s": nv / (t * 1e-6)}
+    ex["sample_generation_scannet"] = sample_generation(dev)
     return ex
+
+
+def sample_generation(dev):
+    """one PosedSdfRgbd.__getitem__ at the ScanNet knobs (configs/rgbd/scannet.yaml:107-111 --
+    100 keyframes x 200 rays x (8 + 19) samples = 540 000 rows): miso_sample_rays alone, the dataset call
+    (draws + sampler + row count read-back), and the CPU restatement of the reference on the same draws."""
+    from miso_amd import ops
+    from miso_amd.grid_opt.datasets.sdf_rgbd import PosedSdfRgbd
+    from miso_amd.grid_opt.utils.utils_data import CameraParameters
+    from oracle import ref_torch as R
+    B, H, W, rays, n_strat, n_surf = 100, 480, 640, 200, 19, 8
+    g = torch.Generator().manual_seed(3)
+    depth = torch.rand(B, H, W, generator=g) * 4.0 + 0.5
+    depth[torch.rand(B, H, W, generator=g) < 0.1] = 0.0
+    ang = torch.rand(B, generator=g) * 6.28
+    Rm = torch.eye(3).repeat(B, 1, 1)
+    Rm[:, 0, 0], Rm[:, 0, 2], Rm[:, 2, 0], Rm[:, 2, 2] = ang.cos(), ang.sin(), -ang.sin(), ang.cos()
+    t = torch.rand(B, 3, 1, generator=g) * 10 - 5
+    cp = CameraParameters(fx=577.6, fy=578.7, cx=318.9, cy=242.7, H=H, W=W)
+    normals = torch.ones(B, H, W, 3)          # estimation is one-time set-up, not part of the per-iteration cost
+    ds = PosedSdfRgbd.from_frames(depth, Rm, t, cp, n_rays=rays, n_strat_samples=n_strat, n_surf_samples=n_surf,
+                                  trunc_dist=0.15, device=dev, normals=normals)
+    n = B * rays
+    ph = torch.randint(0, H, (n,), generator=g)
+    pw = torch.randint(0, W, (n,), generator=g)
+    u = torch.rand(n, n_strat, generator=g)
+    gg = torch.randn(n, n_surf - 1, generator=g) * 0.1
+    draws = tuple(a.to(dev) for a in (ph, pw, u, gg))
+    out = ops.RayBatch(n, n_strat + n_surf, dev)
+    t_kernel = time_kernel(lambda: ds.sample_batch(out=out, draws=draws), iters=20, warm=3)
+    rows = out.rows()
+    for _ in range(3):
+        ds[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ds[0]
+    torch.cuda.synchronize()
+    t_item = (time.perf_counter() - t0) / 10 * 1e6
+    pb = torch.arange(B).repeat_interleave(rays)
+    knobs = dict(min_depth=0.07, dist_behind_surf=0.1, trunc_dist=0.15, n_strat=n_strat, n_surf=n_surf)
+    Tm = torch.eye(4).repeat(B, 1, 1)
+    Tm[:, :3, :3], Tm[:, :3, 3:] = Rm, t
+    t0 = time.perf_counter()
+    for _ in range(3):
+        R.rgbd_sdf_samples(ds._depth_batch.cpu(), Tm, Rm, t, (cp.fx, cp.fy, cp.cx, cp.cy), pb, ph, pw, u, gg,
+                           normals=normals, **knobs)
+    t_cpu = (time.perf_counter() - t0) / 3 * 1e6
+    # algorithmic bytes per row: coords 12 + frame id 8 + labels 16 written; per ray 4 depth + 16 pixel + 4 per draw read
+    b_alg = rows * 36 + n * (20 + 4 * (n_strat + n_surf - 1))
+    return {"rows": rows, "sampler_us": t_kernel, "rows_per_s": rows / (t_kernel * 1e-6),
+            "algorithmic_GBps": b_alg / (t_kernel * 1e-6) / 1e9, "dataset_getitem_us": t_item,
+            "cpu_port_us": t_cpu, "cpu_port_note": "oracle.rgbd_sdf_samples (vectorised: the reference's per-keyframe "
+                                                   "Python loop of sdf_rgbd.py:438-445 is not in it)"}
 
 
 def main():

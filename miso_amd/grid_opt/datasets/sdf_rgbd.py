@@ -179,14 +179,19 @@ class PosedSdfRgbd(SubmapDataset):
                 sel = ids.to(self.device)
                 hit = (self._depth_batch[sel], self._T_WC_batch[sel], self._norm_batch[sel], self._R_gt_dev[sel],
                        self._t_gt_dev[sel], ids)
-            hit = hit[:5] + (hit[5].to(self.device),)
+            c = self._cam_params
+            sampler = ops.RaySampler(hit[0], hit[1], hit[3], hit[4], (c.fx, c.fy, c.cx, c.cy), normals=hit[2],
+                                     frame_ids=hit[5], rays_per_frame=self.n_rays, min_depth=self.min_depth,
+                                     dist_behind_surf=self.dist_behind_surf, trunc_dist=self.trunc_dist,
+                                     n_strat=self.n_strat_samples, n_surf=self.n_surf_samples)
+            hit = hit[:5] + (hit[5].to(self.device), sampler)
             self._frame_cache = {key: hit}
         return hit
 
     def sample_batch(self, out=None, keep_world=False, draws=None) -> ops.RayBatch:
         """One batch of n_rays pixels per selected keyframe -> RayBatch (capacity rays * S rows, live count on the
         device).  ``draws`` = (pix_h, pix_w, u, g) overrides the random draws (tests)."""
-        depth, T_WC, norm, R, t, ids = self._selected_frames()
+        depth, T_WC, norm, R, t, ids, sampler = self._selected_frames()
         c, nf = self._cam_params, depth.shape[0]
         total = self.n_rays * nf
         if draws is None:
@@ -195,12 +200,7 @@ class PosedSdfRgbd(SubmapDataset):
             g = torch.randn(total, max(self.n_surf_samples - 1, 0), device=self.device) * 0.1   # utils_sample.py:284
         else:
             ph, pw, u, g = draws
-        return ops.sample_rays(depth, T_WC, R, t, (c.fx, c.fy, c.cx, c.cy), ph, pw, u,
-                               g if self.n_surf_samples > 1 else None, normals=norm, frame_ids=ids,
-                               rays_per_frame=self.n_rays, min_depth=self.min_depth,
-                               dist_behind_surf=self.dist_behind_surf, trunc_dist=self.trunc_dist,
-                               n_strat=self.n_strat_samples, n_surf=self.n_surf_samples, out=out,
-                               keep_world=keep_world)
+        return sampler(ph, pw, u, g, out=out, keep_world=keep_world)
 
     def sample_points(self, depth_batch=None, T_WC_batch=None, norm_batch=None, active_loss_approx=None):
         """World-frame samples of the current selection (reference :221-293): {'pc' (rays,S,3), 'z_vals'}."""

@@ -835,59 +835,78 @@ class RayBatch:
         return int(self.counts[1].item()) * self.S
 
 
+class RaySampler:
+    """Frames + sampling knobs bound once (ctypes structs, workspace); each call is one miso_sample_rays."""
+
+    def __init__(self, depth, T_WC, R_wk, t_wk, intrinsics, *, min_depth, dist_behind_surf, trunc_dist, n_strat,
+                 n_surf, rays_per_frame=0, normals=None, frame_ids=None):
+        _require_hip(depth, T_WC, R_wk, t_wk, normals)
+        dev = depth.device
+        B, H, W = depth.shape
+
+        def f32(t, shape):
+            t = t.detach().to(torch.float32).contiguous()
+            assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+            return t
+
+        self._keep = [f32(depth, (B, H, W)), f32(T_WC, (B, 4, 4)), f32(R_wk, (B, 3, 3)),
+                      f32(t_wk.reshape(B, 3), (B, 3))]
+        fr = _lib.RayFrames()
+        fr.depth, fr.T_WC, fr.R_wk, fr.t_wk = (t.data_ptr() for t in self._keep)
+        if normals is not None:
+            self._keep.append(f32(normals, (B, H, W, 3)))
+            fr.normals = self._keep[-1].data_ptr()
+        if frame_ids is not None:
+            self._keep.append(frame_ids.detach().to(device=dev, dtype=torch.int64).contiguous())
+            assert self._keep[-1].numel() == B
+            fr.frame_ids = self._keep[-1].data_ptr()
+        fr.n_frames, fr.H, fr.W = B, H, W
+        fr.fx, fr.fy, fr.cx, fr.cy = (float(v) for v in intrinsics)
+        edges = torch.linspace(0, 1, n_strat + 1, dtype=torch.float32)        # utils_sample.py:214-216
+        self._edges = (C.c_float * (n_strat + 1))(*edges.tolist())
+        self.cfg = _lib.RaySampling(float(min_depth), float(dist_behind_surf), float(trunc_dist), int(n_strat),
+                                    int(n_surf), int(rays_per_frame), C.cast(self._edges, C.POINTER(C.c_float)))
+        self.frames, self.device, self.B = fr, dev, B
+        self.n_strat, self.n_surf, self.S = int(n_strat), int(n_surf), int(n_strat + n_surf)
+        self._ws = None
+
+    def __call__(self, pix_h, pix_w, u, g, pix_b=None, out: Optional[RayBatch] = None, keep_world=False) -> RayBatch:
+        _require_hip(u, g)
+        n_rays = pix_h.numel()
+        for t in (pix_h, pix_w, pix_b):
+            if t is not None and not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == n_rays):
+                raise RuntimeError("pixel indices must be contiguous int64 tensors on the HIP device, one per ray")
+        if self.n_strat > 0:
+            assert u.is_contiguous() and tuple(u.shape) == (n_rays, self.n_strat)
+        if self.n_surf > 1:
+            assert g.is_contiguous() and tuple(g.shape) == (n_rays, self.n_surf - 1)
+        if out is None:
+            out = RayBatch(n_rays, self.S, self.device, keep_world=keep_world)
+        assert out.n_rays == n_rays and out.S == self.S
+        lib = _lib.load()
+        need = max(int(lib.miso_sample_rays_workspace_bytes(n_rays, self.B)), 1)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.device, dtype=torch.uint8)
+        _lib.check(lib.miso_sample_rays(C.byref(self.frames), C.byref(self.cfg), n_rays, _ptr(pix_b), _ptr(pix_h),
+                                        _ptr(pix_w), _ptr(u if self.n_strat > 0 else None),
+                                        _ptr(g if self.n_surf > 1 else None), _ptr(self._ws), _ptr(out.coords_frame),
+                                        _ptr(out.sample_frame_ids), _ptr(out.aux), _ptr(out.pc_world),
+                                        _ptr(out.z_vals), _ptr(out.counts), _stream(out.aux)), "miso_sample_rays")
+        return out
+
+
 def sample_rays(depth, T_WC, R_wk, t_wk, intrinsics, pix_h, pix_w, u, g, *, min_depth, dist_behind_surf,
                 trunc_dist, n_strat, n_surf, rays_per_frame=0, pix_b=None, normals=None, frame_ids=None,
-                out: Optional[RayBatch] = None, keep_world=False, workspace=None) -> RayBatch:
+                out: Optional[RayBatch] = None, keep_world=False) -> RayBatch:
     """PosedSdfRgbd.getitem_sdf (grid_opt/datasets/sdf_rgbd.py:381-483) for one batch of pixels, on the device:
     miso_sample_rays.  ``intrinsics`` = (fx, fy, cx, cy); draws ``u`` (n_rays, n_strat) and ``g`` (n_rays, n_surf-1)
     are consumed by the rays that pass the depth filter, in order."""
-    _require_hip(depth, T_WC, R_wk, t_wk, u, g, normals)
-    dev = depth.device
+    sampler = RaySampler(depth, T_WC, R_wk, t_wk, intrinsics, min_depth=min_depth, dist_behind_surf=dist_behind_surf,
+                         trunc_dist=trunc_dist, n_strat=n_strat, n_surf=n_surf, rays_per_frame=rays_per_frame,
+                         normals=normals, frame_ids=frame_ids)
+    _require_hip(u, g)
     if not (pix_h.is_cuda and pix_w.is_cuda and (pix_b is None or pix_b.is_cuda)):
         raise RuntimeError("miso_amd ops run on the HIP device only (no CPU fallback); pixel indices are on the host")
-    B, H, W = depth.shape
-    n_rays = pix_h.numel()
-    S = n_strat + n_surf
-
-    def f32(t, shape):
-        t = t.detach().to(torch.float32).contiguous()
-        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
-        return t
-
-    def i64(t):
-        t = t.detach().reshape(-1).to(torch.int64).contiguous()
-        assert t.numel() == n_rays
-        return t
-
-    keep = [f32(depth, (B, H, W)), f32(T_WC, (B, 4, 4)), f32(R_wk, (B, 3, 3)), f32(t_wk.reshape(B, 3), (B, 3))]
-    fr = _lib.RayFrames()
-    fr.depth, fr.T_WC, fr.R_wk, fr.t_wk = (t.data_ptr() for t in keep)
-    if normals is not None:
-        keep.append(f32(normals, (B, H, W, 3)))
-        fr.normals = keep[-1].data_ptr()
-    if frame_ids is not None:
-        keep.append(frame_ids.detach().to(device=dev, dtype=torch.int64).contiguous())
-        assert keep[-1].numel() == B
-        fr.frame_ids = keep[-1].data_ptr()
-    fr.n_frames, fr.H, fr.W = B, H, W
-    fr.fx, fr.fy, fr.cx, fr.cy = (float(v) for v in intrinsics)
-    edges = torch.linspace(0, 1, n_strat + 1, dtype=torch.float32)        # utils_sample.py:214-216
-    edges_c = (C.c_float * (n_strat + 1))(*edges.tolist())
-    cfg = _lib.RaySampling(float(min_depth), float(dist_behind_surf), float(trunc_dist), int(n_strat), int(n_surf),
-                           int(rays_per_frame), C.cast(edges_c, C.POINTER(C.c_float)))
-    ph, pw = i64(pix_h), i64(pix_w)
-    pb = i64(pix_b) if pix_b is not None else None
-    uu = f32(u, (n_rays, n_strat)) if n_strat > 0 else None
-    gg = f32(g, (n_rays, n_surf - 1)) if n_surf > 1 else None
-    if out is None:
-        out = RayBatch(n_rays, S, dev, keep_world=keep_world)
-    assert out.n_rays == n_rays and out.S == S
-    lib = _lib.load()
-    if workspace is None:
-        workspace = torch.empty(max(int(lib.miso_sample_rays_workspace_bytes(n_rays, B)), 1), device=dev,
-                                dtype=torch.uint8)
-    _lib.check(lib.miso_sample_rays(C.byref(fr), C.byref(cfg), n_rays, _ptr(pb), _ptr(ph), _ptr(pw), _ptr(uu),
-                                    _ptr(gg), _ptr(workspace), _ptr(out.coords_frame), _ptr(out.sample_frame_ids),
-                                    _ptr(out.aux), _ptr(out.pc_world), _ptr(out.z_vals), _ptr(out.counts),
-                                    _stream(depth)), "miso_sample_rays")
-    return out
+    i64 = lambda t: None if t is None else t.detach().reshape(-1).to(torch.int64).contiguous()
+    c32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+    return sampler(i64(pix_h), i64(pix_w), c32(u), c32(g), pix_b=i64(pix_b), out=out, keep_world=keep_world)
