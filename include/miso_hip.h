@@ -179,12 +179,17 @@ int miso_sdf_fwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
  * launch (nothing to zero, no atomics: same-address atomics serialise at ~13 ns each and every
  * workgroup ends at about the same time).  The loss is the column sum: [.,0] weight_sdf * sdf
  * term, [.,1] weight_fs * free-space term.
- * sdf (caller order) may be NULL. */
+ * sdf (caller order) may be NULL.
+ * n_live (one int32 on the DEVICE, or NULL): number of live rows when the batch is a fixed-capacity
+ * buffer whose other rows are neutral padding (valid = sign = weight = 0, as miso_sample_rays
+ * leaves them).  The reference's means run over the rows of the batch (loss.py:627-635, :698-700),
+ * so with padding they must divide by the live count, which only the device knows; NULL = n. */
 #define MISO_LOSS_SLOTS 512
 int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                              const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf,
                              float weight_fs, float trunc_dist, const float* loss_inputs, float* sdf,
-                             uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots, void* stream);
+                             uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots,
+                             const int32_t* n_live, void* stream);
 /* The owner-computes gradient on its own: rows of d loss / d feats (row pitch ld_d floats,
  * a multiple of 4; 16-B aligned base) -> level[l].grad for every level with a non-NULL grad,
  * written (MISO_F_GRAD_OVERWRITE) or accumulated, without atomics.  Rows are in the binned
@@ -324,8 +329,10 @@ int64_t miso_sample_rays_workspace_bytes(int64_t n_rays, int32_t n_frames);
  * sample_frame_ids (rows) int64, aux (rows,4) = {sdf, valid, sign, weight} -- the row layout
  * miso_sdf_fwd_sorted_loss reads -- with valid = |sdf| < trunc_dist, sign = -1 / 0 / +1 beyond the
  * truncation band, weight = 1; optional pc_world (rows,3) and z_vals (rows) (NULL to skip).
- * Rows past the packed ones are neutral padding (zeros: no loss, no gradient).
- * counts (2 x int32, device) = {rays after the first filter, rays kept}; kept*S rows are live. */
+ * Rows past the packed ones are neutral padding: aux = 0 (no loss, no gradient), coordinates and frame id
+ * borrowed from a live sample so that a padded batch keeps the spatial spread of the live one.
+ * counts (4 x int32, device) = {rays after the first filter, rays kept, live rows = kept * S, 0};
+ * &counts[2] is what miso_sdf_fwd_sorted_loss takes as n_live. */
 int miso_sample_rays(const miso_ray_frames_t* frames, const miso_ray_sampling_t* sampling, int64_t n_rays,
                      const int64_t* pix_b, const int64_t* pix_h, const int64_t* pix_w, const float* u,
                      const float* g, void* workspace, float* coords_frame, int64_t* sample_frame_ids,

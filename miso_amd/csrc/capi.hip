@@ -364,7 +364,8 @@ int miso_encode_fwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted,
 int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                              const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf,
                              float weight_fs, float trunc_dist, const float* loss_inputs, float* sdf,
-                             uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots, void* stream) {
+                             uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots,
+                             const int32_t* n_live, void* stream) {
   int rc = check_sorted(sorted, n);
   if (rc) return rc;
   if ((loss_type != 1 && loss_type != 2) || !loss_slots || (n > 0 && (!loss_inputs || !grad_sdf_sorted)))
@@ -377,6 +378,7 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
   lin.aux = reinterpret_cast<const float4*>(loss_inputs);
   lin.gsdf_sorted = grad_sdf_sorted; lin.loss_out = loss_slots;
   lin.inv_n = n > 0 ? 1.0f / (float)n : 0.0f;
+  lin.n_live = n_live;
   return sdf_fwd_impl(grid, mlp, packed, nullptr, n, sdf, relu_mask, sorted, stream, &lin);
 }
 

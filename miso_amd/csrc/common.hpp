@@ -156,6 +156,7 @@ struct LossInK {
   float* gsdf_sorted;  // (N) out: d loss / d sdf, binned order
   float* loss_out;     // (MISO_LOSS_SLOTS, 2): every slot written by the launch
   float inv_n;
+  const int32_t* n_live;   // device count of live rows (the rest is neutral padding), or nullptr: the means divide by it
 };
 
 }  // namespace miso

@@ -16,8 +16,8 @@
 //
 // Output rows are ray-major, [surface, near x (n_surf-1), stratified x n_strat] inside a ray
 // (torch.cat order, utils_sample.py:296-297).  Rows past the last valid ray are neutral padding
-// (coords 0, weight 0, valid 0, sign 0): they add nothing to any loss or gradient, so a fixed-capacity
-// batch can flow through a captured step with the live count kept on the device.
+// (weight 0, valid 0, sign 0, sdf 0, at the position of some live sample): they add nothing to any loss or
+// gradient, so a fixed-capacity batch can flow through a captured step with the live count kept on the device.
 #include "common.hpp"
 
 namespace miso {
@@ -221,19 +221,52 @@ __global__ __launch_bounds__(RAY_BLOCK) void ray_emit_kernel(RayK k) {
     if (k.pc_world) { k.pc_world[out * 3] = p[0]; k.pc_world[out * 3 + 1] = p[1]; k.pc_world[out * 3 + 2] = p[2]; }
     if (k.z_vals) k.z_vals[out] = z;
   }
-  // neutral padding for this block's dropped rays
+  // Padding for this block's dropped rays: zero labels (no loss, no gradient) at the POSITION of a live sample --
+  // a padded batch still goes through the binned trainer step, and thousands of rows parked on one point
+  // would all land in one tile, which a single wave drains serially.  Borrow a ray of this block, or, when the
+  // whole block is dead, probe the slot table for any live ray; only with no live ray at all do zeros remain.
   const int64_t in_block = (k.n_rays - first) < RAY_BLOCK ? (k.n_rays - first) : RAY_BLOCK;
   const int64_t pad0 = ((int64_t)all2 + (first - base2)) * S;
   const int64_t npad = (in_block - nv) * S;
   for (int64_t i = threadIdx.x; i < npad; i += RAY_BLOCK) {
+#pragma clang fp contract(off)
     const int64_t out = pad0 + i;
-    k.coords[out * 3] = 0.0f; k.coords[out * 3 + 1] = 0.0f; k.coords[out * 3 + 2] = 0.0f;
-    k.ids[out] = k.frame_ids ? k.frame_ids[0] : 0;
+    Ray ray;
+    int sl = -1;
+    if (nv > 0) {
+      const int lr = (int)(i % nv);
+      ray = rays[lr];
+      sl = slots[lr];
+    } else if (all2 > 0) {
+      uint64_t q = ((uint64_t)(first + i) * 0x9E3779B97F4A7C15ull) % (uint64_t)k.n_rays;
+      for (int tries = 0; tries < 64 && sl < 0; ++tries, q = (q + 1) % (uint64_t)k.n_rays) {
+        sl = k.slot[q];
+        if (sl >= 0) {
+          int b, h, w;
+          float depth;
+          ray_first_filter(k, (int64_t)q, b, depth, h, w);
+          ray_setup(k, b, h, w, depth, ray);
+        }
+      }
+    }
+    float c[3] = {0.0f, 0.0f, 0.0f}, p[3] = {0.0f, 0.0f, 0.0f}, z = 0.0f;
+    int64_t id = k.frame_ids ? k.frame_ids[0] : 0;
+    if (sl >= 0) {
+      z = ray_z(k, ray, sl, (int)((i / (nv > 0 ? nv : 1)) % S));
+      ray_point(ray, z, p);
+      const float* R = k.R_wk + (int64_t)ray.b * 9;
+      const float* ti = k.t_inv + (int64_t)ray.b * 3;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) c[a] = ((p[0] * R[a] + p[1] * R[3 + a]) + p[2] * R[6 + a]) + ti[a];
+      id = k.frame_ids ? k.frame_ids[ray.b] : (int64_t)ray.b;
+    }
+    k.coords[out * 3] = c[0]; k.coords[out * 3 + 1] = c[1]; k.coords[out * 3 + 2] = c[2];
+    k.ids[out] = id;
     k.aux[out] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (k.pc_world) { k.pc_world[out * 3] = 0.0f; k.pc_world[out * 3 + 1] = 0.0f; k.pc_world[out * 3 + 2] = 0.0f; }
-    if (k.z_vals) k.z_vals[out] = 0.0f;
+    if (k.pc_world) { k.pc_world[out * 3] = p[0]; k.pc_world[out * 3 + 1] = p[1]; k.pc_world[out * 3 + 2] = p[2]; }
+    if (k.z_vals) k.z_vals[out] = z;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) k.counts[1] = all2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { k.counts[1] = all2; k.counts[2] = all2 * S; k.counts[3] = 0; }
 }
 
 // t_inv[b] = -(R_wk[b]^T t_wk[b])   (utils_geometry.py:238)
@@ -258,7 +291,7 @@ hipError_t launch_sample_rays(const miso_ray_frames_t& f, const miso_ray_samplin
                               int64_t n_rays, const int64_t* pix_b, const int64_t* pix_h, const int64_t* pix_w,
                               const float* u, const float* g, void* workspace, float* coords, int64_t* ids,
                               float* aux, float* pc_world, float* z_vals, int32_t* counts, hipStream_t s) {
-  if (n_rays == 0) return hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), s);
+  if (n_rays == 0) return hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s);
   const unsigned blocks = (unsigned)((n_rays + RAY_BLOCK - 1) / RAY_BLOCK);
   RayK k;
   k.depth = f.depth; k.normals = f.normals; k.T_WC = f.T_WC; k.R_wk = f.R_wk; k.frame_ids = f.frame_ids;

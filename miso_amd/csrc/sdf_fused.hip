@@ -208,6 +208,8 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
   const float bo = smem[pl.o_bo];
 
   float loss_sdf = 0.0f, loss_fs = 0.0f;
+  float inv_n = lin.inv_n;   // mean over the batch rows -- or over the live rows of a padded batch
+  if (lin.p.loss_type && lin.n_live) { const int live = *lin.n_live; inv_n = 1.0f / (float)(live > 1 ? live : 1); }
   ChunkSched sched(nchunks, wave, 4, perm != nullptr);
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     // keep the (chunk-invariant) LDS reads of biases / weights inside the loop:
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
       float gsd, gfs;
       map_loss_one(lin.p, sdf_v, l_in.x, l_in.w, l_in.y == 1.0f, lin.p.w_fs > 0.f && l_in.z == 1.0f, gsd, gfs,
                    loss_sdf, loss_fs);
-      lin.gsdf_sorted[p] = (gsd + gfs) * lin.inv_n;
+      lin.gsdf_sorted[p] = (gsd + gfs) * inv_n;
     }
     if (mask) {
       uint32_t* mo = mask + (chunk * 64 + lane) * MW;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
     if (threadIdx.x == 0) {
       const float a = (smem[0] + smem[2]) + (smem[4] + smem[6]), b = (smem[1] + smem[3]) + (smem[5] + smem[7]);
       float2* slots = reinterpret_cast<float2*>(lin.loss_out);
-      slots[blockIdx.x] = make_float2(lin.p.w_sdf * a * lin.inv_n, lin.p.w_fs * b * lin.inv_n);
+      slots[blockIdx.x] = make_float2(lin.p.w_sdf * a * inv_n, lin.p.w_fs * b * inv_n);
       for (int sl = blockIdx.x + gridDim.x; sl < MISO_LOSS_SLOTS; sl += gridDim.x) slots[sl] = make_float2(0.f, 0.f);
     }
   }

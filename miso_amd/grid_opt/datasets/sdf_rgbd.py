@@ -61,8 +61,9 @@ def read_kitti_format_poses(filename):
 class PosedSdfRgbd(SubmapDataset):
     def __init__(self, dataset_root: str, num_input_frames: int, cam_params, min_depth=0.07, max_depth=12.0,
                  voxel_size=None, n_rays=2 ** 10, dist_behind_surf=0.1, n_strat_samples=3, n_surf_samples=4,
-                 trunc_dist=0.30, frame_downsample=1, device='cuda:0', use_clip=False):
+                 trunc_dist=0.30, frame_downsample=1, device='cuda:0', use_clip=False, padded=False):
         super().__init__()
+        self.padded = padded
         if use_clip:
             raise NotImplementedError("the CLIP branch of the reference dataset is outside this path")
         self._configure(cam_params, min_depth, max_depth, voxel_size, n_rays, dist_behind_surf, n_strat_samples,
@@ -91,10 +92,11 @@ class PosedSdfRgbd(SubmapDataset):
     def from_frames(cls, depth_batch, R_world_frame_gt, t_world_frame_gt, cam_params, R_world_frame=None,
                     t_world_frame=None, min_depth=0.07, max_depth=12.0, voxel_size=None, n_rays=2 ** 10,
                     dist_behind_surf=0.1, n_strat_samples=3, n_surf_samples=4, trunc_dist=0.30, device='cuda:0',
-                    normals=None):
+                    normals=None, padded=False):
         """In-memory construction: (B,H,W) depth in metres and (B,3,3)/(B,3,1) keyframe poses."""
         self = cls.__new__(cls)
         SubmapDataset.__init__(self)
+        self.padded = padded
         self._configure(cam_params, min_depth, max_depth, voxel_size, n_rays, dist_behind_surf, n_strat_samples,
                         n_surf_samples, trunc_dist, device)
         self._num_total = depth_batch.shape[0]
@@ -144,9 +146,9 @@ class PosedSdfRgbd(SubmapDataset):
 
     def sampled_points_at_kf(self, kf_id):
         self.select_keyframes([kf_id])
-        model_input, _ = self.__getitem__(0)
+        b = self.sample_batch()
         self.unselect_keyframes()
-        return model_input['coords_frame']
+        return b.coords_frame[:b.rows()]
 
     def get_odometry_at_pose(self, src_id):
         T_src = utils_geometry.pose_matrix(*self.noisy_kf_pose_in_world(src_id))
@@ -212,7 +214,16 @@ class PosedSdfRgbd(SubmapDataset):
                 "depth_batch": self._selected_frames()[0]}
 
     def getitem_sdf(self, index, draws=None):
+        """Exact-size rows like the reference (one read-back of the row count), or with ``padded=True`` the whole
+        fixed-capacity batch plus ``input_dict['live_rows']`` (int32 on the device): dropped rays leave neutral
+        rows at the tail, nothing is read back and the batch shape never changes, so the trainer replays one
+        captured step."""
         b = self.sample_batch(draws=draws)
+        if self.padded:
+            aux = b.aux
+            input_dict = {'coords_frame': b.coords_frame, 'sample_frame_ids': b.sample_frame_ids[:, None],
+                          'weights': aux[:, 3:4], 'live_rows': b.live_rows}
+            return input_dict, {'sdf': aux[:, 0:1], 'sdf_valid': aux[:, 1:2] > 0, 'sdf_signs': aux[:, 2:3]}
         n = b.rows()
         aux = b.aux[:n]
         input_dict = {'coords_frame': b.coords_frame[:n], 'sample_frame_ids': b.sample_frame_ids[:n, None],

@@ -251,6 +251,15 @@ class MisoLossMappingBase(BaseLoss):
             else:
                 loss_dict['free_space'] = self.weight_fs * miso_loss_free_space(
                     pred_sdf=pred_sdf, gt_sdf=gt_sdf, gt_sdf_sign=gt_sign, trunc_dist=self.trunc_dist)
+        live = model_input.get('live_rows')
+        if live is not None:
+            # padded batch (datasets with padded=True): the row means above ran over all N rows, of which
+            # only `live` carry samples -- the padding adds nothing to the sums, so rescale to the mean over
+            # the live rows, which is what the reference computes on its exact-size batch
+            scale = float(gt_sdf.shape[0]) / live.reshape(()).clamp(min=1).to(pred_sdf.dtype)
+            for k in (f'sdf_{self.loss_type}', 'free_space', 'eik'):
+                if k in loss_dict:
+                    loss_dict[k] = loss_dict[k] * scale
         if self.use_stability:
             loss_dict.update(compute_feature_stability_loss(model, coords_world))
         if self.weight_clip > 0:

@@ -137,8 +137,9 @@ class Trainer(object):
         if not any(need) or any(f.requires_grad and not nd for f, nd in zip(feats, need)):
             return None      # a feature grid would receive a gradient that no optimizer consumes: keep autograd's view
         n = coords_frame.shape[0]
+        live = model_input.get('live_rows')          # padded batch (datasets with padded=True): count on the device
         ignore = tuple(bool(v) for v in model.ignore_level_)
-        key = (n, need, ignore, lf.loss_type, float(lf.weight_sdf), float(lf.weight_fs), lf.trunc_dist,
+        key = (n, live is not None, need, ignore, lf.loss_type, float(lf.weight_sdf), float(lf.weight_fs), lf.trunc_dist,
                tuple(f.data_ptr() for f in feats))
         cache = self.__dict__.setdefault('_mapping_steps', {})
         step = cache.get(key)
@@ -148,13 +149,13 @@ class Trainer(object):
             step = MappingStep([f.data for f in feats], meta, pack, n, lf.loss_type, float(lf.weight_sdf),
                                float(lf.weight_fs) if lf.weight_fs > 0 else 0.0,
                                0.0 if lf.trunc_dist is None else float(lf.trunc_dist), need_levels=need,
-                               keep_sdf=False)
+                               keep_sdf=False, padded=live is not None)
             cache[key] = step
         with torch.no_grad():
             frame_ids = model_input['sample_frame_ids'][0, :, 0]
             coords_world = lf.world_coords(model, coords_frame, frame_ids)
             step.set_batch(coords_world, gt['sdf'][0], gt['sdf_valid'][0], gt['sdf_signs'][0],
-                           model_input['weights'][0])
+                           model_input['weights'][0], live_rows=live)
         step.run()
         for f, g, nd in zip(feats, step.grads, need):
             f.grad = g if nd else None

@@ -500,13 +500,17 @@ def sdf_mask_words(pack: DecoderPack) -> int:
 
 
 def sdf_fwd_loss_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatch, loss_inputs, mask, gsdf_sorted,
-                     loss_slots, loss_type="L1", weight_sdf=1.0, weight_fs=0.0, trunc_dist=0.0, sdf_out=None):
+                     loss_slots, loss_type="L1", weight_sdf=1.0, weight_fs=0.0, trunc_dist=0.0, sdf_out=None,
+                     n_live=None):
     """Binned forward with the mapping loss folded in (miso_sdf_fwd_sorted_loss).  loss_inputs (N,4):
     {target, valid, sign, weight} per point, caller order.  Writes d loss / d sdf in binned order to
     ``gsdf_sorted`` (feed it to sdf_bwd_raw(..., gsdf_sorted=True)) and the per-workgroup loss sums to
     ``loss_slots`` ((LOSS_SLOTS,2) floats, fully overwritten; the loss is loss_slots.sum(0)).
-    sdf_out (N,1), caller order, is optional."""
+    sdf_out (N,1), caller order, is optional.  n_live: one int32 on the device = live rows of a padded batch
+    (the means divide by it instead of N)."""
     _require_hip(loss_inputs, gsdf_sorted, loss_slots, *features)
+    if n_live is not None:
+        assert n_live.is_cuda and n_live.dtype == torch.int32 and n_live.numel() == 1
     m, packed = pack.get()
     n = sorted_batch.n
     assert loss_inputs.shape == (n, 4) and loss_inputs.is_contiguous()
@@ -516,7 +520,7 @@ def sdf_fwd_loss_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatc
     _lib.check(_lib.load().miso_sdf_fwd_sorted_loss(
         C.byref(g), C.byref(m), _ptr(packed), C.byref(sorted_batch.struct), n, _LOSS_TYPES[loss_type],
         float(weight_sdf), float(weight_fs), float(trunc_dist), _ptr(loss_inputs), _ptr(sdf_out), _ptr(mask),
-        _ptr(gsdf_sorted), _ptr(loss_slots), _stream(gsdf_sorted)), "miso_sdf_fwd_sorted_loss")
+        _ptr(gsdf_sorted), _ptr(loss_slots), _ptr(n_live), _stream(gsdf_sorted)), "miso_sdf_fwd_sorted_loss")
 
 
 def grad_pull_raw(features, meta, sorted_batch: SortedBatch, dfeat, grads, overwrite: bool = True,
@@ -829,10 +833,15 @@ class RayBatch:
         self.aux = torch.empty(cap, 4, device=device, dtype=torch.float32)
         self.pc_world = torch.empty(cap, 3, device=device, dtype=torch.float32) if keep_world else None
         self.z_vals = torch.empty(cap, device=device, dtype=torch.float32) if keep_world else None
-        self.counts = torch.zeros(2, device=device, dtype=torch.int32)
+        self.counts = torch.zeros(4, device=device, dtype=torch.int32)   # rays after filter 1, rays kept, live rows, 0
+
+    @property
+    def live_rows(self) -> torch.Tensor:
+        """(1,) int32 on the device: what the padded trainer step divides its means by."""
+        return self.counts[2:3]
 
     def rows(self) -> int:
-        return int(self.counts[1].item()) * self.S
+        return int(self.counts[2].item())
 
 
 class RaySampler:

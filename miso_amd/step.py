@@ -22,8 +22,12 @@ class MappingStep:
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
                  trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
                  sort: Optional[bool] = None, need_levels: Optional[Sequence[bool]] = None,
-                 keep_sdf: bool = True):
-        """need_levels: which levels get a gradient (default all) -- the coarse-to-fine schedule of
+                 keep_sdf: bool = True, padded: bool = False):
+        """padded: the batch buffers hold ``n_points`` rows of which only ``self.live_rows`` (one int32 on the
+        device, set through set_batch) are live, the rest neutral padding (valid = sign = weight = 0); the loss
+        means divide by the live count.  Lets a sampler with a data-dependent row count (depth holes) feed ONE
+        captured graph.
+        need_levels: which levels get a gradient (default all) -- the coarse-to-fine schedule of
         GridTrainer optimises one level at a time.  keep_sdf: also leave the predicted SDF of the batch
         in ``self.sdf`` (caller order); a training loop only needs the loss and the gradients, and on
         the binned path the scattered write costs 1.6 us."""
@@ -58,13 +62,19 @@ class MappingStep:
             self.exp_avg = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
             self.exp_avg_sq = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
             self.t = 0
+        self.live_rows = torch.full((1,), self.n, device=dev, dtype=torch.int32) if padded else None
+        if padded:
+            sort = True        # the live count is read by the binned forward
         if sort is None:   # default: bin when the batch is large enough for it to pay
             sort = ops.SortedBatch.AUTO_MIN_POINTS is not None and self.n >= ops.SortedBatch.AUTO_MIN_POINTS
         self.sorted = ops.SortedBatch(self.n, dev) if sort else None
         self._graph = None
         self._use_graph = use_graph and adam is None  # the Adam step count changes per call
 
-    def set_batch(self, x, target, valid=None, sign=None, weight=None):
+    def set_batch(self, x, target, valid=None, sign=None, weight=None, live_rows=None):
+        if self.live_rows is not None:
+            assert live_rows is not None, "a padded step needs the live row count of every batch"
+            self.live_rows.copy_(live_rows.reshape(1))
         self.x.copy_(x.reshape(self.n, 3))
         self.target.copy_(target.reshape(self.n, 1))
         for buf, src, fill in ((self.valid, valid, 1.0), (self.sign, sign, 0.0), (self.weight, weight, 1.0)):
@@ -91,7 +101,7 @@ class MappingStep:
             # forward + mapping loss: sdf, ReLU bits, d loss / d sdf (binned order) in one launch
             ops.sdf_fwd_loss_raw(self.features, self.meta, self.pack, self.sorted, self.aux, self._mask,
                                  self.gpred, self.loss_slots, lt, ws, wf, td,
-                                 sdf_out=self.sdf if self.keep_sdf else None)
+                                 sdf_out=self.sdf if self.keep_sdf else None, n_live=self.live_rows)
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, self._mask, False,
                             self.need_levels, self.grads, sorted_batch=self.sorted, overwrite=True, gsdf_sorted=True)
         else:

@@ -269,3 +269,91 @@ def test_mapper_trains_from_rgbd_dataset(tmp_path):
     Mapper(net, ds, cfg).mapping([0, 1], iterations=200, level_iterations=100)
     after = loss_now()
     assert after < 0.1 * before, (before, after)      # measured: 0.318 -> 0.0008
+
+
+@pytest.mark.gpu
+def test_padded_batches_feed_one_captured_step(tmp_path):
+    """padded=True: fixed-capacity batches with the live count on the device.  (1) the same draws give the same
+    loss and grid gradients as the exact-size batch, through the op-by-op loss and through MappingStep;
+    (2) a training run with a different number of surviving rays every iteration replays ONE captured step."""
+    import golden_cases as gc
+    from miso_amd import ops
+    from miso_amd.grid_opt.datasets.sdf_rgbd import PosedSdfRgbd
+    from miso_amd.grid_opt.loss import MisoLossMapping
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    from miso_amd.grid_opt.trainer import GridTrainer
+    from miso_amd.grid_opt.utils.utils import prepare_batch
+    from miso_amd.grid_opt.utils.utils_data import CameraParameters
+    from miso_amd.step import MappingStep
+    H, W, rays = 48, 64, 700
+    cp = CameraParameters(fx=50.0, fy=50.0, cx=31.5, cy=23.5, H=H, W=W)
+    g = torch.Generator().manual_seed(4)
+    depth = 1.5 + torch.rand(3, H, W, generator=g)
+    depth[torch.rand(3, H, W, generator=g) < 0.3] = 0.0            # holes: the live row count varies per draw
+    depth[1] = 0.0                                                 # a dead frame: whole blocks of dropped rays
+    R = torch.eye(3).repeat(3, 1, 1)
+    t = torch.tensor([[[0.0], [0.0], [0.0]], [[0.3], [0.1], [0.0]], [[-0.2], [0.0], [0.1]]])
+    kw = dict(n_rays=rays, n_strat_samples=5, n_surf_samples=4, trunc_dist=0.15, device=DEV)
+    exact = PosedSdfRgbd.from_frames(depth, R, t, cp, **kw)
+    padded = PosedSdfRgbd.from_frames(depth, R, t, cp, padded=True, **kw)
+    cfg_model = gc.model_cfg([[-3.0, 3.0], [-2.5, 2.5], [-0.5, 3.5]], 0.5, 4, 2, 4, 32, num_poses=3, init_stddev=1e-2)
+    torch.manual_seed(0)
+    net = GridNet(cfg_model, device=DEV).to(DEV)
+    for k in range(3):
+        net.set_initial_kf_pose(k, R[k], t[k], kf_key=f"KF{k}")
+    net.unlock_feature()
+    net.lock_pose()
+    lf = MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.5, trunc_dist=0.15)
+    n = 3 * rays
+    draws = (torch.randint(0, H, (n,), generator=g).to(DEV), torch.randint(0, W, (n,), generator=g).to(DEV),
+             torch.rand(n, 5, generator=g).to(DEV), (torch.randn(n, 3, generator=g) * 0.1).to(DEV))
+    batch = lambda item: prepare_batch(*[{k: v[None] for k, v in d.items()} for d in item], DEV)
+    res = {}
+    for name, ds in (("exact", exact), ("padded", padded)):
+        mi, gt = batch(ds.getitem_sdf(0, draws=draws))
+        net.zero_grad(set_to_none=True)
+        terms = lf.compute(net, mi, gt)
+        sum(v.mean() for v in terms.values()).backward()
+        res[name] = ({k: float(v.detach()) for k, v in terms.items()}, [f.feature.grad.clone() for f in net.features], mi, gt)
+    live = res["exact"][2]["coords_frame"].shape[1]
+    assert res["padded"][2]["coords_frame"].shape[1] == n * 9 and int(res["padded"][2]["live_rows"]) == live < n * 9
+    for k, v in res["exact"][0].items():
+        assert abs(res["padded"][0][k] - v) <= 1e-5 * abs(v), k
+    for ga, gb in zip(res["exact"][1], res["padded"][1]):
+        assert (ga - gb).abs().max().item() <= 1e-4 * ga.abs().max().item()
+    # the fused step on the padded batch
+    feats = [f.feature.data for f in net.features]
+    meta = net.features[0].grid_meta(net.ignore_level_)
+    mi, gt = res["padded"][2], res["padded"][3]
+    step = MappingStep(feats, meta, net._fused_decoder(), n * 9, "L1", 1.0, 0.5, 0.15, padded=True, use_graph=False)
+    with torch.no_grad():
+        xw = lf.world_coords(net, mi["coords_frame"][0], mi["sample_frame_ids"][0, :, 0])
+    step.set_batch(xw, gt["sdf"][0], gt["sdf_valid"][0], gt["sdf_signs"][0], mi["weights"][0], live_rows=mi["live_rows"])
+    step.run()
+    want = sum(res["exact"][0].values())
+    assert abs(float(step.loss.sum()) - want) <= 1e-5 * abs(want)
+    for ga, gb in zip(res["exact"][1], step.grads):
+        assert (ga - gb).abs().max().item() <= 1e-4 * ga.abs().max().item()
+    # training: one graph for all iterations although the live count changes
+    cfg_train = {"verbose": False, "optimizer": "adam", "learning_rate": 5e-2, "epochs": 40, "ckpt_every": -1,
+                 "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": str(tmp_path),
+                 "relchange_tol": 0, "max_epochs_in_level": 100, "grid_training_mode": "joint"}
+    loader = torch.utils.data.DataLoader(padded, batch_size=1, shuffle=False, num_workers=0)
+    tr = GridTrainer(cfg_train, net, lf, loader, None, DEV, torch.float32)
+    seen = set()
+    orig = MappingStep.set_batch
+
+    def spy(self, *a, **k):
+        seen.add((id(self), int(k["live_rows"])))
+        return orig(self, *a, **k)
+
+    MappingStep.set_batch = spy
+    try:
+        tr.train()
+    finally:
+        MappingStep.set_batch = orig
+    assert len({s for s, _ in seen}) == 1 and len({c for _, c in seen}) > 5
+    net.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        after = sum(float(v.mean()) for v in lf.compute(net, res["exact"][2], res["exact"][3]).values())
+    assert after < 0.9 * want, (want, after)       # random depth is mostly noise: measured 0.062 -> 0.048
