@@ -154,7 +154,15 @@ typedef struct {
   const float* xn_sorted;      /* (N,4) the same normalised to [-1,1] as {x,y,z,0}, 16-B aligned; NULL = absent */
   const int32_t* perm;         /* (N) sorted position -> original index          */
   const int32_t* tile_offsets; /* (tiles^3 + 1) start of every tile in x_sorted  */
+  /* Optional scratch of the owner-computes gradient (miso_grad_pull, miso_sdf_bwd_sorted):
+   * miso_pull_queue_ints(n) int32, ZEROED ONCE by the caller when allocated (the library leaves it
+   * zeroed after every call).  With it, tiles that hold far more points than the average are cut
+   * into slices that run on separate wavefronts -- a batch hugging surfaces instead of filling the
+   * bound would otherwise be limited by its heaviest tile.  NULL / 0: tiles are never cut. */
+  int32_t* pull_queue;
+  int64_t pull_queue_ints;
 } miso_sorted_t;
+int64_t miso_pull_queue_ints(int64_t n);
 
 int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis);
 int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,

@@ -52,7 +52,8 @@ class Mlp(C.Structure):
 
 class Sorted(C.Structure):
     _fields_ = [("tiles_per_axis", C.c_int32), ("x_sorted", C.c_void_p), ("xn_sorted", C.c_void_p),
-                ("perm", C.c_void_p), ("tile_offsets", C.c_void_p)]
+                ("perm", C.c_void_p), ("tile_offsets", C.c_void_p),
+                ("pull_queue", C.c_void_p), ("pull_queue_ints", C.c_int64)]
 
 
 class RayFrames(C.Structure):
@@ -118,6 +119,7 @@ SIGNATURES = {
     "miso_mapping_loss": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
+    "miso_pull_queue_ints": (C.c_int64, [C.c_int64]),
     "miso_sample_rays_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "miso_sample_rays": (C.c_int, [C.POINTER(RayFrames), C.POINTER(RaySampling), C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

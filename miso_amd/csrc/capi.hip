@@ -24,7 +24,8 @@ hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, co
                               float*, hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
-                            uint32_t, int, const float*, hipStream_t);
+                            uint32_t, int, const float*, int32_t*, int64_t, hipStream_t);
+int64_t pull_queue_ints(int64_t);
 hipError_t launch_overlap_count(const float*, const float*, int64_t, const float*, const float*, float*, hipStream_t);
 hipError_t launch_lm_normal_eq(const float*, const float*, const float*, const float*, const float*, int64_t, int,
                                float, float*, hipStream_t);
@@ -300,7 +301,8 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   }
   if (!pull) return MISO_OK;
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace,
-                               g.F, nullptr, pull, overwrite ? 1 : 0, nullptr, st);
+                               g.F, nullptr, pull, overwrite ? 1 : 0, nullptr, sorted->pull_queue,
+                               sorted->pull_queue_ints, st);
 }
 
 int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
@@ -419,7 +421,8 @@ static int grad_pull_impl(const miso_grid_t* grid, const miso_sorted_t* sorted, 
     for (int a = 0; a < 3; ++a) g.gscale[a] = 2.0f / (g.bmax[a] - g.bmin[a]);   // d xn / d x (axis_coord's m)
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, dfeat, ld_d,
                                rows_in_caller_order ? sorted->perm : nullptr, pull,
-                               (grid->flags & MISO_F_GRAD_OVERWRITE) ? 1 : 0, gg_x, (hipStream_t)stream);
+                               (grid->flags & MISO_F_GRAD_OVERWRITE) ? 1 : 0, gg_x, sorted->pull_queue,
+                               sorted->pull_queue_ints, (hipStream_t)stream);
 }
 
 int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
@@ -479,6 +482,8 @@ int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const flo
   return (int)launch_lm_normal_eq(coords_frame, R_frame, grad_sdf_x, sdf, target, n, loss_type, gm_scale, out,
                                   (hipStream_t)stream);
 }
+
+int64_t miso_pull_queue_ints(int64_t n) { return n < 0 ? 0 : pull_queue_ints(n); }
 
 int64_t miso_sample_rays_workspace_bytes(int64_t n_rays, int32_t n_frames) {
   if (n_rays < 0 || n_frames < 0) return 0;

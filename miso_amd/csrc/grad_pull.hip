@@ -31,6 +31,18 @@ constexpr int PULL_LIST = 272;    // compacted candidate ids per level
 constexpr int PULL_CAP = 128;     // staged records per group (2 per lane); < 256: counters are bytes
 constexpr int PULL_RB = 4;        // rounds of 64 vertices pulled per pass over the staged records
 constexpr int PULL_MAXL = 4;      // levels swept together (the fused kernels cover <= 4 levels)
+// Heavy tiles.  One wavefront drains one tile serially (~50 ns per swept candidate), so a batch that piles its
+// points into a few tiles -- depth samples crowd around the cameras and hug surfaces; a uniform batch has ~1700
+// swept candidates per tile -- would be bound by its heaviest tile: 1.5 ms instead of 0.1 ms at the ScanNet
+// shapes.  A tile whose sweep exceeds its slice size is cut into ns slices of every row range; the owning
+// wavefront keeps slice 0 (plain stores, as always) and queues the others, which a second launch of the same
+// kernel ("drain") spreads round-robin over the whole chip and adds atomically.  The slice size is at least
+// PULL_WORK0 candidates and at least 16 per owned vertex: every extra slice costs one atomic per vertex and
+// channel, which pays for a coarse brick under a crowd of points and not for a fine brick in a uniform batch
+// (cfg-2 with every tile cut in two: 73 -> 396 us).
+constexpr int PULL_WORK0 = 1024;
+constexpr int PULL_NS_MAX = 255;
+constexpr int PULL_QHDR = 4;      // queue header: {tail, _, workgroups done, _}; items follow
 
 struct PullK {
   int T;
@@ -46,6 +58,10 @@ struct PullK {
   int bdiv[PULL_MAXL][3];   // size / T per pulled level and axis where T divides the size, else 0
   float inv_size[PULL_MAXL][3];
   int debug;             // ablation (MISO_DEBUG_PULL, dev only): 1 no pull loop, 2 no groups, 4 no sweep
+  int32_t* queue;        // slice queue (see PULL_WORK0) or nullptr: tiles are never split
+  int qcap;              // item capacity
+  int drain;             // 0: one wavefront per tile, slice 0 + queueing; 1: process the queued slices
+  int work0;             // swept candidates per slice
 };
 
 __device__ __forceinline__ int floor_div(int a, int b) {   // b > 0
@@ -107,7 +123,7 @@ __device__ __forceinline__ Brick make_brick(const LevelK& lv, int ta, int tb, in
 template <int C, int MODE>
 __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, const LevelK& lv, const Brick& b,
                                            float* smem, int o_list, int n, int o_arr, int o_rec, int o_df,
-                                           int lane, bool add) {
+                                           int lane, int add) {   // add: 0 store, 1 read-add-store, 2 atomic add
   int* ismem = reinterpret_cast<int*>(smem);
   unsigned* arrw = reinterpret_cast<unsigned*>(smem) + o_arr;
   const unsigned char* arrb = reinterpret_cast<const unsigned char*>(arrw);
@@ -291,7 +307,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
     }
     // ---- (4) store ---------------------------------------------------------------------------------
     if (!lv.grad || (single_rb && pass != npass - 1)) continue;
-    const bool add_eff = add || (!single_rb && gi > 0);
+    const int add_eff = add ? add : ((!single_rb && gi > 0) ? 1 : 0);
     if (lpv8) {   // reduce the 8 lanes of a vertex
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -311,6 +327,13 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
 #pragma unroll
       for (int c = 0; c < C; c += 4) {
         float4 v = make_float4(acc[r][c], acc[r][c + 1], acc[r][c + 2], acc[r][c + 3]);
+        if (add_eff == 2) {   // a queued slice: other wavefronts add to the same brick
+          if (v.x != 0.0f) atomic_add_f32(dst + c, v.x);
+          if (v.y != 0.0f) atomic_add_f32(dst + c + 1, v.y);
+          if (v.z != 0.0f) atomic_add_f32(dst + c + 2, v.z);
+          if (v.w != 0.0f) atomic_add_f32(dst + c + 3, v.w);
+          continue;
+        }
         if (add_eff) {
           const float4 o = *reinterpret_cast<const float4*>(dst + c);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -340,7 +363,25 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   const int T = pk.T, ntiles = T * T * T;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+  int qn = 0;
+  if (pk.drain) {
+    qn = min(pk.queue[0], pk.qcap);
+    if (qn <= 0) return;          // nothing was split (the uniform case): no atomics, counters stay zero
+  }
+  for (int iter = 0;; ++iter) {
+    int tile, sl = 0, ns = 1;
+    if (!pk.drain) {
+      tile = blockIdx.x * 4 + wave + iter * (int)gridDim.x * 4;
+      if (tile >= ntiles) break;
+    } else {
+      // static round-robin over the queued slices (they are of similar size); grabbing them with an atomic
+      // counter would serialise on one address at ~13 ns per grab -- 0.2 ms for 14 K slices
+      const int i = blockIdx.x * 4 + wave + iter * (int)gridDim.x * 4;
+      if (i >= qn) break;
+      const int it = pk.queue[PULL_QHDR + i];
+      if (it < 0) continue;
+      tile = it & 0xfff; sl = (it >> 12) & 0xff; ns = (it >> 20) & 0xff;   // sl < ns <= 255
+    }
     const int ta = tile % T, tb = (tile / T) % T, tc = tile / (T * T);
     const int tabc[3] = {ta, tb, tc};
     // catchment box of every level's brick in normalised coordinates: base corner i0 in
@@ -348,6 +389,7 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
     // a few ulps; and the union of the tile ranges that can hold such points
     float blo[PULL_NLV][3], bhi[PULL_NLV][3];
     int t_lo[3] = {T, T, T}, t_hi[3] = {-1, -1, -1};
+    int nverts_all = 0;
 #pragma unroll
     for (int d = 0; d < PULL_NLV; ++d) {
 #pragma unroll
@@ -357,6 +399,7 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
       const LevelK& lv = g.lv[lvl];
       const Brick b = make_brick(lv, ta, tb, tc, T, pk.bdiv[d]);
       if (b.nverts == 0 || ((g.ignore_mask >> lvl) & 1u)) continue;
+      nverts_all += b.nverts;
       const int size[3] = {lv.X, lv.Y, lv.Z};
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -391,6 +434,29 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
       rs = pk.tile_off[(rz * T + ry) * T + t_lo[0]];
       re = pk.tile_off[(rz * T + ry) * T + t_hi[0] + 1];
     }
+    if (pk.queue && tabled && sweeping) {
+      if (!pk.drain) {
+        int work = re - rs;
+        for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
+        const int slice = max(pk.work0, 16 * nverts_all);
+        ns = __builtin_amdgcn_readfirstlane(min(PULL_NS_MAX, (work + slice - 1) / slice));
+        if (ns > 1) {
+          int pos = 0;
+          if (lane == 0) pos = atomicAdd(&pk.queue[0], ns - 1);
+          pos = __builtin_amdgcn_readfirstlane(pos);
+          const bool fits = pos + ns - 1 <= pk.qcap;     // else: blank what was reserved, keep the tile whole
+          for (int i = lane; i < ns - 1; i += 64)
+            if (pos + i < pk.qcap) pk.queue[PULL_QHDR + pos + i] = fits ? (tile | ((i + 1) << 12) | (ns << 20)) : -1;
+          if (!fits) ns = 1;
+        }
+      }
+      if (ns > 1) {   // this wavefront's slice of every row range
+        const int len = re - rs;
+        const int a = rs + (int)(((int64_t)len * sl) / ns), b = rs + (int)(((int64_t)len * (sl + 1)) / ns);
+        rs = a; re = b;
+      }
+    }
+    const bool atomic = sl > 0;
     int ridx = 0;
     if (sweeping) {
       if (tabled) {
@@ -460,9 +526,9 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
         // collecting, so a fine level's brick is normally pulled and stored once per tile
         if (sweeping && PULL_LIST - n >= 64) continue;
         const bool first = !((stored >> d) & 1u);
-        if (n == 0 && !first) continue;
+        if (n == 0 && (!first || atomic)) continue;
         pull_level<C, MODE>(g, pk, lv, b, smem, o_list + d * PULL_LIST, n, o_arr, o_rec, o_df, lane,
-                      !(first && pk.overwrite));
+                      atomic ? 2 : ((first && pk.overwrite) ? 0 : 1));
         stored |= 1u << d;
 #pragma unroll
         for (int e = 0; e < PULL_NLV; ++e) nlist[e] = (e == d) ? 0 : nlist[e];
@@ -470,6 +536,13 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
       more = sweeping;
     }
     (void)tabc;
+  }
+  if (pk.drain) {   // the last workgroup out rewinds the queue for the next launch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(&pk.queue[2], 1) == (int)gridDim.x - 1) { pk.queue[0] = 0; pk.queue[2] = 0; }
+    }
   }
 }
 
@@ -493,7 +566,7 @@ uint32_t plan_grad_pull(const GridK& g, int T) {
 
 hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, const float* xn,
                             const float* dfeat, int64_t ld, const int* perm, uint32_t level_mask,
-                            int overwrite, const float* ggx, hipStream_t s) {
+                            int overwrite, const float* ggx, int32_t* queue, int64_t queue_ints, hipStream_t s) {
   if (!level_mask) return hipSuccess;
   PullK pk;
   memset(&pk, 0, sizeof(pk));
@@ -509,6 +582,12 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
       pk.lev[pk.nl++] = l;
     }
   pk.overwrite = overwrite;
+  if (queue && queue_ints > PULL_QHDR && T <= 16 && !getenv("MISO_PULL_NO_SPLIT")) {
+    pk.queue = queue;
+    pk.qcap = (int)((queue_ints - PULL_QHDR) < (1 << 30) ? (queue_ints - PULL_QHDR) : (1 << 30));
+  }
+  pk.work0 = PULL_WORK0;
+  if (const char* d = getenv("MISO_PULL_WORK0")) pk.work0 = atoi(d) > PULL_WORK0 ? atoi(d) : PULL_WORK0;   // dev
   if (const char* d = getenv("MISO_DEBUG_PULL")) pk.debug = atoi(d);
   const int per_wave = pk.nl * PULL_LIST + PULL_ARRW + PULL_CAP * (ggx ? 8 : 4) + PULL_CAP * C;
   size_t lds = (size_t)per_wave * 4 * sizeof(float);
@@ -526,7 +605,17 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
     if (e != hipSuccess) return e;
   }
   k<<<blocks, 256, lds, s>>>(g, pk);
+  if (pk.queue) {
+    pk.drain = 1;
+    unsigned dblocks = 1024;
+    if (const char* d = getenv("MISO_PULL_DRAIN_BLOCKS")) dblocks = (unsigned)atoi(d);   // dev
+    k<<<dblocks, 256, lds, s>>>(g, pk);
+  }
   return hipGetLastError();
 }
+
+// ints a slice queue for a batch of n points needs: every point is swept by at most 64 tiles, a slice is cut
+// per PULL_WORK0 swept candidates
+int64_t pull_queue_ints(int64_t n) { return PULL_QHDR + 64 + (n * 64) / PULL_WORK0; }
 
 }  // namespace miso

@@ -405,6 +405,11 @@ class SortedBatch:
         self.struct.xn_sorted = self.xn_sorted.data_ptr()
         self.struct.perm = self.perm.data_ptr()
         self.struct.tile_offsets = self.tile_offsets.data_ptr()
+        # slice queue of the owner-computes gradient (heavy tiles are cut and spread): zeroed once, the
+        # library rewinds it after every use
+        self.pull_queue = torch.zeros(int(_lib.load().miso_pull_queue_ints(self.n)), **i32)
+        self.struct.pull_queue = self.pull_queue.data_ptr()
+        self.struct.pull_queue_ints = self.pull_queue.numel()
 
     def bwd_workspace(self, floats: int) -> torch.Tensor:
         """(N,F) d-feat rows handed from the MFMA backward to the per-tile reduction."""
