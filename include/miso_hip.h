@@ -35,7 +35,8 @@
  *   miso_mapping_loss miso_loss_regression + miso_loss_free_space and their gradient
  *                     w.r.t. the prediction, grid_opt/loss.py:594-635, :668-700, as
  *                     combined by MisoLossMappingBase.compute (loss.py:776-806).
- *   miso_adam_dense   torch.optim.Adam.step on one dense tensor as used by
+ *   miso_adam_dense / miso_adam_active
+ *                     torch.optim.Adam.step on one dense tensor as used by
  *                     grid_opt/trainer.py:196-228 / :410-452.
  *   miso_sample_rays  PosedSdfRgbd.getitem_sdf, grid_opt/datasets/sdf_rgbd.py:381-483 (the step that
  *                     feeds the path): get_batch_data / sample_along_rays
@@ -345,6 +346,18 @@ int miso_sample_rays(const miso_ray_frames_t* frames, const miso_ray_sampling_t*
                      const int64_t* pix_b, const int64_t* pix_h, const int64_t* pix_w, const float* u,
                      const float* g, void* workspace, float* coords_frame, int64_t* sample_frame_ids,
                      float* aux, float* pc_world, float* z_vals, int32_t* counts, void* stream);
+
+/* The same step without the work that changes nothing: an element whose gradient has been zero in
+ * every step so far has exp_avg = exp_avg_sq = 0 and an update of exactly 0.  `active` holds one byte
+ * per MISO_ADAM_CHUNK consecutive floats of the storage ((numel + CHUNK-1)/CHUNK bytes, zeroed by the
+ * caller together with the moments): a chunk is stepped if any of its gradients is non-zero or if it
+ * has been stepped before (then the byte is 1).  Bit-identical to miso_adam_dense; reads 4 B per
+ * element plus 28 B per active element.  All four arrays must be 16-B aligned.  zero_grad clears the
+ * gradient of the stepped chunks -- the others are zero already. */
+#define MISO_ADAM_CHUNK 256
+int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
+                     int64_t numel, double lr, double beta1, double beta2, double eps,
+                     int32_t step /* 1-based */, int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libmiso_hip.so")
 MAX_LEVELS = 8
 MAX_LINEAR = 4
 RAY_MAX_BINS = 64
+ADAM_CHUNK = 256
 
 F_ALIGN_CORNERS = 1
 F_PAD_BORDER = 2
@@ -124,6 +125,8 @@ SIGNATURES = {
     "miso_sample_rays": (C.c_int, [C.POINTER(RayFrames), C.POINTER(RaySampling), C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_adam_active": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int, C.c_void_p]),
     "miso_adam_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int,
                                   C.c_void_p]),

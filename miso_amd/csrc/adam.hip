@@ -14,6 +14,7 @@ struct AdamScalars {
 };
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamScalars& a) {
+#pragma clang fp contract(off)   // one rounding per torch op, and the same bits from every kernel that inlines this
   m = m + a.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
   v = v * a.b2 + (a.one_minus_b2 * g) * g;          // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
   float denom = sqrtf(v) / a.bc2_sqrt + a.eps;      // (sqrt / bias_correction2_sqrt).add_(eps)
@@ -41,6 +42,97 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     adam_one(p[t], g[t], m[t], v[t], a);
     if (ZERO) g[t] = 0.0f;
   }
+}
+
+// Same step, skipping what cannot move.  An element whose gradient has been zero in every step so far has
+// m = v = 0 and its update is lr * 0 / (0 + eps) = 0: the dense kernel reads 16 B and writes 12 B per element to
+// change nothing.  For a submap whose bound is mostly empty space (Newer College: a 120 x 120 x 20 m bound,
+// 144 M floats in the fine level, of which a 6144-point batch touches a few thousand) that is the whole cost of
+// a training step.  Here one wavefront looks at one 256-float chunk of the gradient (1 KB, one float4 per
+// lane); a chunk is updated if any of its gradients is non-zero or if it has ever been updated (`active`, one
+// byte per chunk: once touched, moments decay and the parameters keep moving, exactly as in the dense step).
+// Results are bit-identical to the dense kernel; traffic is 4 B per element plus 28 B per active element, and
+// because every non-zero gradient belongs to an active chunk, ZERO clears exactly what needs clearing.
+constexpr int ADAM_CHUNK = MISO_ADAM_CHUNK;   // floats
+constexpr int ADAM_UN = 4;                    // chunks in flight per wavefront
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         unsigned char* __restrict__ active, int64_t n,
+                                                         AdamScalars a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
+  for (int64_t c0 = wave * ADAM_UN; c0 < nchunks; c0 += nwaves * ADAM_UN) {
+    float4 gg[ADAM_UN];
+    unsigned char act[ADAM_UN];
+#pragma unroll
+    for (int u = 0; u < ADAM_UN; ++u) {
+      const int64_t c = c0 + u, i = c * ADAM_CHUNK + lane * 4;
+      gg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      act[u] = 0;
+      if (c < nchunks) {
+        act[u] = active[c];
+        if (i + 3 < n) gg[u] = *reinterpret_cast<const float4*>(g + i);
+        else {
+          if (i < n) gg[u].x = g[i];
+          if (i + 1 < n) gg[u].y = g[i + 1];
+          if (i + 2 < n) gg[u].z = g[i + 2];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < ADAM_UN; ++u) {
+      const int64_t c = c0 + u, i = c * ADAM_CHUNK + lane * 4;
+      const bool nz = gg[u].x != 0.f || gg[u].y != 0.f || gg[u].z != 0.f || gg[u].w != 0.f;   // NaN counts
+      const bool any = __ballot(nz) != 0ull;
+      if (c >= nchunks || !(any || act[u])) continue;      // wave-uniform
+      if (i + 3 < n) {
+        float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i),
+               vv = *reinterpret_cast<float4*>(v + i);
+        adam_one(pp.x, gg[u].x, mm.x, vv.x, a); adam_one(pp.y, gg[u].y, mm.y, vv.y, a);
+        adam_one(pp.z, gg[u].z, mm.z, vv.z, a); adam_one(pp.w, gg[u].w, mm.w, vv.w, a);
+        *reinterpret_cast<float4*>(p + i) = pp;
+        *reinterpret_cast<float4*>(m + i) = mm;
+        *reinterpret_cast<float4*>(v + i) = vv;
+        if (ZERO && any) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const float ge[3] = {gg[u].x, gg[u].y, gg[u].z};
+        for (int e = 0; e < 3; ++e)
+          if (i + e < n) {
+            adam_one(p[i + e], ge[e], m[i + e], v[i + e], a);
+            if (ZERO) g[i + e] = 0.0f;
+          }
+      }
+      if (!act[u] && lane == 0) active[c] = 1;
+    }
+  }
+}
+
+static AdamScalars adam_scalars(double lr, double b1, double b2, double eps, int step) {
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  AdamScalars a;
+  a.one_minus_b1 = (float)(1.0 - b1);
+  a.b2 = (float)b2;
+  a.one_minus_b2 = (float)(1.0 - b2);
+  a.neg_step_size = (float)(-(lr / bc1));
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.eps = (float)eps;
+  return a;
+}
+
+hipError_t launch_adam_active(float* p, float* g, float* m, float* v, unsigned char* active, int64_t n, double lr,
+                              double b1, double b2, double eps, int step, int zero_grad, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const AdamScalars a = adam_scalars(lr, b1, b2, eps, step);
+  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
+  int64_t blocks = (nchunks + 4 * ADAM_UN - 1) / (4 * ADAM_UN);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (zero_grad) adam_active_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a);
+  else adam_active_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_adam(float* p, float* g, float* m, float* v, int64_t n, double lr, double b1,

@@ -149,7 +149,7 @@ class Trainer(object):
             step = MappingStep([f.data for f in feats], meta, pack, n, lf.loss_type, float(lf.weight_sdf),
                                float(lf.weight_fs) if lf.weight_fs > 0 else 0.0,
                                0.0 if lf.trunc_dist is None else float(lf.trunc_dist), need_levels=need,
-                               keep_sdf=False, padded=live is not None)
+                               keep_sdf=False, padded=live is not None, grads_cleared_by_optimizer=True)
             cache[key] = step
         with torch.no_grad():
             frame_ids = model_input['sample_frame_ids'][0, :, 0]
@@ -160,10 +160,17 @@ class Trainer(object):
         for f, g, nd in zip(feats, step.grads, need):
             f.grad = g if nd else None
         total = step.loss.sum()
+        # small batches scatter into the step's persistent gradient buffers: the optimizer clears what it
+        # consumed in the same pass (a memset of a 0.5 GB level costs as much as the rest of the step)
+        clear = step.sorted is None
         if not torch.isnan(total):
-            self.optimizer.step()
+            self.optimizer.step(clear_grads=clear)
         else:
             logger.warning("Loss is nan! Skip backward step.")
+            if clear:
+                for g in step.grads:
+                    if g is not None:
+                        g.zero_()
         return total
 
     def train_step(self, model_input, gt):

@@ -1,4 +1,5 @@
-"""Dense Adam as a torch.optim.Optimizer backed by miso_adam_dense.
+"""Dense Adam as a torch.optim.Optimizer backed by miso_adam_active (miso_adam_dense's results without the
+passes over elements that no gradient has ever reached: their moments are zero and their update is exactly zero).
 
 Same update and state layout ('step', 'exp_avg', 'exp_avg_sq') as
 torch.optim.Adam(amsgrad=False, weight_decay=0), which is what the reference's
@@ -20,7 +21,9 @@ class DenseAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, clear_grads=False):
+        """clear_grads: leave every .grad zeroed (in the same pass for the big tensors), for callers that
+        accumulate into persistent gradient buffers and would otherwise memset them before the next backward."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -40,11 +43,18 @@ class DenseAdam(torch.optim.Optimizer):
                 t, m, v = st['step'], st['exp_avg'], st['exp_avg_sq']
                 if (p.is_cuda and p.dtype == torch.float32 and p.numel() >= _KERNEL_MIN_NUMEL
                         and g.stride() == p.stride() and m.stride() == p.stride()):
-                    ops.adam_dense_(p, g, m, v, t, lr, b1, b2, eps)
+                    if 'active' not in st:
+                        # state restored from a plain Adam checkpoint: everything may already be moving
+                        st['active'] = ops.adam_active_flags(p)
+                        if t > 1:
+                            st['active'].fill_(1)
+                    ops.adam_active_(p, g, m, v, st['active'], t, lr, b1, b2, eps, zero_grad=clear_grads)
                     continue
                 m.lerp_(g, 1 - b1)
                 v.mul_(b2).addcmul_(g, g, value=1 - b2)
                 bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
                 denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
                 p.addcdiv_(m, denom, value=-(lr / bc1))
+                if clear_grads:
+                    g.zero_()
         return loss

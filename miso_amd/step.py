@@ -22,16 +22,19 @@ class MappingStep:
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
                  trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
                  sort: Optional[bool] = None, need_levels: Optional[Sequence[bool]] = None,
-                 keep_sdf: bool = True, padded: bool = False):
+                 keep_sdf: bool = True, padded: bool = False, grads_cleared_by_optimizer: bool = False):
         """padded: the batch buffers hold ``n_points`` rows of which only ``self.live_rows`` (one int32 on the
         device, set through set_batch) are live, the rest neutral padding (valid = sign = weight = 0); the loss
         means divide by the live count.  Lets a sampler with a data-dependent row count (depth holes) feed ONE
         captured graph.
+        grads_cleared_by_optimizer: the caller's optimizer leaves the gradient buffers zeroed after its step
+        (DenseAdam.step(clear_grads=True)), so the small-batch path does not memset them before scattering.
         need_levels: which levels get a gradient (default all) -- the coarse-to-fine schedule of
         GridTrainer optimises one level at a time.  keep_sdf: also leave the predicted SDF of the batch
         in ``self.sdf`` (caller order); a training loop only needs the loss and the gradients, and on
         the binned path the scattered write costs 1.6 us."""
         self.keep_sdf = bool(keep_sdf)
+        self.external_clear = bool(grads_cleared_by_optimizer)
         self.features = list(features)
         self.meta, self.pack = meta, pack
         self.n = int(n_points)
@@ -61,6 +64,7 @@ class MappingStep:
         if adam is not None:
             self.exp_avg = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
             self.exp_avg_sq = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
+            self.active = [ops.adam_active_flags(f) if nd else None for f, nd in zip(self.features, need)]
             self.t = 0
         self.live_rows = torch.full((1,), self.n, device=dev, dtype=torch.int32) if padded else None
         if padded:
@@ -86,7 +90,7 @@ class MappingStep:
     def _launch(self):
         lt, ws, wf, td = self.loss_cfg
         # binned path: gradients are written owner-computes, nothing to clear
-        need_zero = self.sorted is None and (self.adam is None or self.t == 0)
+        need_zero = self.sorted is None and (self.adam is None or self.t == 0) and not self.external_clear
         if need_zero:
             for g in self.grads:
                 if g is not None:
@@ -117,12 +121,12 @@ class MappingStep:
                             self.need_levels, self.grads)
         if self.adam is not None:
             self.t += 1
-            for p, g, m, v in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq):
+            for p, g, m, v, act in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq, self.active):
                 if g is None:
                     continue
                 # zero_grad=True: the gradient is cleared in the same pass, so the next
                 # iteration needs no memset
-                ops.adam_dense_(p.data, g, m, v, self.t, zero_grad=self.sorted is None, **self.adam)
+                ops.adam_active_(p.data, g, m, v, act, self.t, zero_grad=self.sorted is None, **self.adam)
 
     @property
     def loss(self) -> torch.Tensor:

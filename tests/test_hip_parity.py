@@ -295,6 +295,53 @@ def test_adam_dense_vs_torch():
         torch.testing.assert_close(v.cpu(), opt.state[pc]["exp_avg_sq"], rtol=1e-6, atol=1e-12)
 
 
+@pytest.mark.parametrize("numel", [256 * 40, 256 * 37 + 130, 1027, 5])
+def test_adam_active_is_bit_identical_to_dense(numel):
+    """miso_adam_active steps only the chunks a gradient has ever reached; everything -- parameters, both moments,
+    cleared gradients -- must equal the dense kernel bit for bit over a run in which chunks wake up at different
+    steps, some never, and one gradient is NaN.  Also checked against torch.optim.Adam."""
+    from miso_amd import ops, _lib
+    g = torch.Generator().manual_seed(numel)
+    p0 = torch.randn(numel, generator=g)
+    nchunks = (numel + _lib.ADAM_CHUNK - 1) // _lib.ADAM_CHUNK
+    wake = torch.randint(0, 8, (nchunks,), generator=g)         # step at which a chunk first gets a gradient; >= 6: never
+    grads = []
+    for t in range(6):
+        gr = torch.randn(numel, generator=g) * 1e-2
+        on = ((wake <= t) & (torch.rand(nchunks, generator=g) < 0.7)).repeat_interleave(_lib.ADAM_CHUNK)[:numel]
+        gr = gr * on * (torch.rand(numel, generator=g) < 0.3)      # sparse inside a chunk as well
+        grads.append(gr)
+    if numel > 300:
+        grads[2][7] = float("nan")
+    res = {}
+    for kind in ("dense", "active"):
+        p, m, v = p0.to(DEV).clone(), torch.zeros(numel, device=DEV), torch.zeros(numel, device=DEV)
+        act = ops.adam_active_flags(p)
+        for t, gr in enumerate(grads):
+            gd = gr.to(DEV).clone()
+            zero = t % 2 == 1
+            if kind == "dense":
+                ops.adam_dense_(p, gd, m, v, t + 1, 1e-2, zero_grad=zero)
+            else:
+                ops.adam_active_(p, gd, m, v, act, t + 1, 1e-2, zero_grad=zero)
+            assert bool((gd == 0).all()) == zero or not zero
+            if zero:
+                assert bool((gd == 0).all())
+        res[kind] = (p, m, v, act)
+    for a, b in zip(res["dense"][:3], res["active"][:3]):
+        assert torch.equal(a.cpu().view(torch.int32), b.cpu().view(torch.int32))
+    ever = torch.stack([(gr != 0) for gr in grads]).any(0)
+    ever = torch.nn.functional.pad(ever, (0, nchunks * _lib.ADAM_CHUNK - numel)).reshape(nchunks, -1).any(1)
+    assert torch.equal(res["active"][3].cpu().bool(), ever)
+    if numel <= 300:                                            # no NaN in this run: compare with torch's Adam
+        pc = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([pc], lr=1e-2)
+        for gr in grads:
+            pc.grad = gr.clone()
+            opt.step()
+        torch.testing.assert_close(res["active"][0].cpu(), pc.detach(), rtol=1e-6, atol=1e-7)
+
+
 def test_native_library_is_loaded():
     """The ops above ran through libmiso_hip.so (no eager fallback exists)."""
     from miso_amd import _lib

@@ -20,9 +20,18 @@ cfg = {"name": "grid_net", "spatial_dim": 3,
        "grid": {"type": "regular", "feature_dim": 8, "init_stddev": 1e-2, "bound": [[-1., 1.]] * 3,
                 "base_cell_size": 2.0 / 32, "per_level_scale": 2, "n_levels": 3},
        "pose": {"optimize": False, "num_poses": 1}}
-torch.manual_seed(0)
+shape = os.environ.get("GRID", "cfg2")
 g = torch.Generator().manual_seed(1)
 x = torch.rand(n, 3, generator=g) * 2 - 1
+if shape == "ncd":        # cfg-5, Newer College quad: 120 x 120 x 20 m, cells 1.0 / 0.2 m, C=4 (configs/lidar/ncd_quad.yaml)
+    cfg["grid"].update(feature_dim=4, bound=[[-60., 60.], [-60., 60.], [-5., 15.]], base_cell_size=1.0, per_level_scale=5,
+                       n_levels=2)
+    x = x * torch.tensor([25.0, 25.0, 4.0]) + torch.tensor([5.0, -8.0, 2.0])     # the sensor's surroundings, not the whole bound
+elif shape == "scannet":  # cfg-3: 20 x 10 x 20 m, cells 0.5 / 0.1 m, C=4
+    cfg["grid"].update(feature_dim=4, bound=[[-10., 10.], [-5., 5.], [-10., 10.]], base_cell_size=0.5, per_level_scale=5,
+                       n_levels=2)
+    x = x * torch.tensor([6.0, 2.5, 6.0])
+torch.manual_seed(0)
 batch = ({"coords_frame": x[None].to(dev), "sample_frame_ids": torch.zeros(1, n, 1, dtype=torch.int64, device=dev),
           "weights": torch.ones(1, n, 1, device=dev)},
          {"sdf": (torch.rand(1, n, 1, generator=g) * 0.2 - 0.1).to(dev), "sdf_valid": torch.ones(1, n, 1, device=dev),
