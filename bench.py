@@ -172,7 +172,59 @@ def extras(step, dev):
     ex["align_iteration_level1_driver"] = {"pairs": 1, "vertices": nv, "us_per_iteration": t,
                                            "vertices_per_s": nv / (t * 1e-6)}
     ex["sample_generation_scannet"] = sample_generation(dev)
+    ex["trainer_step_other_shapes"] = trainer_steps(dev)
     return ex
+
+
+def trainer_steps(dev):
+    """GridTrainer.train_step (keyframe transform -> captured step -> Adam) at the grid shapes of BASELINE configs 3
+    and 5, wall time per step: a ScanNet submap (20x10x20 m, cells 0.5/0.1 m, C=4; 540 000 samples around the
+    middle of the bound) and a Newer College submap (120x120x20 m, cells 1.0/0.2 m: 144 M floats in the fine level;
+    6 144 samples around the sensor)."""
+    import tempfile
+    import miso_amd.grid_opt.loss as L
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    from miso_amd.grid_opt.trainer import GridTrainer
+    out = {}
+    shapes = {"cfg3_scannet_540000pts": ([[-10., 10.], [-5., 5.], [-10., 10.]], 0.5, 540000, [6.0, 2.5, 6.0], [0., 0., 0.]),
+              "cfg5_newer_college_6144pts": ([[-60., 60.], [-60., 60.], [-5., 15.]], 1.0, 6144, [25.0, 25.0, 4.0],
+                                             [5.0, -8.0, 2.0])}
+    for name, (bound, cell, n, half, mid) in shapes.items():
+        cfg = {"name": "grid_net", "spatial_dim": 3,
+               "decoder": {"type": "mlp", "hidden_dim": 64, "hidden_layers": 1, "out_dim": 1, "pos_invariant": True,
+                           "fix": True, "pretrained_model": None},
+               "grid": {"type": "regular", "feature_dim": 4, "init_stddev": 1e-2, "bound": bound,
+                        "base_cell_size": cell, "per_level_scale": 5, "n_levels": 2},
+               "pose": {"optimize": False, "num_poses": 1}}
+        g = torch.Generator().manual_seed(1)
+        x = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor(half) + torch.tensor(mid)
+        batch = ({"coords_frame": x[None].to(dev), "sample_frame_ids": torch.zeros(1, n, 1, dtype=torch.int64, device=dev),
+                  "weights": torch.ones(1, n, 1, device=dev)},
+                 {"sdf": (torch.rand(1, n, 1, generator=g) * 0.2 - 0.1).to(dev),
+                  "sdf_valid": torch.ones(1, n, 1, device=dev), "sdf_signs": torch.zeros(1, n, 1, device=dev)})
+        torch.manual_seed(0)
+        net = GridNet(cfg, device=dev).to(dev)
+        net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+        net.unlock_feature()
+        net.lock_pose()
+        tcfg = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 1, "ckpt_every": -1,
+                "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": tempfile.mkdtemp(),
+                "relchange_tol": 0, "max_epochs_in_level": 1000, "grid_training_mode": "joint"}
+        lossf = L.MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
+        tr = GridTrainer(tcfg, net, lossf, None, None, dev, torch.float32)
+        for _ in range(5):
+            tr.train_step(*batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            tr.train_step(*batch)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / 30 * 1e6
+        out[name] = {"us_per_step": us, "grid_floats": sum(f.feature.numel() for f in net.features),
+                     "point_samples_per_s": n / (us * 1e-6)}
+        del tr, net
+        torch.cuda.empty_cache()
+    return out
 
 
 def sample_generation(dev):

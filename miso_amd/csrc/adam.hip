@@ -62,24 +62,26 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
                                                          unsigned char* __restrict__ active, int64_t n,
                                                          AdamScalars a) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
-  for (int64_t c0 = wave * ADAM_UN; c0 < nchunks; c0 += nwaves * ADAM_UN) {
-    float4 gg[ADAM_UN];
-    unsigned char act[ADAM_UN];
+  // wave-uniform chunk indices (readfirstlane): the flag bytes become scalar loads
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t nfull = n / ADAM_CHUNK;            // whole chunks: float4 path
+  for (int64_t c0 = wave * ADAM_UN; c0 < nfull; c0 += nwaves * ADAM_UN) {
+    float4 gg[ADAM_UN], pp[ADAM_UN], mm[ADAM_UN], vv[ADAM_UN];
+    bool act[ADAM_UN];
+    // chunks already moving: everything is loaded at once, as in the dense kernel; the others show their
+    // gradient first
 #pragma unroll
     for (int u = 0; u < ADAM_UN; ++u) {
       const int64_t c = c0 + u, i = c * ADAM_CHUNK + lane * 4;
+      act[u] = false;
       gg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      act[u] = 0;
-      if (c < nchunks) {
-        act[u] = active[c];
-        if (i + 3 < n) gg[u] = *reinterpret_cast<const float4*>(g + i);
-        else {
-          if (i < n) gg[u].x = g[i];
-          if (i + 1 < n) gg[u].y = g[i + 1];
-          if (i + 2 < n) gg[u].z = g[i + 2];
+      if (c < nfull) {
+        act[u] = active[c] != 0;
+        gg[u] = *reinterpret_cast<const float4*>(g + i);
+        if (act[u]) {
+          pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
+          vv[u] = *reinterpret_cast<float4*>(v + i);
         }
       }
     }
@@ -88,25 +90,32 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
       const int64_t c = c0 + u, i = c * ADAM_CHUNK + lane * 4;
       const bool nz = gg[u].x != 0.f || gg[u].y != 0.f || gg[u].z != 0.f || gg[u].w != 0.f;   // NaN counts
       const bool any = __ballot(nz) != 0ull;
-      if (c >= nchunks || !(any || act[u])) continue;      // wave-uniform
-      if (i + 3 < n) {
-        float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i),
-               vv = *reinterpret_cast<float4*>(v + i);
-        adam_one(pp.x, gg[u].x, mm.x, vv.x, a); adam_one(pp.y, gg[u].y, mm.y, vv.y, a);
-        adam_one(pp.z, gg[u].z, mm.z, vv.z, a); adam_one(pp.w, gg[u].w, mm.w, vv.w, a);
-        *reinterpret_cast<float4*>(p + i) = pp;
-        *reinterpret_cast<float4*>(m + i) = mm;
-        *reinterpret_cast<float4*>(v + i) = vv;
-        if (ZERO && any) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        const float ge[3] = {gg[u].x, gg[u].y, gg[u].z};
-        for (int e = 0; e < 3; ++e)
-          if (i + e < n) {
-            adam_one(p[i + e], ge[e], m[i + e], v[i + e], a);
-            if (ZERO) g[i + e] = 0.0f;
-          }
+      if (c >= nfull || !(any || act[u])) continue;      // wave-uniform
+      if (!act[u]) {
+        pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
+        vv[u] = *reinterpret_cast<float4*>(v + i);
+        if (lane == 0) active[c] = 1;
       }
-      if (!act[u] && lane == 0) active[c] = 1;
+      adam_one(pp[u].x, gg[u].x, mm[u].x, vv[u].x, a); adam_one(pp[u].y, gg[u].y, mm[u].y, vv[u].y, a);
+      adam_one(pp[u].z, gg[u].z, mm[u].z, vv[u].z, a); adam_one(pp[u].w, gg[u].w, mm[u].w, vv[u].w, a);
+      *reinterpret_cast<float4*>(p + i) = pp[u];
+      *reinterpret_cast<float4*>(m + i) = mm[u];
+      *reinterpret_cast<float4*>(v + i) = vv[u];
+      if (ZERO && any) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // the ragged last chunk (numel % 256 elements), element-wise by the first wavefront
+  if (wave == 0 && nfull * ADAM_CHUNK < n) {
+    const int64_t c = nfull;
+    bool nz = false;
+    for (int64_t i = c * ADAM_CHUNK + lane; i < n; i += 64) nz = nz || g[i] != 0.f;
+    const bool was = active[c] != 0;
+    if (__ballot(nz) != 0ull || was) {
+      for (int64_t i = c * ADAM_CHUNK + lane; i < n; i += 64) {
+        adam_one(p[i], g[i], m[i], v[i], a);
+        if (ZERO) g[i] = 0.0f;
+      }
+      if (!was && lane == 0) active[c] = 1;
     }
   }
 }
