@@ -111,6 +111,7 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
     sharded over ranks.  Every rank must hold all submaps (sync_submaps) and identical pose
     parameters; results equal the single-process run up to fp32 summation order."""
     from torch.utils.data import DataLoader
+    from miso_amd.grid_opt.utils.utils import collate_batch_of_one
     rank, world = rank_world()
 
     def pose_params():
@@ -118,7 +119,7 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
 
     params = pose_params()
     optimizer = DenseAdam([{'params': params, 'lr': lr}], lr=lr)
-    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0, collate_fn=collate_batch_of_one)
     loss_name, loss_func = pairwise_loss_tuple
     if submap_pairs is None:
         n = grid_atlas.num_submaps

@@ -3,6 +3,7 @@ import logging
 
 import torch
 from torch.utils.data import DataLoader, Dataset
+from miso_amd.grid_opt.utils.utils import collate_batch_of_one
 
 import miso_amd.grid_opt.utils.utils as utils
 import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
@@ -53,7 +54,7 @@ def generic_align_submap_pair(grid_atlas: GridAtlas, dataset: Dataset, src_id: i
     """Align dst to src by optimising dst's pose only (reference :41-87)."""
     assert src_id < grid_atlas.num_submaps and dst_id < grid_atlas.num_submaps
     grid_dst = grid_atlas.get_submap(dst_id)
-    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0, collate_fn=collate_batch_of_one)
     optimizer = DenseAdam([{'params': grid_atlas.params_for_submap_pose(dst_id), 'lr': lr}], lr=lr)
     loss_name, loss_func = pairwise_loss_tuple
     prev = None
@@ -84,7 +85,7 @@ def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pair
         return [p for s in range(1, grid_atlas.num_submaps) for p in grid_atlas.params_for_submap_pose(s)]
 
     optimizer = DenseAdam([{'params': pose_params(), 'lr': lr}], lr=lr)
-    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0, collate_fn=collate_batch_of_one)
     loss_name, loss_func = pairwise_loss_tuple
     if submap_pairs is None:
         n = grid_atlas.num_submaps

@@ -5,6 +5,7 @@ from copy import deepcopy
 
 import torch
 from torch.utils.data import DataLoader, Dataset
+from miso_amd.grid_opt.utils.utils import collate_batch_of_one
 
 from .configs import cfg_loss
 from .models.grid_atlas import GridAtlas
@@ -26,7 +27,7 @@ def initialize_grid_net(grid: GridNet, init_mode='encode', encoder=None, encoder
 
 
 def _run(model, dataset, loss, cfg_train, device, eval_tuples=()):
-    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0, collate_fn=collate_batch_of_one)
     trainer = GridTrainer(cfg_train, model, loss, loader, None, device, torch.float32)
     for name, func in eval_tuples:
         trainer.register_eval_func(name=name, func=func)

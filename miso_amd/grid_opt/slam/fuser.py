@@ -4,6 +4,7 @@ not reproduced)."""
 import math
 
 from torch.utils.data import DataLoader
+from miso_amd.grid_opt.utils.utils import collate_batch_of_one
 
 from miso_amd.grid_opt.align.miso import align_multiple_submaps_hierarchical
 from miso_amd.grid_opt.models.grid_atlas import GridAtlas
@@ -14,7 +15,7 @@ class Fuser:
         assert isinstance(model, GridAtlas), "Model must be an instance of GridAtlas."
         self.model = model
         self.dataset = dataset
-        self.train_loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+        self.train_loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0, collate_fn=collate_batch_of_one)
         self.cfg = cfg
 
     def align(self):

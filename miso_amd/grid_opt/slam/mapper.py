@@ -4,6 +4,7 @@ from copy import deepcopy
 
 import torch
 from torch.utils.data import DataLoader
+from miso_amd.grid_opt.utils.utils import collate_batch_of_one
 
 from miso_amd.grid_opt.loss import MisoLossMapping
 from miso_amd.grid_opt.models.grid_net import GridNet
@@ -17,7 +18,7 @@ class Mapper:
         assert isinstance(model, GridNet), f"Invalid model type {type(model)}."
         self.grid = model
         self.dataset = dataset
-        self.train_loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+        self.train_loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0, collate_fn=collate_batch_of_one)
         self.cfg = cfg
         m = cfg['mapping']
         self.lr = m['learning_rate']

@@ -7,6 +7,7 @@ from typing import List
 
 import torch
 from torch.utils.data import DataLoader
+from miso_amd.grid_opt.utils.utils import collate_batch_of_one
 
 import miso_amd.grid_opt.utils.utils as utils
 import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
@@ -24,7 +25,7 @@ class Tracker:
         assert isinstance(model, GridNet), "Model must be an instance of GridNet."
         self.grid = model
         self.dataset = dataset
-        self.train_loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0)
+        self.train_loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0, collate_fn=collate_batch_of_one)
         self.cfg = cfg
         t = cfg['tracking']
         self.lr = t['learning_rate']

@@ -123,6 +123,25 @@ def sanitize_tensor_dict(input_dict):
     return {k: (torch.nan_to_num(v) if v.is_floating_point() else v) for k, v in input_dict.items()}
 
 
+def collate_batch_of_one(items):
+    """``collate_fn`` for the loaders every driver builds with ``batch_size=1`` (reference mapper.py:40 etc.): the
+    default collation stacks, i.e. copies every tensor of the item into a new one with a leading 1 -- at 540 000
+    rows per item that is 160 us of copies per iteration.  A view does the same job."""
+    if len(items) != 1:
+        return torch.utils.data.default_collate(items)
+
+    def lead(v):
+        if isinstance(v, torch.Tensor):
+            return v[None]
+        if isinstance(v, dict):
+            return {k: lead(x) for k, x in v.items()}
+        if isinstance(v, (tuple, list)):
+            return type(v)(lead(x) for x in v)
+        return torch.utils.data.default_collate([v])
+
+    return lead(items[0])
+
+
 def prepare_batch(model_input, gt, device='cuda:0'):
     model_input = sanitize_tensor_dict({k: v.to(device) for k, v in model_input.items()})
     gt = sanitize_tensor_dict({k: v.to(device) for k, v in gt.items()})

@@ -10,6 +10,7 @@ from miso_amd.grid_opt.loss import MisoLossMapping
 from miso_amd.grid_opt.models.grid_net import GridNet
 from miso_amd.grid_opt.trainer import GridTrainer
 from miso_amd.grid_opt.utils.utils_data import CameraParameters
+from miso_amd.grid_opt.utils.utils import collate_batch_of_one
 dev = 'cuda:0'
 B, H, W, rays = 100, 480, 640, 200
 g = torch.Generator().manual_seed(3)
@@ -35,7 +36,7 @@ for padded in ((True,) if os.environ.get('MISO_E2E_ONLY_PADDED') else (False, Tr
     cfg_train = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-2, "epochs": 1, "ckpt_every": -1,
                  "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": "/tmp/e2e",
                  "relchange_tol": 0, "max_epochs_in_level": 1000, "grid_training_mode": "joint"}
-    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0, collate_fn=collate_batch_of_one)
     tr = GridTrainer(cfg_train, net, lf, loader, None, dev, torch.float32)
     tr.total_steps, tr.total_epoch_time = 0, 0
     for e in range(5):
