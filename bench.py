@@ -394,6 +394,9 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "algorithmic_bytes_per_point": dom[2], "kernel_us": dom[1]}
+    if dom[0] == "grad_pull_kernel":
+        roofline["launches"] = ("grad_pull_kernel<..,false> + its drain launch <..,true> (slices of over-full tiles; "
+                                "finds an empty queue on this uniform batch, ~2 us); kernel_us covers both")
 
     out = {
         "metric": "3D point-samples/sec (encode+decode fwd+bwd), 262144-pt batch",

@@ -347,7 +347,9 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
 
 // One wavefront per spatial tile.  The 3x3x3 tile neighbourhood is swept ONCE for all pulled
 // levels (a candidate's coordinates are loaded once and tested against every level's box).
-template <int C, int NLV, int MODE>
+// DRAIN = false: one wavefront per tile (slice 0 of a cut tile, queueing the rest); true: the second launch that
+// works off the queued slices -- a separate instantiation so that profiles tell the two apart.
+template <int C, int NLV, int MODE, bool DRAIN>
 __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   constexpr int PULL_NLV = NLV;   // levels swept together
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -364,13 +366,13 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
   int qn = 0;
-  if (pk.drain) {
+  if (DRAIN) {
     qn = min(pk.queue[0], pk.qcap);
     if (qn <= 0) return;          // nothing was split (the uniform case): no atomics, counters stay zero
   }
   for (int iter = 0;; ++iter) {
     int tile, sl = 0, ns = 1;
-    if (!pk.drain) {
+    if (!DRAIN) {
       tile = blockIdx.x * 4 + wave + iter * (int)gridDim.x * 4;
       if (tile >= ntiles) break;
     } else {
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
       re = pk.tile_off[(rz * T + ry) * T + t_hi[0] + 1];
     }
     if (pk.queue && tabled && sweeping) {
-      if (!pk.drain) {
+      if (!DRAIN) {
         int work = re - rs;
         for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
         const int slice = max(pk.work0, 16 * nverts_all);
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
     }
     (void)tabc;
   }
-  if (pk.drain) {   // the last workgroup out rewinds the queue for the next launch
+  if (DRAIN) {   // the last workgroup out rewinds the queue for the next launch
     __syncthreads();
     if (threadIdx.x == 0) {
       __threadfence();
@@ -596,7 +598,12 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   unsigned blocks = (unsigned)((ntiles + 3) / 4);
   if (blocks > 2048u) blocks = 2048u;
   void (*k)(GridK, PullK) = nullptr;
-#define PICK(c, n) if (C == c && pk.nl == n) k = ggx ? grad_pull_kernel<c, n, 1> : grad_pull_kernel<c, n, 0>;
+  void (*kd)(GridK, PullK) = nullptr;
+#define PICK(c, n)                                                                            \
+  if (C == c && pk.nl == n) {                                                                 \
+    k = ggx ? grad_pull_kernel<c, n, 1, false> : grad_pull_kernel<c, n, 0, false>;            \
+    kd = ggx ? grad_pull_kernel<c, n, 1, true> : grad_pull_kernel<c, n, 0, true>;             \
+  }
   PICK(8, 1) PICK(8, 2) PICK(8, 3) PICK(8, 4) PICK(4, 1) PICK(4, 2) PICK(4, 3) PICK(4, 4)
 #undef PICK
   if (!k) return hipErrorInvalidValue;
@@ -609,7 +616,11 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
     pk.drain = 1;
     unsigned dblocks = 1024;
     if (const char* d = getenv("MISO_PULL_DRAIN_BLOCKS")) dblocks = (unsigned)atoi(d);   // dev
-    k<<<dblocks, 256, lds, s>>>(g, pk);
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    kd<<<dblocks, 256, lds, s>>>(g, pk);
   }
   return hipGetLastError();
 }

@@ -21,7 +21,9 @@ shutil.copy(f"{src}/trace/bench_kernel_stats.csv", f"profiles/{tag}_kernel_stats
 
 def short(name):
     m = re.search(r"(?:miso::)?(\w+)(?:<|\()", name.replace("void ", ""))
-    return m.group(1) if m else name[:40]
+    base = m.group(1) if m else name[:40]
+    # the second ("drain") launch of the gradient pull is its own instantiation <..., true>
+    return base + "_drain" if base == "grad_pull_kernel" and re.search(r",\s*true>", name) else base
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
