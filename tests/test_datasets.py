@@ -357,3 +357,80 @@ def test_padded_batches_feed_one_captured_step(tmp_path):
     with torch.no_grad():
         after = sum(float(v.mean()) for v in lf.compute(net, res["exact"][2], res["exact"][3]).values())
     assert after < 0.9 * want, (want, after)       # random depth is mostly noise: measured 0.062 -> 0.048
+
+
+def _room_scan(pose_R, pose_t, n, rs):
+    """n lidar returns (sensor frame) from inside an axis-aligned room [-15,15] x [-12,12] x [0,6] m."""
+    d = rs.standard_normal((n, 3))
+    d[:, 2] *= 0.4
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dw = d @ pose_R.T
+    o = pose_t.reshape(3)
+    lo, hi = np.array([-15.0, -12.0, 0.0]), np.array([15.0, 12.0, 6.0])
+    with np.errstate(divide="ignore"):
+        tt = np.where(dw > 0, (hi - o) / dw, (lo - o) / dw)
+    r = tt.min(axis=1, keepdims=True)
+    return d * r
+
+
+@pytest.mark.gpu
+def test_slam_system_tracks_and_maps_lidar_frames(tmp_path):
+    """System.run (tracker: Gauss-Newton through miso_lm_normal_eq; mapper: captured trainer step) on lidar frames
+    of a synthetic room, starting every keyframe from a biased odometry guess: all keyframes consumed, a second
+    submap opened when the first is full, and tracking pulls the keyframes back towards the truth."""
+    from miso_amd.grid_opt.datasets.sdf_3d_lidar import PosedSdf3DLidar
+    from miso_amd.grid_opt.models.grid_atlas import GridAtlas
+    from miso_amd.grid_opt.slam.system import System
+    rs = np.random.RandomState(3)
+    F = 7
+    poses_gt = np.tile(np.eye(4), (F, 1, 1))
+    poses_init = poses_gt.copy()
+    for f in range(F):
+        poses_gt[f, :3, :3] = gc.rodrigues([0.0, 0.0, 0.05 * f])
+        poses_gt[f, :3, 3] = [-3.0 + 1.0 * f, 0.3 * f, 1.5]
+    # odometry with a constant bias: 6 cm and 0.6 deg per step
+    bias = np.eye(4)
+    bias[:3, :3] = gc.rodrigues([0.0, 0.0, 0.0105])
+    bias[:3, 3] = [0.05, -0.03, 0.01]
+    poses_init[0] = poses_gt[0]
+    for f in range(1, F):
+        poses_init[f] = poses_init[f - 1] @ (np.linalg.inv(poses_gt[f - 1]) @ poses_gt[f]) @ bias
+    scans = [_room_scan(poses_gt[f, :3, :3], poses_gt[f, :3, 3], 6000, rs) for f in range(F)]
+    common = dict(trunc_dist=0.5, min_dist_ratio=0.5, crop=False, device=DEV)
+    ds_track = PosedSdf3DLidar.from_frames(scans, poses_gt, poses_init, frame_samples=4096, frame_batchsize=4096,
+                                           near_surface_n=0, free_space_n=0, behind_surface_n=0, **common)
+    ds_map = PosedSdf3DLidar.from_frames(scans, poses_gt, poses_init, frame_samples=4096, frame_batchsize=1024,
+                                         near_surface_n=4, near_surface_std=0.25, free_space_n=2, behind_surface_n=1,
+                                         **common)
+    cfg = {"device": DEV,
+           "model": gc.model_cfg([[-25.0, 25.0], [-25.0, 25.0], [-4.0, 8.0]], 2.0, 4, 2, 4, 64, num_poses=F,
+                                 init_stddev=0.0),
+           "tracking": dict(solver="lm", learning_rate=1e-3, loss_type="GM", trunc_dist=None, gm_scale_sdf=0.3,
+                            lm_lambda=1e-4, lm_max_iter=10, lm_tol_deg=0.01, lm_tol_m=0.001, verbose=False),
+           "mapping": dict(learning_rate=2e-2, loss_type="L2", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.5,
+                           trunc_dist=0.5, finite_diff_eps=0.5, grad_method="finitediff", eik_trunc_dist=0.5,
+                           verbose=False, max_replay_frames=5, max_replay_freq=10, gm_scale_sdf=0.3),
+           "system": dict(init_odom="external", submap_size=5, submap_local_bound=[[-25, 25], [-25, 25], [-4, 8]],
+                          submap_fov_thresh=0.0, save_submap_mesh=False, log_dir=str(tmp_path)),
+           "train": {"trainer": "base", "verbose": False, "optimizer": "adam", "learning_rate": 2e-2, "epochs": 50,
+                     "ckpt_every": -1, "eval_every": -1, "eval_metric": None, "pretrained_model": None,
+                     "log_dir": str(tmp_path), "relchange_tol": 0, "max_epochs_in_level": 100,
+                     "grid_training_mode": "coordinate+joint"}}
+    torch.manual_seed(0)
+    atlas = GridAtlas(cfg["model"], device=DEV).to(DEV)
+    T0 = torch.tensor(poses_gt[0], dtype=torch.float32)
+    system = System(atlas, ds_track, ds_map, cfg, R_world_origin=T0[:3, :3], t_world_origin=T0[:3, 3:], verbose=False)
+    system.init_iterations, system.kf_iterations = 150, 40      # a random frozen decoder needs more steps than MISO's
+    system.run()
+    assert atlas.num_keyframes == F and atlas.num_submaps == 2
+    assert atlas.anchor_kf_for_submap(1) == 5
+    err_track, err_odom = [], []
+    for f in range(1, 5):                                        # keyframes tracked inside the first submap
+        R, t = atlas.updated_kf_pose_in_world(f)
+        assert torch.isfinite(R).all() and torch.isfinite(t).all()
+        err_track.append(float(np.linalg.norm(t.detach().cpu().numpy().reshape(3) - poses_gt[f, :3, 3])))
+        err_odom.append(float(np.linalg.norm(poses_init[f, :3, 3] - poses_gt[f, :3, 3])))
+    print("translation error tracked", err_track, "odometry only", err_odom)
+    # measured: tracked 0.25 / 0.17 / 0.12 / 0.11 m against a drift of 0.06 / 0.11 / 0.16 / 0.20 m -- the map of a
+    # single scan is thin at first, then tracking holds the error while the odometry keeps drifting
+    assert err_track[-1] < 0.8 * err_odom[-1] and max(err_track) < 0.5, (err_track, err_odom)
