@@ -60,5 +60,5 @@ def optimize_grid_atlas(grid_atlas: GridAtlas, dataset: Dataset, cfg: dict, iter
     cfg_train = deepcopy(cfg['train'])
     cfg_train.update(max_epochs_in_level=50, relchange_tol=0, grid_training_mode=train_mode,
                      epochs=iterations, learning_rate=learning_rate, verbose=True, eval_every=-1)
-    info = _run(grid_atlas, dataset, cfg_loss(cfg), cfg_train, cfg['device'])
-    return grid_atlas, info
+    _run(grid_atlas, dataset, cfg_loss(cfg), cfg_train, cfg['device'])
+    return grid_atlas, {}          # the reference hands back an empty info dict here (:153-154)

@@ -201,7 +201,7 @@ class Trainer(object):
             total = self.train_step(model_input, gt)
             self.total_steps += 1
             if self.verbose and step % 10 == 0:
-                logger.info(f"Train epoch {epoch} step {step} | train_loss={float(total):.2e}.")
+                logger.info(f"Train epoch {epoch} step {step} | train_loss={float(total.detach()):.2e}.")
             gpu_time += self.timer.check()[1]
         self.total_epoch_time += gpu_time
 

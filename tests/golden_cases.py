@@ -219,3 +219,53 @@ def lidar_inputs(case=None):
         pts = t.reshape(1, 3).astype(np.float64) + d * rs.uniform(2.0, 30.0, (c["n_points"][f], 1))
         frames.append(dict(R=R, t=t, points_global=pts))
     return frames
+
+
+# --- extra rows: SDF-space pair loss, scatter-average pooling ------------------
+def atlas_second_kf_pose(s):
+    """Pose (in its submap) of the second keyframe of submap s; the anchor keyframe sits at identity."""
+    rs = np.random.RandomState(ATLAS["seed"] + 50 + s)
+    R = rodrigues(rs.uniform(-0.3, 0.3, 3)).astype(np.float32)
+    t = rs.uniform(-0.4, 0.4, (3, 1)).astype(np.float32)
+    return R, t
+
+
+def atlas_sdf_batch(n=900):
+    """One dataset batch in keyframe frames: rows spread over the 2 keyframes of each of the 3 submaps (global ids
+    0..5), some rows invalid, some far enough out to leave the other submap's bound."""
+    rs = np.random.RandomState(ATLAS["seed"] + 77)
+    b = np.asarray(ATLAS["bound"], dtype=np.float32)
+    coords = (rs.uniform(-0.1, 1.1, (n, 3)).astype(np.float32) * (b[:, 1] - b[:, 0]) + b[:, 0])
+    ids = rs.randint(0, 2 * ATLAS["n_submaps"], size=(n, 1)).astype(np.int64)
+    valid = (rs.uniform(0, 1, (n, 1)) > 0.15).astype(np.float32)
+    sdf = (0.1 * rs.standard_normal((n, 1))).astype(np.float32)
+    return dict(coords_frame=coords[None], sample_frame_ids=ids[None], weights=np.ones((1, n, 1), np.float32)), \
+        dict(sdf=sdf[None], sdf_valid=valid[None], sdf_signs=np.zeros((1, n, 1), np.float32))
+
+
+POOL = dict(seed=61, bound=[[-1.0, 1.0], [-0.5, 0.55], [0.0, 1.3]], cell=0.3, n=700, d=5)
+
+
+def pool_inputs():
+    """Points in and slightly around the bound (outside ones are clamped into the border cells) + features."""
+    c = POOL
+    rs = np.random.RandomState(c["seed"])
+    b = np.asarray(c["bound"], dtype=np.float32)
+    pts = rs.uniform(-0.08, 1.08, (c["n"], 3)).astype(np.float32) * (b[:, 1] - b[:, 0]) + b[:, 0]
+    pts[:40] = pts[40:80] + 1e-3 * rs.standard_normal((40, 3)).astype(np.float32)      # crowded cells
+    feats = rs.standard_normal((c["n"], c["d"])).astype(np.float32)
+    return pts, feats
+
+
+def local_opt_cfg(loss_name):
+    """cfg dict for grid_opt.local_opt (cfg['loss'] -> cfg_loss, cfg['train'] -> GridTrainer)."""
+    return {"device": "cpu",
+            "model": {"name": "grid_net"},
+            "loss": {"name": loss_name, "trunc_weight": 5.0, "trunc_distance": 0.15, "noise_std": 0, "orien_loss": 0,
+                     "eik_weight": 0, "grad_weight": 0, "eik_apply_dist": 0.1, "smooth_weight": 0, "smooth_std": 0.05,
+                     "loss_type": "L1", "slam_mode": False, "pose_reg_weight": 0, "pose_thresh_m": 1.0,
+                     "pose_thresh_rad": 1.0, "feat_reg_weight": 0},
+            "train": {"trainer": "grid", "verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 1,
+                      "ckpt_every": -1, "eval_every": -1, "eval_metric": None, "pretrained_model": None,
+                      "log_dir": "/tmp/miso_golden_log", "relchange_tol": 0, "max_epochs_in_level": 2,
+                      "grid_training_mode": "joint"}}

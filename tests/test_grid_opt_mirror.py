@@ -363,3 +363,111 @@ def test_extract_fields_matches_pointwise_queries(device_backend):
     ws, bs = R.decoder_params({k: T(v) for k, v in gc.make_decoder(case).items()})
     ref = R.sdf_stock([T(f) for f in gc.make_features(case)], b, pts, ws, bs).reshape(res, res, res)
     close(T(u), ref, 0, 1e-5)
+
+
+# ---- rows pinned by tests/golden/extra.npz (tools/make_goldens.py gen_extra) ---------------------------------------
+class _OneBatch(torch.utils.data.Dataset):
+    def __init__(self, mi, g):
+        self.mi, self.g = mi, g
+
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, i):
+        return ({k: T(v[0]) for k, v in self.mi.items()}, {k: T(v[0]) for k, v in self.g.items()})
+
+
+def make_atlas_two_kf(dev):
+    """make_atlas with a second, non-identity keyframe in every submap (global keyframe ids 2s, 2s+1)."""
+    from miso_amd.grid_opt.models.grid_atlas import GridAtlas
+    c = gc.ATLAS
+    cfg = gc.model_cfg(c["bound"], c["base_cell"], c["scale"], c["n_levels"], c["fdim"], c["hidden"])
+    atlas = GridAtlas(cfg, device=dev)
+    dec = {k: T(v) for k, v in gc.make_decoder(c).items()}
+    for s, sub in enumerate(gc.atlas_inputs()):
+        atlas.add_submap(torch.tensor(c["bound"], dtype=torch.float32), T(sub["R"]), T(sub["t"]), num_poses=2)
+        atlas.add_kf(torch.eye(3), torch.zeros(3, 1))
+        R2, t2 = gc.atlas_second_kf_pose(s)
+        atlas.add_kf(T(R2), T(t2))
+        net = atlas.get_submap(s)
+        with torch.no_grad():
+            for l, f in enumerate(sub["features"]):
+                net.features[l].feature.copy_(T(f))
+        net.decoder.load_state_dict(dec)
+        atlas.set_submap_pose_correction(s, T(sub["dr"]).to(dev), T(sub["dt"]).to(dev))
+    return atlas.to(dev)
+
+
+def test_grid_pool_3d_avg_matches_reference(device_backend):
+    """Scatter-average pooling of point features onto a regular grid (reference utils.py:239-291): crowded cells,
+    points outside the bound clamped into the border cells, empty cells stay zero."""
+    from miso_amd.grid_opt.utils.utils import grid_pool_3d_avg
+    dev = device_backend
+    pts, feats = gc.pool_inputs()
+    out = grid_pool_3d_avg(T(pts).to(dev), T(feats).to(dev), torch.tensor(gc.POOL["bound"], dtype=torch.float32).to(dev),
+                           gc.POOL["cell"])
+    close(out, T(G("extra")["pool"]), 0, 2e-6)
+
+
+def test_pairwise_loss_sdf_matches_reference(device_backend):
+    """SDF-space pair loss (reference align/miso.py:14-113): observed rows of src's keyframes through the per-keyframe
+    rigid maps, src -> world -> dst, bound / validity masks, both submaps' encode + decode; L2 / L1 / GM values and the
+    cotangents of both submaps' pose corrections."""
+    import miso_amd.grid_opt.align.miso as AM
+    dev = device_backend
+    g = G("extra")
+    atlas = make_atlas_two_kf(dev)
+    mi, gt = gc.atlas_sdf_batch()
+    loader = torch.utils.data.DataLoader(_OneBatch(mi, gt), batch_size=1, shuffle=False, num_workers=0)
+    for (a, b) in [(0, 1), (1, 2), (2, 0)]:
+        for lt in ("L2", "L1", "GM"):
+            atlas.zero_grad(set_to_none=True)
+            d = AM.pairwise_loss_sdf(atlas, loader, a, b, align_loss=lt, device=dev)
+            assert list(d) == [f"align_sdf_{a}_{b}"]
+            (val,) = d.values()
+            key = f"pairsdf_{a}_{b}_{lt}"
+            assert abs(val.item() - float(g[key])) <= 3e-5 * abs(float(g[key])), (key, val.item(), float(g[key]))
+            val.backward()
+            for which, s in (("src", a), ("dst", b)):
+                close(atlas.rotation_corrections[s].grad, T(g[key + f"_gR_{which}"]), 2e-3, 2e-3)
+                close(atlas.translation_corrections[s].grad, T(g[key + f"_gt_{which}"]), 2e-3, 2e-3)
+
+
+def test_local_opt_matches_reference(device_backend, tmp_path):
+    """local_opt.optimize_grid_net (iSDF loss) and optimize_grid_atlas (iSDFSubmap loss) through GridTrainer
+    (reference local_opt.py:60-154): features after 5 joint / 4 coordinate iterations, info dict contract."""
+    import miso_amd.grid_opt.local_opt as LO
+    dev = device_backend
+    g = G("extra")
+    case = gc.CASES["small"]
+    pts = gc.make_points(case)
+    n = pts.shape[0]
+    sdf_t = gc.make_targets(case, n)[0]
+    cfg = gc.local_opt_cfg("iSDF")
+    cfg["device"] = dev
+    cfg["train"]["log_dir"] = str(tmp_path)
+    net = make_gridnet(case, dev, stability=True)
+    net.unlock_feature()
+    net.lock_pose()
+    ds = _OneBatch({"coords": pts[None], "normals": np.zeros((1, n, 3), np.float32)},
+                   {"sdf": sdf_t[None], "grad_vec": np.zeros((1, n, 3), np.float32)})
+    net2, info = LO.optimize_grid_net(net, ds, cfg, iterations=5, learning_rate=2e-3, train_mode="joint",
+                                      iterations_per_level=2)
+    assert net2 is net and set(info) == {"trainer_epoch", "trainer_epoch_time", "trainer_total_loss"}
+    for l in range(case["n_levels"]):
+        close(net.features[l].feature, T(g[f"localopt_net_feat{l}"]), 0, 3e-6)
+
+    atlas = make_atlas_two_kf(dev)
+    mi, gt = gc.atlas_sdf_batch()
+    owner = (mi["sample_frame_ids"] // 2).astype(np.int64)
+    ds = _OneBatch({"coords_submap": mi["coords_frame"], "submap_idxs": owner}, {"sdf": gt["sdf"], "sdf_valid": gt["sdf_valid"]})
+    cfg = gc.local_opt_cfg("iSDFSubmap")
+    cfg["device"] = dev
+    cfg["train"]["log_dir"] = str(tmp_path)
+    atlas2, info = LO.optimize_grid_atlas(atlas, ds, cfg, iterations=4, learning_rate=2e-3, train_mode="coordinate")
+    assert atlas2 is atlas and info == {}
+    for s in range(gc.ATLAS["n_submaps"]):
+        for l in range(gc.ATLAS["n_levels"]):
+            close(atlas.get_submap(s).features[l].feature, T(g[f"localopt_atlas_s{s}_feat{l}"]), 0, 3e-6)
+    close(torch.stack([p for p in atlas.rotation_corrections]), T(g["localopt_atlas_dr"]), 0, 3e-6)
+    close(torch.stack([p for p in atlas.translation_corrections]), T(g["localopt_atlas_dt"]), 0, 3e-6)

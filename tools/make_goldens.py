@@ -514,6 +514,109 @@ def gen_samples(gc):
     np.savez_compressed(gc.golden_path("samples"), **out)
 
 
+# --------------------------------------------------------------------------- #
+def build_atlas_two_kf(GridAtlas, gc):
+    """build_atlas with a second, non-identity keyframe in every submap (global keyframe ids 2s, 2s+1)."""
+    c = gc.ATLAS
+    cfg = gc.model_cfg(c["bound"], c["base_cell"], c["scale"], c["n_levels"], c["fdim"], c["hidden"])
+    atlas = GridAtlas(cfg, device="cpu")
+    dec = {k: T(v) for k, v in gc.make_decoder(c).items()}
+    for s, sub in enumerate(gc.atlas_inputs()):
+        atlas.add_submap(torch.tensor(c["bound"], dtype=torch.float32), T(sub["R"]), T(sub["t"]), num_poses=2)
+        atlas.add_kf(torch.eye(3), torch.zeros(3, 1))
+        R2, t2 = gc.atlas_second_kf_pose(s)
+        atlas.add_kf(T(R2), T(t2))
+        net = atlas.get_submap(s)
+        with torch.no_grad():
+            for l, f in enumerate(sub["features"]):
+                net.features[l].feature.copy_(T(f))
+        net.decoder.load_state_dict(dec)
+        atlas.set_submap_pose_correction(s, T(sub["dr"]), T(sub["dt"]))
+    return atlas
+
+
+class _OneBatch(torch.utils.data.Dataset):
+    def __init__(self, mi, g):
+        self.mi, self.g = mi, g
+
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, i):
+        return ({k: T(v[0]) for k, v in self.mi.items()}, {k: T(v[0]) for k, v in self.g.items()})
+
+
+def gen_extra(GridNet, GridAtlas, miso, rtrainer, gc):
+    """Rows without a golden so far: grid_pool_3d_avg, pairwise_loss_sdf (SDF-space pair loss through the per-keyframe
+    loop), local_opt.optimize_grid_net / optimize_grid_atlas (iSDF / iSDFSubmap losses through GridTrainer)."""
+    import grid_opt.utils.utils as ru
+    import grid_opt.local_opt as rlocal
+    out = {}
+    # -- scatter-average pooling (utils.py:239-291)
+    pts, feats = gc.pool_inputs()
+    out["pool"] = ru.grid_pool_3d_avg(T(pts), T(feats), torch.tensor(gc.POOL["bound"], dtype=torch.float32),
+                                      gc.POOL["cell"]).numpy()
+    # -- pairwise_loss_sdf (align/miso.py:14-113)
+    atlas = build_atlas_two_kf(GridAtlas, gc)
+    mi, g = gc.atlas_sdf_batch()
+    loader = torch.utils.data.DataLoader(_OneBatch(mi, g), batch_size=1, shuffle=False, num_workers=0)
+    for (a, b) in [(0, 1), (1, 2), (2, 0)]:
+        for lt in ("L2", "L1", "GM"):
+            for p in atlas.parameters():
+                p.grad = None
+            d = miso.pairwise_loss_sdf(atlas, loader, a, b, align_loss=lt, device="cpu")
+            (val,) = d.values()
+            key = f"pairsdf_{a}_{b}_{lt}"
+            assert list(d) == [f"align_sdf_{a}_{b}"]
+            out[key] = np.float64(val.item())
+            val.backward()
+            for which, s in (("src", a), ("dst", b)):
+                out[key + f"_gR_{which}"] = atlas.rotation_corrections[s].grad.numpy().copy()
+                out[key + f"_gt_{which}"] = atlas.translation_corrections[s].grad.numpy().copy()
+
+    class _Writer:  # harness patch: tensorboard is absent from the image
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+    rtrainer.SummaryWriter = _Writer
+    # -- local_opt.optimize_grid_net with the iSDF loss (local_opt.py:60-103)
+    case = dict(gc.CASES["small"])
+    pts = gc.make_points(case)
+    n = pts.shape[0]
+    sdf_t = gc.make_targets(case, n)[0]
+    cfg = gc.local_opt_cfg("iSDF")
+    net = build_gridnet(GridNet, gc, case, num_poses=1, optimize_pose=False, stability=True)
+    net.unlock_feature()
+    net.lock_pose()
+    ds = _OneBatch({"coords": pts[None], "normals": np.zeros((1, n, 3), np.float32)},
+                   {"sdf": sdf_t[None], "grad_vec": np.zeros((1, n, 3), np.float32)})
+    net, info = rlocal.optimize_grid_net(net, ds, cfg, iterations=5, learning_rate=2e-3, train_mode="joint",
+                                         iterations_per_level=2)
+    for l in range(case["n_levels"]):
+        out[f"localopt_net_feat{l}"] = net.features[l].feature.detach().numpy().copy()
+    out["localopt_net_epochs"] = np.asarray(info["trainer_epoch"], dtype=np.int64)
+    out["localopt_net_loss"] = np.asarray(info["trainer_total_loss"], dtype=np.float64)
+    # -- local_opt.optimize_grid_atlas with the iSDFSubmap loss (local_opt.py:127-154)
+    atlas = build_atlas_two_kf(GridAtlas, gc)
+    mi, g = gc.atlas_sdf_batch()
+    nrow = mi["coords_frame"].shape[1]
+    owner = (mi["sample_frame_ids"] // 2).astype(np.int64)
+    ds = _OneBatch({"coords_submap": mi["coords_frame"], "submap_idxs": owner}, {"sdf": g["sdf"], "sdf_valid": g["sdf_valid"]})
+    atlas, info = rlocal.optimize_grid_atlas(atlas, ds, gc.local_opt_cfg("iSDFSubmap"), iterations=4, learning_rate=2e-3,
+                                             train_mode="coordinate")
+    for s in range(gc.ATLAS["n_submaps"]):
+        for l in range(gc.ATLAS["n_levels"]):
+            out[f"localopt_atlas_s{s}_feat{l}"] = atlas.get_submap(s).features[l].feature.detach().numpy().copy()
+    assert info == {}
+    out["localopt_atlas_dr"] = np.stack([p.detach().numpy().copy() for p in atlas.rotation_corrections])
+    out["localopt_atlas_dt"] = np.stack([p.detach().numpy().copy() for p in atlas.translation_corrections])
+    np.savez_compressed(gc.golden_path("extra"), **out)
+    print("[extra] ok", {k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
+
+
 def main():
     import_reference()
     import golden_cases as gc
@@ -530,7 +633,7 @@ def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
-    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples"]
+    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra"]
     for name in which:
         if name in gc.CASES:
             gen_encode_decode(name, GridNet, rloss, gc)
@@ -546,6 +649,8 @@ def main():
             gen_so3(rgeom, gc)
         elif name == "samples":
             gen_samples(gc)
+        elif name == "extra":
+            gen_extra(GridNet, GridAtlas, miso, rtrainer, gc)
 
 
 if __name__ == "__main__":
