@@ -38,6 +38,9 @@
  *   miso_adam_dense / miso_adam_active
  *                     torch.optim.Adam.step on one dense tensor as used by
  *                     grid_opt/trainer.py:196-228 / :410-452.
+ *   miso_mc_count / miso_mc_emit / miso_mc_vertices
+ *                     mcubes.marching_cubes as called by extract_geometry, grid_opt/utils/utils_sdf.py:89-101
+ *                     (the step after the path: SDF volume -> triangle mesh).
  *   miso_sample_rays  PosedSdfRgbd.getitem_sdf, grid_opt/datasets/sdf_rgbd.py:381-483 (the step that
  *                     feeds the path): get_batch_data / sample_along_rays
  *                     (grid_opt/utils/utils_sample.py:142-302), bounds_ray (sdf_rgbd.py:525-534), the
@@ -358,6 +361,35 @@ int miso_sample_rays(const miso_ray_frames_t* frames, const miso_ray_sampling_t*
 int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
                      int64_t numel, double lr, double beta1, double beta2, double eps,
                      int32_t step /* 1-based */, int zero_grad, void* stream);
+
+/* --- marching cubes on the dense SDF volume ------------------------------------
+ * Replaces mcubes.marching_cubes(u, threshold) as called by extract_geometry
+ * (grid_opt/utils/utils_sdf.py:89-101; PyMCubes is a third-party dependency of the reference) with the
+ * volume left in HBM.  vol: (nx, ny, nz) fp32, z fastest -- the layout of extract_fields' u[x, y, z].
+ * A cell is "inside" at a corner where vol < iso.  Cells are visited in x-major order, MISO_MC_BLOCK
+ * consecutive cells per block; triangles come out in that order (a cell's triangles in table order).
+ *   miso_mc_blocks      number of blocks = length of block_counts / block_offsets.
+ *   miso_mc_count       block_counts[b] (int32, device) = triangles of block b's cells.
+ *   miso_mc_emit        block_offsets[b] (int64, device) = exclusive prefix sum of block_counts (the caller's
+ *                       cumsum); keys (capacity_tris x 3, int64): for every triangle corner the lattice edge
+ *                       it lies on, 3 * linear_index(low sample) + axis with linear_index = (x*ny + y)*nz + z
+ *                       and axis 0/1/2 = x/y/z.  Triangles past capacity_tris are dropped.
+ *                       Raw triangles are counter-clockwise seen from the vol < iso side.
+ *   miso_mc_vertices    verts[i] (n x 3 fp32, index coordinates (x, y, z)) = position of edge key keys[i]:
+ *                       low sample + (iso - u_a) / (u_b - u_a) along the axis.  The caller welds corners by
+ *                       sorting / uniquing the keys first (vertices shared between cells are emitted once).
+ *   miso_mc_case_table  copies the 256 x 16 table (15 edge ids, -1 padded, + triangle count; edge id =
+ *                       4*axis + a + 2*b, (a, b) = the edge's other two corner coordinates in increasing axis
+ *                       order; case bit c = corner x + 2y + 4z) to HOST memory. */
+#define MISO_MC_BLOCK 256
+int64_t miso_mc_blocks(int32_t nx, int32_t ny, int32_t nz);
+int miso_mc_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, int32_t* block_counts,
+                  void* stream);
+int miso_mc_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* block_offsets,
+                 int64_t capacity_tris, int64_t* keys, void* stream);
+int miso_mc_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys,
+                     int64_t n, float* verts, void* stream);
+int miso_mc_case_table(int8_t* table_host);
 
 #ifdef __cplusplus
 }

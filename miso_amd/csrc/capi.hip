@@ -26,6 +26,11 @@ uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
                             uint32_t, int, const float*, int32_t*, int64_t, hipStream_t);
 int64_t pull_queue_ints(int64_t);
+int64_t mc_blocks(int32_t, int32_t, int32_t);
+hipError_t launch_mc_count(const float*, int32_t, int32_t, int32_t, float, int32_t*, hipStream_t);
+hipError_t launch_mc_emit(const float*, int32_t, int32_t, int32_t, float, const int64_t*, int64_t, int64_t*, hipStream_t);
+hipError_t launch_mc_vertices(const float*, int32_t, int32_t, float, const int64_t*, int64_t, float*, hipStream_t);
+void mc_copy_table(int8_t*);
 hipError_t launch_overlap_count(const float*, const float*, int64_t, const float*, const float*, float*, hipStream_t);
 hipError_t launch_lm_normal_eq(const float*, const float*, const float*, const float*, const float*, int64_t, int,
                                float, float*, hipStream_t);
@@ -547,6 +552,46 @@ int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_s
     return MISO_E_BADARG;
   return (int)launch_adam_active(param, grad, exp_avg, exp_avg_sq, active, numel, lr, beta1, beta2, eps, step,
                                  zero_grad, (hipStream_t)stream);
+}
+
+static int mc_check_dims(int32_t nx, int32_t ny, int32_t nz) {
+  if (nx < 1 || ny < 1 || nz < 1) return MISO_E_BADARG;
+  // cell ids are 32-bit; sample indices (and keys = 3 * index + axis) are 64-bit
+  if ((int64_t)nx * ny * nz >= ((int64_t)1 << 31)) return MISO_E_TOOLARGE;
+  return 0;
+}
+
+int64_t miso_mc_blocks(int32_t nx, int32_t ny, int32_t nz) {
+  if (mc_check_dims(nx, ny, nz)) return -1;
+  return mc_blocks(nx, ny, nz);
+}
+
+int miso_mc_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, int32_t* block_counts,
+                  void* stream) {
+  if (int rc = mc_check_dims(nx, ny, nz)) return rc;
+  if (mc_blocks(nx, ny, nz) > 0 && (!vol || !block_counts)) return MISO_E_BADARG;
+  return (int)launch_mc_count(vol, nx, ny, nz, iso, block_counts, (hipStream_t)stream);
+}
+
+int miso_mc_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* block_offsets,
+                 int64_t capacity_tris, int64_t* keys, void* stream) {
+  if (int rc = mc_check_dims(nx, ny, nz)) return rc;
+  if (capacity_tris < 0) return MISO_E_BADARG;
+  if (mc_blocks(nx, ny, nz) > 0 && capacity_tris > 0 && (!vol || !block_offsets || !keys)) return MISO_E_BADARG;
+  return (int)launch_mc_emit(vol, nx, ny, nz, iso, block_offsets, capacity_tris, keys, (hipStream_t)stream);
+}
+
+int miso_mc_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys, int64_t n,
+                     float* verts, void* stream) {
+  if (int rc = mc_check_dims(nx, ny, nz)) return rc;
+  if (n < 0 || (n > 0 && (!vol || !keys || !verts))) return MISO_E_BADARG;
+  return (int)launch_mc_vertices(vol, ny, nz, iso, keys, n, verts, (hipStream_t)stream);
+}
+
+int miso_mc_case_table(int8_t* table_host) {
+  if (!table_host) return MISO_E_BADARG;
+  mc_copy_table(table_host);
+  return 0;
 }
 
 }  // extern "C"

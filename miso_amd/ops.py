@@ -942,3 +942,38 @@ def sample_rays(depth, T_WC, R_wk, t_wk, intrinsics, pix_h, pix_w, u, g, *, min_
     i64 = lambda t: None if t is None else t.detach().reshape(-1).to(torch.int64).contiguous()
     c32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
     return sampler(i64(pix_h), i64(pix_w), c32(u), c32(g), pix_b=i64(pix_b), out=out, keep_world=keep_world)
+
+
+def marching_cubes(vol: torch.Tensor, iso: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Triangle mesh of the level set ``vol == iso`` of a dense (nx, ny, nz) fp32 volume in HBM: vertices (V, 3)
+    fp32 in index coordinates (x, y, z) and triangles (T, 3) int64, both on the device.  Replaces
+    ``mcubes.marching_cubes(u, threshold)`` of extract_geometry (grid_opt/utils/utils_sdf.py:89-101): two sweeps
+    over the cells (miso_mc_count / miso_mc_emit), corners welded by their lattice-edge key, one vertex per unique
+    key (miso_mc_vertices).  Vertices are ordered by key, triangles by cell (x-major) then table order.  One host
+    read-back (the triangle count sizes the output)."""
+    _require_hip(vol)
+    assert vol.ndim == 3, "marching_cubes takes a (nx, ny, nz) volume"
+    lib = _lib.load()
+    u = vol.detach().contiguous()
+    nx, ny, nz = (int(s) for s in u.shape)
+    dev, st = u.device, _stream(u)
+    nb = lib.miso_mc_blocks(nx, ny, nz)
+    if nb < 0:
+        raise RuntimeError("marching_cubes: volume too large (>= 2^31 samples) or an empty axis")
+    empty = (torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev))
+    if nb == 0:
+        return empty
+    counts = torch.empty(nb, dtype=torch.int32, device=dev)
+    _lib.check(lib.miso_mc_count(_ptr(u), nx, ny, nz, float(iso), _ptr(counts), st), "miso_mc_count")
+    incl = torch.cumsum(counts, 0, dtype=torch.int64)
+    offs = (incl - counts).contiguous()
+    n_tri = int(incl[-1].item())
+    if n_tri == 0:
+        return empty
+    keys = torch.empty((n_tri, 3), dtype=torch.int64, device=dev)
+    _lib.check(lib.miso_mc_emit(_ptr(u), nx, ny, nz, float(iso), _ptr(offs), n_tri, _ptr(keys), st), "miso_mc_emit")
+    uniq, inv = torch.unique(keys.view(-1), sorted=True, return_inverse=True)
+    verts = torch.empty((uniq.shape[0], 3), dtype=torch.float32, device=dev)
+    _lib.check(lib.miso_mc_vertices(_ptr(u), nx, ny, nz, float(iso), _ptr(uniq), uniq.shape[0], _ptr(verts), st),
+               "miso_mc_vertices")
+    return verts, inv.view(-1, 3)
