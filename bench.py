@@ -175,8 +175,35 @@ def extras(step, dev):
     ex["align_iteration_level1_driver"] = {"pairs": 1, "vertices": nv, "us_per_iteration": t,
                                            "vertices_per_s": nv / (t * 1e-6)}
     ex["sample_generation_scannet"] = sample_generation(dev)
+    ex["mesh_extraction_256"] = mesh_extraction(step, dev)
     ex["trainer_step_other_shapes"] = trainer_steps(dev)
     return ex
+
+
+def mesh_extraction(step, dev, res=256):
+    """The step after the path: SDF volume of the cfg-2 submap on a res^3 lattice (slab-wise fused
+    forward) and marching cubes on it where it lies, against the numpy oracle on the same volume (kind 'port';
+    the reference's PyMCubes is not in this image)."""
+    from miso_amd import ops
+    from miso_amd.grid_opt.utils import utils_sdf as US
+    from oracle import mcubes_ref as M  # checker / baseline leg only
+    feats, meta, pack = step.features, step.meta, step.pack
+    lo, hi = torch.tensor(meta.bound_min), torch.tensor(meta.bound_max)
+    query = lambda p: ops.sdf_fwd_raw(p, feats, meta, pack, False)[0]
+    t0 = time.perf_counter()
+    vol = US.extract_fields_device(lo, hi, res, query, device=dev)
+    torch.cuda.synchronize()
+    t_field = (time.perf_counter() - t0) * 1e6
+    iso = float(vol.median())                 # a random decoder's field need not cross zero
+    t_mc = time_kernel(lambda: ops.marching_cubes(vol, iso), iters=10, warm=2)
+    v, f = ops.marching_cubes(vol, iso)
+    t0 = time.perf_counter()
+    rv, rf = M.marching_cubes(vol.cpu().numpy(), iso)
+    t_cpu = (time.perf_counter() - t0) * 1e6
+    same = bool((f.cpu().numpy() == rf).all() and (v.cpu().numpy() == rv).all())
+    return {"resolution": res, "field_us": t_field, "marching_cubes_us": t_mc, "triangles": int(f.shape[0]),
+            "vertices": int(v.shape[0]), "volume_GBps": 4 * res ** 3 / t_mc / 1e3, "cpu_port_us": t_cpu,
+            "equals_cpu_port": same}
 
 
 def trainer_steps(dev):

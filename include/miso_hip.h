@@ -38,7 +38,7 @@
  *   miso_adam_dense / miso_adam_active
  *                     torch.optim.Adam.step on one dense tensor as used by
  *                     grid_opt/trainer.py:196-228 / :410-452.
- *   miso_mc_count / miso_mc_emit / miso_mc_vertices
+ *   miso_mc_classify / miso_mc_emit / miso_mc_vertices
  *                     mcubes.marching_cubes as called by extract_geometry, grid_opt/utils/utils_sdf.py:89-101
  *                     (the step after the path: SDF volume -> triangle mesh).
  *   miso_sample_rays  PosedSdfRgbd.getitem_sdf, grid_opt/datasets/sdf_rgbd.py:381-483 (the step that
@@ -365,30 +365,38 @@ int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_s
 /* --- marching cubes on the dense SDF volume ------------------------------------
  * Replaces mcubes.marching_cubes(u, threshold) as called by extract_geometry
  * (grid_opt/utils/utils_sdf.py:89-101; PyMCubes is a third-party dependency of the reference) with the
- * volume left in HBM.  vol: (nx, ny, nz) fp32, z fastest -- the layout of extract_fields' u[x, y, z].
- * A cell is "inside" at a corner where vol < iso.  Cells are visited in x-major order, MISO_MC_BLOCK
- * consecutive cells per block; triangles come out in that order (a cell's triangles in table order).
- *   miso_mc_blocks      number of blocks = length of block_counts / block_offsets.
- *   miso_mc_count       block_counts[b] (int32, device) = triangles of block b's cells.
- *   miso_mc_emit        block_offsets[b] (int64, device) = exclusive prefix sum of block_counts (the caller's
- *                       cumsum); keys (capacity_tris x 3, int64): for every triangle corner the lattice edge
- *                       it lies on, 3 * linear_index(low sample) + axis with linear_index = (x*ny + y)*nz + z
- *                       and axis 0/1/2 = x/y/z.  Triangles past capacity_tris are dropped.
- *                       Raw triangles are counter-clockwise seen from the vol < iso side.
- *   miso_mc_vertices    verts[i] (n x 3 fp32, index coordinates (x, y, z)) = position of edge key keys[i]:
- *                       low sample + (iso - u_a) / (u_b - u_a) along the axis.  The caller welds corners by
- *                       sorting / uniquing the keys first (vertices shared between cells are emitted once).
- *   miso_mc_case_table  copies the 256 x 16 table (15 edge ids, -1 padded, + triangle count; edge id =
- *                       4*axis + a + 2*b, (a, b) = the edge's other two corner coordinates in increasing axis
- *                       order; case bit c = corner x + 2y + 4z) to HOST memory. */
-#define MISO_MC_BLOCK 256
-int64_t miso_mc_blocks(int32_t nx, int32_t ny, int32_t nz);
-int miso_mc_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, int32_t* block_counts,
-                  void* stream);
-int miso_mc_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* block_offsets,
-                 int64_t capacity_tris, int64_t* keys, void* stream);
-int miso_mc_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys,
-                     int64_t n, float* verts, void* stream);
+ * volume left in HBM, read once, and no sort.  vol: (nx, ny, nz) fp32, z fastest -- the layout of
+ * extract_fields' u[x, y, z].  A corner is "inside" where vol < iso.
+ * A sample ROW is the nz samples of one (x, y), row id = x*ny + y; a CHUNK is 64 consecutive z of a row.
+ * W = nx*ny*ceil(nz/64) (row, chunk) pairs.  Vertices are numbered by the key ((x*ny + y)*3 + axis)*nz + z of
+ * the lattice edge they sit on ((x,y,z) = the edge's low sample, axis 0/1/2 = x/y/z); triangles are listed
+ * cell by cell in x-major order, a cell's triangles in table order, counter-clockwise seen from the
+ * vol < iso side.
+ *   miso_mc_words           W; -1 for a bad / too large shape (>= 2^31 samples).
+ *   miso_mc_workspace_bytes device scratch shared by the three launches (sign bitmap, vertex bitmap, two work
+ *                           lists: 5 bits per sample); 8-byte aligned.
+ *   miso_mc_classify        one sweep over the volume: fills the workspace and counts (4W + 2 int32, device):
+ *                           [0, 3W) vertices per (row, axis, chunk), [3W, 4W) triangles per (row, chunk),
+ *                           [4W] = chunks with triangles, [4W + 1] = chunks with vertices (the lengths of the
+ *                           work lists the next two launches run over: the caller reads them back with the totals).
+ *   miso_mc_emit            offsets (4W int64, device) = exclusive prefix sums of counts[0, 3W) and of
+ *                           counts[3W, 4W) (the caller's two cumsums), same layout; n_tri_chunks = counts[4W].
+ *                           faces (capacity_tris x 3 int64) = vertex indices.
+ *   miso_mc_vertices        n_vert_chunks = counts[4W + 1].  verts (capacity_verts x 3 fp32), index coordinates
+ *                           (x, y, z): low sample + (iso - u_a) / (u_b - u_a) along the edge's axis.
+ *                           Triangles / vertices past the capacities are dropped.
+ *   miso_mc_case_table      copies the 256 x 16 table (15 edge ids, -1 padded, + triangle count; edge id =
+ *                           4*axis + a + 2*b, (a, b) = the edge's other two corner coordinates in increasing axis
+ *                           order; case bit c = corner x + 2y + 4z) to HOST memory. */
+int64_t miso_mc_words(int32_t nx, int32_t ny, int32_t nz);
+int64_t miso_mc_workspace_bytes(int32_t nx, int32_t ny, int32_t nz);
+int miso_mc_classify(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, void* workspace,
+                     int32_t* counts, void* stream);
+int miso_mc_emit(int32_t nx, int32_t ny, int32_t nz, void* workspace, const int64_t* offsets,
+                 int32_t n_tri_chunks, int64_t capacity_tris, int64_t* faces, void* stream);
+int miso_mc_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, void* workspace,
+                     const int64_t* offsets, int32_t n_vert_chunks, int64_t capacity_verts, float* verts,
+                     void* stream);
 int miso_mc_case_table(int8_t* table_host);
 
 #ifdef __cplusplus

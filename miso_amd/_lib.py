@@ -127,12 +127,14 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_adam_active": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int, C.c_void_p]),
-    "miso_mc_blocks": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
-    "miso_mc_count": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
-    "miso_mc_emit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
+    "miso_mc_words": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "miso_mc_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "miso_mc_classify": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "miso_mc_emit": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                C.c_void_p, C.c_void_p]),
-    "miso_mc_vertices": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int64,
-                                   C.c_void_p, C.c_void_p]),
+    "miso_mc_vertices": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                   C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "miso_mc_case_table": (C.c_int, [C.c_void_p]),
     "miso_adam_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int,

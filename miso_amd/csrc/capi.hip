@@ -26,10 +26,12 @@ uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
                             uint32_t, int, const float*, int32_t*, int64_t, hipStream_t);
 int64_t pull_queue_ints(int64_t);
-int64_t mc_blocks(int32_t, int32_t, int32_t);
-hipError_t launch_mc_count(const float*, int32_t, int32_t, int32_t, float, int32_t*, hipStream_t);
-hipError_t launch_mc_emit(const float*, int32_t, int32_t, int32_t, float, const int64_t*, int64_t, int64_t*, hipStream_t);
-hipError_t launch_mc_vertices(const float*, int32_t, int32_t, float, const int64_t*, int64_t, float*, hipStream_t);
+int64_t mc_words(int32_t, int32_t, int32_t);
+int64_t mc_workspace_bytes(int32_t, int32_t, int32_t);
+hipError_t launch_mc_classify(const float*, int32_t, int32_t, int32_t, float, void*, int32_t*, hipStream_t);
+hipError_t launch_mc_emit(int32_t, int32_t, int32_t, void*, const int64_t*, int32_t, int64_t, int64_t*, hipStream_t);
+hipError_t launch_mc_vertices(const float*, int32_t, int32_t, int32_t, float, void*, const int64_t*, int32_t, int64_t,
+                              float*, hipStream_t);
 void mc_copy_table(int8_t*);
 hipError_t launch_overlap_count(const float*, const float*, int64_t, const float*, const float*, float*, hipStream_t);
 hipError_t launch_lm_normal_eq(const float*, const float*, const float*, const float*, const float*, int64_t, int,
@@ -561,31 +563,41 @@ static int mc_check_dims(int32_t nx, int32_t ny, int32_t nz) {
   return 0;
 }
 
-int64_t miso_mc_blocks(int32_t nx, int32_t ny, int32_t nz) {
+int64_t miso_mc_words(int32_t nx, int32_t ny, int32_t nz) {
   if (mc_check_dims(nx, ny, nz)) return -1;
-  return mc_blocks(nx, ny, nz);
+  return mc_words(nx, ny, nz);
 }
 
-int miso_mc_count(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, int32_t* block_counts,
-                  void* stream) {
-  if (int rc = mc_check_dims(nx, ny, nz)) return rc;
-  if (mc_blocks(nx, ny, nz) > 0 && (!vol || !block_counts)) return MISO_E_BADARG;
-  return (int)launch_mc_count(vol, nx, ny, nz, iso, block_counts, (hipStream_t)stream);
+int64_t miso_mc_workspace_bytes(int32_t nx, int32_t ny, int32_t nz) {
+  if (mc_check_dims(nx, ny, nz)) return -1;
+  return mc_workspace_bytes(nx, ny, nz);
 }
 
-int miso_mc_emit(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* block_offsets,
-                 int64_t capacity_tris, int64_t* keys, void* stream) {
+int miso_mc_classify(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, void* workspace,
+                     int32_t* counts, void* stream) {
   if (int rc = mc_check_dims(nx, ny, nz)) return rc;
-  if (capacity_tris < 0) return MISO_E_BADARG;
-  if (mc_blocks(nx, ny, nz) > 0 && capacity_tris > 0 && (!vol || !block_offsets || !keys)) return MISO_E_BADARG;
-  return (int)launch_mc_emit(vol, nx, ny, nz, iso, block_offsets, capacity_tris, keys, (hipStream_t)stream);
+  if (!vol || !workspace || !counts || (((uintptr_t)workspace) & 7u)) return MISO_E_BADARG;
+  return (int)launch_mc_classify(vol, nx, ny, nz, iso, workspace, counts, (hipStream_t)stream);
 }
 
-int miso_mc_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, const int64_t* keys, int64_t n,
-                     float* verts, void* stream) {
+int miso_mc_emit(int32_t nx, int32_t ny, int32_t nz, void* workspace, const int64_t* offsets, int32_t n_tri_chunks,
+                 int64_t capacity_tris, int64_t* faces, void* stream) {
   if (int rc = mc_check_dims(nx, ny, nz)) return rc;
-  if (n < 0 || (n > 0 && (!vol || !keys || !verts))) return MISO_E_BADARG;
-  return (int)launch_mc_vertices(vol, ny, nz, iso, keys, n, verts, (hipStream_t)stream);
+  if (capacity_tris < 0 || n_tri_chunks < 0 || n_tri_chunks > mc_words(nx, ny, nz) || !workspace || !offsets ||
+      (capacity_tris > 0 && !faces))
+    return MISO_E_BADARG;
+  return (int)launch_mc_emit(nx, ny, nz, workspace, offsets, n_tri_chunks, capacity_tris, faces, (hipStream_t)stream);
+}
+
+int miso_mc_vertices(const float* vol, int32_t nx, int32_t ny, int32_t nz, float iso, void* workspace,
+                     const int64_t* offsets, int32_t n_vert_chunks, int64_t capacity_verts, float* verts,
+                     void* stream) {
+  if (int rc = mc_check_dims(nx, ny, nz)) return rc;
+  if (capacity_verts < 0 || n_vert_chunks < 0 || n_vert_chunks > mc_words(nx, ny, nz) || !vol || !workspace ||
+      !offsets || (capacity_verts > 0 && !verts))
+    return MISO_E_BADARG;
+  return (int)launch_mc_vertices(vol, nx, ny, nz, iso, workspace, offsets, n_vert_chunks, capacity_verts, verts,
+                                 (hipStream_t)stream);
 }
 
 int miso_mc_case_table(int8_t* table_host) {

@@ -947,33 +947,32 @@ def sample_rays(depth, T_WC, R_wk, t_wk, intrinsics, pix_h, pix_w, u, g, *, min_
 def marching_cubes(vol: torch.Tensor, iso: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor]:
     """Triangle mesh of the level set ``vol == iso`` of a dense (nx, ny, nz) fp32 volume in HBM: vertices (V, 3)
     fp32 in index coordinates (x, y, z) and triangles (T, 3) int64, both on the device.  Replaces
-    ``mcubes.marching_cubes(u, threshold)`` of extract_geometry (grid_opt/utils/utils_sdf.py:89-101): two sweeps
-    over the cells (miso_mc_count / miso_mc_emit), corners welded by their lattice-edge key, one vertex per unique
-    key (miso_mc_vertices).  Vertices are ordered by key, triangles by cell (x-major) then table order.  One host
-    read-back (the triangle count sizes the output)."""
+    ``mcubes.marching_cubes(u, threshold)`` of extract_geometry (grid_opt/utils/utils_sdf.py:89-101): one sweep
+    over the volume (miso_mc_classify: sign cases + a ballot bitmap of the crossed lattice edges), then triangles
+    as vertex indices (miso_mc_emit) and vertex positions (miso_mc_vertices) -- shared vertices are numbered by
+    bitmap rank, nothing is sorted.  Vertices are ordered by (x, y, axis, z) of their edge, triangles by cell
+    (x-major) then table order.  One host read-back (the counts size the outputs)."""
     _require_hip(vol)
     assert vol.ndim == 3, "marching_cubes takes a (nx, ny, nz) volume"
     lib = _lib.load()
     u = vol.detach().contiguous()
     nx, ny, nz = (int(s) for s in u.shape)
     dev, st = u.device, _stream(u)
-    nb = lib.miso_mc_blocks(nx, ny, nz)
-    if nb < 0:
+    W = lib.miso_mc_words(nx, ny, nz)
+    if W < 0:
         raise RuntimeError("marching_cubes: volume too large (>= 2^31 samples) or an empty axis")
-    empty = (torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev))
-    if nb == 0:
-        return empty
-    counts = torch.empty(nb, dtype=torch.int32, device=dev)
-    _lib.check(lib.miso_mc_count(_ptr(u), nx, ny, nz, float(iso), _ptr(counts), st), "miso_mc_count")
-    incl = torch.cumsum(counts, 0, dtype=torch.int64)
-    offs = (incl - counts).contiguous()
-    n_tri = int(incl[-1].item())
-    if n_tri == 0:
-        return empty
-    keys = torch.empty((n_tri, 3), dtype=torch.int64, device=dev)
-    _lib.check(lib.miso_mc_emit(_ptr(u), nx, ny, nz, float(iso), _ptr(offs), n_tri, _ptr(keys), st), "miso_mc_emit")
-    uniq, inv = torch.unique(keys.view(-1), sorted=True, return_inverse=True)
-    verts = torch.empty((uniq.shape[0], 3), dtype=torch.float32, device=dev)
-    _lib.check(lib.miso_mc_vertices(_ptr(u), nx, ny, nz, float(iso), _ptr(uniq), uniq.shape[0], _ptr(verts), st),
-               "miso_mc_vertices")
-    return verts, inv.view(-1, 3)
+    ws = torch.empty((lib.miso_mc_workspace_bytes(nx, ny, nz) + 7) // 8, dtype=torch.int64, device=dev)
+    counts = torch.empty(4 * W + 2, dtype=torch.int32, device=dev)
+    _lib.check(lib.miso_mc_classify(_ptr(u), nx, ny, nz, float(iso), _ptr(ws), _ptr(counts), st), "miso_mc_classify")
+    offs = torch.empty(4 * W + 2, dtype=torch.int64, device=dev)
+    torch.cumsum(counts[:3 * W], 0, dtype=torch.int64, out=offs[:3 * W])
+    torch.cumsum(counts[3 * W:4 * W], 0, dtype=torch.int64, out=offs[3 * W:4 * W])
+    offs[4 * W:] = counts[4 * W:]
+    n_vert, n_tri, tri_chunks, vert_chunks = (int(v) for v in offs[[3 * W - 1, 4 * W - 1, 4 * W, 4 * W + 1]].tolist())
+    offs -= counts                                   # inclusive -> exclusive
+    verts = torch.empty((n_vert, 3), dtype=torch.float32, device=dev)
+    faces = torch.empty((n_tri, 3), dtype=torch.int64, device=dev)
+    _lib.check(lib.miso_mc_emit(nx, ny, nz, _ptr(ws), _ptr(offs), tri_chunks, n_tri, _ptr(faces), st), "miso_mc_emit")
+    _lib.check(lib.miso_mc_vertices(_ptr(u), nx, ny, nz, float(iso), _ptr(ws), _ptr(offs), vert_chunks, n_vert,
+                                    _ptr(verts), st), "miso_mc_vertices")
+    return verts, faces

@@ -150,7 +150,7 @@ def marching_cubes(u, iso=0.0):
 
     Vertex v of an edge between samples a (lower index) and b: a + (iso - u_a) / (u_b - u_a)
     along the edge's axis, in float32.  Vertices are unique and sorted by their edge key
-    ``3 * linear_index(a) + axis``; triangles are ordered by cell (x-major) then table order."""
+    ``((x*ny + y)*3 + axis)*nz + z`` (a = (x, y, z)); triangles are ordered by cell (x-major) then table order."""
     u = np.asarray(u, dtype=np.float32)
     nx, ny, nz = u.shape
     tab, cnt = case_table()
@@ -168,8 +168,7 @@ def marching_cubes(u, iso=0.0):
         ee = np.where(live, e, 0)
         a = cells + CORNERS[EDGE_ENDS[ee, 0]]
         axis = ee // 4
-        lin = (a[:, 0] * ny + a[:, 1]) * nz + a[:, 2]
-        keys.append(np.where(live, 3 * lin + axis, -1))
+        keys.append(np.where(live, ((a[:, 0] * ny + a[:, 1]) * 3 + axis) * nz + a[:, 2], -1))
         b = a.copy()
         b[np.arange(len(a)), axis] += 1
         ua, ub = u[a[:, 0], a[:, 1], a[:, 2]], u[b[:, 0], b[:, 1], b[:, 2]]

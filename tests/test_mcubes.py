@@ -79,9 +79,12 @@ def test_compiled_case_table_equals_derivation():
     tab, cnt = M.case_table()
     assert np.array_equal(got[:, :15], tab) and np.array_equal(got[:, 15], cnt.astype(np.int8))
     assert lib.miso_mc_case_table(None) == _lib.E_BADARG
-    assert lib.miso_mc_blocks(0, 4, 4) == -1 and lib.miso_mc_blocks(2048, 2048, 2048) == -1
-    assert lib.miso_mc_blocks(1, 4, 4) == 0 and lib.miso_mc_blocks(9, 9, 5) == 1 and lib.miso_mc_blocks(9, 9, 6) == 2
-    assert lib.miso_mc_count(None, 4, 4, 4, 0.0, None, None) == _lib.E_BADARG
+    assert lib.miso_mc_words(0, 4, 4) == -1 and lib.miso_mc_words(2048, 2048, 2048) == -1
+    assert lib.miso_mc_words(1, 4, 4) == 4 and lib.miso_mc_words(3, 3, 65) == 18 and lib.miso_mc_words(256, 256, 256) == 1 << 18
+    # per row and chunk of 64 samples: one sign word, three vertex words, two work-list slots
+    assert lib.miso_mc_workspace_bytes(3, 3, 65) == 18 * 40
+    assert lib.miso_mc_classify(None, 4, 4, 4, 0.0, None, None, None) == _lib.E_BADARG
+    assert lib.miso_mc_emit(4, 4, 4, None, None, 0, 0, None, None) == _lib.E_BADARG
 
 
 def test_ply_roundtrip_and_normals(tmp_path):

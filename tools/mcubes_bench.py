@@ -38,25 +38,35 @@ def main():
         del x, y, z
         u = u.contiguous()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        nb = lib.miso_mc_blocks(n, n, n)
-        counts = torch.empty(nb, dtype=torch.int32, device=dev)
+        W = lib.miso_mc_words(n, n, n)
+        ws_bytes = lib.miso_mc_workspace_bytes(n, n, n)
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=dev)
+        counts = torch.empty(4 * W + 2, dtype=torch.int32, device=dev)
+        offs = torch.empty(4 * W, dtype=torch.int64, device=dev)
         P = lambda t: C.c_void_p(t.data_ptr())
-        t_count = timeit(lambda: lib.miso_mc_count(P(u), n, n, n, 0.0, P(counts), st))
-        incl = torch.cumsum(counts, 0, dtype=torch.int64)
-        offs = (incl - counts).contiguous()
-        nt = int(incl[-1])
-        keys = torch.empty((nt, 3), dtype=torch.int64, device=dev)
-        t_emit = timeit(lambda: lib.miso_mc_emit(P(u), n, n, n, 0.0, P(offs), nt, P(keys), st))
-        t_unique = timeit(lambda: torch.unique(keys.view(-1), sorted=True, return_inverse=True), iters=5, warm=1)
-        uniq, inv = torch.unique(keys.view(-1), sorted=True, return_inverse=True)
-        verts = torch.empty((uniq.shape[0], 3), dtype=torch.float32, device=dev)
-        t_verts = timeit(lambda: lib.miso_mc_vertices(P(u), n, n, n, 0.0, P(uniq), uniq.shape[0], P(verts), st))
-        t_all = timeit(lambda: ops.marching_cubes(u, 0.0), iters=5, warm=1)
+        t_cls = timeit(lambda: lib.miso_mc_classify(P(u), n, n, n, 0.0, P(ws), P(counts), st))
+
+        def scan():
+            torch.cumsum(counts[:3 * W], 0, dtype=torch.int64, out=offs[:3 * W])
+            torch.cumsum(counts[3 * W:4 * W], 0, dtype=torch.int64, out=offs[3 * W:])
+            offs.sub_(counts[:4 * W])
+
+        t_scan = timeit(scan)
+        scan()
+        nv = int(offs[3 * W - 1] + counts[3 * W - 1])
+        nt = int(offs[4 * W - 1] + counts[4 * W - 1])
+        tch, vch = int(counts[4 * W]), int(counts[4 * W + 1])
+        faces = torch.empty((nt, 3), dtype=torch.int64, device=dev)
+        verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        t_emit = timeit(lambda: lib.miso_mc_emit(n, n, n, P(ws), P(offs), tch, nt, P(faces), st))
+        t_verts = timeit(lambda: lib.miso_mc_vertices(P(u), n, n, n, 0.0, P(ws), P(offs), vch, nv, P(verts), st))
+        t_all = timeit(lambda: ops.marching_cubes(u, 0.0), iters=10, warm=2)
         vol_bytes = 4 * n ** 3
-        out[f"res{n}"] = {"triangles": nt, "vertices": int(uniq.shape[0]),
-                          "count_us": t_count, "count_GBps": vol_bytes / t_count / 1e3,
-                          "emit_us": t_emit, "emit_GBps": (vol_bytes + 24 * nt) / t_emit / 1e3,
-                          "unique_us": t_unique, "vertices_us": t_verts, "marching_cubes_total_us": t_all}
+        cls_bytes = vol_bytes + ws_bytes            # volume read once, workspace written once
+        out[f"res{n}"] = {"triangles": nt, "vertices": nv, "chunks": W, "chunks_with_triangles": tch, "chunks_with_vertices": vch, "workspace_MB": ws_bytes / 1e6,
+                          "classify_us": t_cls, "classify_GBps": cls_bytes / t_cls / 1e3,
+                          "scan_us": t_scan, "emit_us": t_emit,
+                          "vertices_us": t_verts, "marching_cubes_total_us": t_all}
     print(json.dumps(out))
 
 
