@@ -269,3 +269,18 @@ def local_opt_cfg(loss_name):
                       "ckpt_every": -1, "eval_every": -1, "eval_metric": None, "pretrained_model": None,
                       "log_dir": "/tmp/miso_golden_log", "relchange_tol": 0, "max_epochs_in_level": 2,
                       "grid_training_mode": "joint"}}
+
+
+# --- rigid-map / point-cloud helpers of utils_geometry ---------------------------
+def geometry_inputs():
+    rs = np.random.RandomState(91)
+    F = 4
+    R = np.stack([rodrigues(rs.uniform(-1.0, 1.0, 3)) for _ in range(F)]).astype(np.float32)
+    t = rs.uniform(-2.0, 2.0, (F, 3, 1)).astype(np.float32)
+    dr = rs.uniform(-0.2, 0.2, (F, 3)).astype(np.float32)
+    dt = rs.uniform(-0.3, 0.3, (F, 3, 1)).astype(np.float32)
+    spans = np.array([[0, 50], [50, 50], [50, 130], [130, 200]], dtype=np.int64)     # one empty frame
+    pts = rs.uniform(-3.0, 3.0, (200, 3)).astype(np.float32)
+    cloud = (rs.standard_normal((3000, 3)) * np.array([6.0, 6.0, 1.5])).astype(np.float32)
+    stamps = rs.uniform(0, 1, (3000, 1)).astype(np.float32)
+    return dict(R=R, t=t, dr=dr, dt=dt, spans=spans, pts=pts, cloud=cloud, stamps=stamps)

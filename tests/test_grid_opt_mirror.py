@@ -3,6 +3,8 @@ vectors captured from the reference: GridNet / GridAtlas queries, the Miso and i
 losses, the trainer step, pairwise alignment, LM tracking.  Runs twice: on CPU with the
 oracle standing in for the HIP operators (host logic only), and on the GPU with the
 real library (marked gpu)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -471,3 +473,105 @@ def test_local_opt_matches_reference(device_backend, tmp_path):
             close(atlas.get_submap(s).features[l].feature, T(g[f"localopt_atlas_s{s}_feat{l}"]), 0, 3e-6)
     close(torch.stack([p for p in atlas.rotation_corrections]), T(g["localopt_atlas_dr"]), 0, 3e-6)
     close(torch.stack([p for p in atlas.translation_corrections]), T(g["localopt_atlas_dt"]), 0, 3e-6)
+
+
+def test_geometry_helpers_match_reference(tmp_path):
+    """utils_geometry beyond the rigid maps (frame changes of pose sets, batched world transform with the anchored
+    first frame, AABB, voxel down-sampling, range crop, error metrics, random pose perturbations from numpy's global
+    RNG, KITTI pose files) against rows produced by the reference (tests/golden/geometry.npz)."""
+    import miso_amd.grid_opt.utils.utils_geometry as UG
+    g = G("geometry")
+    x = gc.geometry_inputs()
+    close(UG.batch_transform_to_world_frame(T(x["pts"]), T(x["spans"]), T(x["R"]), T(x["t"]), T(x["dr"]), T(x["dt"])),
+          T(g["batch_world"]), 0, 3e-6)
+    Rf, tf = UG.transform_poses_from(T(x["R"]), T(x["t"]), T(x["R"][1]), T(x["t"][1]))
+    close(Rf, T(g["poses_from_R"]), 0, 1e-6)
+    close(tf, T(g["poses_from_t"]), 0, 2e-6)
+    close(UG.aabb_torch(T(x["cloud"]), buffer=0.25), T(g["aabb"]), 0, 0)
+    for vs in (0.5, 2.0):
+        assert np.array_equal(UG.voxel_down_sample_torch(T(x["cloud"]), vs).numpy(), g[f"voxel_{vs}"])
+    p, s = UG.crop_points(T(x["cloud"]), T(x["stamps"]), min_z_th=-1.0, max_z_th=2.0, min_range=2.75, max_range=9.0)
+    assert np.array_equal(p.numpy(), g["crop_pts"]) and np.array_equal(s.numpy(), g["crop_ts"])
+    assert UG.crop_points(T(x["cloud"]), None)[1] is None
+    assert abs(UG.translation_rmse(T(x["t"]), T(x["dt"])) - float(g["t_rmse"])) < 1e-6
+    assert abs(UG.translation_mean_error(T(x["t"]), T(x["dt"])) - float(g["t_mean"])) < 1e-6
+    assert abs(UG.chordal_to_degree(0.7) - float(g["chordal_deg"])) < 1e-12
+    np.random.seed(7)
+    close(UG.gaussian_translations(5, 0.5), T(g["gauss_t"]), 0, 0)
+    close(UG.uniform_translations(5, np.array([[-1.0, 1.0], [0.0, 2.0], [3.0, 4.0]])), T(g["uniform_t"]), 0, 0)
+    close(UG.fixed_length_translations(5, 0.3), T(g["fixed_len_t"]), 0, 1e-7)
+    close(UG.wrapped_gaussian_rotations(5, std_rad=0.2), T(g["wrapped_R"]), 0, 1e-6)
+    close(UG.fixed_angle_rotations(5, 0.4), T(g["fixed_angle_R"]), 0, 1e-6)
+    poses = np.tile(np.eye(4), (4, 1, 1))
+    poses[:, :3, :3], poses[:, :3, 3:] = x["R"], x["t"]
+    UG.write_kitti_format_poses(str(tmp_path / "traj"), poses)
+    assert open(tmp_path / "traj_kitti.txt", "rb").read() == g["kitti_text"].tobytes()
+    assert np.array_equal(np.stack(UG.read_kitti_format_poses(str(tmp_path / "traj_kitti.txt"))), g["kitti_read"])
+    (tmp_path / "bad.txt").write_text("1 2 3\n")
+    assert UG.read_kitti_format_poses(str(tmp_path / "bad.txt")) is None
+    ok = [UG.check_numpy_pose_matrix(poses[0]), UG.check_numpy_pose_matrix(poses[0] * 1.01),
+          UG.check_numpy_pose_matrix(np.full((4, 4), np.nan))]
+    assert ok == [bool(v) for v in g["pose_ok"]]
+    # the two helpers whose pytorch3d calls are not shimmed: pinned by their defining properties
+    R0, t0 = T(x["R"][0]), T(x["t"][0])
+    for k in range(1, 4):
+        dr, dt = UG.get_pose_correction(R0, t0, T(x["R"][k]), T(x["t"][k]))
+        assert dr.shape == (1, 3) and dt.shape == (3, 1)
+        Rn, tn = UG.apply_pose_correction(R0, t0, dr, dt)
+        close(Rn, T(x["R"][k]), 0, 3e-6)
+        close(tn, T(x["t"][k]), 0, 1e-6)
+    close(UG.get_pose_correction(R0, t0, R0, t0)[0], torch.zeros(1, 3), 0, 1e-6)
+    ang = torch.tensor([[0.0, 0.0, 0.1], [0.3, 0.0, 0.0], [0.0, -0.2, 0.0]])
+    Ra = UG.so3_exp_map(ang)
+    eye = UG.identity_rotations(3)
+    assert abs(UG.rotation_rmse(Ra, eye) - np.degrees(np.sqrt((0.01 + 0.09 + 0.04) / 3))) < 1e-3
+    assert abs(UG.rotation_mean_error(Ra, eye) - np.degrees(0.2)) < 1e-3
+
+
+def test_files_written_by_the_reference_load(device_backend, tmp_path):
+    """a Trainer.save_model checkpoint (reference trainer.py:319-332) and a whole-module pickle
+    torch.save(grid_atlas) (demo/build_submaps.py:141), both written by the reference itself
+    (tools/make_goldens.py gen_formats), load through miso_amd.compat: same state-dict keys, same dotted class
+    paths, and the loaded objects answer queries like the reference did before saving."""
+    import miso_amd.compat  # noqa: F401
+    import miso_amd.grid_opt.loss as L
+    from miso_amd.grid_opt.models.grid_atlas import GridAtlas
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    from miso_amd.grid_opt.trainer import GridTrainer
+    dev = device_backend
+    g = G("formats")
+    case = gc.CASES["small"]
+    ck_path = os.path.join(gc.GOLDEN_DIR, "ref_checkpoint.pt")
+    ck = torch.load(ck_path, weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "train_dict", "val_dict"}
+    net = make_gridnet(case, dev)
+    assert sorted(net.state_dict().keys()) == [str(k) for k in g["ckpt_keys"]]
+    # through the trainer's own loading path (cfg['pretrained_model'])
+    with torch.no_grad():
+        for f in net.features:
+            f.feature.zero_()
+    cfg_train = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 0, "ckpt_every": -1,
+                 "eval_every": -1, "eval_metric": None, "pretrained_model": ck_path, "log_dir": str(tmp_path),
+                 "relchange_tol": 0, "max_epochs_in_level": 2, "grid_training_mode": "joint"}
+    lossf = L.MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
+    GridTrainer(cfg_train, net, lossf, None, None, dev, torch.float32)
+    xq = T(gc.make_points(case)[:256]).to(dev)
+    close(net(xq), T(g["ckpt_forward"]), 0, 1e-5)
+    # our own checkpoint of the loaded model carries the same keys
+    assert set(net.state_dict().keys()) == set(ck["model_state_dict"].keys())
+
+    atlas = torch.load(os.path.join(gc.GOLDEN_DIR, "ref_atlas.pth"), weights_only=False, map_location="cpu")
+    assert type(atlas) is GridAtlas and type(atlas.get_submap(0)) is GridNet
+    atlas.to(dev)
+    atlas.device = dev
+    xw = T(g["atlas_x"]).to(dev)
+    close(atlas(xw), T(g["atlas_forward"]), 0, 1e-5)
+    close(atlas.query_feature(xw), T(g["atlas_query_feature"]), 0, 2e-6)
+    R, t = atlas.updated_kf_pose_in_world(3)
+    close(R, T(g["atlas_kf3_R"]), 0, 1e-6)
+    close(t, T(g["atlas_kf3_t"]), 0, 1e-6)
+    assert [atlas.anchor_kf_for_submap(0), atlas.anchor_kf_for_submap(1)] == g["atlas_anchor"].tolist()
+    # and it can be saved and loaded again
+    torch.save(atlas, tmp_path / "again.pth")
+    again = torch.load(tmp_path / "again.pth", weights_only=False)
+    close(again(xw), T(g["atlas_forward"]), 0, 1e-5)

@@ -617,6 +617,110 @@ def gen_extra(GridNet, GridAtlas, miso, rtrainer, gc):
     print("[extra] ok", {k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
 
 
+def gen_geometry(rgeom, gc):
+    """utils_geometry helpers that run without pytorch3d's un-shimmed functions (so3_relative_angle and
+    matrix_to_axis_angle are not restated in tools/ref_shims, so rotation_rmse / get_pose_correction are not here)."""
+    import tempfile
+    g = gc.geometry_inputs()
+    out = {}
+    out["batch_world"] = rgeom.batch_transform_to_world_frame(T(g["pts"]), T(g["spans"]), T(g["R"]), T(g["t"]), T(g["dr"]),
+                                                              T(g["dt"])).numpy()
+    Rf, tf = rgeom.transform_poses_from(T(g["R"]), T(g["t"]), T(g["R"][1]), T(g["t"][1]))
+    out["poses_from_R"], out["poses_from_t"] = Rf.numpy(), tf.numpy()
+    out["aabb"] = rgeom.aabb_torch(T(g["cloud"]), buffer=0.25).numpy()
+    for vs in (0.5, 2.0):
+        out[f"voxel_{vs}"] = rgeom.voxel_down_sample_torch(T(g["cloud"]), vs).numpy()
+    p, s = rgeom.crop_points(T(g["cloud"]), T(g["stamps"]), min_z_th=-1.0, max_z_th=2.0, min_range=2.75, max_range=9.0)
+    out["crop_pts"], out["crop_ts"] = p.numpy(), s.numpy()
+    out["t_rmse"] = np.float64(rgeom.translation_rmse(T(g["t"]), T(g["dt"])))
+    out["t_mean"] = np.float64(rgeom.translation_mean_error(T(g["t"]), T(g["dt"])))
+    out["chordal_deg"] = np.float64(rgeom.chordal_to_degree(0.7))
+    np.random.seed(7)
+    out["gauss_t"] = rgeom.gaussian_translations(5, 0.5).numpy()
+    out["uniform_t"] = rgeom.uniform_translations(5, np.array([[-1.0, 1.0], [0.0, 2.0], [3.0, 4.0]])).numpy()
+    out["fixed_len_t"] = rgeom.fixed_length_translations(5, 0.3).numpy()
+    out["wrapped_R"] = rgeom.wrapped_gaussian_rotations(5, std_rad=0.2).numpy()
+    out["fixed_angle_R"] = rgeom.fixed_angle_rotations(5, 0.4).numpy()
+    poses = np.tile(np.eye(4), (4, 1, 1))
+    poses[:, :3, :3], poses[:, :3, 3:] = g["R"], g["t"]
+    with tempfile.TemporaryDirectory() as d:
+        rgeom.write_kitti_format_poses(os.path.join(d, "traj"), poses)
+        out["kitti_text"] = np.frombuffer(open(os.path.join(d, "traj_kitti.txt"), "rb").read(), dtype=np.uint8)
+        out["kitti_read"] = np.stack(rgeom.read_kitti_format_poses(os.path.join(d, "traj_kitti.txt")))
+    out["pose_ok"] = np.array([rgeom.check_numpy_pose_matrix(poses[0]), rgeom.check_numpy_pose_matrix(poses[0] * 1.01),
+                               rgeom.check_numpy_pose_matrix(np.full((4, 4), np.nan))])
+    np.savez_compressed(gc.golden_path("geometry"), **out)
+    print("[geometry] ok", {k: v.shape for k, v in out.items()})
+
+
+def gen_formats(GridNet, GridAtlas, rloss, rtrainer, gc):
+    """On-disk formats written BY THE REFERENCE (data only: tensors, plain containers and, for the whole-module
+    pickle, dotted class names): a Trainer.save_model checkpoint (trainer.py:319-332) and torch.save(grid_atlas)
+    as demo/build_submaps.py:141 writes it.  tests/ loads them through miso_amd.compat."""
+    import shutil
+    import tempfile
+    case = dict(gc.CASES["small"])
+    pts = gc.make_points(case)
+    n = pts.shape[0]
+    sdf_t, valid, sign, weight = gc.make_targets(case, n)
+    net = build_gridnet(GridNet, gc, case, num_poses=1, optimize_pose=False, stability=True)
+    net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+    net.unlock_feature()
+    net.lock_pose()
+    ds = _OneBatch({"coords_frame": pts[None], "sample_frame_ids": np.zeros((1, n, 1), np.int64), "weights": weight[None]},
+                   {"sdf": sdf_t[None], "sdf_valid": valid[None], "sdf_signs": sign[None]})
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)
+
+    class _Writer:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+    rtrainer.SummaryWriter = _Writer
+    d = tempfile.mkdtemp()
+    cfg_train = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 3, "ckpt_every": -1,
+                 "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": d, "relchange_tol": 0,
+                 "max_epochs_in_level": 2, "grid_training_mode": "joint"}
+    lossf = rloss.MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
+    tr = rtrainer.GridTrainer(cfg_train, net, lossf, loader, None, "cpu", torch.float32)
+    tr.train()
+    tr.save_model(3, "ref_checkpoint")
+    shutil.copy(os.path.join(tr.ckpt_dir, "ref_checkpoint.pt"), os.path.join(gc.GOLDEN_DIR, "ref_checkpoint.pt"))
+    xq = T(pts[:256])
+    out = {"ckpt_forward": net(xq).detach().numpy(), "ckpt_keys": np.array(sorted(net.state_dict().keys()))}
+    # whole-module pickle of a two-submap atlas (small bound so that the fixture stays small)
+    c = dict(gc.ATLAS, bound=[[-1.0, 1.0], [-0.5, 0.5], [-1.0, 1.0]])
+    cfg = gc.model_cfg(c["bound"], c["base_cell"], c["scale"], c["n_levels"], c["fdim"], c["hidden"])
+    atlas = GridAtlas(cfg, device="cpu")
+    dec = {k: T(v) for k, v in gc.make_decoder(c).items()}
+    rs = np.random.RandomState(17)
+    for s_ in range(2):
+        atlas.add_submap(torch.tensor(c["bound"], dtype=torch.float32), T(gc.rodrigues([0.0, 0.1 * s_, 0.0]).astype(np.float32)),
+                         torch.tensor([[0.9 * s_], [0.0], [0.1 * s_]]), num_poses=2)
+        atlas.add_kf(torch.eye(3), torch.zeros(3, 1))
+        atlas.add_kf(T(gc.rodrigues([0.05, 0.0, 0.1]).astype(np.float32)), torch.tensor([[0.1], [0.05], [0.0]]))
+        sub = atlas.get_submap(s_)
+        with torch.no_grad():
+            for f in sub.features:
+                f.feature.copy_(T((rs.standard_normal(tuple(f.feature.shape)) * 0.1).astype(np.float32)))
+        sub.decoder.load_state_dict(dec)
+        atlas.set_submap_pose_correction(s_, T(rs.uniform(-0.05, 0.05, (1, 3)).astype(np.float32)),
+                                         T(rs.uniform(-0.1, 0.1, (3, 1)).astype(np.float32)))
+    torch.save(atlas, os.path.join(gc.GOLDEN_DIR, "ref_atlas.pth"))
+    xw = T(rs.uniform(-1.0, 1.8, (300, 3)).astype(np.float32))
+    out["atlas_x"] = xw.numpy()
+    out["atlas_forward"] = atlas(xw).detach().numpy()
+    out["atlas_query_feature"] = atlas.query_feature(xw).detach().numpy()
+    R1, t1 = atlas.updated_kf_pose_in_world(3)
+    out["atlas_kf3_R"], out["atlas_kf3_t"] = R1.detach().numpy(), t1.detach().numpy()
+    out["atlas_anchor"] = np.array([atlas.anchor_kf_for_submap(0), atlas.anchor_kf_for_submap(1)])
+    np.savez_compressed(gc.golden_path("formats"), **out)
+    print("[formats] ok", {k: v.shape for k, v in out.items()}, os.path.getsize(os.path.join(gc.GOLDEN_DIR, "ref_atlas.pth")),
+          os.path.getsize(os.path.join(gc.GOLDEN_DIR, "ref_checkpoint.pt")))
+
+
 def main():
     import_reference()
     import golden_cases as gc
@@ -633,7 +737,7 @@ def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
-    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra"]
+    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra", "geometry", "formats"]
     for name in which:
         if name in gc.CASES:
             gen_encode_decode(name, GridNet, rloss, gc)
@@ -649,6 +753,10 @@ def main():
             gen_so3(rgeom, gc)
         elif name == "samples":
             gen_samples(gc)
+        elif name == "geometry":
+            gen_geometry(rgeom, gc)
+        elif name == "formats":
+            gen_formats(GridNet, GridAtlas, rloss, rtrainer, gc)
         elif name == "extra":
             gen_extra(GridNet, GridAtlas, miso, rtrainer, gc)
 
