@@ -1,11 +1,12 @@
 """Convenience API: initialise and optimise a GridNet / GridAtlas with the iSDF loss
-(reference: grid_opt/local_opt.py).  The learned-encoder initialisation is out of scope
-(needs pretrained encoder weights that are not shipped); 'zero' and 'randn' are kept."""
+(reference: grid_opt/local_opt.py).  Initialisation modes: 'zero', 'randn', and 'encode' -- the learned
+initialisation through models.encoder.Encoder (upstream's pretrained predictor weights are not shipped; any
+FeaturePrediction state dict with upstream's keys loads)."""
 from copy import deepcopy
 
 import torch
 from torch.utils.data import DataLoader, Dataset
-from miso_amd.grid_opt.utils.utils import collate_batch_of_one
+from miso_amd.grid_opt.utils.utils import PerfTimer, collate_batch_of_one
 
 from .configs import cfg_loss
 from .models.grid_atlas import GridAtlas
@@ -22,7 +23,22 @@ def initialize_grid_net(grid: GridNet, init_mode='encode', encoder=None, encoder
     elif init_mode == 'randn':
         grid.randn_features(std=1e-4)
     else:
-        raise NotImplementedError("encoder-based initialisation is outside the MI355X hot path")
+        assert encoder is not None and encoder_observation is not None
+        if encoder_stop_level is None:
+            encoder_stop_level = grid.num_levels
+        grid.zero_features()
+        model_id = encoder.register_grid_model(grid)
+        timer = PerfTimer(activate=True)
+        timer.reset()
+        corrections = encoder.predict_corrections_until_level(model_id=model_id, stop_level=encoder_stop_level,
+                                                              observation=encoder_observation, pred_std=0,
+                                                              store_corrections=False)
+        _, gpu_time = timer.check()
+        with torch.no_grad():
+            for level in range(grid.num_levels):
+                assert grid.features[level].feature.shape == corrections[level].shape
+                grid.features[level].feature.copy_(corrections[level])
+        info['total_encoder_time'] = gpu_time
     return grid, info
 
 

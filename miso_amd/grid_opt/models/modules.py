@@ -53,3 +53,89 @@ class MLPNet(nn.Module):
             pack = ops.DecoderPack(ws, bs)
             self.__dict__['_pack'] = pack   # not a module attribute: stays out of state_dict / pickles
         return pack
+
+
+# --------------------------------------------------------------------------- #
+# Learned initialisation: the per-level feature predictor
+# --------------------------------------------------------------------------- #
+class ConvInterp(nn.Module):
+    """A few 3x3x3 convolutions (+ReLU, optional max-pool after each) whose output volume is resampled to a
+    requested spatial size: trilinear when growing, area-averaged when shrinking (reference modules.py:107-181).
+    The convolutions are plain library calls (MIOpen) -- they see one small residual volume per level."""
+
+    def __init__(self, dim, in_channels, base_channels=4, hidden_layers=2, kernel_size=3, padding=1,
+                 reduction_factor=2, dtype=torch.float32, device='cuda:0', name='ConvInterp'):
+        super().__init__()
+        if dim != 3:
+            raise ValueError("only the 3-D variant is on the MISO path (2-D grids are unused by every config)")
+        self.name, self.d = name, dim
+        self.pool = nn.MaxPool3d(kernel_size=reduction_factor, stride=reduction_factor) if reduction_factor > 1 else None
+        self.conv_layers = nn.ModuleList()
+        width = in_channels
+        for i in range(hidden_layers):
+            out = base_channels * (2 ** i)
+            self.conv_layers.append(nn.Conv3d(width, out, kernel_size=kernel_size, stride=1, padding=padding,
+                                              dtype=dtype, device=device))
+            width = out
+        self.output_channels = width
+
+    def forward(self, x):
+        for conv in self.conv_layers:
+            x = torch.relu(conv(x))
+            if self.pool is not None:
+                x = self.pool(x)
+        return x
+
+    def forward_and_interpolate(self, x, output_spatial_size):
+        x = self.forward(x)
+        have, want = tuple(x.shape[2:]), tuple(int(v) for v in output_spatial_size)
+        if all(h <= w for h, w in zip(have, want)):
+            return nn.functional.interpolate(x, size=want, mode='trilinear', align_corners=False)
+        if all(h > w for h, w in zip(have, want)):
+            return nn.functional.interpolate(x, size=want, mode='area')
+        raise ValueError(f"Invalid input and output size! input_size={have}, output_size={want}. ")
+
+
+class FeaturePrediction(nn.Module):
+    """Per-voxel features of one grid level from pooled residual volumes (and optionally coarser features): two
+    ConvInterp towers resampled to the level's shape, concatenated per voxel, then a 2x16 MLP with bias
+    (reference modules.py:235-319).  State-dict keys as upstream: ``residual_processor.conv_layers.*``,
+    ``feature_processor.conv_layers.*``, ``mlp.network.*``."""
+
+    def __init__(self, d, fdim, rdim=1, feature_processor=True, residual_processor=True, normalize_output=False,
+                 device='cuda:0', initial_param_std=None):
+        super().__init__()
+        self.d = d
+        width = 0
+        self.feature_processor = self.residual_processor = None
+        if feature_processor:
+            self.feature_processor = ConvInterp(d, fdim, reduction_factor=1, hidden_layers=2, device=device,
+                                                name=f'feature_proc_{d}D')
+            width += self.feature_processor.output_channels
+        if residual_processor:
+            self.residual_processor = ConvInterp(d, rdim, reduction_factor=1, hidden_layers=2, device=device,
+                                                 name=f'residual_proc_{d}D')
+            width += self.residual_processor.output_channels
+        self.mlp = MLPNet(input_dim=width, output_dim=fdim, hidden_dim=16, hidden_layers=2, bias=True).to(device)
+        self.normalize_output = normalize_output
+        if initial_param_std is not None:
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.normal_(m.weight, std=initial_param_std)
+                    nn.init.normal_(m.bias, std=initial_param_std)
+
+    def predict(self, coarse_features, coarse_residuals, output_spatial_size):
+        """(1, fdim, *size): coarse_features (1,fdim,..) or None, coarse_residuals (1,rdim,..) or None."""
+        if self.d != 3:
+            raise ValueError(f"Invalid dimension: {self.d}!")
+        towers = []
+        for proc, vol in ((self.feature_processor, coarse_features), (self.residual_processor, coarse_residuals)):
+            if proc is not None:
+                towers.append(proc.forward_and_interpolate(vol, output_spatial_size)[0])        # (C, H, W, D)
+        assert towers, "Input to MLP is empty! "
+        per_voxel = torch.cat(towers, dim=0).flatten(1).T                                       # (H*W*D, C)
+        out = self.mlp(per_voxel)
+        if self.normalize_output:
+            out = out / (out.norm(dim=-1, keepdim=True) + 1e-8)          # utils.normalize_last_dim
+        size = tuple(int(v) for v in output_spatial_size)
+        return out.T.reshape(1, -1, *size)

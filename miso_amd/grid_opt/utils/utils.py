@@ -12,6 +12,11 @@ from miso_amd import ops
 logger = logging.getLogger(__name__)
 
 
+def normalize_last_dim(A: torch.Tensor, epsilon=1e-8):
+    """Rows scaled to unit length, A / (|A| + eps) (reference utils.py:16-19)."""
+    return A / (torch.norm(A, dim=-1, keepdim=True) + epsilon)
+
+
 def _bounds_for(queries: torch.Tensor, bounds: torch.Tensor):
     d = bounds.shape[0]
     assert queries.shape[-1] == d

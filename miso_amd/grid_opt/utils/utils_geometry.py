@@ -92,7 +92,7 @@ def get_pose_correction(R, t, Rnew, tnew):
 
 
 def _unit_rows(v):
-    return v / v.norm(dim=-1, keepdim=True)
+    return v / (v.norm(dim=-1, keepdim=True) + 1e-8)          # utils.normalize_last_dim
 
 
 def uniform_translations(k, bound):

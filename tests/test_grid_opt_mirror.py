@@ -575,3 +575,76 @@ def test_files_written_by_the_reference_load(device_backend, tmp_path):
     torch.save(atlas, tmp_path / "again.pth")
     again = torch.load(tmp_path / "again.pth", weights_only=False)
     close(again(xw), T(g["atlas_forward"]), 0, 1e-5)
+
+
+def test_encoder_initialisation_matches_reference(device_backend):
+    """residual pooling -> FeaturePrediction (3-D convs, trilinear resampling, per-voxel MLP) ->
+    per-level corrections, coarse to fine; the pre-training loss with its gradient to one level's predictor; and
+    local_opt.initialize_grid_net(init_mode='encode') -- against the reference run with the same seeded predictor
+    weights (tests/golden/encoder.npz; the weights travel as plain state-dict arrays)."""
+    import miso_amd.grid_opt.local_opt as LO
+    from miso_amd.grid_opt.models.encoder import Encoder, EncoderObservation, EncoderPretrainLoss
+    dev = device_backend
+    g = G("encoder")
+    case = gc.CASES["small"]
+    cfg = {"device": dev, "model": gc.model_cfg(case["bound"], case["base_cell"], case["scale"], case["n_levels"],
+                                                case["fdim"], case["hidden"])}
+
+    def make_encoder():
+        enc = Encoder(cfg).to(dev)
+        for l in range(2):
+            sd = {k[len(f"enc{l}."):]: T(g[k]) for k in g.files if k.startswith(f"enc{l}.")}
+            assert set(sd) == set(enc.feature_encoders[l].state_dict())          # upstream's keys
+            enc.feature_encoders[l].load_state_dict(sd)
+        return enc
+
+    enc = make_encoder()
+    assert not any(p.requires_grad for p in enc.feature_encoders.parameters())
+    net = make_gridnet(case, dev)
+    pts = gc.make_points(case)
+    n = pts.shape[0]
+    sdf_t, valid, sign, _ = gc.make_targets(case, n)
+    obs = EncoderObservation(coords_world=T(pts).to(dev), gt_sdf=T(sdf_t).to(dev), gt_sdf_sign=T(sign).to(dev),
+                             gt_sdf_valid=T(valid).to(dev))
+    mid = enc.register_grid_model(net)
+    assert mid == 0 and enc.correction_key(0, 1) == "gridnet0_correction_level1"
+    res = enc.compute_residuals(mid, [torch.zeros_like(f.feature) for f in net.features], obs)
+    for k in ("sdf_constraint", "fs_constraint", "fs_upper_constraint", "fs_lower_constraint"):
+        close(res[k], T(g[f"res_{k}"]), 0, 2e-6)
+    close(enc.compute_encoder_inputs_from_residuals(res, mid, 1), T(g["enc_inputs_l1"]), 0, 2e-6)
+    corr = enc.predict_corrections_until_level(mid, 2, obs, pred_std=0, store_corrections=True)
+    for l in range(2):
+        close(corr[l], T(g[f"corr{l}"]), 0, 2e-5)
+        close(enc.get_grid_correction(mid, l), T(g[f"corr{l}"]), 0, 2e-5)
+    assert float(enc.stored_corrections_until_level(mid, 1)[1].abs().sum()) == float(g["stored_until1_l1_abs"])
+    assert "encoder_inputs_model0_level1" in enc.intermediate_results
+
+    enc.lock_all_params()
+    enc.unlock_encoder_at_level(1)
+    lossf = EncoderPretrainLoss(target_level=1, sdf_weight=3e3, sign_weight=10.0, pred_std=0.0)
+    net2 = make_gridnet(case, dev, num_poses=2)
+    mid2 = enc.register_grid_model(net2)
+    spans = np.array([[0, n // 2], [n // 2, n]], dtype=np.int64)
+    mi = {"dataset_index": torch.tensor([mid2]), "coords_frame": T(pts)[None].to(dev), "frame_indices": T(spans)[None],
+          "R_world_frame": torch.eye(3).repeat(2, 1, 1)[None].to(dev), "t_world_frame": torch.zeros(1, 2, 3, 1, device=dev)}
+    gt = {"sdf": T(sdf_t)[None].to(dev), "sdf_valid": T(valid)[None].to(dev), "sdf_signs": T(sign)[None].to(dev)}
+    ld = lossf.compute(enc, mi, gt)
+    assert set(ld) == {"sdf", "free_space"}
+    assert abs(ld["sdf"].item() - float(g["pretrain_sdf"])) <= 2e-4 * float(g["pretrain_sdf"])
+    assert abs(ld["free_space"].item() - float(g["pretrain_fs"])) <= 2e-4 * float(g["pretrain_fs"])
+    sum(ld.values()).backward()
+    for k, p in enc.feature_encoders[1].named_parameters():
+        close(p.grad, T(g[f"pretrain_grad.{k}"]), 2e-3, 1e-4)
+    assert all(p.grad is None for p in enc.feature_encoders[0].parameters())
+
+    enc3 = make_encoder()
+    net3 = make_gridnet(case, dev)
+    net3b, info = LO.initialize_grid_net(net3, "encode", enc3, obs)
+    assert net3b is net3 and set(info) == {"total_encoder_time"}
+    for l in range(2):
+        close(net3.features[l].feature, T(g[f"init_feat{l}"]), 0, 2e-5)
+    # the other two modes
+    LO.initialize_grid_net(net3, "zero")
+    assert all(float(f.feature.detach().abs().sum()) == 0.0 for f in net3.features)
+    LO.initialize_grid_net(net3, "randn")
+    assert all(0 < float(f.feature.detach().std()) < 1e-3 for f in net3.features)

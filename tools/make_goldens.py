@@ -721,6 +721,79 @@ def gen_formats(GridNet, GridAtlas, rloss, rtrainer, gc):
           os.path.getsize(os.path.join(gc.GOLDEN_DIR, "ref_checkpoint.pt")))
 
 
+def gen_encoder(GridNet, gc):
+    """Learned initialisation (grid_opt/models/encoder.py, modules.FeaturePrediction, local_opt.initialize_grid_net)
+    with seeded random predictor weights (upstream's pretrained ones are not shipped).  Harness patch: the reference's
+    query goes through the CUDA extension module `cuda_gridsample` (utils.py:116-118), absent here; its first-order
+    semantics are F.grid_sample's (cuda_gridsample.py:84), which stands in -- the eikonal / smoothness terms that need
+    the second order stay off."""
+    import types
+    import torch.nn.functional as F
+    cu = types.ModuleType("cuda_gridsample")
+    cu.grid_sample_3d = lambda input, grid, padding_mode="zeros", align_corners=True: F.grid_sample(
+        input, grid, padding_mode=padding_mode, align_corners=align_corners)
+    sys.modules["cuda_gridsample"] = cu
+    import grid_opt.models.encoder as renc
+    import grid_opt.models.modules as rmod
+    import grid_opt.local_opt as rlocal
+    # harness patch: ConvInterp builds its convolutions on 'cuda:0' by default before FeaturePrediction moves them
+    d = list(rmod.ConvInterp.__init__.__defaults__)
+    rmod.ConvInterp.__init__.__defaults__ = tuple("cpu" if v == "cuda:0" else v for v in d)
+    case = dict(gc.CASES["small"])
+    cfg = {"device": "cpu", "model": gc.model_cfg(case["bound"], case["base_cell"], case["scale"], case["n_levels"],
+                                                  case["fdim"], case["hidden"])}
+    torch.manual_seed(5)
+    enc = renc.Encoder(cfg)
+    out = {}
+    for l, fe in enumerate(enc.feature_encoders):
+        for k, v in fe.state_dict().items():
+            out[f"enc{l}.{k}"] = v.numpy().copy()
+    net = build_gridnet(GridNet, gc, case, num_poses=1, optimize_pose=False)
+    pts = gc.make_points(case)
+    n = pts.shape[0]
+    sdf_t, valid, sign, _ = gc.make_targets(case, n)
+    obs = renc.EncoderObservation(coords_world=T(pts), gt_sdf=T(sdf_t), gt_sdf_sign=T(sign), gt_sdf_valid=T(valid))
+    mid = enc.register_grid_model(net)
+    res = enc.compute_residuals(mid, [torch.zeros_like(f.feature) for f in net.features], obs)
+    for k in ("sdf_constraint", "fs_constraint", "fs_upper_constraint", "fs_lower_constraint"):
+        out[f"res_{k}"] = res[k].detach().numpy()
+    out["enc_inputs_l1"] = enc.compute_encoder_inputs_from_residuals(res, mid, 1).detach().numpy()
+    corr = enc.predict_corrections_until_level(mid, 2, obs, pred_std=0, store_corrections=True)
+    for l, c in enumerate(corr):
+        out[f"corr{l}"] = c.detach().numpy()
+    out["stored_until1_l1_abs"] = np.float64(enc.stored_corrections_until_level(mid, 1)[1].abs().sum().item())
+    # pre-training loss of level 1 and its gradient to that level's predictor
+    enc.lock_all_params()
+    enc.unlock_encoder_at_level(1)
+    lossf = renc.EncoderPretrainLoss(target_level=1, sdf_weight=3e3, sign_weight=10.0, pred_std=0.0)
+    F_ = 2
+    spans = np.array([[0, n // 2], [n // 2, n]], dtype=np.int64)
+    mi = {"dataset_index": torch.tensor([mid]), "coords_frame": T(pts)[None], "frame_indices": T(spans)[None],
+          "R_world_frame": torch.eye(3).repeat(F_, 1, 1)[None], "t_world_frame": torch.zeros(1, F_, 3, 1)}
+    g = {"sdf": T(sdf_t)[None], "sdf_valid": T(valid)[None], "sdf_signs": T(sign)[None]}
+    # the grid under test needs 2 pose slots for the 2 frames
+    net2 = build_gridnet(GridNet, gc, case, num_poses=2, optimize_pose=False)
+    mid2 = enc.register_grid_model(net2)
+    mi["dataset_index"] = torch.tensor([mid2])
+    ld = lossf.compute(enc, mi, g)
+    total = sum(v for v in ld.values())
+    total.backward()
+    out["pretrain_sdf"], out["pretrain_fs"] = np.float64(ld["sdf"].item()), np.float64(ld["free_space"].item())
+    for k, p in enc.feature_encoders[1].named_parameters():
+        out[f"pretrain_grad.{k}"] = p.grad.numpy().copy()
+    # local_opt.initialize_grid_net(init_mode='encode')
+    enc3 = renc.Encoder(cfg)
+    for l in range(2):
+        enc3.feature_encoders[l].load_state_dict(enc.feature_encoders[l].state_dict())
+    net3 = build_gridnet(GridNet, gc, case, num_poses=1, optimize_pose=False)
+    net3, info = rlocal.initialize_grid_net(net3, "encode", enc3, obs)
+    for l in range(2):
+        out[f"init_feat{l}"] = net3.features[l].feature.detach().numpy().copy()
+    assert set(info) == {"total_encoder_time"}
+    np.savez_compressed(gc.golden_path("encoder"), **out)
+    print("[encoder] ok", {k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
+
+
 def main():
     import_reference()
     import golden_cases as gc
@@ -737,7 +810,7 @@ def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
-    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra", "geometry", "formats"]
+    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra", "geometry", "formats", "encoder"]
     for name in which:
         if name in gc.CASES:
             gen_encode_decode(name, GridNet, rloss, gc)
@@ -757,6 +830,8 @@ def main():
             gen_geometry(rgeom, gc)
         elif name == "formats":
             gen_formats(GridNet, GridAtlas, rloss, rtrainer, gc)
+        elif name == "encoder":
+            gen_encoder(GridNet, gc)
         elif name == "extra":
             gen_extra(GridNet, GridAtlas, miso, rtrainer, gc)
 
