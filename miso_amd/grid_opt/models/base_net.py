@@ -14,6 +14,15 @@ class BaseNet(nn.Module):
         self.bound = torch.tensor(cfg['grid']['bound'], device=device, dtype=dtype)
         assert self.bound.shape == (self.d, 2)
 
+    def _apply(self, fn, *args, **kwargs):
+        """``.to()`` / ``.cuda()`` also move the bound, a plain tensor attribute (upstream leaves it on the device
+        the model was built on)."""
+        out = super()._apply(fn, *args, **kwargs)
+        self.bound = fn(self.bound)
+        if isinstance(self.device, (str, torch.device)):
+            self.device = self.bound.device
+        return out
+
     def forward(self, x: torch.Tensor):
         raise NotImplementedError
 

@@ -162,6 +162,16 @@ class GridAtlas(BaseNet):
         assert 0 <= submap_id < self.num_submaps
         return self.submaps[submap_id]
 
+    def _apply(self, fn, *args, **kwargs):
+        """``.to()`` / ``.cuda()`` also move the submap base poses, which live in plain lists (upstream leaves
+        them behind, so an atlas pickled from one device cannot be used on another)."""
+        out = super()._apply(fn, *args, **kwargs)
+        self.R_world_submap_list = [fn(R) for R in self.R_world_submap_list]
+        self.t_world_submap_list = [fn(t) for t in self.t_world_submap_list]
+        if self.R_world_submap_list:
+            self.device = self.R_world_submap_list[0].device
+        return out
+
     # ---- poses -------------------------------------------------------------------------------
     def initial_submap_pose(self, submap_id: int) -> Tuple[Tensor, Tensor]:
         return self.R_world_submap_list[submap_id], self.t_world_submap_list[submap_id]

@@ -21,6 +21,11 @@ class FeatureGridBase(torch.nn.Module):
         self.d, self.fdim, self.bound = d, fdim, bound
         self.cell_size, self.dtype, self.name = cell_size, dtype, name
 
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.bound = fn(self.bound)          # plain tensor attribute: follows the module across devices
+        return out
+
     def interpolate(self, x):
         raise NotImplementedError
 

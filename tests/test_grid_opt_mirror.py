@@ -563,7 +563,6 @@ def test_files_written_by_the_reference_load(device_backend, tmp_path):
     atlas = torch.load(os.path.join(gc.GOLDEN_DIR, "ref_atlas.pth"), weights_only=False, map_location="cpu")
     assert type(atlas) is GridAtlas and type(atlas.get_submap(0)) is GridNet
     atlas.to(dev)
-    atlas.device = dev
     xw = T(g["atlas_x"]).to(dev)
     close(atlas(xw), T(g["atlas_forward"]), 0, 1e-5)
     close(atlas.query_feature(xw), T(g["atlas_query_feature"]), 0, 2e-6)
