@@ -33,7 +33,7 @@ __device__ __attribute__((aligned(16))) const int8_t kMcTable[256][16] = {
 #include "mc_table.inc"
 };
 
-constexpr int MC_SIGN_WORDS = 8;   // sign words per wave of mc_signs_kernel
+constexpr int MC_SIGN_WORDS = 4;   // independent loads per lane in flight in mc_signs_kernel
 
 struct McDims {
   int32_t nx, ny, nz;
@@ -62,24 +62,24 @@ __host__ __device__ inline McWorkspace mc_carve(void* base, const McDims& d) {
 __global__ __launch_bounds__(256) void mc_signs_kernel(const float* __restrict__ u, McDims d, float iso,
                                                        uint64_t* __restrict__ signs, int32_t* __restrict__ counts) {
   const int lane = threadIdx.x & 63;
-  const int64_t n_words = (int64_t)d.n_rows * d.n_chunks;
-  if (blockIdx.x == 0 && threadIdx.x < 2) counts[4 * n_words + threadIdx.x] = 0;   // the work-list lengths
-  const int64_t w0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * MC_SIGN_WORDS;
-  bool below[MC_SIGN_WORDS];
+  if (blockIdx.x == 0 && threadIdx.x < 2) counts[4 * d.n_rows * d.n_chunks + threadIdx.x] = 0;   // work-list lengths
+  // one wave per sample row: no index divisions, MC_SIGN_WORDS independent 256-byte loads in flight per wave
+  const int32_t row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (row >= d.n_rows) return;
+  const float* __restrict__ src = u + (int64_t)row * d.nz;
+  uint64_t* __restrict__ dst = signs + (int64_t)row * d.n_chunks;
+  for (int c0 = 0; c0 < d.n_chunks; c0 += MC_SIGN_WORDS) {
+    bool below[MC_SIGN_WORDS];
 #pragma unroll
-  for (int k = 0; k < MC_SIGN_WORDS; ++k) {
-    const int64_t w = w0 + k;
-    below[k] = false;
-    if (w < n_words) {
-      const int64_t row = w / d.n_chunks;
-      const int32_t z = (int32_t)(w - row * d.n_chunks) * 64 + lane;
-      if (z < d.nz) below[k] = u[row * d.nz + z] < iso;
+    for (int k = 0; k < MC_SIGN_WORDS; ++k) {
+      const int32_t z = (c0 + k) * 64 + lane;
+      below[k] = z < d.nz && src[z] < iso;
     }
-  }
 #pragma unroll
-  for (int k = 0; k < MC_SIGN_WORDS; ++k) {
-    const uint64_t word = __ballot(below[k]);
-    if (lane == 0 && w0 + k < n_words) signs[w0 + k] = word;
+    for (int k = 0; k < MC_SIGN_WORDS; ++k) {
+      const uint64_t word = __ballot(below[k]);
+      if (lane == 0 && c0 + k < d.n_chunks) dst[c0 + k] = word;
+    }
   }
 }
 
@@ -154,13 +154,13 @@ __device__ __forceinline__ void mc_append(bool active, int32_t* __restrict__ len
 __global__ __launch_bounds__(256) void mc_edges_kernel(McDims d, McWorkspace ws, int32_t* __restrict__ counts) {
   __shared__ __attribute__((aligned(16))) int8_t tab[256][16];
   mc_stage_table(tab);
-  const int64_t n_words = (int64_t)d.n_rows * d.n_chunks;
-  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t n_words = d.n_rows * d.n_chunks;          // < 2^31 / 64
+  const int32_t w = blockIdx.x * 256 + threadIdx.x;
   int n_tri = 0;
   bool any_vertex = false;
   if (w < n_words) {
-    const int32_t row = (int32_t)(w / d.n_chunks);
-    const int ch = (int)(w - (int64_t)row * d.n_chunks);
+    const int32_t row = w / d.n_chunks;
+    const int ch = w - row * d.n_chunks;
     const int32_t x = row / d.ny, y = row - x * d.ny;
     const bool hx = x + 1 < d.nx, hy = y + 1 < d.ny;
     const McCellWords c = mc_cell_words(d, ws.signs, row, hx, hy, ch);
@@ -182,12 +182,12 @@ __global__ __launch_bounds__(256) void mc_edges_kernel(McDims d, McWorkspace ws,
     counts[v] = __popcll(wx);
     counts[v + d.n_chunks] = __popcll(wy);
     counts[v + 2 * d.n_chunks] = __popcll(wz);
-    counts[3 * n_words + w] = n_tri;
+    counts[3 * (int64_t)n_words + w] = n_tri;
     any_vertex = (wx | wy | wz) != 0ull;
   }
   __shared__ int32_t slot[4];
-  mc_append(n_tri > 0, counts + 4 * n_words, ws.tri_list, (int32_t)w, slot);
-  mc_append(any_vertex, counts + 4 * n_words + 1, ws.vert_list, (int32_t)w, slot + 2);
+  mc_append(n_tri > 0, counts + 4 * (int64_t)n_words, ws.tri_list, w, slot);
+  mc_append(any_vertex, counts + 4 * (int64_t)n_words + 1, ws.vert_list, w, slot + 2);
 }
 
 // index of the vertex on the edge out of sample (row, z) along `axis`
@@ -304,8 +304,7 @@ hipError_t launch_mc_classify(const float* u, int32_t nx, int32_t ny, int32_t nz
   const McDims d = make_dims(nx, ny, nz);
   const McWorkspace ws = mc_carve(workspace, d);
   const int64_t n_words = mc_words(nx, ny, nz);
-  const int64_t per_block = 4 * MC_SIGN_WORDS;
-  mc_signs_kernel<<<(uint32_t)((n_words + per_block - 1) / per_block), 256, 0, s>>>(u, d, iso, ws.signs, counts);
+  mc_signs_kernel<<<(uint32_t)((d.n_rows + 3) / 4), 256, 0, s>>>(u, d, iso, ws.signs, counts);
   mc_edges_kernel<<<(uint32_t)((n_words + 255) / 256), 256, 0, s>>>(d, ws, counts);
   return hipGetLastError();
 }
