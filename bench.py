@@ -97,9 +97,20 @@ def cpu_baseline(data, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s or k >= 12:
             break
     dt = (time.perf_counter() - t0) / k
+    # the same on ONE thread: ATen's 3-D grid_sample is serial for batch size 1, so the figure
+    # barely moves with the core count
+    torch.set_num_threads(1)
+    try:
+        t1 = time.perf_counter()
+        it()
+        it()
+        dt1 = (time.perf_counter() - t1) / 2
+    finally:
+        torch.set_num_threads(cores)
     return {"value": N_POINTS / dt, "unit": "point-samples/s", "cores": cores, "kind": "port",
             "sample": f"{k} full fwd+bwd iterations of 262144 points (stock torch CPU ops arranged as "
-                      f"the reference: F.grid_sample per level, cat, nn.Sequential, L1), {dt:.2f} s each"}, pred
+                      f"the reference: F.grid_sample per level, cat, nn.Sequential, L1), {dt:.2f} s each",
+            "one_thread_value": N_POINTS / dt1}, pred
 
 
 def extras(step, dev):
