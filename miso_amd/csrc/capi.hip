@@ -52,6 +52,8 @@ hipError_t launch_mapping_loss(int, float, float, float, const float*, const flo
 
 using namespace miso;
 
+static uint32_t plan_dense(const GridK& g, int T, int64_t n, uint32_t pull);
+
 namespace {
 
 // which pointer of a level a call needs
@@ -289,6 +291,8 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   uint32_t pull = 0;
   if (sorted && sorted->xn_sorted && workspace && want_grid && ((uintptr_t)workspace & 15u) == 0)
     pull = plan_grad_pull(g, sorted->tiles_per_axis);
+  const uint32_t dense = (pull && sorted) ? plan_dense(g, sorted->tiles_per_axis, n, pull) : 0u;
+  pull &= ~dense;
   hipStream_t st = (hipStream_t)stream;
   if (overwrite) {
     // levels that are still scattered with atomics start from zero; pulled levels need no fill
@@ -304,7 +308,7 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   if (n == 0 && !pull) return MISO_OK;
   if (n > 0) {
     rc = (int)launch_sdf_bwd(C, L, H, NH, gp, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
-                             pull ? workspace : nullptr, pull,
+                             pull ? workspace : nullptr, pull | (dense << 16),
                              sorted && (grid->flags & MISO_F_GRAD_SDF_SORTED), st);
     if (rc) return rc;
   }
@@ -394,6 +398,21 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
 }
 
 // levels (with a gradient requested) the owner-computes pull covers for this grid
+// Coarse levels under a crowd: a tile owns at most 3 vertices per axis and holds on average >= MISO_DENSE_MIN
+// points (default 100).  The pull would cut such tiles into atomic slices, each sweeping 27 tiles; the fused
+// backward walks the chunk's vertex box instead (sdf_fused.hip, "dense wave scatter").  Subset of `pull`.
+static uint32_t plan_dense(const GridK& g, int T, int64_t n, uint32_t pull) {
+  static const int dense_min = [] { const char* e = getenv("MISO_DENSE_MIN"); return e ? atoi(e) : 100; }();
+  uint32_t dense = 0;
+  if (dense_min <= 0 || n < (int64_t)dense_min * T * T * T) return 0;
+  for (int l = 0; l < g.n_levels && l < 16; ++l) {
+    const LevelK& lv = g.lv[l];
+    if (((pull >> l) & 1u) && (lv.X + T - 1) / T <= 3 && (lv.Y + T - 1) / T <= 3 && (lv.Z + T - 1) / T <= 3)
+      dense |= 1u << l;
+  }
+  return dense;
+}
+
 static int pull_plan(const miso_grid_t* grid, int32_t tiles_per_axis, GridK* g, int* C, uint32_t* mask) {
   bool v4;
   int rc = convert_grid(grid, g, false, &v4);
@@ -406,6 +425,12 @@ static int pull_plan(const miso_grid_t* grid, int32_t tiles_per_axis, GridK* g, 
     if (g->lv[l].C != *C) return MISO_OK;
   *mask = plan_grad_pull(*g, tiles_per_axis);
   return MISO_OK;
+}
+
+uint32_t miso_sdf_bwd_dense_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n) {
+  GridK g; int C; uint32_t mask;
+  if (pull_plan(grid, tiles_per_axis, &g, &C, &mask)) return 0;
+  return plan_dense(g, tiles_per_axis, n, mask);
 }
 
 uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis) {

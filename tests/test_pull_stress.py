@@ -156,3 +156,41 @@ def test_heavy_tiles_are_cut_and_summed_exactly(shape, monkeypatch):
     for a, w, c in zip(g_split, g_whole, g_atomic):
         assert relerr(a, w) < 2e-5
         assert relerr(a, c) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_dense_wave_scatter_matches_pull_and_atomics(seed, monkeypatch):
+    """the dense wave scatter of coarse levels (forced on with MISO_DENSE_MIN=1 before the library
+    reads the knob is not possible in-process, so the crowd is real): a batch that averages >= 100 points per tile
+    on a two-level ScanNet-like grid takes the dense path for the coarse level; its gradients equal the unsorted
+    atomic path's to fp32 summation-order tolerance."""
+    from miso_amd import ops
+    torch.manual_seed(seed)
+    dev = "cuda:0"
+    C, H = 4, 64
+    sizes = [(8, 5, 8), (40, 25, 40)]                     # (X, Y, Z): coarse bricks <= 3 per axis at 16^3 tiles
+    feats = [(torch.randn(1, C, z, y, x, device=dev) * 1e-2).contiguous(memory_format=torch.channels_last_3d)
+             for (x, y, z) in sizes]
+    meta = ops.GridMeta.from_bound([[-2.0, 2.0], [-1.0, 1.5], [-2.0, 2.0]])
+    lin = [torch.nn.Linear(2 * C, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.data.to(dev) for l in lin], [l.bias.data.to(dev) for l in lin])
+    n = 100 * 4096 + 777                                  # >= 100 per tile on average
+    x = torch.rand(n, 3, device=dev) * torch.tensor([1.6, 0.9, 1.2], device=dev) + torch.tensor([-0.9, -0.2, 0.1], device=dev)
+    x[:50] = torch.rand(50, 3, device=dev) * 8 - 4        # some far outside the bound
+    gs = torch.randn(n, 1, device=dev) / n
+    import ctypes
+    from miso_amd import _lib
+    grid = ops._fill_grid(feats, meta, grads=[torch.zeros_like(f) for f in feats])
+    assert _lib.load().miso_sdf_bwd_dense_levels(ctypes.byref(grid), 16, n) == 0b11      # both levels walk densely
+    assert _lib.load().miso_sdf_bwd_dense_levels(ctypes.byref(grid), 16, 64 * 4096) == 0  # a thin batch: the pull
+    sdf, mask = ops.sdf_fwd_raw(x, feats, meta, pack, True)
+    want = [torch.zeros_like(f) for f in feats]
+    ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask, False, [True, True], want)
+    sb = ops.SortedBatch(n, dev).sort(x, meta)
+    _, mask_s = ops.sdf_fwd_raw(x, feats, meta, pack, True, sorted_batch=sb)
+    got = [torch.full_like(f, 7.0) for f in feats]        # overwrite mode must not depend on what was there
+    ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask_s, False, [True, True], got, sorted_batch=sb, overwrite=True)
+    for a, b in zip(got, want):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-12
