@@ -38,6 +38,8 @@
  *   miso_adam_dense / miso_adam_active
  *                     torch.optim.Adam.step on one dense tensor as used by
  *                     grid_opt/trainer.py:196-228 / :410-452.
+ *   miso_rigid_by_index  the per-keyframe frame change of a sample batch (grid_opt/loss.py:763-774 around
+ *                     transform_points_to, grid_opt/utils/utils_geometry.py:214-225).
  *   miso_mc_classify / miso_mc_emit / miso_mc_vertices
  *                     mcubes.marching_cubes as called by extract_geometry, grid_opt/utils/utils_sdf.py:89-101
  *                     (the step after the path: SDF volume -> triangle mesh).
@@ -365,6 +367,15 @@ int miso_sample_rays(const miso_ray_frames_t* frames, const miso_ray_sampling_t*
 int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
                      int64_t numel, double lr, double beta1, double beta2, double eps,
                      int32_t step /* 1-based */, int zero_grad, void* stream);
+
+/* --- per-keyframe rigid map of a sample batch ---------------------------------
+ * y[i] = R[idx[i]] x[i] + t[idx[i]] (transpose = 0) or R[idx[i]]^T x[i] (+ t if given; transpose = 1: the cotangent
+ * of x).  R (n_poses x 9, row-major 3x3), t (n_poses x 3) or NULL, idx (n) int64 clamped into [0, n_poses),
+ * x / y (n x 3), all DEVICE.  Replaces the per-keyframe Python loops of the losses (grid_opt/loss.py:763-774,
+ * grid_opt/loss_isdf.py:52-61, grid_opt/align/miso.py:44-53) around transform_points_to
+ * (grid_opt/utils/utils_geometry.py:214-225). */
+int miso_rigid_by_index(const float* R, const float* t, const int64_t* idx, const float* x, int64_t n,
+                        int32_t n_poses, int transpose, float* y, void* stream);
 
 /* --- marching cubes on the dense SDF volume ------------------------------------
  * Replaces mcubes.marching_cubes(u, threshold) as called by extract_geometry

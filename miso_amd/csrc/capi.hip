@@ -26,6 +26,8 @@ uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
                             uint32_t, int, const float*, int32_t*, int64_t, hipStream_t);
 int64_t pull_queue_ints(int64_t);
+hipError_t launch_rigid_by_index(const float*, const float*, const int64_t*, const float*, int64_t, int32_t, int, float*,
+                                 hipStream_t);
 int64_t mc_words(int32_t, int32_t, int32_t);
 int64_t mc_workspace_bytes(int32_t, int32_t, int32_t);
 hipError_t launch_mc_classify(const float*, int32_t, int32_t, int32_t, float, void*, int32_t*, hipStream_t);
@@ -579,6 +581,12 @@ int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_s
     return MISO_E_BADARG;
   return (int)launch_adam_active(param, grad, exp_avg, exp_avg_sq, active, numel, lr, beta1, beta2, eps, step,
                                  zero_grad, (hipStream_t)stream);
+}
+
+int miso_rigid_by_index(const float* R, const float* t, const int64_t* idx, const float* x, int64_t n, int32_t n_poses,
+                        int transpose, float* y, void* stream) {
+  if (n < 0 || n_poses < 1 || !R || (n > 0 && (!idx || !x || !y))) return MISO_E_BADARG;
+  return (int)launch_rigid_by_index(R, t, idx, x, n, n_poses, transpose, y, (hipStream_t)stream);
 }
 
 static int mc_check_dims(int32_t nx, int32_t ny, int32_t nz) {

@@ -1,0 +1,52 @@
+// Per-keyframe rigid map of a sample batch: y_i = R[idx_i] x_i + t[idx_i]  (or R[idx_i]^T x_i, the cotangent
+// of x).  The reference walks the keyframes in Python -- nonzero, index, matmul, index_put per keyframe, with a
+// host sync each (grid_opt/loss.py:763-774, loss_isdf.py:52-61, align/miso.py:44-53; the map itself is
+// transform_points_to, utils/utils_geometry.py:214-225).  A gather formulation in tensor ops moves an (N,3,3)
+// temporary through HBM three times; here it is one pass: 8 B of index + 12 B in + 12 B out per row, the K
+// poses (K <= a few hundred) come from L1/L2.
+#include "common.hpp"
+
+namespace miso {
+namespace {
+
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void rigid_by_index_kernel(const float* __restrict__ R, const float* __restrict__ t,
+                                                             const int64_t* __restrict__ idx,
+                                                             const float* __restrict__ x, int64_t n, int32_t K,
+                                                             float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int64_t k = idx[i];
+  k = k < 0 ? 0 : (k >= K ? K - 1 : k);           // an index outside [0, K) would read past the pose table
+  const float* r = R + k * 9;
+  const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+  float o[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    // the order of torch's row-times-matrix product: ((a r0) + b r1) + c r2, then the translation
+    const float r0 = TRANSPOSE ? r[j] : r[3 * j], r1 = TRANSPOSE ? r[3 + j] : r[3 * j + 1],
+                r2 = TRANSPOSE ? r[6 + j] : r[3 * j + 2];
+    float s = __fmul_rn(a, r0);
+    s = __fmaf_rn(b, r1, s);
+    s = __fmaf_rn(c, r2, s);
+    o[j] = t ? __fadd_rn(s, t[k * 3 + j]) : s;
+  }
+  y[3 * i] = o[0];
+  y[3 * i + 1] = o[1];
+  y[3 * i + 2] = o[2];
+}
+
+}  // namespace
+
+hipError_t launch_rigid_by_index(const float* R, const float* t, const int64_t* idx, const float* x, int64_t n,
+                                 int32_t K, int transpose, float* y, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (transpose)
+    rigid_by_index_kernel<true><<<blocks, 256, 0, s>>>(R, t, idx, x, n, K, y);
+  else
+    rigid_by_index_kernel<false><<<blocks, 256, 0, s>>>(R, t, idx, x, n, K, y);
+  return hipGetLastError();
+}
+
+}  // namespace miso

@@ -33,6 +33,8 @@ class _RigidByIndex(torch.autograd.Function):
     @staticmethod
     def forward(ctx, R, t, idx, x):
         ctx.save_for_backward(R, idx, x)
+        if x.is_cuda and x.dtype == torch.float32:
+            return ops.rigid_by_index(R, t, idx, x)
         return (R[idx] * x.unsqueeze(1)).sum(dim=2) + t[idx]
 
     @staticmethod
@@ -51,7 +53,10 @@ class _RigidByIndex(torch.autograd.Function):
                 gt += sel.T @ g[lo:hi]
             gR = gR.view(K, 3, 3)
         if ctx.needs_input_grad[3]:
-            gx = (R[idx] * g.unsqueeze(2)).sum(dim=1)                                 # R^T g
+            if g.is_cuda and g.dtype == torch.float32:
+                gx = ops.rigid_by_index(R, None, idx, g, transpose=True)                  # R^T g
+            else:
+                gx = (R[idx] * g.unsqueeze(2)).sum(dim=1)
         return gR, gt, None, gx
 
 

@@ -976,3 +976,19 @@ def marching_cubes(vol: torch.Tensor, iso: float = 0.0) -> Tuple[torch.Tensor, t
     _lib.check(lib.miso_mc_vertices(_ptr(u), nx, ny, nz, float(iso), _ptr(ws), _ptr(offs), vert_chunks, n_vert,
                                     _ptr(verts), st), "miso_mc_vertices")
     return verts, faces
+
+
+def rigid_by_index(R: torch.Tensor, t: Optional[torch.Tensor], idx: torch.Tensor, x: torch.Tensor,
+                   transpose: bool = False) -> torch.Tensor:
+    """y[i] = R[idx[i]] x[i] + t[idx[i]] (or R[idx[i]]^T x[i] with ``transpose``) in one pass (miso_rigid_by_index);
+    R (K,3,3), t (K,3) or None, idx (N,) int64, x (N,3).  No autograd here: grid_opt.loss._RigidByIndex wraps it."""
+    _require_hip(R, t, x)
+    R = R.detach().contiguous()
+    t = None if t is None else t.detach().contiguous()
+    x = x.detach().contiguous()
+    idx = idx.contiguous()
+    assert idx.dtype == torch.int64 and idx.is_cuda and idx.shape == (x.shape[0],) and x.shape[1] == 3
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().miso_rigid_by_index(_ptr(R), _ptr(t), _ptr(idx), _ptr(x), x.shape[0], R.shape[0],
+                                               1 if transpose else 0, _ptr(y), _stream(x)), "miso_rigid_by_index")
+    return y

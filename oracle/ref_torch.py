@@ -251,6 +251,17 @@ def transfrom_points_from(points_dst, R_dst_src, t_dst_src):
     return transform_points_to(points_dst, R_dst_src.T, -R_dst_src.T @ t_dst_src)
 
 
+def transform_by_keyframe_loop(coords_frame, frame_ids, R_all, t_all):
+    """The reference's per-keyframe loop (grid_opt/loss.py:763-774; same shape in loss_isdf.py:52-61 and
+    align/miso.py:44-53): for every keyframe id present, the rows carrying it are mapped by
+    transform_points_to with that keyframe's pose.  R_all (K,3,3), t_all (K,3,1)."""
+    out = coords_frame.clone()
+    for k in torch.unique(frame_ids).tolist():
+        rows = torch.nonzero(frame_ids == k, as_tuple=False).squeeze(1)
+        out[rows] = transform_points_to(coords_frame[rows], R_all[k], t_all[k])
+    return out
+
+
 def coords_in_bound(coords, bound):
     """grid_opt/utils/utils_geometry.py:11-27 -- inclusive box test, (N,1) bool."""
     return ((coords >= bound[:, 0]) & (coords <= bound[:, 1])).all(dim=1).unsqueeze(1)

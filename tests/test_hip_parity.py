@@ -798,3 +798,38 @@ def test_binned_path_ragged_and_empty(n):
     assert torch.equal(sdf, ref_s)
     for a, b in zip(grads, ref_g):
         assert relerr(a, b) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,K", [(0, 1), (1, 1), (777, 5), (100000, 97)])
+def test_rigid_by_index_vs_oracle(n, K):
+    """miso_rigid_by_index against the reference's per-keyframe loop (oracle.transform_by_keyframe_loop), forward,
+    transposed (the cotangent of the points), and through the autograd node the losses use (pose cotangents)."""
+    from miso_amd import ops
+    from miso_amd.grid_opt.loss import rigid_by_index
+    from oracle import ref_torch as R_
+    import golden_cases as gc_
+    rs = np.random.RandomState(n + K)
+    Rm = torch.from_numpy(np.stack([gc_.rodrigues(rs.uniform(-1, 1, 3)) for _ in range(K)]).astype(np.float32))
+    tm = torch.from_numpy(rs.uniform(-5, 5, (K, 3, 1)).astype(np.float32))
+    idx = torch.from_numpy(rs.randint(0, K, size=n).astype(np.int64))
+    x = torch.from_numpy(rs.uniform(-10, 10, (n, 3)).astype(np.float32))
+    want = R_.transform_by_keyframe_loop(x, idx, Rm, tm)
+    got = ops.rigid_by_index(Rm.to(DEV), tm.reshape(K, 3).to(DEV), idx.to(DEV), x.to(DEV))
+    assert got.shape == (n, 3)
+    if n:
+        assert (got.cpu() - want).abs().max().item() <= 4e-6           # |R x + t| <= 22: a couple of ulp
+    gT = ops.rigid_by_index(Rm.to(DEV), None, idx.to(DEV), x.to(DEV), transpose=True)
+    wantT = torch.einsum("nji,nj->ni", Rm[idx], x)
+    if n:
+        assert (gT.cpu() - wantT).abs().max().item() <= 4e-6
+    if n == 0:
+        return
+    # autograd node: cotangents of R, t, x against the loop differentiated by torch on the CPU
+    Rc, tc, xc = Rm.clone().requires_grad_(True), tm.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    w = torch.from_numpy(rs.standard_normal((n, 3)).astype(np.float32))
+    (R_.transform_by_keyframe_loop(xc, idx, Rc, tc) * w).sum().backward()
+    Rg, tg, xg = (Rm.to(DEV).requires_grad_(True), tm.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True))
+    (rigid_by_index(Rg, tg, idx.to(DEV), xg) * w.to(DEV)).sum().backward()
+    for a, b in ((Rg.grad, Rc.grad), (tg.grad, tc.grad), (xg.grad, xc.grad)):
+        assert (a.cpu() - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
