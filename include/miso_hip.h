@@ -362,11 +362,14 @@ int miso_sample_rays(const miso_ray_frames_t* frames, const miso_ray_sampling_t*
  * caller together with the moments): a chunk is stepped if any of its gradients is non-zero or if it
  * has been stepped before (then the byte is 1).  Bit-identical to miso_adam_dense; reads 4 B per
  * element plus 28 B per active element.  All four arrays must be 16-B aligned.  zero_grad clears the
- * gradient of the stepped chunks -- the others are zero already. */
+ * gradient of the stepped chunks -- the others are zero already.
+ * guard (device float, or NULL): the loss of the step.  If it is NaN the launch changes no parameter, moment or
+ * flag (the reference's NaN guard, grid_opt/trainer.py:213-219: "Loss is nan! Skip backward step") and only
+ * clears the gradients it was asked to clear -- the host can launch without reading the loss back first. */
 #define MISO_ADAM_CHUNK 256
 int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
                      int64_t numel, double lr, double beta1, double beta2, double eps,
-                     int32_t step /* 1-based */, int zero_grad, void* stream);
+                     int32_t step /* 1-based */, int zero_grad, const float* guard, void* stream);
 
 /* --- per-keyframe rigid map of a sample batch ---------------------------------
  * y[i] = R[idx[i]] x[i] + t[idx[i]] (transpose = 0) or R[idx[i]]^T x[i] (+ t if given; transpose = 1: the cotangent

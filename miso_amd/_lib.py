@@ -127,7 +127,8 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_adam_active": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int, C.c_void_p]),
+                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int, C.c_void_p,
+                                   C.c_void_p]),
     "miso_rigid_by_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int,
                                       C.c_void_p, C.c_void_p]),
     "miso_mc_words": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -60,8 +60,12 @@ template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p, float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v,
                                                          unsigned char* __restrict__ active, int64_t n,
-                                                         AdamScalars a) {
+                                                         AdamScalars a, const float* __restrict__ guard) {
   const int lane = threadIdx.x & 63;
+  // guard (optional, device): the step's loss.  NaN => the reference skips backward and optimizer step
+  // (grid_opt/trainer.py:213-219); here the launch leaves parameters, moments and flags alone (and still clears
+  // the consumed gradients when asked), so the host need not read the loss back before launching.
+  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
   // wave-uniform chunk indices (readfirstlane): the flag bytes become scalar loads
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -91,6 +95,10 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
       const bool nz = gg[u].x != 0.f || gg[u].y != 0.f || gg[u].z != 0.f || gg[u].w != 0.f;   // NaN counts
       const bool any = __ballot(nz) != 0ull;
       if (c >= nfull || !(any || act[u])) continue;      // wave-uniform
+      if (skip) {
+        if (ZERO && any) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
       if (!act[u]) {
         pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
         vv[u] = *reinterpret_cast<float4*>(v + i);
@@ -112,10 +120,10 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
     const bool was = active[c] != 0;
     if (__ballot(nz) != 0ull || was) {
       for (int64_t i = c * ADAM_CHUNK + lane; i < n; i += 64) {
-        adam_one(p[i], g[i], m[i], v[i], a);
+        if (!skip) adam_one(p[i], g[i], m[i], v[i], a);
         if (ZERO) g[i] = 0.0f;
       }
-      if (!was && lane == 0) active[c] = 1;
+      if (!skip && !was && lane == 0) active[c] = 1;
     }
   }
 }
@@ -133,14 +141,15 @@ static AdamScalars adam_scalars(double lr, double b1, double b2, double eps, int
 }
 
 hipError_t launch_adam_active(float* p, float* g, float* m, float* v, unsigned char* active, int64_t n, double lr,
-                              double b1, double b2, double eps, int step, int zero_grad, hipStream_t s) {
+                              double b1, double b2, double eps, int step, int zero_grad, const float* guard,
+                              hipStream_t s) {
   if (n == 0) return hipSuccess;
   const AdamScalars a = adam_scalars(lr, b1, b2, eps, step);
   const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
   int64_t blocks = (nchunks + 4 * ADAM_UN - 1) / (4 * ADAM_UN);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (zero_grad) adam_active_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a);
-  else adam_active_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a);
+  if (zero_grad) adam_active_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard);
+  else adam_active_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard);
   return hipGetLastError();
 }
 

@@ -46,8 +46,8 @@ hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
 int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
                        hipStream_t);
-hipError_t launch_adam_active(float*, float*, float*, float*, unsigned char*, int64_t, double, double, double, double,
-                              int, int, hipStream_t);
+hipError_t launch_adam_active(float*, float*, float*, float*, unsigned char*, int64_t, double, double, double, double, int,
+                              int, const float*, hipStream_t);
 hipError_t launch_mapping_loss(int, float, float, float, const float*, const float*, const float*,
                                const float*, const float*, int64_t, float*, float*, float*, hipStream_t);
 }  // namespace miso
@@ -574,13 +574,14 @@ int miso_adam_dense(float* param, float* grad, float* exp_avg, float* exp_avg_sq
 }
 
 int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active, int64_t numel,
-                     double lr, double beta1, double beta2, double eps, int32_t step, int zero_grad, void* stream) {
+                     double lr, double beta1, double beta2, double eps, int32_t step, int zero_grad,
+                     const float* guard, void* stream) {
   if (numel < 0 || step < 1 || (numel > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !active)))
     return MISO_E_BADARG;
   if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15u)
     return MISO_E_BADARG;
   return (int)launch_adam_active(param, grad, exp_avg, exp_avg_sq, active, numel, lr, beta1, beta2, eps, step,
-                                 zero_grad, (hipStream_t)stream);
+                                 zero_grad, guard, (hipStream_t)stream);
 }
 
 int miso_rigid_by_index(const float* R, const float* t, const int64_t* idx, const float* x, int64_t n, int32_t n_poses,

@@ -163,14 +163,9 @@ class Trainer(object):
         # small batches scatter into the step's persistent gradient buffers: the optimizer clears what it
         # consumed in the same pass (a memset of a 0.5 GB level costs as much as the rest of the step)
         clear = step.sorted is None
-        if not torch.isnan(total):
-            self.optimizer.step(clear_grads=clear)
-        else:
-            logger.warning("Loss is nan! Skip backward step.")
-            if clear:
-                for g in step.grads:
-                    if g is not None:
-                        g.zero_()
+        # NaN guard (reference :213-219) on the device: the optimizer's kernels leave everything alone if the
+        # loss is NaN and the host hears about it one step later -- no read-back between backward and step
+        self.optimizer.step(clear_grads=clear, guard=total)
         return total
 
     def train_step(self, model_input, gt):

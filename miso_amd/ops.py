@@ -612,16 +612,17 @@ def adam_active_flags(param) -> torch.Tensor:
 
 
 def adam_active_(param, grad, exp_avg, exp_avg_sq, active, step: int, lr: float, beta1: float = 0.9,
-                 beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = False):
+                 beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = False, guard: Optional[torch.Tensor] = None):
     """adam_dense_ that skips the chunks that cannot move (miso_adam_active): bit-identical results, 4 B per
-    element + 28 B per element of the chunks a gradient has ever reached."""
-    _require_hip(param, grad, exp_avg, exp_avg_sq)
+    element + 28 B per element of the chunks a gradient has ever reached.  guard: device scalar (the step's loss);
+    if it is NaN the launch leaves parameters, moments and flags alone (the reference's NaN guard on the device)."""
+    _require_hip(param, grad, exp_avg, exp_avg_sq, guard)
     for t in (grad, exp_avg, exp_avg_sq):
         assert t.shape == param.shape and t.stride() == param.stride(), "Adam state must share the param layout"
     assert active.dtype == torch.uint8 and active.numel() * _lib.ADAM_CHUNK >= param.numel()
     _lib.check(_lib.load().miso_adam_active(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(active),
                                             param.numel(), lr, beta1, beta2, eps, step, int(zero_grad),
-                                            _stream(param)), "miso_adam_active")
+                                            _ptr(guard), _stream(param)), "miso_adam_active")
 
 
 # --------------------------------------------------------------------------- #

@@ -6,12 +6,21 @@ torch.optim.Adam(amsgrad=False, weight_decay=0), which is what the reference's
 trainers and alignment loops construct (grid_opt/trainer.py:96-97, :424-437;
 grid_opt/align/base.py:110-111).  Big dense tensors (the feature grids) take one
 HIP launch each; tiny ones (pose vectors) and CPU tensors use the identical
-formula in a few torch ops.  Parameters whose .grad is None are skipped, as torch does."""
+formula in a few torch ops.  Parameters whose .grad is None are skipped, as torch does.
+
+NaN guard without a host round trip: ``step(guard=loss)`` hands the device scalar to the kernels, which leave
+everything alone if it is NaN (what the reference does after reading the loss back, grid_opt/trainer.py:213-219).
+The host learns about a skipped step one call later (a pinned copy + event, resolved before the next step is
+launched, by which time it has long completed) and takes the step count back, so the bias corrections stay those
+of torch.optim.Adam."""
+import logging
 import math
 
 import torch
 
 from . import ops
+
+logger = logging.getLogger(__name__)
 
 _KERNEL_MIN_NUMEL = 4096
 
@@ -19,11 +28,47 @@ _KERNEL_MIN_NUMEL = 4096
 class DenseAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.skipped_steps = 0
+        self._pending = None          # (pinned loss copy, event, states stepped under that guard)
+        self._guard_host = None       # one pinned float + one event, reused: a guard is resolved before the next
+
+    def resolve_guard(self):
+        """Account for the last guarded step: if its loss was NaN the device skipped it -- take the step counts back."""
+        pending = self.__dict__.get('_pending')
+        if pending is None:
+            return
+        host, event, states = pending
+        self._pending = None
+        event.synchronize()
+        if bool(torch.isnan(host[0])):
+            for st in states:
+                st['step'] -= 1
+            self.skipped_steps += 1
+            logger.warning("Loss is nan! Skip backward step.")
+
+    def state_dict(self):
+        self.resolve_guard()
+        return super().state_dict()
 
     @torch.no_grad()
-    def step(self, closure=None, clear_grads=False):
+    def step(self, closure=None, clear_grads=False, guard=None):
         """clear_grads: leave every .grad zeroed (in the same pass for the big tensors), for callers that
-        accumulate into persistent gradient buffers and would otherwise memset them before the next backward."""
+        accumulate into persistent gradient buffers and would otherwise memset them before the next backward.
+        guard: device scalar; NaN => nothing is updated (see the module docstring)."""
+        self.resolve_guard()
+        if guard is not None and not guard.is_cuda:
+            if bool(torch.isnan(guard)):                  # host tensors: the plain check
+                logger.warning("Loss is nan! Skip backward step.")
+                self.skipped_steps += 1
+                if clear_grads:
+                    for group in self.param_groups:
+                        for p in group['params']:
+                            if p.grad is not None:
+                                p.grad.zero_()
+                return None
+            guard = None
+        ok = None                     # device flag "loss is a number", formed only if a tiny tensor needs it
+        stepped = []
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -40,6 +85,7 @@ class DenseAdam(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['step'] += 1
+                stepped.append(st)
                 t, m, v = st['step'], st['exp_avg'], st['exp_avg_sq']
                 if (p.is_cuda and p.dtype == torch.float32 and p.numel() >= _KERNEL_MIN_NUMEL
                         and g.stride() == p.stride() and m.stride() == p.stride()):
@@ -48,13 +94,28 @@ class DenseAdam(torch.optim.Optimizer):
                         st['active'] = ops.adam_active_flags(p)
                         if t > 1:
                             st['active'].fill_(1)
-                    ops.adam_active_(p, g, m, v, st['active'], t, lr, b1, b2, eps, zero_grad=clear_grads)
+                    ops.adam_active_(p, g, m, v, st['active'], t, lr, b1, b2, eps, zero_grad=clear_grads,
+                                     guard=None if guard is None else guard.detach().reshape(1))
                     continue
+                if guard is not None:
+                    if ok is None:
+                        ok = ~torch.isnan(guard.detach()).reshape(())
+                    keep = (p.clone(), m.clone(), v.clone())
                 m.lerp_(g, 1 - b1)
                 v.mul_(b2).addcmul_(g, g, value=1 - b2)
                 bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
                 denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
                 p.addcdiv_(m, denom, value=-(lr / bc1))
+                if guard is not None:                     # tiny tensors: undo on the device if the loss was NaN
+                    for cur, old in zip((p, m, v), keep):
+                        cur.copy_(torch.where(ok, cur, old))
                 if clear_grads:
                     g.zero_()
+        if guard is not None and stepped:
+            if self._guard_host is None:
+                self._guard_host = (torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event())
+            host, event = self._guard_host
+            host.copy_(guard.detach().reshape(1), non_blocking=True)
+            event.record()
+            self._pending = (host, event, stepped)
         return loss

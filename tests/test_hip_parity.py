@@ -833,3 +833,37 @@ def test_rigid_by_index_vs_oracle(n, K):
     (rigid_by_index(Rg, tg, idx.to(DEV), xg) * w.to(DEV)).sum().backward()
     for a, b in ((Rg.grad, Rc.grad), (tg.grad, tc.grad), (xg.grad, xc.grad)):
         assert (a.cpu() - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_adam_nan_guard_on_the_device():
+    """DenseAdam.step(guard=loss): a NaN loss leaves parameters, moments, flags and (one call later) the step counts
+    alone -- the reference's "Loss is nan! Skip backward step" (trainer.py:213-219) without a read-back -- and the
+    steps around it are bit-identical to an optimizer that never saw the NaN step."""
+    from miso_amd.optim import DenseAdam
+    torch.manual_seed(0)
+    big = torch.randn(3, 5000, device=DEV)
+    tiny = torch.randn(1, 3, device=DEV)
+    grads = [(torch.randn_like(big), torch.randn_like(tiny)) for _ in range(4)]
+
+    def run(with_nan):
+        pb, pt = big.clone().requires_grad_(True), tiny.clone().requires_grad_(True)
+        opt = DenseAdam([pb, pt], lr=1e-2)
+        for k, (gb, gt) in enumerate(grads):
+            if with_nan and k == 2:                       # an extra, poisoned step in the middle
+                pb.grad, pt.grad = torch.full_like(pb, float("nan")), torch.full_like(pt, float("nan"))
+                opt.step(clear_grads=True, guard=torch.tensor(float("nan"), device=DEV))
+                assert float(pb.grad.abs().sum()) == 0.0 and float(pt.grad.abs().sum()) == 0.0   # consumed all the same
+            pb.grad, pt.grad = gb.clone(), gt.clone()
+            opt.step(guard=torch.tensor(0.5, device=DEV))
+        sd = opt.state_dict()
+        return pb.detach(), pt.detach(), opt, sd
+
+    a_b, a_t, opt_a, sd_a = run(False)
+    b_b, b_t, opt_b, sd_b = run(True)
+    assert torch.equal(a_b, b_b) and torch.equal(a_t, b_t)
+    assert opt_a.skipped_steps == 0 and opt_b.skipped_steps == 1
+    for sa, sb in zip(sd_a["state"].values(), sd_b["state"].values()):
+        assert sa["step"] == sb["step"] == 4
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    assert torch.isfinite(b_b).all()
