@@ -75,6 +75,79 @@ def generic_align_submap_pair(grid_atlas: GridAtlas, dataset: Dataset, src_id: i
     return {'cpu_time_sec': cpu_time, 'gpu_time_sec': gpu_time}
 
 
+def _captured_alignment_loop(grid_atlas, params, batched, submap_pairs, check_intersection, reg, lr, num_iters,
+                             loss_name, verbose):
+    """The whole pose-Adam iteration -- zero the gradients, all pair losses behind one autograd node, backward
+    through the batched exponential map, Adam on the 6(S-1) pose numbers -- captured ONCE in a HIP graph and
+    replayed: an iteration is ~60 tiny launches plus the pair kernels, and eagerly the host needs 3x as long to
+    issue them as the GPU to run them.  Adam is torch's own with ``capturable=True`` (step counts on the device;
+    same formula as the reference's torch.optim.Adam).  The first three iterations run eagerly on a side stream,
+    as graph capture wants; losses and relative pose changes of every iteration are kept on the device and
+    logged afterwards.  Returns False (nothing done) if the capture cannot be made; the caller's eager loop runs."""
+    dev = params[0].device
+    total_iters = num_iters + 1
+    if total_iters < 8:
+        return False
+    hist = torch.zeros((total_iters, 2), device=dev)              # loss, relative change
+    it_dev = torch.zeros(1, device=dev, dtype=torch.long)
+    prev = [torch.zeros_like(p) for p in params]
+    one = torch.ones(1, device=dev, dtype=torch.long)
+    optimizer = torch.optim.Adam(params, lr=lr, capturable=True, foreach=False)
+
+    def iteration():
+        loss_dict = dict(batched(grid_atlas, submap_pairs, check_intersection))
+        if reg is not None:
+            loss_dict.update(reg())
+        total = sum(loss_dict.values())
+        total.backward()
+        with torch.no_grad():
+            for q, p in zip(prev, params):
+                q.copy_(p)
+        optimizer.step()
+        with torch.no_grad():
+            num = sum(torch.sum((p - q) ** 2) for p, q in zip(params, prev))
+            den = sum(torch.sum(q ** 2) for q in prev)
+            # upstream compares the parameters AFTER iterations k and k-1 (base.py:152-158)
+            row = torch.stack((total.detach(), torch.sqrt(num / den))).reshape(1, 2)
+            hist.index_copy_(0, it_dev, row)
+            it_dev.add_(one)
+
+    snapshot = [p.detach().clone() for p in params]
+    graph = None
+    try:
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                optimizer.zero_grad(set_to_none=True)
+                iteration()
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            iteration()
+    except Exception as exc:                                        # pragma: no cover - depends on the runtime
+        logger.warning(f"alignment loop not captured ({type(exc).__name__}: {exc}); running it op by op")
+        with torch.no_grad():
+            for p, q in zip(params, snapshot):
+                p.copy_(q)
+                p.grad = None
+        return False
+    for _ in range(total_iters - 3):
+        graph.replay()
+    for p in params:
+        p.grad = None
+    if verbose:
+        rows = hist.cpu().tolist()
+        for it, (loss, change) in enumerate(rows):
+            # the change upstream logs at iteration k is between the parameters after k and after k-1: inf at k = 0
+            shown = float('inf') if it == 0 else rows[it][1]
+            logger.info(f"AlignMulti_{loss_name} iteration {it}: loss = {loss:.2e}, pose_relchange={shown:.2e}, "
+                        f"lr={lr:.2e}")
+    return True
+
+
 def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pairwise_loss_tuple, num_iters=10,
                                    lr=1e-2, rel_change_thresh=0, submap_pairs=None, check_intersection=True,
                                    pose_reg_weight=0, pose_thresh_rad=1.0, pose_thresh_m=1.0, verbose=True,
@@ -94,6 +167,18 @@ def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pair
     iteration_results = dict()
     prev = None
     it = 0
+    batched_fn = getattr(loss_func, 'batched', None)
+    params = pose_params()
+    if (batched_fn is not None and not save_iterations and rel_change_thresh <= 0 and params
+            and all(p.is_cuda and p.requires_grad for p in params)
+            and not getattr(grid_atlas, 'no_captured_alignment', False)):
+        reg = None
+        if pose_reg_weight > 0:
+            reg = lambda: grid_atlas_pose_trust_region_loss(grid_atlas, thresh_rad=pose_thresh_rad,        # noqa: E731
+                                                            thresh_m=pose_thresh_m, weight=pose_reg_weight)
+        if _captured_alignment_loop(grid_atlas, params, batched_fn, submap_pairs, check_intersection, reg, lr,
+                                    num_iters, loss_name, verbose):
+            it = num_iters + 1
     while it <= num_iters:
         if save_iterations:
             iteration_results[it] = iteration_results_helper(grid_atlas)

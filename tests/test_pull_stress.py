@@ -193,4 +193,4 @@ def test_dense_wave_scatter_matches_pull_and_atomics(seed, monkeypatch):
     ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask_s, False, [True, True], got, sorted_batch=sb, overwrite=True)
     for a, b in zip(got, want):
         scale = b.abs().max().item()
-        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-12
+        assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-12      # thousands of fp32 terms per coarse vertex, in two orders
