@@ -388,7 +388,7 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
   if ((loss_type != 1 && loss_type != 2) || !loss_slots || (n > 0 && (!loss_inputs || !grad_sdf_sorted)))
     return MISO_E_BADARG;
   if (((uintptr_t)loss_inputs & 15u) != 0) return MISO_E_BADARG;
-  if (n == 0) return (int)hipMemsetAsync(loss_slots, 0, MISO_LOSS_SLOTS * 2 * sizeof(float), (hipStream_t)stream);
+  if (n == 0) return (int)launch_zero_words(loss_slots, MISO_LOSS_SLOTS * 2, (hipStream_t)stream);
   LossInK lin;
   memset(&lin, 0, sizeof(lin));
   lin.p.loss_type = loss_type; lin.p.w_sdf = weight_sdf; lin.p.w_fs = weight_fs; lin.p.trunc = trunc_dist;

@@ -41,6 +41,9 @@ __device__ __forceinline__ void load_point(const GridK& g, const float* __restri
   }
 }
 
+// clears n_words 32-bit words with a kernel (loss.hip; see there why not hipMemsetAsync)
+hipError_t launch_zero_words(void* p, int n_words, hipStream_t s);
+
 struct MlpK {
   const float* w[MISO_MAX_LINEAR];
   const float* b[MISO_MAX_LINEAR];

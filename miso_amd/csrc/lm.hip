@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void lm_normal_eq_kernel(LmK k) {
 
 hipError_t launch_lm_normal_eq(const float* x, const float* R, const float* grad, const float* sdf, const float* gt,
                                int64_t n, int loss_type, float gm_scale, float* out, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(out, 0, 32 * sizeof(float), s);
+  hipError_t e = launch_zero_words(out, 32, s);
   if (e != hipSuccess || n == 0) return e;
   LmK k{x, R, grad, sdf, gt, n, loss_type, gm_scale, out};
   unsigned blocks = (unsigned)((n + 255) / 256);

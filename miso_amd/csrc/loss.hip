@@ -65,11 +65,25 @@ __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const flo
   }
 }
 
+// Small accumulators are cleared by a kernel, not by hipMemsetAsync: inside a captured HIP graph the 8-byte memset
+// node in front of the atomics of mapping_loss_kernel left garbage in the two sums now and then (seen on ROCm 7.2
+// with the unsorted trainer step replayed back to back: the loss read 0xFEFE.. / NaN while every input was finite).
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+hipError_t launch_zero_words(void* p, int n_words, hipStream_t s) {
+  if (n_words <= 0) return hipSuccess;
+  zero_words_kernel<<<(n_words + 255) / 256, 256, 0, s>>>(reinterpret_cast<uint32_t*>(p), n_words);
+  return hipGetLastError();
+}
+
 hipError_t launch_mapping_loss(int loss_type, float w_sdf, float w_fs, float trunc, const float* pred,
                                const float* targ, const float* valid, const float* sign,
                                const float* weight, int64_t n, float* gpred, float* gpred_fs,
                                float* loss_out, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(loss_out, 0, 2 * sizeof(float), s);
+  hipError_t e = launch_zero_words(loss_out, 2, s);
   if (e != hipSuccess || n == 0) return e;
   MapLossK p{loss_type, w_sdf, w_fs, trunc};
   const uintptr_t al = (uintptr_t)pred | (uintptr_t)targ | (uintptr_t)valid | (uintptr_t)sign | (uintptr_t)weight |

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void overlap_count_kernel(const float* __restr
 
 hipError_t launch_overlap_count(const float* pose, const float* p, int64_t n, const float* bmin, const float* bmax,
                                 float* out, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+  hipError_t e = launch_zero_words(out, 1, s);
   if (e != hipSuccess || n == 0) return e;
   // enough workgroups to pull 12 B per vertex at HBM speed, few enough that their one atomic each
   // (same address, ~13 ns apiece) stays a short tail
@@ -191,7 +191,7 @@ hipError_t launch_overlap_count(const float* pose, const float* p, int64_t n, co
 
 hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, const float* p, const float* fsrc,
                               int64_t ld, int64_t n, int loss_type, float* out, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(out, 0, 24 * sizeof(float), s);
+  hipError_t e = launch_zero_words(out, 24, s);
   if (e != hipSuccess || n == 0) return e;
   PairK k{pose, p, fsrc, ld, n, loss_type, out};
   unsigned blocks = (unsigned)((n + 255) / 256);

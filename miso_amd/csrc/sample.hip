@@ -291,7 +291,7 @@ hipError_t launch_sample_rays(const miso_ray_frames_t& f, const miso_ray_samplin
                               int64_t n_rays, const int64_t* pix_b, const int64_t* pix_h, const int64_t* pix_w,
                               const float* u, const float* g, void* workspace, float* coords, int64_t* ids,
                               float* aux, float* pc_world, float* z_vals, int32_t* counts, hipStream_t s) {
-  if (n_rays == 0) return hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), s);
+  if (n_rays == 0) return launch_zero_words(counts, 4, s);
   const unsigned blocks = (unsigned)((n_rays + RAY_BLOCK - 1) / RAY_BLOCK);
   RayK k;
   k.depth = f.depth; k.normals = f.normals; k.T_WC = f.T_WC; k.R_wk = f.R_wk; k.frame_ids = f.frame_ids;

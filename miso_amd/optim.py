@@ -29,7 +29,7 @@ class DenseAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.skipped_steps = 0
-        self._pending = None          # (pinned loss copy, event, states stepped under that guard)
+        self._pending = None          # (pinned loss copy, event, states stepped under that guard, device scalar)
         self._guard_host = None       # one pinned float + one event, reused: a guard is resolved before the next
 
     def resolve_guard(self):
@@ -37,7 +37,7 @@ class DenseAdam(torch.optim.Optimizer):
         pending = self.__dict__.get('_pending')
         if pending is None:
             return
-        host, event, states = pending
+        host, event, states, _src = pending
         self._pending = None
         event.synchronize()
         if bool(torch.isnan(host[0])):
@@ -115,7 +115,10 @@ class DenseAdam(torch.optim.Optimizer):
             if self._guard_host is None:
                 self._guard_host = (torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event())
             host, event = self._guard_host
-            host.copy_(guard.detach().reshape(1), non_blocking=True)
+            src = guard.detach().reshape(1)
+            host.copy_(src, non_blocking=True)
             event.record()
-            self._pending = (host, event, stepped)
+            # the device scalar stays referenced until the copy has been consumed: a caller that drops the loss
+            # right away would hand its block back to the allocator while the asynchronous copy may still read it
+            self._pending = (host, event, stepped, src)
         return loss
