@@ -92,7 +92,10 @@ def _captured_alignment_loop(grid_atlas, params, batched, submap_pairs, check_in
     it_dev = torch.zeros(1, device=dev, dtype=torch.long)
     prev = [torch.zeros_like(p) for p in params]
     one = torch.ones(1, device=dev, dtype=torch.long)
-    optimizer = torch.optim.Adam(params, lr=lr, capturable=True, foreach=False)
+    try:        # one multi-tensor kernel for the 2(S-1) pose tensors instead of ~15 launches per tensor
+        optimizer = torch.optim.Adam(params, lr=lr, capturable=True, fused=True)
+    except (RuntimeError, TypeError, ValueError):
+        optimizer = torch.optim.Adam(params, lr=lr, capturable=True, foreach=False)
 
     def iteration():
         loss_dict = dict(batched(grid_atlas, submap_pairs, check_intersection))
@@ -100,6 +103,9 @@ def _captured_alignment_loop(grid_atlas, params, batched, submap_pairs, check_in
             loss_dict.update(reg())
         total = sum(loss_dict.values())
         total.backward()
+        if not verbose:                      # nothing to report afterwards: no bookkeeping kernels in the graph
+            optimizer.step()
+            return
         with torch.no_grad():
             for q, p in zip(prev, params):
                 q.copy_(p)
