@@ -169,24 +169,32 @@ def extras(step, dev):
         def __getitem__(self, i):
             return 0
 
+    import miso_amd.grid_opt.align.base as AB
+
+    def latent(at, ld, a, b):
+        return AM.pairwise_loss_latent(at, ld, a, b, level=1, fdim=4, align_loss="L2", device=dev)
+
+    latent.device_gate = True
+    latent.batched = lambda at, pairs, chk: AM.pairwise_loss_latent_batched(at, pairs, level=1, fdim=4,
+                                                                            check_intersection=chk, device=dev)
+
     def run(n_it):
         # every run starts from the same perturbed pose: the work per iteration follows the overlap
         atlas.set_submap_pose_correction(1, torch.tensor([[0.02, -0.03, 0.01]], device=dev),
                                          torch.tensor([[0.1], [-0.05], [0.08]], device=dev))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        AM.align_multiple_submaps_hierarchical(atlas, _DS(), level_iters=n_it - 1, latent_levels=[1],
-                                               skip_finetune=True, device=dev, verbose=False)
+        AB.generic_align_multiple_submaps(atlas, _DS(), ("latent1", latent), num_iters=n_it - 1, lr=1e-3, verbose=False)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    run(12)                                  # warm-up (a captured loop: three eager iterations, capture, replays)
-    # wall time of a whole 120-iteration level as a caller sees it: coordinates re-derived, three eager
-    # iterations, graph capture, 117 replays (differencing two run lengths is noisier than the replays are long)
-    t = min(run(120), run(120))
-    ex["align_level1_120_iterations"] = {"pairs": 1, "vertices": nv, "ms_total": t * 1e3,
-                                         "us_per_iteration_incl_capture": t / 120 * 1e6,
-                                         "vertices_per_s": nv * 120 / t}
+    run(12)                                  # warm-up
+    # generic_align_multiple_submaps as the hierarchical driver calls it (pose Adam, overlap gate, all pairs behind
+    # one autograd node; the loop is captured after three eager iterations): wall time of a 20- and a 120-iteration
+    # level, and the cost of one further iteration
+    t20, t120 = min(run(20), run(20)), min(run(120), run(120))
+    ex["align_level1_driver"] = {"pairs": 1, "vertices": nv, "ms_20_iterations": t20 * 1e3,
+                                 "ms_120_iterations": t120 * 1e3, "us_per_further_iteration": (t120 - t20) / 100 * 1e6}
     ex["sample_generation_scannet"] = sample_generation(dev)
     ex["mesh_extraction_256"] = mesh_extraction(step, dev)
     ex["trainer_step_other_shapes"] = trainer_steps(dev)
