@@ -195,9 +195,13 @@ def extras(step, dev):
     t20, t120 = min(run(20), run(20)), min(run(120), run(120))
     ex["align_level1_driver"] = {"pairs": 1, "vertices": nv, "ms_20_iterations": t20 * 1e3,
                                  "ms_120_iterations": t120 * 1e3, "us_per_further_iteration": (t120 - t20) / 100 * 1e6}
-    ex["sample_generation_scannet"] = sample_generation(dev)
-    ex["mesh_extraction_256"] = mesh_extraction(step, dev)
-    ex["trainer_step_other_shapes"] = trainer_steps(dev)
+    for key, fn in (("sample_generation_scannet", lambda: sample_generation(dev)),
+                    ("mesh_extraction_256", lambda: mesh_extraction(step, dev)),
+                    ("trainer_step_other_shapes", lambda: trainer_steps(dev))):
+        try:
+            ex[key] = fn()
+        except Exception as exc:  # noqa: BLE001
+            ex[key] = {"error": f"{type(exc).__name__}: {exc}"}
     return ex
 
 
@@ -465,7 +469,10 @@ def main():
         "binned": sb is not None,
     }
     if world == 1 and not args.no_extras:
-        out["extras"] = extras(step, dev)
+        try:                      # secondary figures must never cost the headline line
+            out["extras"] = extras(step, dev)
+        except Exception as exc:  # noqa: BLE001
+            out["extras"] = {"error": f"{type(exc).__name__}: {exc}"}
     if world == 1 and not args.no_cpu_baseline:
         cb, pred_cpu = cpu_baseline(data)
         out["cpu_baseline"] = cb
