@@ -30,6 +30,9 @@
  *   miso_pair_latent  pairwise_loss_latent, grid_opt/align/miso.py:116-211 (L2 / L1),
  *                     with the rigid maps of grid_opt/utils/utils_geometry.py:214-240.
  *   miso_overlap_count GridAtlas.check_submap_intersection, grid_opt/models/grid_atlas.py:405-420.
+ *   miso_align_iteration_a / _b
+ *                     one iteration of generic_align_multiple_submaps, grid_opt/align/base.py:127-160 (all pairs,
+ *                     so3_exp_map backward, trust region, NaN guard, torch.optim.Adam on the pose corrections).
  *   miso_lm_normal_eq Tracker.lm_step, grid_opt/slam/tracker.py:148-212 (J, H = J^T W J,
  *                     g = J^T W r with the L2 / Geman-McClure weights of :139-146).
  *   miso_mapping_loss miso_loss_regression + miso_loss_free_space and their gradient
@@ -272,6 +275,66 @@ int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float
  * caller compares count / N with its threshold on the device or reads it back. */
 int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, const float* bound_min,
                        const float* bound_max, float* count_out, void* stream);
+
+/* --- fused pose-Adam iteration of latent submap alignment ----------------------
+ * generic_align_multiple_submaps (grid_opt/align/base.py:89-163) with pairwise_loss_latent (L2 / L1,
+ * grid_opt/align/miso.py:116-211) as the pair loss: Adam over the pose corrections (dr_s, dt_s) of submaps
+ * 1..S-1, submap 0 fixed.  One iteration = miso_align_iteration_a (poses from the corrections, overlap gate and
+ * latent residual of EVERY pair in one launch each, pose cotangents pulled back through R0 Exp(dr)) followed by
+ * miso_align_iteration_b (trust-region regulariser, NaN guard, Adam, relative-change early stop, bookkeeping).
+ * Between the two the caller may all-reduce `flat` (6S + 1 floats: d loss / d (dr_s, dt_s) for every submap, then
+ * the summed pair loss) over ranks that each hold a share of the pair list (miso_amd/dist.py); nothing is read
+ * back by the host inside the loop.
+ *
+ * miso_align_pair_t   one (src, dst) pair: the destination's levels 0..level (data only) with its bound, the
+ *                     source's cached voxel centres and its features there (as miso_pair_latent), and the
+ *                     source's finest-level voxel centres for the overlap gate of base.py:134 /
+ *                     GridAtlas.check_submap_intersection (NULL = pair always on).
+ * miso_align_plan_build  converts n_pairs descriptors into the device layout the kernels read:
+ *                     miso_align_plan_bytes(n_pairs) bytes of HOST memory, which the caller copies to the device
+ *                     and passes as cfg->plan; fills cfg->vec4 / max_n / max_gate_n.
+ * state               miso_align_state_layout(...) floats on the device, ZEROED by the caller before the first
+ *                     iteration; offsets[11] (in floats) = {params (S,6: dr, dt), pose (S,12: R, t), out (P,24),
+ *                     overlap counts (P), pair losses (P, weighted, gated), flat (6S+2), adam exp_avg (S,6),
+ *                     exp_avg_sq (S,6), ctrl (8 x int32: Adam steps taken, stopped flag, iterations run, NaN-skipped
+ *                     iterations), ring, ring row length}.  Ring row k (ring_iters rows): {total loss, relative
+ *                     pose change (inf at k = 0)} of iteration k [+ (S,4,4) poses BEFORE its step when save_poses:
+ *                     iteration_results_helper, base.py:29-39].  The caller writes the initial corrections into
+ *                     `params` and reads the final ones from there.
+ * Once the relative change falls below rel_change_thresh (base.py:157-158) the stopped flag is set and further
+ * iterations change nothing. */
+typedef struct {
+  miso_grid_t dst_grid;
+  const float* coords_src;  /* (n,3) */
+  const float* feats_src;   /* (n, ld_feats) */
+  int64_t ld_feats, n;
+  const float* gate_coords; /* (gate_n,3) or NULL */
+  int64_t gate_n;
+  int32_t src, dst;         /* submap indices */
+} miso_align_pair_t;
+
+typedef struct {
+  int32_t n_submaps, n_pairs;
+  int32_t loss_type;         /* 1 = L1 (row-wise 2-norm), 2 = L2 */
+  int32_t ring_iters, save_poses;
+  int32_t vec4;              /* set by miso_align_plan_build */
+  int64_t max_n, max_gate_n; /* set by miso_align_plan_build */
+  float align_weight, overlap_thresh;
+  float reg_weight, reg_thresh_rad, reg_thresh_m; /* grid_atlas_pose_trust_region_loss, base.py:20-27; 0 = off */
+  float rel_change_thresh;
+  double lr, beta1, beta2, eps;
+  const float* R0;           /* (S,9) base rotations, device */
+  const float* t0;           /* (S,3) base translations, device */
+  const void* plan;          /* device copy of the plan blob */
+  float* state;              /* device */
+} miso_align_t;
+
+int64_t miso_align_plan_bytes(int32_t n_pairs);
+int miso_align_plan_build(const miso_align_pair_t* pairs, miso_align_t* cfg, void* plan_host);
+int64_t miso_align_state_layout(int32_t n_submaps, int32_t n_pairs, int32_t ring_iters, int32_t save_poses,
+                                int64_t* offsets /* [11] or NULL */);
+int miso_align_iteration_a(const miso_align_t* cfg, void* stream);
+int miso_align_iteration_b(const miso_align_t* cfg, void* stream);
 
 /* --- tracker: Gauss-Newton normal equations ------------------------------
  * coords_frame (N,3): samples in the keyframe frame; R_frame (9 floats, DEVICE, row-major):

@@ -70,6 +70,23 @@ class RaySampling(C.Structure):
                 ("bin_edges", C.POINTER(C.c_float))]
 
 
+class AlignPair(C.Structure):
+    _fields_ = [("dst_grid", Grid), ("coords_src", C.c_void_p), ("feats_src", C.c_void_p),
+                ("ld_feats", C.c_int64), ("n", C.c_int64), ("gate_coords", C.c_void_p), ("gate_n", C.c_int64),
+                ("src", C.c_int32), ("dst", C.c_int32)]
+
+
+class Align(C.Structure):
+    _fields_ = [("n_submaps", C.c_int32), ("n_pairs", C.c_int32), ("loss_type", C.c_int32),
+                ("ring_iters", C.c_int32), ("save_poses", C.c_int32), ("vec4", C.c_int32),
+                ("max_n", C.c_int64), ("max_gate_n", C.c_int64),
+                ("align_weight", C.c_float), ("overlap_thresh", C.c_float),
+                ("reg_weight", C.c_float), ("reg_thresh_rad", C.c_float), ("reg_thresh_m", C.c_float),
+                ("rel_change_thresh", C.c_float),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("R0", C.c_void_p), ("t0", C.c_void_p), ("plan", C.c_void_p), ("state", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/miso_hip.h declares
 SIGNATURES = {
     "miso_version": (C.c_char_p, []),
@@ -140,6 +157,11 @@ SIGNATURES = {
     "miso_mc_vertices": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                    C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "miso_mc_case_table": (C.c_int, [C.c_void_p]),
+    "miso_align_plan_bytes": (C.c_int64, [C.c_int32]),
+    "miso_align_plan_build": (C.c_int, [C.POINTER(AlignPair), C.POINTER(Align), C.c_void_p]),
+    "miso_align_state_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "miso_align_iteration_a": (C.c_int, [C.POINTER(Align), C.c_void_p]),
+    "miso_align_iteration_b": (C.c_int, [C.POINTER(Align), C.c_void_p]),
     "miso_adam_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int,
                                   C.c_void_p]),

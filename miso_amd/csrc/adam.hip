@@ -9,18 +9,6 @@
 
 namespace miso {
 
-struct AdamScalars {
-  float one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps;
-};
-
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamScalars& a) {
-#pragma clang fp contract(off)   // one rounding per torch op, and the same bits from every kernel that inlines this
-  m = m + a.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * a.b2 + (a.one_minus_b2 * g) * g;          // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-  float denom = sqrtf(v) / a.bc2_sqrt + a.eps;      // (sqrt / bias_correction2_sqrt).add_(eps)
-  p = p + (a.neg_step_size * m) / denom;            // addcdiv_(exp_avg, denom, value=-step_size)
-}
-
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                   float* __restrict__ m, float* __restrict__ v,

@@ -1,0 +1,284 @@
+// Fused pose-Adam iteration of latent submap alignment.
+//
+// Reference: generic_align_multiple_submaps, grid_opt/align/base.py:89-163, driving pairwise_loss_latent
+// (grid_opt/align/miso.py:116-211).  One iteration there is, per pair, two so3_exp_map chains, two affine maps, a
+// nonzero compaction, two multi-level grid_sample calls and their autograd backward, then torch.optim.Adam on the
+// 2(S-1) pose tensors -- ~200 tiny launches and several host syncs per pair.  Here an iteration is five launches
+// whatever the number of pairs:
+//
+//   prologue    (dr_s, dt_s) -> R_s = R0_s Exp(dr_s), t_s = t0_s + dt_s for every submap (GridAtlas.updated_submap_pose,
+//               grid_atlas.py:250-268, utils_geometry.apply_pose_correction :78-99); clears the accumulators; writes
+//               the (S,4,4) pose snapshot of iteration_results_helper (base.py:29-39) into the ring
+//   overlap     check_submap_intersection of every pair (grid_atlas.py:405-420), pair_latent.hip, grid.y = pair
+//   pairs       the masked latent residual + 23 pose-cotangent sums of every pair, pair_latent.hip, grid.y = pair
+//   epilogue A  per pair: normalise, nan_to_num (base.py:138-141), overlap gate; per submap: sum the cotangents of
+//               its pairs, pull them back through R0 Exp(.) -> d loss / d (dr_s, dt_s); writes `flat` = 6S pose
+//               gradients + the summed pair loss.  With the pair list sharded over ranks (miso_amd/dist.py) `flat`
+//               is what the ONE all-reduce of the iteration sums.
+//   epilogue B  trust-region regulariser (base.py:20-27), NaN guard (:147-151), Adam on the poses of submaps 1..S-1
+//               (:104-111), relative pose change + early stop (:152-158), loss / change into the ring.
+//
+// Everything the host reads (losses, changes, snapshots, iteration count) stays on the device until the loop ends.
+#include <math.h>
+#include <string.h>
+
+#include "common.hpp"
+#include "align.hpp"
+
+namespace miso {
+
+AlignLayout align_layout(int S, int P, int ring_iters, int save_poses) {
+  AlignLayout L;
+  int64_t o = 0;
+  L.params = o; o += up4(6 * S);
+  L.pose = o; o += up4(12 * S);
+  L.out = o; o += up4(24 * (int64_t)P);
+  L.cnt = o; o += up4(P);
+  L.pair_loss = o; o += up4(P);
+  L.flat = o; o += up4(6 * S + 2);
+  L.adam_m = o; o += up4(6 * S);
+  L.adam_v = o; o += up4(6 * S);
+  L.ctrl = o; o += 8;
+  L.ring_row = 2 + (save_poses ? 16 * S : 0);
+  L.ring = o; o += (int64_t)ring_iters * L.ring_row;
+  L.total = o;
+  return L;
+}
+
+// so3_exp_map(log_rot, eps = 1e-4) of pytorch3d as restated in miso_amd/so3.py, fp32, same op order
+__device__ __forceinline__ void so3_exp(const float w[3], float E[9]) {
+#pragma clang fp contract(off)
+  const float sq = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+  const float ang = sqrtf(fmaxf(sq, 1e-4f));
+  const float a = sinf(ang) / ang, b = (1.0f - cosf(ang)) / (ang * ang);
+  const float K[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+  float KK[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) KK[i * 3 + j] = (K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j]) + K[i * 3 + 2] * K[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) E[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + a * K[i] + b * KK[i];
+}
+
+__global__ __launch_bounds__(256) void align_prologue_kernel(AlignK k) {
+  int32_t* ctrl = reinterpret_cast<int32_t*>(k.state + k.L.ctrl);
+  if (ctrl[CTRL_STOPPED]) return;
+  const int it = ctrl[CTRL_ITER];
+  for (int s = threadIdx.x; s < k.S; s += blockDim.x) {
+    const float* prm = k.state + k.L.params + 6 * s;
+    const float w[3] = {prm[0], prm[1], prm[2]};
+    float E[9], R[9];
+    so3_exp(w, E);
+    const float* R0 = k.R0 + 9 * s;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[i * 3 + j] = (R0[i * 3] * E[j] + R0[i * 3 + 1] * E[3 + j]) + R0[i * 3 + 2] * E[6 + j];
+    float t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = k.t0[3 * s + i] + prm[3 + i];
+    float* pose = k.state + k.L.pose + 12 * s;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) pose[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pose[9 + i] = t[i];
+    if (k.save_poses && it < k.ring_iters) {      // utils_geometry.pose_matrix(R, t), row-major 4x4
+      float* m = k.state + k.L.ring + (int64_t)it * k.L.ring_row + 2 + 16 * s;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        m[i * 4] = R[i * 3]; m[i * 4 + 1] = R[i * 3 + 1]; m[i * 4 + 2] = R[i * 3 + 2]; m[i * 4 + 3] = t[i];
+      }
+      m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
+    }
+  }
+  // accumulators of the pair stage and the reduction buffer (out, cnt, pair_loss are adjacent; flat follows)
+  float* z = k.state + k.L.out;
+  const int64_t nz = (k.L.flat + up4(6 * k.S + 2)) - k.L.out;
+  for (int64_t i = threadIdx.x; i < nz; i += blockDim.x) z[i] = 0.0f;
+}
+
+__device__ __forceinline__ float nan_to_num_f(float v) {
+  if (v != v) return 0.0f;
+  if (isinf(v)) return v > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  return v;
+}
+
+// d loss / d w for R = R0 Exp(w), given gR = d loss / d R: G = R0^T gR, Exp = I + a K + b K^2 with
+// a = sin(th)/th, b = (1 - cos th)/th^2, th = sqrt(max(|w|^2, eps)) -- the clamp passes no gradient below eps
+// (torch.clamp backward), so near w = 0 only the a dK and b d(K^2) terms remain.  In double: three values per
+// submap per iteration, and the a', b' differences cancel badly in fp32.
+__device__ __forceinline__ void so3_exp_backward(const float w_[3], const double G[9], double gw[3]) {
+  const double w[3] = {w_[0], w_[1], w_[2]};
+  const float sqf = (w_[0] * w_[0] + w_[1] * w_[1]) + w_[2] * w_[2];
+  const bool live = sqf >= 1e-4f;
+  const double th = sqrt(fmax((double)sqf, 1e-4));
+  const double s = sin(th), c = cos(th);
+  const double a = s / th, b = (1.0 - c) / (th * th);
+  const double K[9] = {0., -w[2], w[1], w[2], 0., -w[0], -w[1], w[0], 0.};
+  double KK[9], M[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) KK[i * 3 + j] = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+  // M = G K^T + K^T G
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double v = 0.;
+      for (int q = 0; q < 3; ++q) v += G[i * 3 + q] * K[j * 3 + q] + K[q * 3 + i] * G[q * 3 + j];
+      M[i * 3 + j] = v;
+    }
+  double gk = 0., gkk = 0.;
+  for (int i = 0; i < 9; ++i) { gk += G[i] * K[i]; gkk += G[i] * KK[i]; }
+  const double da = live ? (th * c - s) / (th * th) / th : 0.;                     // a'(th) / th
+  const double db = live ? (th * s - 2.0 * (1.0 - c)) / (th * th * th) / th : 0.;  // b'(th) / th
+  const double veeG[3] = {G[7] - G[5], G[2] - G[6], G[3] - G[1]};
+  const double veeM[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
+  for (int q = 0; q < 3; ++q) gw[q] = a * veeG[q] + b * veeM[q] + (da * gk + db * gkk) * w[q];
+}
+
+__global__ __launch_bounds__(64) void align_epilogue_a_kernel(AlignK k) {
+  const int32_t* ctrl = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl);
+  if (ctrl[CTRL_STOPPED]) return;
+  const float* out = k.state + k.L.out;
+  const float* cnt = k.state + k.L.cnt;
+  const float* pose = k.state + k.L.pose;
+  float* flat = k.state + k.L.flat;
+  for (int s = threadIdx.x; s < k.S; s += blockDim.x) {
+    double gR[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, gt[3] = {0., 0., 0.};
+    for (int p = 0; p < k.P; ++p) {
+      const AlignPairK& d = k.plan[p];
+      if (d.src != s && d.dst != s) continue;
+      const float* o = out + 24 * p;
+      const float denom = fmaxf(o[1], 1.0f) * (k.loss_type == 2 ? d.n_ch : 1.0f);
+      const float val = o[0] / denom;
+      const bool finite = (val == val) && !isinf(val);          // nan_to_num passes no gradient otherwise
+      const float gate = d.gate_p ? ((cnt[p] / (float)d.gate_n) > k.overlap_thresh ? 1.0f : 0.0f) : 1.0f;
+      if (!finite || gate == 0.0f) continue;
+      const double sc = (double)k.align_weight / (double)denom;
+      const float* Rd = pose + 12 * d.dst;
+      const double h[3] = {(double)Rd[0] * o[2] + (double)Rd[1] * o[3] + (double)Rd[2] * o[4],
+                           (double)Rd[3] * o[2] + (double)Rd[4] * o[3] + (double)Rd[5] * o[4],
+                           (double)Rd[6] * o[2] + (double)Rd[7] * o[3] + (double)Rd[8] * o[4]};
+      if (d.src == s) {
+        for (int i = 0; i < 9; ++i) gR[i] += o[14 + i] * sc;
+        for (int i = 0; i < 3; ++i) gt[i] += h[i] * sc;
+      } else {
+        for (int i = 0; i < 9; ++i) gR[i] += o[5 + i] * sc;
+        for (int i = 0; i < 3; ++i) gt[i] -= h[i] * sc;
+      }
+    }
+    const float* R0 = k.R0 + 9 * s;
+    double G[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) G[i * 3 + j] = R0[i] * gR[j] + R0[3 + i] * gR[3 + j] + R0[6 + i] * gR[6 + j];
+    const float* prm = k.state + k.L.params + 6 * s;
+    const float w[3] = {prm[0], prm[1], prm[2]};
+    double gw[3];
+    so3_exp_backward(w, G, gw);
+    for (int i = 0; i < 3; ++i) { flat[6 * s + i] = (float)gw[i]; flat[6 * s + 3 + i] = (float)gt[i]; }
+  }
+  if (threadIdx.x == 0) {     // pair losses in list order (the reference sums its loss dict in insertion order)
+    float* pl = k.state + k.L.pair_loss;
+    float total = 0.0f;
+    for (int p = 0; p < k.P; ++p) {
+      const AlignPairK& d = k.plan[p];
+      const float* o = out + 24 * p;
+      const float denom = fmaxf(o[1], 1.0f) * (k.loss_type == 2 ? d.n_ch : 1.0f);
+      const float gate = d.gate_p ? ((cnt[p] / (float)d.gate_n) > k.overlap_thresh ? 1.0f : 0.0f) : 1.0f;
+      const float v = gate != 0.0f ? nan_to_num_f(o[0] / denom) * k.align_weight : 0.0f;
+      pl[p] = v;
+      total += v;
+    }
+    flat[6 * k.S] = total;
+  }
+}
+
+__global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
+  int32_t* ctrl = reinterpret_cast<int32_t*>(k.state + k.L.ctrl);
+  if (ctrl[CTRL_STOPPED]) return;
+  __shared__ float s_total;
+  __shared__ float s_nr[64], s_nt[64];           // |dr_s|, |dt_s| BEFORE the step (S <= 64, checked by the entry point)
+  __shared__ double s_num[64], s_den[64];
+  float* prm = k.state + k.L.params;
+  const float* flat = k.state + k.L.flat;
+  for (int s = threadIdx.x; s < k.S; s += blockDim.x) {
+    const float* p = prm + 6 * s;
+    s_nr[s] = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+    s_nt[s] = sqrtf((p[3] * p[3] + p[4] * p[4]) + p[5] * p[5]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float total = flat[6 * k.S];
+    if (k.reg_weight > 0.0f) {      // grid_atlas_pose_trust_region_loss over ALL submaps, in its dict order
+      for (int s = 0; s < k.S; ++s) {
+        total += k.reg_weight * fmaxf(s_nr[s] - k.reg_rad, 0.0f);
+        total += k.reg_weight * fmaxf(s_nt[s] - k.reg_m, 0.0f);
+      }
+    }
+    s_total = total;
+  }
+  __syncthreads();
+  const float total = s_total;
+  const bool skip = total != total;      // "Loss at iter .. is nan! Skip backward step." (base.py:147-151)
+  const int t = ctrl[CTRL_STEP] + 1;
+  const double bc1 = 1.0 - pow(k.b1, (double)t), bc2 = 1.0 - pow(k.b2, (double)t);
+  AdamScalars a;
+  a.one_minus_b1 = (float)(1.0 - k.b1); a.b2 = (float)k.b2; a.one_minus_b2 = (float)(1.0 - k.b2);
+  a.neg_step_size = (float)(-(k.lr / bc1)); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)k.eps;
+  double num = 0., den = 0.;
+  for (int i = threadIdx.x; i < 6 * (k.S - 1); i += blockDim.x) {
+    const int s = 1 + i / 6, c = i % 6;      // submap 0 stays fixed (base.py:104-107)
+    const int j = 6 * s + c;
+    const float old = prm[j];
+    float g = flat[j];
+    if (k.reg_weight > 0.0f) {               // d/dp of weight * relu(|p| - thresh)
+      const float nrm = c < 3 ? s_nr[s] : s_nt[s];
+      if (nrm - (c < 3 ? k.reg_rad : k.reg_m) > 0.0f) g += k.reg_weight * (old / nrm);
+    }
+    float pv = old;
+    if (!skip) {
+      float m = k.state[k.L.adam_m + j], v = k.state[k.L.adam_v + j];
+      adam_one(pv, g, m, v, a);
+      k.state[k.L.adam_m + j] = m; k.state[k.L.adam_v + j] = v;
+      prm[j] = pv;
+    }
+    num += ((double)pv - old) * ((double)pv - old);
+    den += (double)old * old;
+  }
+  __syncthreads();
+  s_num[threadIdx.x] = num; s_den[threadIdx.x] = den;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double n = 0., d = 0.;
+    for (int i = 0; i < 64; ++i) { n += s_num[i]; d += s_den[i]; }
+    const int it = ctrl[CTRL_ITER];
+    // relative_param_change (utils.py:507-516): after iteration k against after iteration k-1; inf at k = 0
+    const float rel = (it == 0) ? INFINITY : (float)sqrt(n / d);
+    if (it < k.ring_iters) {
+      float* row = k.state + k.L.ring + (int64_t)it * k.L.ring_row;
+      row[0] = total; row[1] = rel;
+    }
+    if (skip) ctrl[CTRL_SKIPPED] += 1; else ctrl[CTRL_STEP] = t;
+    if (rel < k.rel_thresh) ctrl[CTRL_STOPPED] = 1;
+    ctrl[CTRL_ITER] = it + 1;
+  }
+}
+
+hipError_t launch_pair_batch(const AlignPairK*, int, int64_t, int64_t, bool, const float*, int, float*, float*,
+                             const int32_t*, hipStream_t);
+
+hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, bool vec4, hipStream_t s) {
+  align_prologue_kernel<<<1, 256, 0, s>>>(k);
+  const int32_t* stopped = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl) + CTRL_STOPPED;
+  hipError_t e = launch_pair_batch(k.plan, k.P, max_n, max_gate_n, vec4, k.state + k.L.pose, k.loss_type,
+                                   k.state + k.L.out, k.state + k.L.cnt, stopped, s);
+  if (e != hipSuccess) return e;
+  align_epilogue_a_kernel<<<1, 64, 0, s>>>(k);
+  return hipGetLastError();
+}
+
+hipError_t launch_align_b(const AlignK& k, hipStream_t s) {
+  align_epilogue_b_kernel<<<1, 64, 0, s>>>(k);
+  return hipGetLastError();
+}
+
+}  // namespace miso

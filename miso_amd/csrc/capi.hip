@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "align.hpp"
 
 namespace miso {
 hipError_t launch_encode_fwd(const GridK&, bool, const float*, int64_t, float*, int64_t, const int*, hipStream_t);
@@ -50,6 +51,8 @@ hipError_t launch_adam_active(float*, float*, float*, float*, unsigned char*, in
                               int, const float*, hipStream_t);
 hipError_t launch_mapping_loss(int, float, float, float, const float*, const float*, const float*,
                                const float*, const float*, int64_t, float*, float*, float*, hipStream_t);
+hipError_t launch_align_a(const AlignK&, int64_t, int64_t, bool, hipStream_t);
+hipError_t launch_align_b(const AlignK&, hipStream_t);
 }  // namespace miso
 
 using namespace miso;
@@ -506,6 +509,84 @@ int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, co
   if (n < 0 || !pose || !bound_min || !bound_max || !count_out || (n > 0 && !coords_src)) return MISO_E_BADARG;
   if (n >= ((int64_t)1 << 24)) return MISO_E_TOOLARGE;     // the fp32 count stays exact
   return (int)launch_overlap_count(pose, coords_src, n, bound_min, bound_max, count_out, (hipStream_t)stream);
+}
+
+int64_t miso_align_plan_bytes(int32_t n_pairs) {
+  return n_pairs < 0 ? 0 : (int64_t)(n_pairs > 0 ? n_pairs : 1) * (int64_t)sizeof(AlignPairK);
+}
+
+int miso_align_plan_build(const miso_align_pair_t* pairs, miso_align_t* cfg, void* plan_host) {
+  if (!cfg || cfg->n_pairs < 0 || cfg->n_submaps < 1 || cfg->n_submaps > 64) return MISO_E_BADARG;
+  if (cfg->n_pairs > 0 && (!pairs || !plan_host)) return MISO_E_BADARG;
+  AlignPairK* out = reinterpret_cast<AlignPairK*>(plan_host);
+  bool v4_all = true;
+  int64_t max_n = 0, max_gate = 0;
+  for (int p = 0; p < cfg->n_pairs; ++p) {
+    const miso_align_pair_t& in = pairs[p];
+    if (in.src < 0 || in.src >= cfg->n_submaps || in.dst < 0 || in.dst >= cfg->n_submaps || in.src == in.dst)
+      return MISO_E_BADARG;
+    if (in.n < 0 || in.gate_n < 0 || (in.n > 0 && (!in.coords_src || !in.feats_src))) return MISO_E_BADARG;
+    if (in.gate_n >= ((int64_t)1 << 24)) return MISO_E_TOOLARGE;     // the fp32 count stays exact
+    AlignPairK& d = out[p];
+    memset(&d, 0, sizeof(d));
+    bool v4;
+    int rc = convert_grid(&in.dst_grid, &d.g, true, &v4);
+    if (rc) return rc;
+    if (d.g.flags & (MISO_F_COORDS_NORMALIZED | MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER)) return MISO_E_UNSUPPORTED;
+    if (in.ld_feats < d.g.F) return MISO_E_BADARG;
+    v4_all = v4_all && v4;
+    d.p = in.coords_src; d.fsrc = in.feats_src; d.ld = in.ld_feats; d.n = in.n;
+    d.gate_p = in.gate_n > 0 ? in.gate_coords : nullptr; d.gate_n = in.gate_n;
+    d.src = in.src; d.dst = in.dst; d.n_ch = (float)d.g.F;
+    if (in.n > max_n) max_n = in.n;
+    if (d.gate_p && in.gate_n > max_gate) max_gate = in.gate_n;
+  }
+  cfg->vec4 = v4_all ? 1 : 0;
+  cfg->max_n = max_n;
+  cfg->max_gate_n = max_gate;
+  return MISO_OK;
+}
+
+int64_t miso_align_state_layout(int32_t n_submaps, int32_t n_pairs, int32_t ring_iters, int32_t save_poses,
+                                int64_t* offsets) {
+  if (n_submaps < 1 || n_submaps > 64 || n_pairs < 0 || ring_iters < 0) return 0;
+  const AlignLayout L = align_layout(n_submaps, n_pairs, ring_iters, save_poses);
+  if (offsets) {
+    const int64_t o[11] = {L.params, L.pose, L.out, L.cnt, L.pair_loss, L.flat, L.adam_m, L.adam_v, L.ctrl, L.ring,
+                           L.ring_row};
+    for (int i = 0; i < 11; ++i) offsets[i] = o[i];
+  }
+  return L.total;
+}
+
+static int align_k(const miso_align_t* c, AlignK* k) {
+  if (!c || c->n_submaps < 1 || c->n_submaps > 64 || c->n_pairs < 0 || c->ring_iters < 0) return MISO_E_BADARG;
+  if (!c->R0 || !c->t0 || !c->state || (c->n_pairs > 0 && !c->plan)) return MISO_E_BADARG;
+  if (c->loss_type != 1 && c->loss_type != 2) return MISO_E_BADARG;
+  if (((uintptr_t)c->state & 15u) != 0) return MISO_E_BADARG;
+  memset(k, 0, sizeof(*k));
+  k->S = c->n_submaps; k->P = c->n_pairs; k->loss_type = c->loss_type; k->ring_iters = c->ring_iters;
+  k->save_poses = c->save_poses;
+  k->align_weight = c->align_weight; k->overlap_thresh = c->overlap_thresh; k->reg_weight = c->reg_weight;
+  k->reg_rad = c->reg_thresh_rad; k->reg_m = c->reg_thresh_m; k->rel_thresh = c->rel_change_thresh;
+  k->lr = c->lr; k->b1 = c->beta1; k->b2 = c->beta2; k->eps = c->eps;
+  k->R0 = c->R0; k->t0 = c->t0; k->plan = reinterpret_cast<const AlignPairK*>(c->plan); k->state = c->state;
+  k->L = align_layout(k->S, k->P, k->ring_iters, k->save_poses);
+  return MISO_OK;
+}
+
+int miso_align_iteration_a(const miso_align_t* cfg, void* stream) {
+  AlignK k;
+  int rc = align_k(cfg, &k);
+  if (rc) return rc;
+  return (int)launch_align_a(k, cfg->max_n, cfg->max_gate_n, cfg->vec4 != 0, (hipStream_t)stream);
+}
+
+int miso_align_iteration_b(const miso_align_t* cfg, void* stream) {
+  AlignK k;
+  int rc = align_k(cfg, &k);
+  if (rc) return rc;
+  return (int)launch_align_b(k, (hipStream_t)stream);
 }
 
 int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const float* grad_sdf_x,

@@ -120,6 +120,35 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One (src, dst) pair of a fused alignment iteration, as the batched kernels of pair_latent.hip read it from the
+// device-resident plan (built on the host by miso_align_plan_build from miso_align_pair_t).
+struct AlignPairK {
+  GridK g;              // destination levels 0..level (data only) and bound
+  const float* p;       // (n,3) source vertices in the source frame
+  const float* fsrc;    // (n, ld) source features
+  int64_t ld, n;
+  const float* gate_p;  // (gate_n,3) finest-level source vertices for the overlap gate, or nullptr: always on
+  int64_t gate_n;
+  int32_t src, dst;
+  float n_ch;           // channels compared (the L2 mean divides by count * n_ch)
+  int32_t _pad;
+};
+
+// One torch.optim.Adam update (amsgrad=False, weight_decay=0) as torch forms it op by op; shared by adam.hip
+// (dense grids) and align.hip (the 6(S-1) pose numbers of the alignment loop).
+struct AdamScalars {
+  float one_minus_b1, b2, one_minus_b2, neg_step_size, bc2_sqrt, eps;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamScalars& a) {
+#pragma clang fp contract(off)   // one rounding per torch op, and the same bits from every kernel that inlines this
+  m = m + a.one_minus_b1 * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.b2 + (a.one_minus_b2 * g) * g;          // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  float denom = sqrtf(v) / a.bc2_sqrt + a.eps;      // (sqrt / bias_correction2_sqrt).add_(eps)
+  p = p + (a.neg_step_size * m) / denom;            // addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+
 // Pointwise mapping loss (grid_opt/loss.py:594-635, :668-700) shared by loss.hip and the fused
 // backward.  g / gf: d(w_sdf * sdf term) / ds and d(w_fs * free-space term) / ds BEFORE the 1/N of
 // the mean; s_sdf / s_fs accumulate the unweighted term sums.

@@ -28,19 +28,23 @@ struct PairK {
   float* out;          // 24 floats, zeroed by the launcher
 };
 
+// One workgroup's share (grid-stride from block bx of nbx) of one pair.  pose_s / pose_d: R[9] t[3] of the source
+// and the destination submap.  Shared by the single-pair kernel and the batched one (one launch for all pairs of an
+// alignment iteration, grid.y = pair, descriptors in device memory).
 template <bool VEC4>
-__global__ __launch_bounds__(256) void pair_latent_kernel(GridK g, PairK k) {
+__device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __restrict__ pose_s,
+                                                 const float* __restrict__ pose_d, const PairK& k, unsigned bx,
+                                                 unsigned nbx) {
   float Rs[9], ts[3], Rd[9], td[3];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { Rs[i] = k.pose[i]; Rd[i] = k.pose[12 + i]; }
+  for (int i = 0; i < 9; ++i) { Rs[i] = pose_s[i]; Rd[i] = pose_d[i]; }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { ts[i] = k.pose[9 + i]; td[i] = k.pose[21 + i]; }
+  for (int i = 0; i < 3; ++i) { ts[i] = pose_s[9 + i]; td[i] = pose_d[9 + i]; }
   float acc[23];
 #pragma unroll
   for (int i = 0; i < 23; ++i) acc[i] = 0.0f;
 
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < k.n;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t idx = (int64_t)bx * blockDim.x + threadIdx.x; idx < k.n; idx += (int64_t)nbx * blockDim.x) {
     const float px = k.p[idx * 3 + 0], py = k.p[idx * 3 + 1], pz = k.p[idx * 3 + 2];
     const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
                         Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
@@ -142,21 +146,41 @@ __global__ __launch_bounds__(256) void pair_latent_kernel(GridK g, PairK k) {
   }
 }
 
+template <bool VEC4>
+__global__ __launch_bounds__(256) void pair_latent_kernel(GridK g, PairK k) {
+  pair_latent_body<VEC4>(g, k.pose, k.pose + 12, k, blockIdx.x, gridDim.x);
+}
+
+// All pairs of one alignment iteration in one launch: blockIdx.y = pair, the pair's descriptor (destination
+// levels, source vertices and features) is read from the device-resident plan, the two poses from the (S,12)
+// table the prologue kernel of align.hip wrote.  out_all: (P,24), zeroed by that prologue.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void pair_latent_batch_kernel(const AlignPairK* __restrict__ plan,
+                                                               const float* __restrict__ pose_all, int loss_type,
+                                                               float* __restrict__ out_all,
+                                                               const int32_t* __restrict__ stopped) {
+  if (stopped && *stopped) return;
+  const AlignPairK& d = plan[blockIdx.y];
+  if ((int64_t)blockIdx.x * blockDim.x >= d.n) return;
+  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y};
+  pair_latent_body<VEC4>(d.g, pose_all + 12 * d.src, pose_all + 12 * d.dst, k, blockIdx.x, gridDim.x);
+}
+
 // Overlap test of two submaps (GridAtlas.check_submap_intersection, grid_opt/models/grid_atlas.py:405-420):
 // how many of the source vertices land inside the destination bound after src -> world -> dst.
 // The reference materialises both (N,3) transforms and a bool mask for ~4e6 vertices per pair per
 // alignment iteration; here one pass, one float out.
-__global__ __launch_bounds__(256) void overlap_count_kernel(const float* __restrict__ pose,
-                                                           const float* __restrict__ p, int64_t n, float bmin0,
-                                                           float bmin1, float bmin2, float bmax0, float bmax1,
-                                                           float bmax2, float* __restrict__ out) {
+__device__ __forceinline__ void overlap_count_body(const float* __restrict__ pose_s, const float* __restrict__ pose_d,
+                                                   const float* __restrict__ p, int64_t n, float bmin0,
+                                                   float bmin1, float bmin2, float bmax0, float bmax1,
+                                                   float bmax2, float* __restrict__ out, unsigned bx, unsigned nbx) {
   float Rs[9], ts[3], Rd[9], td[3];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { Rs[i] = pose[i]; Rd[i] = pose[12 + i]; }
+  for (int i = 0; i < 9; ++i) { Rs[i] = pose_s[i]; Rd[i] = pose_d[i]; }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { ts[i] = pose[9 + i]; td[i] = pose[21 + i]; }
+  for (int i = 0; i < 3; ++i) { ts[i] = pose_s[9 + i]; td[i] = pose_d[9 + i]; }
   float cnt = 0.0f;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t idx = (int64_t)bx * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)nbx * blockDim.x) {
     const float px = p[idx * 3 + 0], py = p[idx * 3 + 1], pz = p[idx * 3 + 2];
     // same operation order as pair_latent_kernel, so both agree on which vertices are inside
     const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
@@ -174,6 +198,25 @@ __global__ __launch_bounds__(256) void overlap_count_kernel(const float* __restr
     const float v = (red[0] + red[1]) + (red[2] + red[3]);
     if (v != 0.0f) atomic_add_f32(out, v);      // integer-valued partial counts: exact below 2^24 in total
   }
+}
+
+__global__ __launch_bounds__(256) void overlap_count_kernel(const float* __restrict__ pose,
+                                                           const float* __restrict__ p, int64_t n, float bmin0,
+                                                           float bmin1, float bmin2, float bmax0, float bmax1,
+                                                           float bmax2, float* __restrict__ out) {
+  overlap_count_body(pose, pose + 12, p, n, bmin0, bmin1, bmin2, bmax0, bmax1, bmax2, out, blockIdx.x, gridDim.x);
+}
+
+// The overlap gate of every pair of the plan in one launch (blockIdx.y = pair); cnt_all (P) zeroed by the prologue.
+__global__ __launch_bounds__(256) void overlap_count_batch_kernel(const AlignPairK* __restrict__ plan,
+                                                                 const float* __restrict__ pose_all,
+                                                                 float* __restrict__ cnt_all,
+                                                                 const int32_t* __restrict__ stopped) {
+  if (stopped && *stopped) return;
+  const AlignPairK& d = plan[blockIdx.y];
+  if (!d.gate_p || (int64_t)blockIdx.x * blockDim.x >= d.gate_n) return;
+  overlap_count_body(pose_all + 12 * d.src, pose_all + 12 * d.dst, d.gate_p, d.gate_n, d.g.bmin[0], d.g.bmin[1],
+                     d.g.bmin[2], d.g.bmax[0], d.g.bmax[1], d.g.bmax[2], cnt_all + blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 hipError_t launch_overlap_count(const float* pose, const float* p, int64_t n, const float* bmin, const float* bmax,
@@ -198,6 +241,25 @@ hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, cons
   if (blocks > 2048u) blocks = 2048u;
   if (vec4) pair_latent_kernel<true><<<blocks, 256, 0, s>>>(g, k);
   else pair_latent_kernel<false><<<blocks, 256, 0, s>>>(g, k);
+  return hipGetLastError();
+}
+
+// The pair stage of one fused alignment iteration (align.hip): overlap counts, then the pair residuals.
+hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t max_n, int64_t max_gate_n, bool vec4,
+                             const float* pose_all, int loss_type, float* out_all, float* cnt_all,
+                             const int32_t* stopped, hipStream_t s) {
+  if (n_pairs <= 0) return hipSuccess;
+  if (max_gate_n > 0) {
+    unsigned blocks = (unsigned)((max_gate_n + 2047) / 2048);
+    if (blocks > 512u) blocks = 512u;
+    overlap_count_batch_kernel<<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, cnt_all, stopped);
+  }
+  if (max_n > 0) {
+    unsigned blocks = (unsigned)((max_n + 255) / 256);
+    if (blocks > 2048u) blocks = 2048u;
+    if (vec4) pair_latent_batch_kernel<true><<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
+    else pair_latent_batch_kernel<false><<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
+  }
   return hipGetLastError();
 }
 

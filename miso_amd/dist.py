@@ -23,8 +23,6 @@ import torch
 import torch.distributed as dist
 
 import miso_amd.grid_opt.utils.utils as utils
-from miso_amd.grid_opt.align.base import grid_atlas_pose_trust_region_loss, iteration_results_helper
-from miso_amd.optim import DenseAdam
 
 logger = logging.getLogger(__name__)
 
@@ -107,74 +105,30 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
                                        rel_change_thresh=0, submap_pairs=None, check_intersection=True,
                                        pose_reg_weight=0, pose_thresh_rad=1.0, pose_thresh_m=1.0,
                                        verbose=False, save_iterations=False):
-    """generic_align_multiple_submaps (grid_opt/align/base.py:89-163) with the pair list
-    sharded over ranks.  Every rank must hold all submaps (sync_submaps) and identical pose
-    parameters; results equal the single-process run up to fp32 summation order."""
-    from torch.utils.data import DataLoader
-    from miso_amd.grid_opt.utils.utils import collate_batch_of_one
+    """generic_align_multiple_submaps (grid_opt/align/base.py:89-163) with the pair list sharded over ranks.
+    Every rank must hold all submaps (sync_submaps) and identical pose parameters.
+
+    The loop is base.fused_alignment_loop: this rank's pairs go through ONE overlap launch and ONE pair launch per
+    iteration (no per-pair Python, no host sync on the overlap test or the NaN guard), the 6S + 1 floats of pose
+    gradients + loss are all-reduced, and the identical regulariser / NaN guard / Adam step runs on every rank, so
+    the replicas stay bit-identical.  Results equal the single-process run up to fp32 summation order of the pair
+    sums.  The pair loss must carry ``fused`` (align.miso.latent_loss_for_level)."""
+    from miso_amd.grid_opt.align.base import fused_alignment_loop
     rank, world = rank_world()
-
-    def pose_params():
-        return [p for s in range(1, grid_atlas.num_submaps) for p in grid_atlas.params_for_submap_pose(s)]
-
-    params = pose_params()
-    optimizer = DenseAdam([{'params': params, 'lr': lr}], lr=lr)
-    loader = DataLoader(dataset, shuffle=True, batch_size=1, num_workers=0, collate_fn=collate_batch_of_one)
     loss_name, loss_func = pairwise_loss_tuple
+    fused = getattr(loss_func, 'fused', None)
+    if fused is None:
+        raise ValueError("align_multiple_submaps_distributed needs a fused pair loss "
+                         "(miso_amd.grid_opt.align.miso.latent_loss_for_level); the SDF fine-tune stage is not sharded")
     if submap_pairs is None:
         n = grid_atlas.num_submaps
         submap_pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
     my_pairs = partition_pairs(submap_pairs, rank, world)
-    sizes = [p.numel() for p in params]
-    flat = torch.zeros(sum(sizes) + 1, dtype=torch.float32, device=params[0].device)
     timer = utils.PerfTimer(activate=True)
-    iteration_results = dict()
-    prev = None
-    it = 0
-    while it <= num_iters:
-        if save_iterations:
-            iteration_results[it] = iteration_results_helper(grid_atlas)
-        optimizer.zero_grad()
-        loss_dict = {}
-        for src_id, dst_id in my_pairs:
-            if check_intersection and not bool(grid_atlas.check_submap_intersection(src_id, dst_id)):
-                continue
-            pair = loss_func(grid_atlas, loader, src_id, dst_id)
-            loss_dict.update({k: torch.nan_to_num(v) for k, v in pair.items()})
-        if pose_reg_weight > 0 and rank == 0:   # replicated term: counted once
-            loss_dict.update(grid_atlas_pose_trust_region_loss(grid_atlas, thresh_rad=pose_thresh_rad,
-                                                               thresh_m=pose_thresh_m, weight=pose_reg_weight))
-        local = sum(loss_dict.values()) if loss_dict else None
-        if local is not None and local.requires_grad:
-            local.backward(retain_graph=False)
-        # ---- the one collective of the iteration ------------------------------------------
-        flat.zero_()
-        off = 0
-        for p, k in zip(params, sizes):
-            if p.grad is not None:
-                flat[off:off + k] = p.grad.reshape(-1)
-            off += k
-        if local is not None:
-            flat[-1] = local.detach()
-        if world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        total = flat[-1]
-        if not torch.isnan(total):
-            off = 0
-            for p, k in zip(params, sizes):
-                p.grad = flat[off:off + k].view_as(p).clone()
-                off += k
-            optimizer.step()
-        else:
-            logger.warning(f"Loss at iter {it} is nan! Skip backward step.")
-        cur = [p.clone().detach() for p in params]
-        change = utils.relative_param_change(cur, prev)
-        prev = cur
-        if verbose and rank == 0:
-            logger.info(f"AlignMultiDist_{loss_name} iteration {it}: loss = {float(total):.2e}, "
-                        f"pose_relchange={change:.2e}")
-        if change < rel_change_thresh:
-            break
-        it += 1
+    reduce = (lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM)) if world > 1 else None
+    iteration_results = fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr, num_iters,
+                                             rel_change_thresh, pose_reg_weight, pose_thresh_rad, pose_thresh_m,
+                                             verbose and rank == 0, save_iterations, f"{loss_name}[rank {rank}/{world}]",
+                                             reduce=reduce, my_pairs=my_pairs)
     cpu_time, gpu_time = timer.check()
     return {'cpu_time_sec': cpu_time, 'gpu_time_sec': gpu_time, 'iteration_results': iteration_results}

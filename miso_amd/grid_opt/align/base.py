@@ -75,83 +75,91 @@ def generic_align_submap_pair(grid_atlas: GridAtlas, dataset: Dataset, src_id: i
     return {'cpu_time_sec': cpu_time, 'gpu_time_sec': gpu_time}
 
 
-def _captured_alignment_loop(grid_atlas, params, batched, submap_pairs, check_intersection, reg, lr, num_iters,
-                             loss_name, verbose):
-    """The whole pose-Adam iteration -- zero the gradients, all pair losses behind one autograd node, backward
-    through the batched exponential map, Adam on the 6(S-1) pose numbers -- captured ONCE in a HIP graph and
-    replayed: an iteration is ~60 tiny launches plus the pair kernels, and eagerly the host needs 3x as long to
-    issue them as the GPU to run them.  Adam is torch's own with ``capturable=True`` (step counts on the device;
-    same formula as the reference's torch.optim.Adam).  The first three iterations run eagerly on a side stream,
-    as graph capture wants; losses and relative pose changes of every iteration are kept on the device and
-    logged afterwards.  Returns False (nothing done) if the capture cannot be made; the caller's eager loop runs."""
-    dev = params[0].device
-    total_iters = num_iters + 1
-    if total_iters < 8:
-        return False
-    hist = torch.zeros((total_iters, 2), device=dev)              # loss, relative change
-    it_dev = torch.zeros(1, device=dev, dtype=torch.long)
-    prev = [torch.zeros_like(p) for p in params]
-    one = torch.ones(1, device=dev, dtype=torch.long)
-    try:        # one multi-tensor kernel for the 2(S-1) pose tensors instead of ~15 launches per tensor
-        optimizer = torch.optim.Adam(params, lr=lr, capturable=True, fused=True)
-    except (RuntimeError, TypeError, ValueError):
-        optimizer = torch.optim.Adam(params, lr=lr, capturable=True, foreach=False)
+def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr, num_iters, rel_change_thresh,
+                         pose_reg_weight, pose_thresh_rad, pose_thresh_m, verbose, save_iterations, loss_name,
+                         reduce=None, my_pairs=None, use_graph=True):
+    """The whole loop of generic_align_multiple_submaps on the device (ops.AlignPlan: miso_align_iteration_a / _b).
+
+    One iteration is five launches whatever the number of pairs -- poses from the corrections, the overlap gate
+    and the latent residual of every pair (one launch each, grid.y = pair), the pull-back of the pose cotangents
+    through R0 Exp(dr), then regulariser + NaN guard + Adam + early-stop test -- and the host reads nothing until
+    the loop ends: per-iteration losses, relative changes and (save_iterations) the (S,4,4) pose snapshots of
+    iteration_results_helper are written to a device ring by the kernels.  So the loop also stays on the device
+    under the reference's own alignment config (verbose: True, save_iterations: True, configs/rgbd/scannet.yaml:65-66).
+
+    fused: dict(inputs=callable(atlas, pairs, check_intersection) -> list of pair dicts for ops.AlignPlan,
+    align_loss, align_weight[, overlap_thresh]).  reduce / my_pairs: the multi-rank hook of miso_amd.dist -- this
+    rank evaluates ``my_pairs`` only and ``reduce(flat)`` sums the 6S + 1 floats over ranks between the two halves
+    of the iteration.  Returns the ``iteration_results`` dict."""
+    from miso_amd import ops
+    S = grid_atlas.num_submaps
+    dev = grid_atlas.rotation_corrections[0].device
+    pairs = list(submap_pairs if my_pairs is None else my_pairs)
+    total_iters = num_iters + 1                       # upstream runs num_iters + 1 iterations (base.py:127)
+    R0 = torch.stack([R.to(dev) for R in grid_atlas.R_world_submap_list])
+    t0 = torch.stack([t.to(dev) for t in grid_atlas.t_world_submap_list])
+    plan = ops.AlignPlan(R0, t0, fused['inputs'](grid_atlas, pairs, check_intersection),
+                         loss_type=fused['align_loss'], align_weight=fused['align_weight'],
+                         overlap_thresh=fused.get('overlap_thresh', 1e-2), lr=lr,
+                         reg_weight=pose_reg_weight if pose_reg_weight > 0 else 0.0, reg_thresh_rad=pose_thresh_rad,
+                         reg_thresh_m=pose_thresh_m, rel_change_thresh=rel_change_thresh, ring_iters=total_iters,
+                         save_poses=save_iterations)
+    with torch.no_grad():
+        dr = torch.cat([p.detach().reshape(1, 3) for p in grid_atlas.rotation_corrections], dim=0)
+        dt = torch.cat([p.detach().reshape(1, 3) for p in grid_atlas.translation_corrections], dim=0)
+        plan.params.copy_(torch.cat((dr, dt), dim=1))
 
     def iteration():
-        loss_dict = dict(batched(grid_atlas, submap_pairs, check_intersection))
-        if reg is not None:
-            loss_dict.update(reg())
-        total = sum(loss_dict.values())
-        total.backward()
-        if not verbose:                      # nothing to report afterwards: no bookkeeping kernels in the graph
-            optimizer.step()
-            return
-        with torch.no_grad():
-            for q, p in zip(prev, params):
-                q.copy_(p)
-        optimizer.step()
-        with torch.no_grad():
-            num = sum(torch.sum((p - q) ** 2) for p, q in zip(params, prev))
-            den = sum(torch.sum(q ** 2) for q in prev)
-            # upstream compares the parameters AFTER iterations k and k-1 (base.py:152-158)
-            row = torch.stack((total.detach(), torch.sqrt(num / den))).reshape(1, 2)
-            hist.index_copy_(0, it_dev, row)
-            it_dev.add_(one)
+        plan.iteration_a()
+        if reduce is not None:
+            reduce(plan.flat)
+        plan.iteration_b()
 
-    snapshot = [p.detach().clone() for p in params]
+    done = 0
     graph = None
-    try:
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                optimizer.zero_grad(set_to_none=True)
+    if use_graph and reduce is None and dev.type == 'cuda' and total_iters >= 8:
+        try:        # level 0 iterations are ~30 us of GPU work: replay them instead of issuing five launches each
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                iteration()                                           # iteration 0, eagerly (capture wants a warm-up)
+            cur.wait_stream(side)
+            done = 1
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 iteration()
-        cur.wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        except Exception as exc:                                    # pragma: no cover - depends on the runtime
+            logger.warning(f"alignment iteration not captured ({type(exc).__name__}: {exc}); issuing it launch by launch")
+            graph = None
+    check_every = 16 if rel_change_thresh > 0 else 0
+    while done < total_iters:
+        if graph is not None:
+            graph.replay()
+        else:
             iteration()
-    except Exception as exc:                                        # pragma: no cover - depends on the runtime
-        logger.warning(f"alignment loop not captured ({type(exc).__name__}: {exc}); running it op by op")
-        with torch.no_grad():
-            for p, q in zip(params, snapshot):
-                p.copy_(q)
-                p.grad = None
-        return False
-    for _ in range(total_iters - 3):
-        graph.replay()
-    for p in params:
-        p.grad = None
-    if verbose:
-        rows = hist.cpu().tolist()
-        for it, (loss, change) in enumerate(rows):
-            # the change upstream logs at iteration k is between the parameters after k and after k-1: inf at k = 0
-            shown = float('inf') if it == 0 else rows[it][1]
-            logger.info(f"AlignMulti_{loss_name} iteration {it}: loss = {loss:.2e}, pose_relchange={shown:.2e}, "
-                        f"lr={lr:.2e}")
-    return True
+        done += 1
+        if check_every and done % check_every == 0 and plan.ctrl()['stopped']:
+            break                                                    # further iterations would change nothing
+    ctrl = plan.ctrl()
+    with torch.no_grad():
+        prm = plan.params.clone()
+        for s in range(1, S):                                        # submap 0 is fixed
+            grid_atlas.rotation_corrections[s].copy_(prm[s, :3].reshape(1, 3))
+            grid_atlas.translation_corrections[s].copy_(prm[s, 3:].reshape(3, 1))
+    ran = ctrl['iterations']
+    iteration_results = dict()
+    if verbose or save_iterations or ctrl['skipped']:
+        ring = plan.ring()[:ran].cpu()
+        for it in range(ran):
+            if save_iterations:
+                iteration_results[it] = ring[it, 2:].reshape(S, 4, 4).to(dev)
+            if verbose:
+                logger.info(f"AlignMulti_{loss_name} iteration {it}: loss = {ring[it, 0].item():.2e}, "
+                            f"pose_relchange={ring[it, 1].item():.2e}, lr={lr:.2e}")
+        if ctrl['skipped']:
+            logger.warning(f"AlignMulti_{loss_name}: loss was nan in {ctrl['skipped']} iteration(s); their steps were skipped.")
+    return iteration_results
 
 
 def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pairwise_loss_tuple, num_iters=10,
@@ -173,18 +181,14 @@ def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pair
     iteration_results = dict()
     prev = None
     it = 0
-    batched_fn = getattr(loss_func, 'batched', None)
     params = pose_params()
-    if (batched_fn is not None and not save_iterations and rel_change_thresh <= 0 and params
-            and all(p.is_cuda and p.requires_grad for p in params)
-            and not getattr(grid_atlas, 'no_captured_alignment', False)):
-        reg = None
-        if pose_reg_weight > 0:
-            reg = lambda: grid_atlas_pose_trust_region_loss(grid_atlas, thresh_rad=pose_thresh_rad,        # noqa: E731
-                                                            thresh_m=pose_thresh_m, weight=pose_reg_weight)
-        if _captured_alignment_loop(grid_atlas, params, batched_fn, submap_pairs, check_intersection, reg, lr,
-                                    num_iters, loss_name, verbose):
-            it = num_iters + 1
+    fused = getattr(loss_func, 'fused', None)
+    if (fused is not None and params and all(p.requires_grad for p in params)
+            and not getattr(grid_atlas, 'no_fused_alignment', False)):
+        iteration_results = fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr, num_iters,
+                                                 rel_change_thresh, pose_reg_weight, pose_thresh_rad, pose_thresh_m,
+                                                 verbose, save_iterations, loss_name)
+        it = num_iters + 1
     while it <= num_iters:
         if save_iterations:
             iteration_results[it] = iteration_results_helper(grid_atlas)

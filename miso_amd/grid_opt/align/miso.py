@@ -163,6 +163,25 @@ def pairwise_loss_latent_batched(grid_atlas: GridAtlas, pairs, level: int, fdim=
     return {f'align_latent_level{level}_{a}_{b}': losses[i] for i, (a, b) in enumerate(pairs)}
 
 
+def latent_pair_inputs(grid_atlas: GridAtlas, pairs, level: int, fdim=4, check_intersection=True):
+    """Per-pair inputs of ops.AlignPlan for pairwise_loss_latent at ``level`` (default options: L2 / L1, bound mask
+    on, no stability / truncation pruning, no subsampling): the source's cached alignment vertices and its features
+    there (pose independent: computed once per (submap, level)), the destination's levels 0..level, and the
+    source's finest-level vertices for the overlap gate of base.py:134."""
+    out = []
+    for src_id, dst_id in pairs:
+        sub_from, sub_to = grid_atlas.get_submap(src_id), grid_atlas.get_submap(dst_id)
+        assert fdim == sub_from.fdim
+        nlv = min(level + 1, sub_from.num_levels)
+        coords = grid_atlas.coordinates_for_alignment(submap_id=src_id, level=level)
+        out.append(dict(src=src_id, dst=dst_id, coords=coords,
+                        feats_src=_src_features(grid_atlas, src_id, level, coords, nlv),
+                        feats_dst=[g.feature.detach() for g in sub_to.features[:nlv]],
+                        meta_dst=sub_to.features[0].grid_meta(sub_to.ignore_level_[:nlv]),
+                        gate_pts=grid_atlas._finest_vertices(src_id) if check_intersection else None))
+    return out
+
+
 def pairwise_loss_sdf(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id: int, align_weight=3000,
                       align_loss='L2', use_bound=True, stability_thresh=0, covariance_thresh=None,
                       subsample_points=None, gm_scale_sdf=0.1, device="cuda:0"):
@@ -210,6 +229,38 @@ def pairwise_loss_sdf(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id: i
     return {key: val * align_weight}
 
 
+def latent_loss_for_level(grid_atlas: GridAtlas, level: int, align_weight=3000, align_loss="L2", use_bound=True,
+                          stability_thresh=0, subsample_points=None, device="cuda:0"):
+    """The pair-loss callable generic_align_multiple_submaps takes (``loss(atlas, loader, src, dst) -> dict``) for
+    pairwise_loss_latent at ``level``, carrying what lets the driver avoid the per-pair host work when the default
+    options are on (L2 / L1, bound mask, no stability pruning, no subsampling) and the atlas lives on the GPU:
+    ``device_gate`` (overlap decided on the device), ``batched`` (all pairs behind one autograd node) and ``fused``
+    (the whole pose-Adam loop on the device, base.fused_alignment_loop)."""
+    from miso_amd import ops as _ops
+
+    def latent(atlas, loader, a, b):
+        return pairwise_loss_latent(atlas, loader, a, b, level=level, align_weight=align_weight,
+                                    align_loss=align_loss, use_bound=use_bound, stability_thresh=stability_thresh,
+                                    subsample_points=subsample_points, device=device)
+    default_opts = (align_loss in ('L2', 'L1') and use_bound and stability_thresh <= 0 and subsample_points is None)
+    on_gpu = (default_opts and str(device).startswith('cuda')
+              and grid_atlas.get_submap(0).features[0].feature.is_cuda)
+    # the fused pair kernel is cheap enough to run on non-overlapping pairs too: let the driver gate it on the
+    # device instead of synchronising on check_submap_intersection per pair
+    latent.device_gate = on_gpu
+    if on_gpu:
+        def latent_all(atlas, pairs, check_intersection):
+            return pairwise_loss_latent_batched(atlas, pairs, level=level, fdim=atlas.get_submap(0).fdim,
+                                                align_weight=align_weight, align_loss=align_loss,
+                                                check_intersection=check_intersection, device=device)
+        latent.batched = latent_all
+    if on_gpu or (default_opts and getattr(_ops.AlignPlan, 'cpu_ok', False)):
+        latent.fused = dict(align_loss=align_loss, align_weight=align_weight,
+                            inputs=lambda atlas, pairs, chk: latent_pair_inputs(
+                                atlas, pairs, level=level, fdim=atlas.get_submap(0).fdim, check_intersection=chk))
+    return latent
+
+
 def align_multiple_submaps_hierarchical(grid_atlas: GridAtlas, dataset, level_iters=10, finetune_iters=10,
                                         level_thresh=0.0, lr=1e-2, align_weight=3000, align_loss="L2",
                                         use_bound=True, stability_thresh=0, subsample_points=None,
@@ -225,22 +276,9 @@ def align_multiple_submaps_hierarchical(grid_atlas: GridAtlas, dataset, level_it
                   pose_thresh_rad=pose_thresh_rad, verbose=verbose, save_iterations=save_iterations)
     levels = range(grid_atlas.num_levels) if latent_levels is None else latent_levels
     for lvl in levels:
-        def latent(atlas, loader, a, b, _l=lvl):
-            return pairwise_loss_latent(atlas, loader, a, b, level=_l, align_weight=align_weight,
-                                        align_loss=align_loss, use_bound=use_bound,
-                                        stability_thresh=stability_thresh, subsample_points=subsample_points,
-                                        device=device)
-        # the fused pair kernel is cheap enough to run on non-overlapping pairs too: let the driver
-        # gate it on the device instead of synchronising on check_submap_intersection per pair
-        latent.device_gate = (align_loss in ('L2', 'L1') and use_bound and stability_thresh <= 0
-                              and subsample_points is None and str(device).startswith('cuda'))
-        if latent.device_gate and grid_atlas.get_submap(0).features[0].feature.is_cuda:
-            # all pairs of an iteration behind one autograd node
-            def latent_all(atlas, pairs, check_intersection, _l=lvl):
-                return pairwise_loss_latent_batched(atlas, pairs, level=_l, fdim=atlas.get_submap(0).fdim,
-                                                    align_weight=align_weight, align_loss=align_loss,
-                                                    check_intersection=check_intersection, device=device)
-            latent.batched = latent_all
+        latent = latent_loss_for_level(grid_atlas, lvl, align_weight=align_weight, align_loss=align_loss,
+                                       use_bound=use_bound, stability_thresh=stability_thresh,
+                                       subsample_points=subsample_points, device=device)
         name = f'hier_latent_level{lvl}_{align_loss}'
         res = generic_align_multiple_submaps(grid_atlas, dataset, (name, latent), num_iters=level_iters,
                                              rel_change_thresh=level_thresh, **common)

@@ -797,6 +797,112 @@ def pair_latent_multi(R_all, t_all, plan) -> torch.Tensor:
     return _PairLatentMulti.apply(R_all, t_all, plan)
 
 
+class AlignPlan:
+    """Device-resident state of one fused alignment run (miso_align_iteration_a / _b): Adam over the pose
+    corrections of submaps 1..S-1 on the summed latent pair losses, generic_align_multiple_submaps
+    (grid_opt/align/base.py:89-163) with pairwise_loss_latent (grid_opt/align/miso.py:116-211, L2 / L1).  An
+    iteration is ``iteration_a()`` (poses, overlap gates, every pair's residual and pose cotangents, pulled back to
+    d loss / d (dr, dt)) then ``iteration_b()`` (regulariser, NaN guard, Adam, early stop, bookkeeping); in between a
+    multi-rank caller all-reduces ``flat`` (6S pose gradients + the pair-loss sum).  The host reads nothing inside
+    the loop: losses, relative changes and pose snapshots of every iteration sit in ``ring()`` afterwards.
+
+    R0 (S,3,3) / t0 (S,3,1): base poses.  pairs: dicts with ``src``, ``dst``, ``coords`` (n,3), ``feats_src``
+    (n, >= F), ``feats_dst`` (list of level tensors, levels 0..level), ``meta_dst`` (GridMeta) and ``gate_pts``
+    ((m,3) finest-level vertices of src, or None: no overlap gate)."""
+
+    def __init__(self, R0, t0, pairs, *, loss_type="L2", align_weight=3000.0, overlap_thresh=1e-2, lr=1e-2,
+                 betas=(0.9, 0.999), eps=1e-8, reg_weight=0.0, reg_thresh_rad=1.0, reg_thresh_m=1.0,
+                 rel_change_thresh=0.0, ring_iters=0, save_poses=False):
+        _require_hip(R0, t0)
+        lib = _lib.load()
+        dev = R0.device
+        S, P = int(R0.shape[0]), len(pairs)
+        self.S, self.P, self.device = S, P, dev
+        self._R0 = R0.detach().reshape(S, 9).contiguous().clone()
+        self._t0 = t0.detach().reshape(S, 3).contiguous().clone()
+        cfg = _lib.Align()
+        cfg.n_submaps, cfg.n_pairs, cfg.loss_type = S, P, _LOSS_TYPES[loss_type]
+        cfg.ring_iters, cfg.save_poses = int(ring_iters), int(bool(save_poses))
+        cfg.align_weight, cfg.overlap_thresh = float(align_weight), float(overlap_thresh)
+        cfg.reg_weight, cfg.reg_thresh_rad, cfg.reg_thresh_m = float(reg_weight), float(reg_thresh_rad), float(reg_thresh_m)
+        cfg.rel_change_thresh = float(rel_change_thresh)
+        cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
+        self._keep = []
+        descs = (_lib.AlignPair * max(P, 1))()
+        for i, pr in enumerate(pairs):
+            feats_dst = [f.detach() for f in pr["feats_dst"]]
+            coords = pr["coords"].detach().contiguous()
+            fsrc = _rows(pr["feats_src"].detach())
+            _require_hip(coords, fsrc, *feats_dst)
+            d = descs[i]
+            d.dst_grid = _fill_grid(feats_dst, pr["meta_dst"])
+            d.coords_src, d.feats_src = coords.data_ptr(), fsrc.data_ptr()
+            d.n = coords.shape[0]
+            d.ld_feats = fsrc.stride(0) if d.n else _feature_dim(feats_dst)
+            gate = pr.get("gate_pts")
+            if gate is not None:
+                gate = gate.detach().contiguous()
+                _require_hip(gate)
+                d.gate_coords, d.gate_n = gate.data_ptr(), gate.shape[0]
+            d.src, d.dst = int(pr["src"]), int(pr["dst"])
+            self._keep.append((feats_dst, coords, fsrc, gate))
+        nbytes = int(lib.miso_align_plan_bytes(P))
+        blob = (C.c_uint8 * nbytes)()
+        _lib.check(lib.miso_align_plan_build(descs, C.byref(cfg), blob), "miso_align_plan_build")
+        self._plan = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        off = (C.c_int64 * 11)()
+        total = int(lib.miso_align_state_layout(S, P, cfg.ring_iters, cfg.save_poses, off))
+        self._off = [int(v) for v in off]
+        self.state = torch.zeros(max(total, 4), device=dev, dtype=torch.float32)
+        cfg.R0, cfg.t0 = self._R0.data_ptr(), self._t0.data_ptr()
+        cfg.plan, cfg.state = self._plan.data_ptr(), self.state.data_ptr()
+        self.cfg = cfg
+        self.ring_iters, self.save_poses = cfg.ring_iters, bool(cfg.save_poses)
+
+    def _view(self, k, n):
+        return self.state[self._off[k]:self._off[k] + n]
+
+    @property
+    def params(self) -> torch.Tensor:
+        """(S,6) = (dr, dt) per submap: write the initial corrections here, read the final ones back."""
+        return self._view(0, 6 * self.S).view(self.S, 6)
+
+    @property
+    def poses(self) -> torch.Tensor:
+        """(S,12) = (R row-major, t) as of the last iteration_a."""
+        return self._view(1, 12 * self.S).view(self.S, 12)
+
+    @property
+    def pair_out(self) -> torch.Tensor:
+        return self._view(2, 24 * self.P).view(self.P, 24)
+
+    @property
+    def pair_losses(self) -> torch.Tensor:
+        """(P,) weighted, gated, nan_to_num'ed pair losses of the last iteration_a."""
+        return self._view(4, self.P)
+
+    @property
+    def flat(self) -> torch.Tensor:
+        """6S + 1 floats: d loss / d (dr_s, dt_s) of every submap from THIS plan's pairs, then their loss sum."""
+        return self._view(5, 6 * self.S + 1)
+
+    def iteration_a(self):
+        _lib.check(_lib.load().miso_align_iteration_a(C.byref(self.cfg), _stream(self.state)), "miso_align_iteration_a")
+
+    def iteration_b(self):
+        _lib.check(_lib.load().miso_align_iteration_b(C.byref(self.cfg), _stream(self.state)), "miso_align_iteration_b")
+
+    def ctrl(self) -> dict:
+        """Host copy of the counters (one sync): Adam steps taken, stopped flag, iterations run, NaN-skipped."""
+        c = self._view(8, 8).view(torch.int32).cpu().tolist()
+        return dict(steps=c[0], stopped=bool(c[1]), iterations=c[2], skipped=c[3])
+
+    def ring(self) -> torch.Tensor:
+        """(ring_iters, 2 [+ 16 S]) rows {loss, relative change [, (S,4,4) poses before the step]}."""
+        row = self._off[10]
+        return self._view(9, self.ring_iters * row).view(self.ring_iters, row)
+
+
 def overlap_count(R_src, t_src, R_dst, t_dst, coords_src, bound_dst) -> torch.Tensor:
     """0-d device tensor: how many of coords_src (N,3) fall inside bound_dst ((3,2) [min,max] rows,
     inclusive) after src -> world -> dst (GridAtlas.check_submap_intersection,

@@ -38,9 +38,112 @@ def mapping_loss(pred, target, valid, sign, weight, loss_type="L1", weight_sdf=1
     return torch.stack((a, b))
 
 
+class AlignPlan:
+    """TEST-ONLY torch restatement of ops.AlignPlan (miso_align_iteration_a / _b) so that the host side of
+    base.fused_alignment_loop and the sharded loop of miso_amd.dist run without a GPU.  Follows
+    generic_align_multiple_submaps (grid_opt/align/base.py:89-163) step by step with autograd."""
+    cpu_ok = True
+
+    def __init__(self, R0, t0, pairs, *, loss_type="L2", align_weight=3000.0, overlap_thresh=1e-2, lr=1e-2,
+                 betas=(0.9, 0.999), eps=1e-8, reg_weight=0.0, reg_thresh_rad=1.0, reg_thresh_m=1.0,
+                 rel_change_thresh=0.0, ring_iters=0, save_poses=False):
+        self.S, self.P = R0.shape[0], len(pairs)
+        self.R0, self.t0, self.pairs = R0.detach().clone(), t0.detach().clone(), pairs
+        self.k = dict(loss_type=loss_type, w=float(align_weight), thr=float(overlap_thresh), lr=float(lr), b1=betas[0],
+                      b2=betas[1], eps=eps, reg=float(reg_weight), rad=float(reg_thresh_rad), m=float(reg_thresh_m),
+                      rel=float(rel_change_thresh))
+        self.params = torch.zeros(self.S, 6)
+        self.flat = torch.zeros(6 * self.S + 1)
+        self.pair_losses = torch.zeros(self.P)
+        self.m, self.v = torch.zeros(self.S, 6), torch.zeros(self.S, 6)
+        self.ring_iters, self.save_poses = int(ring_iters), bool(save_poses)
+        self._ring = torch.zeros(self.ring_iters, 2 + (16 * self.S if save_poses else 0))
+        self._c = dict(steps=0, stopped=False, iterations=0, skipped=0)
+
+    def iteration_a(self):
+        if self._c['stopped']:
+            return
+        k = self.k
+        dr = self.params[:, :3].clone().requires_grad_(True)
+        dt = self.params[:, 3:].clone().requires_grad_(True)
+        Rm = self.R0 @ R.so3_exp_map(dr)
+        tm = self.t0 + dt.reshape(-1, 3, 1)
+        it = self._c['iterations']
+        if self.save_poses and it < self.ring_iters:
+            T = torch.zeros(self.S, 4, 4)
+            T[:, :3, :3], T[:, :3, 3:], T[:, 3, 3] = Rm.detach(), tm.detach(), 1.0
+            self._ring[it, 2:] = T.reshape(-1)
+        total = torch.zeros(())
+        for i, pr in enumerate(self.pairs):
+            a, b = pr["src"], pr["dst"]
+            bound = _bound(pr["meta_dst"])
+            gate = 1.0
+            if pr.get("gate_pts") is not None:
+                with torch.no_grad():
+                    q = R.transfrom_points_from(R.transform_points_to(pr["gate_pts"], Rm[a], tm[a]), Rm[b], tm[b])
+                    gate = float((torch.count_nonzero(R.coords_in_bound(q, bound)) / q.shape[0]) > k['thr'])
+            q = R.transfrom_points_from(R.transform_points_to(pr["coords"], Rm[a], tm[a]), Rm[b], tm[b])
+            inb = R.coords_in_bound(q, bound)
+            w = inb.to(q.dtype)
+            q = torch.where(inb, q, torch.zeros_like(q))      # NaN / far-away rows carry no weight: keep the gather finite
+            F = sum(int(f.shape[1]) for f in pr["feats_dst"])
+            diff = (pr["feats_src"][:, :F] - encode(q, pr["feats_dst"], pr["meta_dst"])) * w
+            n_valid = w.sum().clamp(min=1.0)
+            val = diff.pow(2).sum() / (n_valid * F) if k['loss_type'] == "L2" \
+                else torch.linalg.vector_norm(diff, dim=1).sum() / n_valid
+            val = torch.nan_to_num(val) * k['w'] * gate
+            self.pair_losses[i] = val.detach()
+            total = total + val
+        self.flat.zero_()
+        if total.requires_grad:
+            gr, gt = torch.autograd.grad(total, (dr, dt), allow_unused=True)
+            g = torch.cat((torch.zeros_like(dr) if gr is None else gr, torch.zeros_like(dt) if gt is None else gt), 1)
+            self.flat[:6 * self.S] = g.reshape(-1)
+        self.flat[6 * self.S] = total.detach()
+
+    def iteration_b(self):
+        c, k = self._c, self.k
+        if c['stopped']:
+            return
+        p = self.params.clone().requires_grad_(True)
+        total = self.flat[6 * self.S].clone()
+        g = self.flat[:6 * self.S].reshape(self.S, 6).clone()
+        if k['reg'] > 0:
+            reg = sum(k['reg'] * torch.relu(torch.linalg.norm(p[s, :3]) - k['rad'])
+                      + k['reg'] * torch.relu(torch.linalg.norm(p[s, 3:]) - k['m']) for s in range(self.S))
+            total = total + reg.detach()
+            if reg.requires_grad:
+                g = g + torch.nan_to_num(torch.autograd.grad(reg, p)[0])
+        old = self.params[1:].clone()
+        if not bool(torch.isnan(total)):
+            c['steps'] += 1
+            t = c['steps']
+            m, v, gg = self.m[1:], self.v[1:], g[1:]
+            m.lerp_(gg, 1 - k['b1'])
+            v.mul_(k['b2']).addcmul_(gg, gg, value=1 - k['b2'])
+            denom = (v.sqrt() / (1 - k['b2'] ** t) ** 0.5).add_(k['eps'])
+            self.params[1:] = old.addcdiv(m, denom, value=-(k['lr'] / (1 - k['b1'] ** t)))
+        else:
+            c['skipped'] += 1
+        it = c['iterations']
+        rel = float('inf') if it == 0 else float(torch.sqrt(((self.params[1:] - old) ** 2).sum() / (old ** 2).sum()))
+        if it < self.ring_iters:
+            self._ring[it, 0], self._ring[it, 1] = total, rel
+        if rel < k['rel']:
+            c['stopped'] = True
+        c['iterations'] = it + 1
+
+    def ctrl(self):
+        return dict(self._c)
+
+    def ring(self):
+        return self._ring
+
+
 def install(monkeypatch):
     from miso_amd import ops
     monkeypatch.setattr(ops, "encode", encode)
     monkeypatch.setattr(ops, "grid_sample_3d", grid_sample_3d)
     monkeypatch.setattr(ops, "mapping_loss", mapping_loss)
     monkeypatch.setattr(ops, "sdf_fused_supported", lambda *a, **k: False)
+    monkeypatch.setattr(ops, "AlignPlan", AlignPlan)

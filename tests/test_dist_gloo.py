@@ -69,10 +69,15 @@ def _worker(rank, world, port, out_dir):
 
     res = {}
     for l in range(c["n_levels"]):
-        tup = (f"latent{l}", lambda at, ld, a, b, _l=l: AM.pairwise_loss_latent(
-            at, ld, a, b, level=_l, fdim=c["fdim"], align_loss="L2", device="cpu"))
-        mdist.align_multiple_submaps_distributed(atlas, DS(), tup, num_iters=3, lr=1e-2,
-                                                 pose_reg_weight=1.0, pose_thresh_rad=1e-3, pose_thresh_m=1e-3)
+        # the sharded loop is the fused one (ops.AlignPlan; here its oracle stand-in): this rank's pairs in one
+        # launch, ONE all-reduce of 6S + 1 floats per iteration, identical guard / Adam on every rank
+        tup = (f"latent{l}", AM.latent_loss_for_level(atlas, l, align_loss="L2", device="cpu"))
+        info = mdist.align_multiple_submaps_distributed(atlas, DS(), tup, num_iters=3, lr=1e-2, pose_reg_weight=1.0,
+                                                        pose_thresh_rad=1e-3, pose_thresh_m=1e-3,
+                                                        save_iterations=(l == 0))
+        if l == 0:
+            assert sorted(info["iteration_results"]) == [0, 1, 2, 3]
+            res["snap0"] = torch.stack([info["iteration_results"][i] for i in range(4)]).numpy()
         res[f"dr{l}"] = torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy()
         res[f"dt{l}"] = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
@@ -107,10 +112,15 @@ def test_submap_parallel_world2_matches_single_process(tmp_path, monkeypatch):
             return 0
 
     for l in range(c["n_levels"]):
+        # op-by-op loop: autograd through so3_exp_map, one loss per pair, DenseAdam
         tup = (f"latent{l}", lambda at, ld, x, y, _l=l: AM.pairwise_loss_latent(
             at, ld, x, y, level=_l, fdim=c["fdim"], align_loss="L2", device="cpu"))
-        AB.generic_align_multiple_submaps(atlas, DS(), tup, num_iters=3, lr=1e-2, verbose=False,
-                                          pose_reg_weight=1.0, pose_thresh_rad=1e-3, pose_thresh_m=1e-3)
+        info = AB.generic_align_multiple_submaps(atlas, DS(), tup, num_iters=3, lr=1e-2, verbose=False,
+                                                 pose_reg_weight=1.0, pose_thresh_rad=1e-3, pose_thresh_m=1e-3,
+                                                 save_iterations=(l == 0))
+        if l == 0:
+            snap = torch.stack([info["iteration_results"][i] for i in range(4)]).numpy()
+            np.testing.assert_allclose(a["snap0"], snap, rtol=0, atol=2e-5)
         dr = torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy()
         dt = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
         np.testing.assert_allclose(a[f"dr{l}"], dr, rtol=0, atol=2e-5)

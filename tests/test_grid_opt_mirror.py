@@ -259,37 +259,98 @@ def test_atlas_queries_and_pairwise_alignment(device_backend):
         close(dt, T(g[f"align_l{l}_dt"]), 0, 2e-4)
 
 
-@pytest.mark.gpu
-def test_hierarchical_alignment_batched_path_matches_reference(monkeypatch):
-    """align_multiple_submaps_hierarchical on the GPU takes the batched path (all pairs of an
-    iteration behind one autograd node, overlap gate on the device) and reproduces the reference's
-    pose trajectory (3 (+1) Adam iterations per level, levels in sequence)."""
+class _OneItem(torch.utils.data.Dataset):
+    def __len__(self):
+        return 1
+
+    def __getitem__(self, i):
+        return 0
+
+
+def test_hierarchical_alignment_fused_loop_matches_reference(device_backend, monkeypatch):
+    """align_multiple_submaps_hierarchical takes the fused loop (ops.AlignPlan: every pair of an iteration in one
+    launch, overlap gate / NaN guard / Adam on the device; the oracle stand-in on CPU) and reproduces the
+    reference's pose trajectory (3 (+1) Adam iterations per level, levels in sequence) -- with the reference's own
+    alignment settings verbose=True, save_iterations=True (configs/rgbd/scannet.yaml:65-66), whose per-iteration
+    (S,4,4) snapshots must equal those of the op-by-op loop."""
     from miso_amd import ops
     import miso_amd.grid_opt.align.miso as AM
-    dev = "cuda:0"
+    dev = device_backend
     c = gc.ATLAS
     g = G("atlas")
     atlas = make_atlas(dev)
     calls = []
-    real = ops.pair_latent_multi
-    monkeypatch.setattr(ops, "pair_latent_multi", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-
-    class DS(torch.utils.data.Dataset):
-        def __len__(self):
-            return 1
-
-        def __getitem__(self, i):
-            return 0
-
-    info = AM.align_multiple_submaps_hierarchical(atlas, DS(), level_iters=3, lr=1e-2, align_loss="L2",
-                                                  skip_finetune=True, device=dev, verbose=False)
-    assert len(calls) == c["n_levels"] * 4           # num_iters + 1 iterations per level, one node each
+    real = ops.AlignPlan.iteration_a
+    monkeypatch.setattr(ops.AlignPlan, "iteration_a", lambda self: (calls.append(self.P), real(self))[1])
+    info = AM.align_multiple_submaps_hierarchical(atlas, _OneItem(), level_iters=3, lr=1e-2, align_loss="L2",
+                                                  skip_finetune=True, device=dev, verbose=True, save_iterations=True)
+    assert calls == [3] * (c["n_levels"] * 4)         # num_iters + 1 iterations per level, all 3 pairs in each
     assert {f"hier_latent_level{l}_L2" for l in range(c["n_levels"])} <= set(info)
     l = c["n_levels"] - 1
     dr = torch.stack([p.detach().cpu() for p in atlas.rotation_corrections])
     dt = torch.stack([p.detach().cpu() for p in atlas.translation_corrections])
     close(dr, T(g[f"align_l{l}_dr"]), 0, 2e-4)
     close(dt, T(g[f"align_l{l}_dt"]), 0, 2e-4)
+    # the same run op by op (autograd through so3_exp_map, per-pair losses, DenseAdam): snapshots agree
+    ref = make_atlas(dev)
+    ref.no_fused_alignment = True
+    info_ref = AM.align_multiple_submaps_hierarchical(ref, _OneItem(), level_iters=3, lr=1e-2, align_loss="L2",
+                                                      skip_finetune=True, device=dev, verbose=False, save_iterations=True)
+    for l in range(c["n_levels"]):
+        a, b = info[f"hier_latent_level{l}_L2"]["iteration_results"], info_ref[f"hier_latent_level{l}_L2"]["iteration_results"]
+        assert sorted(a) == sorted(b) == [0, 1, 2, 3]
+        for it in a:
+            assert a[it].shape == (c["n_submaps"], 4, 4)
+            close(a[it].cpu(), b[it].cpu(), 0, 2e-4)
+
+
+def test_fused_alignment_regulariser_nan_guard_and_early_stop(device_backend):
+    """The branches of generic_align_multiple_submaps around the pair losses, through the fused loop: the
+    trust-region regulariser (base.py:20-27,143-145) equals the op-by-op loop; a NaN loss skips the step
+    (base.py:147-151) and leaves the poses alone; rel_change_thresh stops the loop (base.py:157-158) at the same
+    iteration as the op-by-op loop."""
+    import miso_amd.grid_opt.align.base as AB
+    import miso_amd.grid_opt.align.miso as AM
+    dev = device_backend
+    c = gc.ATLAS
+
+    def run(fused, **kw):
+        atlas = make_atlas(dev)
+        atlas.no_fused_alignment = not fused
+        atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+        loss = AM.latent_loss_for_level(atlas, 0, align_loss="L1", device=dev)     # level 0: seconds on the CPU stand-in
+        assert hasattr(loss, "fused")
+        info = AB.generic_align_multiple_submaps(atlas, _OneItem(), ("latent1", loss), lr=1e-2, verbose=False, **kw)
+        dr = torch.stack([p.detach().cpu() for p in atlas.rotation_corrections])
+        dt = torch.stack([p.detach().cpu() for p in atlas.translation_corrections])
+        return dr, dt, info, atlas
+
+    kw = dict(num_iters=4, pose_reg_weight=1.0, pose_thresh_rad=1e-3, pose_thresh_m=1e-3)
+    dr_f, dt_f, _, _ = run(True, **kw)
+    dr_e, dt_e, _, _ = run(False, **kw)
+    close(dr_f, dr_e, 0, 2e-4)
+    close(dt_f, dt_e, 0, 2e-4)
+    # early stop: both loops must break after the same iteration
+    # (relative changes on this problem: 0.122 at iteration 4, 0.109 at iteration 5)
+    kw = dict(num_iters=10, rel_change_thresh=0.115, save_iterations=True)
+    dr_f, dt_f, info_f, _ = run(True, **kw)
+    dr_e, dt_e, info_e, _ = run(False, **kw)
+    assert sorted(info_e["iteration_results"]) == [0, 1, 2, 3, 4, 5]
+    assert sorted(info_f["iteration_results"]) == sorted(info_e["iteration_results"])
+    close(dr_f, dr_e, 0, 3e-4)
+    close(dt_f, dt_e, 0, 3e-4)
+    # NaN: a NaN base translation poisons every pair (nan_to_num'ed to 0, no gradient) and a NaN correction the
+    # regulariser -> total loss NaN -> no step is taken
+    atlas = make_atlas(dev)
+    atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+    with torch.no_grad():
+        atlas.translation_corrections[2][0, 0] = float("nan")
+    before = [p.detach().clone() for p in atlas.params_for_all_submap_poses()]
+    loss = AM.latent_loss_for_level(atlas, 0, device=dev)
+    AB.generic_align_multiple_submaps(atlas, _OneItem(), ("latent0", loss), num_iters=3, lr=1e-2, verbose=False,
+                                      pose_reg_weight=1.0)
+    for p, q in zip(atlas.params_for_all_submap_poses(), before):
+        assert torch.equal(torch.nan_to_num(p.detach(), nan=7.0), torch.nan_to_num(q, nan=7.0))
 
 
 @pytest.mark.parametrize("lt", ["GM", "L2"])
@@ -651,9 +712,10 @@ def test_encoder_initialisation_matches_reference(device_backend):
 
 @pytest.mark.gpu
 def test_captured_alignment_loop_equals_the_eager_one(caplog):
-    """generic_align_multiple_submaps replays the pose-Adam iteration as one HIP graph (>= 8 iterations, batched pair
-    loss): same pose trajectory end point as the op-by-op loop, same info keys, and the per-iteration log lines the
-    reference prints (losses and relative pose changes kept on the device, written out afterwards)."""
+    """generic_align_multiple_submaps runs the pose-Adam loop on the device (fused iteration, replayed as one HIP
+    graph from 8 iterations): same pose trajectory end point as the op-by-op loop, same info keys, and the
+    per-iteration log lines the reference prints (losses and relative pose changes kept on the device, written out
+    afterwards)."""
     import logging
     import miso_amd.grid_opt.align.miso as AM
 
@@ -666,7 +728,7 @@ def test_captured_alignment_loop_equals_the_eager_one(caplog):
 
     def run(captured, verbose=False):
         atlas = make_atlas("cuda:0")
-        atlas.no_captured_alignment = not captured
+        atlas.no_fused_alignment = not captured
         for s in range(atlas.num_submaps):
             atlas.get_submap(s).lock_feature()
         info = AM.align_multiple_submaps_hierarchical(atlas, _DS(), level_iters=14, latent_levels=[0, 1], skip_finetune=True,

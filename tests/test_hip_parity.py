@@ -867,3 +867,82 @@ def test_adam_nan_guard_on_the_device():
         assert sa["step"] == sb["step"] == 4
         assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
     assert torch.isfinite(b_b).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss_type", ["L2", "L1"])
+def test_align_plan_iteration_vs_autograd(loss_type):
+    """miso_align_iteration_a / _b (every pair in one launch, so3_exp_map backward in the epilogue, Adam on the
+    device) against autograd: the per-pair fused op through miso_amd.so3.so3_exp_map for the pose gradients of ALL
+    submaps, torch.optim.Adam for the step."""
+    from test_grid_opt_mirror import make_atlas
+    from miso_amd import ops
+    import miso_amd.grid_opt.align.miso as AM
+    from miso_amd.grid_opt.align.base import grid_atlas_pose_trust_region_loss
+    dev = "cuda:0"
+    atlas = make_atlas(dev)
+    atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+    S = atlas.num_submaps
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    level = 1
+    inputs = AM.latent_pair_inputs(atlas, pairs, level=level, fdim=4, check_intersection=True)
+    R0 = torch.stack(list(atlas.R_world_submap_list))
+    t0 = torch.stack(list(atlas.t_world_submap_list))
+    plan = ops.AlignPlan(R0, t0, inputs, loss_type=loss_type, align_weight=3000.0, lr=1e-2, reg_weight=2.0,
+                         reg_thresh_rad=1e-3, reg_thresh_m=1e-3, ring_iters=4, save_poses=True)
+    dr = torch.cat([p.detach().reshape(1, 3) for p in atlas.rotation_corrections])
+    dt = torch.cat([p.detach().reshape(1, 3) for p in atlas.translation_corrections])
+    plan.params.copy_(torch.cat((dr, dt), 1))
+    plan.iteration_a()
+    # autograd reference
+    atlas.zero_grad(set_to_none=True)
+    losses = []
+    for a, b in pairs:
+        assert bool(atlas.check_submap_intersection(a, b))
+        (v,) = AM.pairwise_loss_latent(atlas, None, a, b, level=level, fdim=4, align_loss=loss_type, device=dev).values()
+        losses.append(v)
+    total = sum(losses)
+    total.backward()
+    flat = plan.flat.cpu()
+    torch.testing.assert_close(plan.pair_losses.cpu(), torch.stack(losses).detach().cpu(), rtol=2e-5, atol=1e-4)
+    assert abs(flat[6 * S].item() - total.item()) <= 2e-5 * abs(total.item())
+    g_ref = torch.cat((torch.cat([p.grad.reshape(1, 3) for p in atlas.rotation_corrections]),
+                       torch.cat([p.grad.reshape(1, 3) for p in atlas.translation_corrections])), 1).cpu()
+    scale = g_ref.abs().max().item()
+    assert (flat[:6 * S].view(S, 6) - g_ref).abs().max().item() <= 2e-4 * scale, (flat[:6 * S].view(S, 6), g_ref)
+    # poses written by the prologue = GridAtlas.updated_submap_pose
+    for s in range(S):
+        R, t = atlas.updated_submap_pose(s)
+        torch.testing.assert_close(plan.poses[s, :9].view(3, 3), R.detach(), rtol=0, atol=2e-6)
+        torch.testing.assert_close(plan.poses[s, 9:].view(3, 1), t.detach(), rtol=0, atol=1e-6)
+    # second half: regulariser + Adam, against torch.optim.Adam on submaps 1..S-1
+    params = [p for s in range(1, S) for p in atlas.params_for_submap_pose(s)]
+    opt = torch.optim.Adam(params, lr=1e-2)
+    reg = sum(grid_atlas_pose_trust_region_loss(atlas, thresh_rad=1e-3, thresh_m=1e-3, weight=2.0).values())
+    reg.backward()
+    opt.step()
+    plan.iteration_b()
+    prm = plan.params.cpu()
+    for s in range(1, S):
+        torch.testing.assert_close(prm[s, :3].reshape(1, 3), atlas.rotation_corrections[s].detach().cpu(), rtol=0, atol=2e-6)
+        torch.testing.assert_close(prm[s, 3:].reshape(3, 1), atlas.translation_corrections[s].detach().cpu(), rtol=0, atol=2e-6)
+    torch.testing.assert_close(prm[0], torch.cat((dr[0], dt[0])).cpu(), rtol=0, atol=0)       # submap 0 is fixed
+    c = plan.ctrl()
+    assert c == dict(steps=1, stopped=False, iterations=1, skipped=0)
+    row = plan.ring()[0].cpu()
+    assert abs(row[0].item() - (total + reg).item()) <= 2e-5 * abs(total.item()) and row[1].item() == float("inf")
+    assert row[2:].view(S, 4, 4)[:, 3].tolist() == [[0.0, 0.0, 0.0, 1.0]] * S
+
+
+@pytest.mark.gpu
+def test_align_plan_rejects_bad_arguments():
+    import ctypes as C
+    from miso_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.Align()
+    cfg.n_submaps, cfg.n_pairs, cfg.loss_type = 0, 0, 2
+    assert lib.miso_align_iteration_a(C.byref(cfg), None) == _lib.E_BADARG
+    cfg.n_submaps = 65
+    assert lib.miso_align_plan_build(None, C.byref(cfg), None) == _lib.E_BADARG
+    assert lib.miso_align_state_layout(65, 1, 0, 0, None) == 0
+    assert lib.miso_align_plan_bytes(-1) == 0
