@@ -69,6 +69,22 @@ def time_kernel(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def host_cpu():
+    """CPU model string and physical core count of this host (lscpu), for the cpu_baseline record."""
+    import subprocess
+    info = {}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = dict((ln.split(":", 1)[0].strip(), ln.split(":", 1)[1].strip()) for ln in txt.splitlines() if ":" in ln)
+        info["cpu_model"] = kv.get("Model name")
+        sockets, cps = int(kv.get("Socket(s)", 0) or 0), int(kv.get("Core(s) per socket", 0) or 0)
+        info["physical_cores"] = sockets * cps or None
+        info["logical_cpus"] = int(kv.get("CPU(s)", 0) or 0) or None
+    except Exception as exc:  # noqa: BLE001
+        info["cpu_model"] = f"unknown ({type(exc).__name__})"
+    return info
+
+
 def cpu_baseline(data, budget_s=20.0):
     """The reference's op sequence (per-level F.grid_sample -> cat -> nn.Sequential -> L1 ->
     backward) restated with stock torch CPU ops (oracle/ref_torch.py, kind 'port'),
@@ -107,10 +123,203 @@ def cpu_baseline(data, budget_s=20.0):
         dt1 = (time.perf_counter() - t1) / 2
     finally:
         torch.set_num_threads(cores)
-    return {"value": N_POINTS / dt, "unit": "point-samples/s", "cores": cores, "kind": "port",
+    return {"value": N_POINTS / dt, "unit": "point-samples/s", "cores": cores, "kind": "port", **host_cpu(),
             "sample": f"{k} full fwd+bwd iterations of 262144 points (stock torch CPU ops arranged as "
                       f"the reference: F.grid_sample per level, cat, nn.Sequential, L1), {dt:.2f} s each",
             "one_thread_value": N_POINTS / dt1}, pred
+
+
+SCANNET_CFG = {"name": "grid_net", "spatial_dim": 3,
+               "decoder": {"type": "mlp", "hidden_dim": 64, "hidden_layers": 1, "out_dim": 1, "pos_invariant": True,
+                           "fix": True, "pretrained_model": None},
+               "grid": {"type": "regular", "feature_dim": 4, "init_stddev": 1e-2,
+                        "bound": [[-10., 10.], [-5., 5.], [-10., 10.]], "base_cell_size": 0.5, "per_level_scale": 5,
+                        "n_levels": 2},
+               "pose": {"optimize": False, "num_poses": 1}}
+
+
+def scannet_atlas(dev, n_submaps=8, perturb=True):
+    """BASELINE configs 3 / 4: n_submaps ScanNet-shaped submaps (bound 20x10x20 m, cells 0.5 / 0.1 m,
+    C=4: 40x20x40 + 200x100x200 per submap), identity rotations, translations on a 2 x (n/2) lattice with 50 %
+    overlap; pose corrections perturbed by up to 10 deg / 0.5 m (seed 55, as demo/align_submaps.py:241-242,267-273).
+    Every rank builds the same atlas from the same seeds."""
+    import math
+    from miso_amd.grid_opt.models.grid_atlas import GridAtlas
+    torch.manual_seed(0)
+    atlas = GridAtlas(SCANNET_CFG, device=dev)
+    lb = torch.tensor(SCANNET_CFG["grid"]["bound"])
+    for s in range(n_submaps):
+        tx, tz = 10.0 * (s // 2), 10.0 * (s % 2)
+        atlas.add_submap(lb, torch.eye(3), torch.tensor([[tx], [0.0], [tz]]), num_poses=1)
+        atlas.add_kf(torch.eye(3), torch.zeros(3, 1))
+    atlas.to(dev)
+    if perturb:
+        g = torch.Generator().manual_seed(55)
+        for s in range(1, n_submaps):
+            axis = torch.randn(3, generator=g)
+            axis = axis / axis.norm()
+            dr = axis * math.radians(10.0) * torch.rand(1, generator=g)
+            dt = (torch.rand(3, generator=g) * 2 - 1) * 0.5
+            atlas.set_submap_pose_correction(s, dr.reshape(1, 3).to(dev), dt.reshape(3, 1).to(dev))
+    return atlas
+
+
+def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
+    """cfg-4: latent alignment of all S(S-1)/2 pairs, generic_align_multiple_submaps with the reference's own
+    alignment settings (verbose + save_iterations, configs/rgbd/scannet.yaml:65-66).  Wall time per iteration of the
+    fused loop; with a process group the pair list is sharded (miso_amd.dist) and each iteration has ONE all-reduce
+    of 6S + 1 floats."""
+    import miso_amd.grid_opt.align.base as AB
+    import miso_amd.grid_opt.align.miso as AM
+    from miso_amd import dist as mdist
+    S = atlas.num_submaps
+    out = {"submaps": S, "pairs": S * (S - 1) // 2, "iterations_timed": iters}
+    start = [(atlas.rotation_corrections[s].detach().clone(), atlas.translation_corrections[s].detach().clone())
+             for s in range(S)]
+
+    class _DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return 0
+
+    for level in levels:
+        loss = AM.latent_loss_for_level(atlas, level, device=dev)
+
+        def run(n_it):
+            for s in range(S):
+                atlas.set_submap_pose_correction(s, *start[s])
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            if dist is not None:
+                mdist.align_multiple_submaps_distributed(atlas, _DS(), (f"latent{level}", loss), num_iters=n_it - 1,
+                                                         lr=1e-2, verbose=True, save_iterations=True)
+            else:
+                AB.generic_align_multiple_submaps(atlas, _DS(), (f"latent{level}", loss), num_iters=n_it - 1, lr=1e-2,
+                                                  verbose=True, save_iterations=True)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            return time.perf_counter() - t0
+
+        run(4)                                      # warm-up (plan build, source features cached)
+        t_a, t_b = min(run(iters), run(iters)), min(run(3 * iters), run(3 * iters))
+        per_it = (t_b - t_a) / (2 * iters)
+        nv = sum(atlas.coordinates_for_alignment(a, level).shape[0] for a in range(S) for b in range(a + 1, S))
+        C_ = SCANNET_CFG["grid"]["feature_dim"]
+        rec = {"source_vertices_per_iteration": nv, "ms_per_iteration": per_it * 1e3,
+               f"ms_{iters}_iterations": t_a * 1e3, "vertices_per_s": nv / per_it,
+               "ms_per_pair_iteration": per_it * 1e3 / out["pairs"]}
+        if dist is None:
+            # pair kernel alone, all pairs in one launch (HIP events), against its algorithmic bytes: 12 B of
+            # coordinates per source vertex + for the in-bound ones 4 C (level+1) B of source features and
+            # 32 C (level+1) B of gathered destination corners (VERDICT r1 item 5)
+            from miso_amd import ops
+            pairs = [(a, b) for a in range(S) for b in range(a + 1, S)]
+            R0 = torch.stack(list(atlas.R_world_submap_list))
+            t0_ = torch.stack(list(atlas.t_world_submap_list))
+            plan = ops.AlignPlan(R0, t0_, loss.fused["inputs"](atlas, pairs, True), ring_iters=1)
+            plan.params.copy_(torch.cat((torch.cat([r.reshape(1, 3) for r, _ in start]),
+                                         torch.cat([t.reshape(1, 3) for _, t in start])), 1))
+            t_k = time_kernel(plan.iteration_a, iters=10, warm=2)
+            inb = float(plan.pair_out[:, 1].sum().item())
+            b_alg = 12 * nv + inb * (4 + 32) * C_ * (level + 1)
+            rec["pair_stage_us"] = t_k
+            rec["in_bound_vertices"] = inb
+            rec["roofline"] = {"bound": "hbm", "kernel": "pair_latent_batch_kernel (+ overlap_count_batch_kernel, "
+                               "prologue, epilogue A)", "achieved": b_alg / (t_k * 1e-6) / 1e9, "peak": 8000.0,
+                               "unit": "GB/s", "frac": b_alg / (t_k * 1e-6) / 8e12,
+                               "algorithmic_bytes": b_alg}
+            del plan
+        else:
+            flat = torch.zeros(6 * S + 1, device=dev)
+            red = lambda: mdist.all_reduce_sum(flat)                                           # noqa: E731
+            for _ in range(5):
+                red()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                red()
+            torch.cuda.synchronize()
+            rec["all_reduce_us"] = (time.perf_counter() - t0) / 50 * 1e6
+            rec["all_reduce_share"] = rec["all_reduce_us"] * 1e-6 / per_it
+            rec["pairs_this_rank"] = len(mdist.partition_pairs([(a, b) for a in range(S) for b in range(a + 1, S)]))
+        out[f"level{level}"] = rec
+    for s in range(S):
+        atlas.set_submap_pose_correction(s, *start[s])
+    return out
+
+
+def map_cfg3(dev, atlas, dist, steps=20, n=540000):
+    """cfg-3: the S submaps mapped submap-parallel (rank r owns {s : s % world == r}, no per-step collective:
+    decoder frozen, grids disjoint), `steps` GridTrainer.train_step iterations of 540 000 samples each per submap,
+    then sync_submaps (every owner broadcasts its grids).  Wall time over all ranks, broadcast included."""
+    import tempfile
+    import miso_amd.grid_opt.loss as L
+    from miso_amd import dist as mdist
+    from miso_amd.grid_opt.trainer import GridTrainer
+    S = atlas.num_submaps
+    mine = mdist.owned_submaps(S)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([6.0, 2.5, 6.0])
+    gt = {"sdf": (torch.rand(1, n, 1, generator=g) * 0.2 - 0.1).to(dev),
+          "sdf_valid": torch.ones(1, n, 1, device=dev), "sdf_signs": torch.zeros(1, n, 1, device=dev)}
+    tcfg = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 1, "ckpt_every": -1,
+            "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": tempfile.mkdtemp(),
+            "relchange_tol": 0, "max_epochs_in_level": 1000, "grid_training_mode": "joint"}
+    trainers = []
+    for s in mine:
+        net = atlas.get_submap(s)
+        net.unlock_feature()
+        net.lock_pose()
+        lossf = L.MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
+        inp = {"coords_frame": x[None].to(dev), "sample_frame_ids": torch.full((1, n, 1), s, dtype=torch.int64, device=dev),
+               "weights": torch.ones(1, n, 1, device=dev)}
+        trainers.append((GridTrainer(tcfg, net, lossf, None, None, dev, torch.float32), inp))
+    for tr, inp in trainers:
+        for _ in range(3):
+            tr.train_step(inp, gt)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for tr, inp in trainers:
+        for _ in range(steps):
+            tr.train_step(inp, gt)
+    torch.cuda.synchronize()
+    t_map = time.perf_counter() - t0
+    mdist.sync_submaps(atlas)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t_all = time.perf_counter() - t0
+    bytes_b = sum(p.numel() * 4 for s in range(S) for p in list(atlas.get_submap(s).parameters())
+                  + list(atlas.get_submap(s).buffers()))
+    for s in mine:
+        atlas.get_submap(s).lock_feature()
+    del trainers
+    torch.cuda.empty_cache()
+    return {"submaps": S, "submaps_this_rank": len(mine), "steps_per_submap": steps, "samples_per_step": n,
+            "map_ms_this_rank": t_map * 1e3, "wall_ms_incl_sync": t_all * 1e3, "sync_ms": (t_all - t_map) * 1e3,
+            "broadcast_bytes": bytes_b, "point_samples_per_s": S * steps * n / t_all}
+
+
+def extras_multi(dev, dist):
+    """Collective-bearing workloads at N > 1 ranks: cfg-3 (submap-parallel mapping + the grid broadcast) and cfg-4
+    (alignment with the pair list sharded and one all-reduce per iteration)."""
+    ex = {}
+    atlas = scannet_atlas(dev, 8)
+    for key, fn in (("cfg3_map_8_submaps_parallel", lambda: map_cfg3(dev, atlas, dist)),
+                    ("cfg4_align_8_submaps_sharded", lambda: (atlas.precompute_coordinates_for_alignment(),
+                                                               align_cfg4(dev, atlas, dist=dist))[1])):
+        try:
+            ex[key] = fn()
+        except Exception as exc:  # noqa: BLE001
+            ex[key] = {"error": f"{type(exc).__name__}: {exc}"}
+    return ex
 
 
 def extras(step, dev):
@@ -160,8 +369,8 @@ def extras(step, dev):
     t = time_kernel(pair, iters=10, warm=2)
     ex["align_pair_latent_level1"] = {"vertices": nv, "us": t, "vertices_per_s": nv / (t * 1e-6)}
 
-    # the same pair through the alignment driver (Adam on the pose corrections, overlap gate,
-    # all pairs of an iteration behind one autograd node): wall time per iteration
+    # the same pair through the alignment driver (generic_align_multiple_submaps: fused pose-Adam loop on the device,
+    # overlap gate, NaN guard) with the reference's own settings verbose + save_iterations: wall time per iteration
     class _DS(torch.utils.data.Dataset):
         def __len__(self):
             return 1
@@ -170,13 +379,7 @@ def extras(step, dev):
             return 0
 
     import miso_amd.grid_opt.align.base as AB
-
-    def latent(at, ld, a, b):
-        return AM.pairwise_loss_latent(at, ld, a, b, level=1, fdim=4, align_loss="L2", device=dev)
-
-    latent.device_gate = True
-    latent.batched = lambda at, pairs, chk: AM.pairwise_loss_latent_batched(at, pairs, level=1, fdim=4,
-                                                                            check_intersection=chk, device=dev)
+    latent = AM.latent_loss_for_level(atlas, 1, device=dev)
 
     def run(n_it):
         # every run starts from the same perturbed pose: the work per iteration follows the overlap
@@ -184,18 +387,26 @@ def extras(step, dev):
                                          torch.tensor([[0.1], [-0.05], [0.08]], device=dev))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        AB.generic_align_multiple_submaps(atlas, _DS(), ("latent1", latent), num_iters=n_it - 1, lr=1e-3, verbose=False)
+        AB.generic_align_multiple_submaps(atlas, _DS(), ("latent1", latent), num_iters=n_it - 1, lr=1e-3, verbose=True,
+                                          save_iterations=True)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
     run(12)                                  # warm-up
-    # generic_align_multiple_submaps as the hierarchical driver calls it (pose Adam, overlap gate, all pairs behind
-    # one autograd node; the loop is captured after three eager iterations): wall time of a 20- and a 120-iteration
-    # level, and the cost of one further iteration
     t20, t120 = min(run(20), run(20)), min(run(120), run(120))
     ex["align_level1_driver"] = {"pairs": 1, "vertices": nv, "ms_20_iterations": t20 * 1e3,
-                                 "ms_120_iterations": t120 * 1e3, "us_per_further_iteration": (t120 - t20) / 100 * 1e6}
-    for key, fn in (("sample_generation_scannet", lambda: sample_generation(dev)),
+                                 "ms_120_iterations": t120 * 1e3, "us_per_further_iteration": (t120 - t20) / 100 * 1e6,
+                                 "settings": "verbose=True, save_iterations=True (configs/rgbd/scannet.yaml:65-66)"}
+    del atlas
+    torch.cuda.empty_cache()
+
+    def cfg4():
+        at = scannet_atlas(dev, 8)
+        at.precompute_coordinates_for_alignment()
+        return align_cfg4(dev, at)
+
+    for key, fn in (("cfg4_align_8_submaps_28_pairs", cfg4),
+                    ("sample_generation_scannet", lambda: sample_generation(dev)),
                     ("mesh_extraction_256", lambda: mesh_extraction(step, dev)),
                     ("trainer_step_other_shapes", lambda: trainer_steps(dev))):
         try:
@@ -336,6 +547,37 @@ def sample_generation(dev):
                                                    "Python loop of sdf_rgbd.py:438-445 is not in it)"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process makes NO GPU call (no torch.cuda.* at all); it
+    starts one child per GPU with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), forwards
+    rank 0's stdout (the ONE JSON line) and exits with the first non-zero child status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:          # a dead rank leaves the others waiting in a collective: end them (exact PIDs)
+                    other.terminate()
+        time.sleep(0.2)
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,12 +587,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     # dev-only overrides to exercise the multi-rank path on a 1-GPU box (ranks share the device,
@@ -361,6 +603,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    collective = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -368,6 +611,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # sanity value of the collective layer: every rank contributes rank + 1 -> world (world + 1) / 2
+        from miso_amd import dist as mdist
+        chk = torch.full((1,), float(rank + 1), device=dev)
+        mdist.all_reduce_sum(chk)
+        collective = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                      "all_reduce_check": chk.item(), "all_reduce_expected": world * (world + 1) / 2}
 
     from miso_amd import ops
     step, data = build_workload(dev, rank)
@@ -390,6 +639,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    multi = None
+    if dist is not None and not args.no_extras:
+        # collective-bearing workloads (every rank takes part; rank 0 reports)
+        try:
+            multi = extras_multi(dev, dist)
+        except Exception as exc:  # noqa: BLE001
+            multi = {"error": f"{type(exc).__name__}: {exc}"}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -440,15 +696,37 @@ def main():
     if t_fwd > dom[1]:
         dom = ("sdf_fwd_kernel", t_fwd, b_fwd)
     achieved = N_POINTS * dom[2] / (dom[1] * 1e-6) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc):
+    # HBM traffic and MFMA busy fraction are PMC figures (rocprofv3 --pmc, separate passes: tools/profile_bench.sh ->
+    # tools/pmc_summary.py -> profiles/<round>_pmc_summary.json).  They are quoted only while that file was measured
+    # on the kernels of THIS tree: it carries the source hash miso_version() embeds.
+    from miso_amd import _lib
+    from miso_amd.csrc_hash import source_hash
+    lib_ver = _lib.load().miso_version().decode()
+    traffic, mfma_pmc, pmc_note = None, None, "no PMC summary for these kernel sources (run tools/profile_bench.sh)"
+    import glob
+    for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
         try:
-            traffic = json.load(open(pmc)).get(dom[0], {}).get("hbm_bytes_per_launch")
+            js = json.load(open(pmc))
         except Exception:
-            traffic = None
+            continue
+        if js.get("_meta", {}).get("source_hash") == source_hash():
+            traffic = js.get(dom[0], {}).get("hbm_bytes_per_launch")
+            mfma_pmc = {k: v["mfma_busy_frac"] for k, v in js.items() if isinstance(v, dict) and "mfma_busy_frac" in v}
+            pmc_note = f"{os.path.basename(pmc)} (kernel sources {source_hash()}, commit {js['_meta'].get('commit')})"
+            break
+    # fp32 MFMA share of the two fused kernels, from the live kernel times: the decoder's matrix FLOPs (frozen
+    # decoder: forward 2(F H + H H + H), backward the same w.r.t. activations) over v_mfma_f32_32x32x2_f32 peak
+    F_ = L * C
+    mlp_flop = 2.0 * (F_ * HIDDEN + HIDDEN * HIDDEN + HIDDEN) * N_POINTS
+    t_bwd_mfma = kernels_us.get("sdf_bwd_kernel(MFMA pass)", t_bwd)
+    mfma = {"peak_TFLOPs": 157.3, "sdf_fwd_kernel": mlp_flop / (t_fwd * 1e-6) / 157.3e12,
+            "sdf_bwd_kernel": mlp_flop / (t_bwd_mfma * 1e-6) / 157.3e12,
+            "definition": "decoder matrix FLOPs / kernel time / fp32 MFMA peak (live, HIP events)"}
+    if mfma_pmc:
+        mfma["pmc_busy_frac"] = mfma_pmc
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                "algorithmic_bytes_per_point": dom[2], "kernel_us": dom[1]}
+                "traffic_source": pmc_note, "algorithmic_bytes_per_point": dom[2], "kernel_us": dom[1],
+                "mfma_frac": mfma}
     if dom[0] == "grad_pull_kernel":
         roofline["launches"] = ("grad_pull_kernel<..,false> + its drain launch <..,true> (slices of over-full tiles; "
                                 "finds an empty queue on this uniform batch, ~2 us); kernel_us covers both")
@@ -467,7 +745,15 @@ def main():
         "step_fraction_of_hbm_roofline": value / world * (20 + 64 * L * C) / 8e12,
         "kernels_us": kernels_us,
         "binned": sb is not None,
+        "library": lib_ver,
+        "step_note": "a training step needs the loss and the gradients, not the per-point SDF in caller order "
+                     "(keep_sdf=False): the 4 B/point SDF write of SURVEY 8(d)'s B_alg is not moved by this step "
+                     "(1 MB of 408 MB); step_fraction_of_hbm_roofline uses the full B_alg = 20 + 64 L C",
     }
+    if collective is not None:
+        out.update(collective)
+    if multi is not None:
+        out["extras_multi_gpu"] = multi
     if world == 1 and not args.no_extras:
         try:                      # secondary figures must never cost the headline line
             out["extras"] = extras(step, dev)

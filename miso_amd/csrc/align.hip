@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256) void align_prologue_kernel(AlignK k) {
   for (int64_t i = threadIdx.x; i < nz; i += blockDim.x) z[i] = 0.0f;
 }
 
+// torch.relu keeps a NaN (fmaxf would drop it, and with it the reference's "loss is nan" skip)
+__device__ __forceinline__ float relu_nan(float v) { return v > 0.0f ? v : (v != v ? v : 0.0f); }
+
 __device__ __forceinline__ float nan_to_num_f(float v) {
   if (v != v) return 0.0f;
   if (isinf(v)) return v > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
@@ -210,8 +213,8 @@ __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
     float total = flat[6 * k.S];
     if (k.reg_weight > 0.0f) {      // grid_atlas_pose_trust_region_loss over ALL submaps, in its dict order
       for (int s = 0; s < k.S; ++s) {
-        total += k.reg_weight * fmaxf(s_nr[s] - k.reg_rad, 0.0f);
-        total += k.reg_weight * fmaxf(s_nt[s] - k.reg_m, 0.0f);
+        total += k.reg_weight * relu_nan(s_nr[s] - k.reg_rad);
+        total += k.reg_weight * relu_nan(s_nt[s] - k.reg_m);
       }
     }
     s_total = total;

@@ -5,6 +5,7 @@
 
 #include "common.hpp"
 #include "align.hpp"
+#include "version.inc"
 
 namespace miso {
 hipError_t launch_encode_fwd(const GridK&, bool, const float*, int64_t, float*, int64_t, const int*, hipStream_t);
@@ -119,7 +120,7 @@ int fused_shape(const GridK& g, bool vec4, const miso_mlp_t* m, int* C, int* L, 
 
 extern "C" {
 
-const char* miso_version(void) { return "miso_hip 0.1 (gfx950)"; }
+const char* miso_version(void) { return "miso_hip 0.2 (gfx950) src=" MISO_SOURCE_HASH; }
 
 const char* miso_error_string(int code) {
   switch (code) {

@@ -61,6 +61,34 @@ def owner_of(submap_id: int, world: Optional[int] = None) -> int:
     return submap_id % (rank_world()[1] if world is None else world)
 
 
+def _needs_host_staging(t: torch.Tensor) -> bool:
+    """gloo moves host memory: device tensors are staged through the host (development runs that put several ranks
+    on one GPU; production is nccl = RCCL, which takes the device pointer as is)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """In-place SUM over ranks of a small flat tensor (the 6S + 1 floats of an alignment iteration)."""
+    if rank_world()[1] == 1:
+        return t
+    if _needs_host_staging(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def _broadcast(t: torch.Tensor, src: int):
+    if _needs_host_staging(t):
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
 def _flat_view(t: torch.Tensor) -> torch.Tensor:
     """Dense 1-D view of a parameter in its physical order (channels-last grids included)."""
     if t.ndim == 5 and t.is_contiguous(memory_format=torch.channels_last_3d):
@@ -88,7 +116,7 @@ def sync_submaps(atlas):
         sub = atlas.get_submap(s)
         for t in list(sub.parameters()) + list(sub.buffers()):
             flat = _flat_view(t.data)
-            dist.broadcast(flat, src=src)
+            _broadcast(flat, src)
             if flat.data_ptr() != t.data.data_ptr():   # a copy was needed: write it back
                 t.data.copy_(flat.view_as(t.data))
 
@@ -125,7 +153,7 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
         submap_pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
     my_pairs = partition_pairs(submap_pairs, rank, world)
     timer = utils.PerfTimer(activate=True)
-    reduce = (lambda flat: dist.all_reduce(flat, op=dist.ReduceOp.SUM)) if world > 1 else None
+    reduce = all_reduce_sum if world > 1 else None
     iteration_results = fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr, num_iters,
                                              rel_change_thresh, pose_reg_weight, pose_thresh_rad, pose_thresh_m,
                                              verbose and rank == 0, save_iterations, f"{loss_name}[rank {rank}/{world}]",

@@ -27,6 +27,13 @@ def test_library_exports_every_declared_symbol():
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in miso_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
     assert b"gfx950" in lib.miso_version()
+    # the library was built from THIS tree: miso_version() embeds a hash of the kernel sources
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("srchash", os.path.join(ROOT, "miso_amd", "csrc", "srchash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert lib.miso_version().decode().endswith("src=" + mod.source_hash()), \
+        "libmiso_hip.so is stale: rebuild with `make -C miso_amd/csrc`"
     assert lib.miso_error_string(2001) == b"bad argument"
 
 

@@ -348,6 +348,14 @@ def test_native_library_is_loaded():
     assert _lib._lib is not None
     maps = open("/proc/self/maps").read()
     assert "libmiso_hip.so" in maps
+    # ... and that library was built from the sources it travels with
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("srchash", os.path.join(root, "miso_amd", "csrc", "srchash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert _lib.load().miso_version().decode().endswith("src=" + mod.source_hash()), "stale libmiso_hip.so"
 
 
 # --------------------------------------------------------------------------- #

@@ -27,8 +27,10 @@ def short(name):
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for kind in ("fetch", "write"):
+for kind in ("fetch", "write", "mfma", "grbm"):
     path = f"{src}/pmc_{kind}/bench_counter_collection.csv"
+    if not os.path.exists(path):
+        continue
     for r in csv.DictReader(open(path)):
         if "miso::" not in r["Kernel_Name"]:
             continue
@@ -40,5 +42,21 @@ for k, d in acc.items():
     out[k] = {"FETCH_SIZE_KiB_avg": f, "WRITE_SIZE_KiB_avg": w, "launches_sampled": len(d.get("FETCH_SIZE", [])),
               "hbm_bytes_per_launch": (2 * f + w) * 1024,
               "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halving, KiB units)"}
+    # fp32 MFMA busy share: SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs of the chip (256 CUs x 4), in shader
+    # cycles; GRBM_GUI_ACTIVE = cycles the kernel kept the GPU busy (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+    busy, act = d.get("SQ_VALU_MFMA_BUSY_CYCLES"), d.get("GRBM_GUI_ACTIVE")
+    if busy and act:
+        b, a = sum(busy) / len(busy), sum(act) / len(act)
+        out[k].update({"SQ_VALU_MFMA_BUSY_CYCLES_avg": b, "GRBM_GUI_ACTIVE_avg": a,
+                       "mfma_busy_frac": b / (a * 1024.0) if a else None})
+sys.path.insert(0, os.getcwd())
+try:
+    from miso_amd.csrc_hash import source_hash
+    import subprocess
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    out["_meta"] = {"source_hash": source_hash(), "commit": commit or None,
+                    "note": "bench.py quotes these figures only while source_hash equals the hash in miso_version()"}
+except Exception as exc:  # noqa: BLE001
+    out["_meta"] = {"error": str(exc)}
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
