@@ -98,11 +98,20 @@ def miso_loss_regression(pred, targ, valid_mask=None, sample_weights=None, loss_
     return torch.mean(sample_weights * per_row)
 
 
-def miso_loss_eikonal(model: BaseNet, coords_world, gt_sdf, eik_trunc_dist, grad_method, finite_diff_eps):
-    """Reference loss.py:638-665."""
+def miso_loss_eikonal(model: BaseNet, coords_world, gt_sdf, eik_trunc_dist, grad_method, finite_diff_eps,
+                      live_rows=None):
+    """Reference loss.py:638-665.  live_rows (device scalar, padded batches only): rows from that index on are
+    padding -- their zero labels would pass the |gt_sdf| < eik_trunc_dist filter -- and stay out of the mean, which
+    then runs over exactly the rows of the reference's exact-size batch."""
+    live = None
+    if live_rows is not None:
+        live = torch.arange(gt_sdf.shape[0], device=gt_sdf.device).unsqueeze(1) < live_rows.reshape(())
     if eik_trunc_dist is not None:
-        keep = torch.nonzero(torch.abs(gt_sdf) < eik_trunc_dist, as_tuple=False)[:, 0]
+        sel = torch.abs(gt_sdf) < eik_trunc_dist
+        keep = torch.nonzero(sel if live is None else sel & live, as_tuple=False)[:, 0]
         x = coords_world[keep, :].clone()
+    elif live is not None:
+        x = coords_world[torch.nonzero(live, as_tuple=False)[:, 0], :].clone()
     else:
         x = coords_world.clone()
     x.requires_grad_(True)
@@ -248,7 +257,7 @@ class MisoLossMappingBase(BaseLoss):
             assert not self.use_clip, "Eikonal loss not supported with CLIP."
             eik = miso_loss_eikonal(model=model, coords_world=coords_world, gt_sdf=gt_sdf,
                                     eik_trunc_dist=self.eik_trunc_dist, grad_method=self.grad_method,
-                                    finite_diff_eps=self.finite_diff_eps)
+                                    finite_diff_eps=self.finite_diff_eps, live_rows=model_input.get('live_rows'))
             loss_dict['eik'] = eik * self.weight_eik
         if self.weight_fs > 0:
             if fused:
@@ -258,11 +267,12 @@ class MisoLossMappingBase(BaseLoss):
                     pred_sdf=pred_sdf, gt_sdf=gt_sdf, gt_sdf_sign=gt_sign, trunc_dist=self.trunc_dist)
         live = model_input.get('live_rows')
         if live is not None:
-            # padded batch (datasets with padded=True): the row means above ran over all N rows, of which
-            # only `live` carry samples -- the padding adds nothing to the sums, so rescale to the mean over
-            # the live rows, which is what the reference computes on its exact-size batch
+            # padded batch (datasets with padded=True): the sdf / free-space means above ran over all N rows, of
+            # which only `live` carry samples -- the padding adds nothing to those sums, so rescale to the mean
+            # over the live rows, which is what the reference computes on its exact-size batch.  (The eikonal
+            # mean divides by its own kept-row count and has the padding rows filtered out above.)
             scale = float(gt_sdf.shape[0]) / live.reshape(()).clamp(min=1).to(pred_sdf.dtype)
-            for k in (f'sdf_{self.loss_type}', 'free_space', 'eik'):
+            for k in (f'sdf_{self.loss_type}', 'free_space'):
                 if k in loss_dict:
                     loss_dict[k] = loss_dict[k] * scale
         if self.use_stability:

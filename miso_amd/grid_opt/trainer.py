@@ -144,19 +144,37 @@ class Trainer(object):
         cache = self.__dict__.setdefault('_mapping_steps', {})
         step = cache.get(key)
         if step is None:
-            cache.clear()            # one live graph: batch sizes rarely alternate
+            # a new key.  Datasets with a data-dependent row count (PosedSdfRgbd(padded=False): depth holes) change
+            # n almost every batch: building a step and capturing a graph that is never replayed would cost more
+            # than the op-by-op path.  So the step of a new key runs its launches eagerly and shares the gradient
+            # buffers of the previous one; the graph is captured only when the same key comes back next time.
+            prev = next(iter(cache.values()), None)
+            cache.clear()            # one live step: batch sizes rarely alternate
             meta = model.features[0].grid_meta(model.ignore_level_)
             step = MappingStep([f.data for f in feats], meta, pack, n, lf.loss_type, float(lf.weight_sdf),
                                float(lf.weight_fs) if lf.weight_fs > 0 else 0.0,
                                0.0 if lf.trunc_dist is None else float(lf.trunc_dist), need_levels=need,
-                               keep_sdf=False, padded=live is not None, grads_cleared_by_optimizer=True)
+                               keep_sdf=False, padded=live is not None, grads_cleared_by_optimizer=True,
+                               use_graph=False,
+                               share_grads=None if prev is None or prev.need_levels != list(need) else prev.grads)
             cache[key] = step
+        elif not step._use_graph and not step.__dict__.get('_seen_again'):
+            step._seen_again = True
+            step._use_graph = True   # same batch shape twice in a row: from now on one graph replay per step
         with torch.no_grad():
             frame_ids = model_input['sample_frame_ids'][0, :, 0]
             coords_world = lf.world_coords(model, coords_frame, frame_ids)
             step.set_batch(coords_world, gt['sdf'][0], gt['sdf_valid'][0], gt['sdf_signs'][0],
                            model_input['weights'][0], live_rows=live)
         step.run()
+        # the reference's optimizer.zero_grad(set_to_none=True) (trainer.py:206): Adam steps every parameter whose
+        # .grad is not None whatever its requires_grad, so a stale gradient on anything this step does not write
+        # (keyframe pose corrections left over from an adam tracking window, a locked level) must not survive
+        mine = {id(f) for f, nd in zip(feats, need) if nd}
+        for group in self.optimizer.param_groups:
+            for p in group['params']:
+                if id(p) not in mine:
+                    p.grad = None
         for f, g, nd in zip(feats, step.grads, need):
             f.grad = g if nd else None
         total = step.loss.sum()

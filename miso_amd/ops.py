@@ -774,7 +774,11 @@ class _PairLatentMulti(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gl):
         out, denom, gate, R_all, src, dst = ctx.saved_tensors
-        s = (gl * gate / denom).view(-1, 1, 1)
+        # nan_to_num in the forward passes no gradient for a non-finite pair loss (its derivative is
+        # grad * isfinite(input)); the raw sums of such a pair may be NaN as well and must not reach the poses
+        finite = torch.isfinite(out[:, 0] / denom)
+        out = torch.where(finite.view(-1, 1), out, torch.zeros_like(out))
+        s = torch.where(finite, torch.nan_to_num(gl) * gate / denom, torch.zeros_like(denom)).view(-1, 1, 1)
         h = R_all[dst] @ out[:, 2:5].unsqueeze(-1)                  # sum_i R_dst g_i, (P,3,1)
         gR = torch.zeros_like(R_all)
         gt = torch.zeros((R_all.shape[0], 3, 1), device=R_all.device, dtype=R_all.dtype)

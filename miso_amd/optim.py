@@ -27,7 +27,11 @@ _KERNEL_MIN_NUMEL = 4096
 
 class DenseAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # the remaining torch.optim.Adam hyper-parameters at their defaults, so that a saved state dict loads into
+        # torch.optim.Adam (its step() reads them) and the other way round
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self.skipped_steps = 0
         self._pending = None          # (pinned loss copy, event, states stepped under that guard, device scalar)
         self._guard_host = None       # one pinned float + one event, reused: a guard is resolved before the next
@@ -48,7 +52,22 @@ class DenseAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         self.resolve_guard()
-        return super().state_dict()
+        sd = super().state_dict()
+        for st in sd['state'].values():
+            st.pop('active', None)            # derived (rebuilt on load): keeps the file a plain Adam state dict
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """Accepts the state of torch.optim.Adam (reference checkpoints, grid_opt/trainer.py:319-329): its 'step' is a
+        float tensor, the kernels take an int; the 'active' chunk flags are rebuilt on the next step."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            if group.get('weight_decay', 0) or group.get('amsgrad', False) or group.get('maximize', False):
+                raise ValueError("DenseAdam implements Adam(weight_decay=0, amsgrad=False, maximize=False) only")
+        for st in self.state.values():
+            if 'step' in st:
+                st['step'] = int(st['step'].item()) if torch.is_tensor(st['step']) else int(st['step'])
+            st.pop('active', None)
 
     @torch.no_grad()
     def step(self, closure=None, clear_grads=False, guard=None):
@@ -96,6 +115,8 @@ class DenseAdam(torch.optim.Optimizer):
                             st['active'].fill_(1)
                     ops.adam_active_(p, g, m, v, st['active'], t, lr, b1, b2, eps, zero_grad=clear_grads,
                                      guard=None if guard is None else guard.detach().reshape(1))
+                    # the kernel wrote through raw pointers: tell autograd / version-keyed caches (DecoderPack)
+                    torch.autograd.graph.increment_version(p)
                     continue
                 if guard is not None:
                     if ok is None:

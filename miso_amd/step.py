@@ -22,7 +22,8 @@ class MappingStep:
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
                  trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
                  sort: Optional[bool] = None, need_levels: Optional[Sequence[bool]] = None,
-                 keep_sdf: bool = True, padded: bool = False, grads_cleared_by_optimizer: bool = False):
+                 keep_sdf: bool = True, padded: bool = False, grads_cleared_by_optimizer: bool = False,
+                 share_grads: Optional[Sequence[Optional[torch.Tensor]]] = None):
         """padded: the batch buffers hold ``n_points`` rows of which only ``self.live_rows`` (one int32 on the
         device, set through set_batch) are live, the rest neutral padding (valid = sign = weight = 0); the loss
         means divide by the live count.  Lets a sampler with a data-dependent row count (depth holes) feed ONE
@@ -59,7 +60,14 @@ class MappingStep:
         need = [True] * len(self.features) if need_levels is None else [bool(v) for v in need_levels]
         assert len(need) == len(self.features)
         self.need_levels = need
-        self.grads = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
+        # share_grads: gradient buffers of a previous step over the same grids (a trainer whose batch size changes
+        # builds a step per size; the dense buffers -- the size of the grids -- are not re-allocated each time)
+        if share_grads is not None and all((g is not None) == nd and (g is None or g.shape == f.shape)
+                                           for g, f, nd in zip(share_grads, self.features, need)):
+            self.grads = list(share_grads)
+            self._shared_grads = True
+        else:
+            self.grads = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
         self.adam = adam
         if adam is not None:
             self.exp_avg = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
@@ -72,6 +80,12 @@ class MappingStep:
         if sort is None:   # default: bin when the batch is large enough for it to pay
             sort = ops.SortedBatch.AUTO_MIN_POINTS is not None and self.n >= ops.SortedBatch.AUTO_MIN_POINTS
         self.sorted = ops.SortedBatch(self.n, dev) if sort else None
+        if getattr(self, "_shared_grads", False) and self.sorted is None:
+            # the small-batch path accumulates onto buffers it expects zeroed; the previous owner may have been a
+            # binned step, which overwrites and never clears
+            for g in self.grads:
+                if g is not None:
+                    g.zero_()
         self._graph = None
         self._use_graph = use_graph and adam is None  # the Adam step count changes per call
 

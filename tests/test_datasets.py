@@ -321,6 +321,22 @@ def test_padded_batches_feed_one_captured_step(tmp_path):
         assert abs(res["padded"][0][k] - v) <= 1e-5 * abs(v), k
     for ga, gb in zip(res["exact"][1], res["padded"][1]):
         assert (ga - gb).abs().max().item() <= 1e-4 * ga.abs().max().item()
+    # the same with the eikonal term on: padding rows carry sdf = 0, which passes the |gt| < eik_trunc_dist
+    # filter -- they must stay out of the eikonal mean, and that mean is not rescaled by N / live
+    for method in ("finitediff", "autograd"):
+        lfe = MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.5, weight_fs=0.5, trunc_dist=0.15,
+                              eik_trunc_dist=0.1, grad_method=method)
+        got = {}
+        for name in ("exact", "padded"):
+            net.zero_grad(set_to_none=True)
+            terms = lfe.compute(net, res[name][2], res[name][3])
+            sum(v.mean() for v in terms.values()).backward()
+            got[name] = ({k: float(v.detach()) for k, v in terms.items()}, [f.feature.grad.clone() for f in net.features])
+        assert "eik" in got["exact"][0] and got["exact"][0]["eik"] > 0
+        for k, v in got["exact"][0].items():
+            assert abs(got["padded"][0][k] - v) <= 2e-5 * abs(v), (method, k, got["padded"][0][k], v)
+        for ga, gb in zip(got["exact"][1], got["padded"][1]):
+            assert (ga - gb).abs().max().item() <= 2e-4 * ga.abs().max().item(), method
     # the fused step on the padded batch
     feats = [f.feature.data for f in net.features]
     meta = net.features[0].grid_meta(net.ignore_level_)
@@ -353,6 +369,26 @@ def test_padded_batches_feed_one_captured_step(tmp_path):
     finally:
         MappingStep.set_batch = orig
     assert len({s for s, _ in seen}) == 1 and len({c for _, c in seen}) > 5
+    # exact-size batches (padded=False): the row count changes with every draw, so a captured graph would never be
+    # replayed.  The trainer then runs each new shape eagerly on ONE set of gradient buffers and captures nothing.
+    loader = torch.utils.data.DataLoader(exact, batch_size=1, shuffle=False, num_workers=0)
+    tr2 = GridTrainer(dict(cfg_train, epochs=8), net, lf, loader, None, DEV, torch.float32)
+    made, sizes = [], set()
+    init = MappingStep.__init__
+
+    def spy_init(self, *a, **k):
+        init(self, *a, **k)
+        made.append(self)
+        sizes.add(self.n)
+
+    MappingStep.__init__ = spy_init
+    try:
+        tr2.train()
+    finally:
+        MappingStep.__init__ = init
+    assert len(sizes) > 3 and len(made) >= len(sizes)
+    assert all(st._graph is None for st in made)                                  # nothing captured
+    assert len({tuple(g.data_ptr() for g in st.grads if g is not None) for st in made}) == 1   # buffers shared
     net.zero_grad(set_to_none=True)
     with torch.no_grad():
         after = sum(float(v.mean()) for v in lf.compute(net, res["exact"][2], res["exact"][3]).values())

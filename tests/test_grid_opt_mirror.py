@@ -755,3 +755,76 @@ def test_captured_alignment_loop_equals_the_eager_one(caplog):
     lines = [r.getMessage() for r in caplog.records if "AlignMulti_hier_latent_level1_L2 iteration" in r.getMessage()]
     assert len(lines) == 15 and "pose_relchange=inf" in lines[0] and "iteration 14" in lines[-1]
     assert not any("not captured" in r.getMessage() for r in caplog.records)
+
+
+@pytest.mark.gpu
+def test_captured_mapping_step_ignores_stale_gradients_of_other_parameters(tmp_path):
+    """Adam steps every parameter whose .grad is not None, whatever its requires_grad.  After an
+    adam tracking window the keyframe pose corrections carry a gradient; the joint optimizer of the mapping phase
+    holds them too (model.parameters()), and the captured step -- which bypasses optimizer.zero_grad() -- must not
+    let that stale gradient move the locked poses (the reference's zero_grad(set_to_none=True) drops it)."""
+    from miso_amd.grid_opt.loss import MisoLossMapping
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    from miso_amd.grid_opt.trainer import GridTrainer
+    dev = "cuda:0"
+    c = gc.ATLAS
+    cfg = gc.model_cfg(c["bound"], c["base_cell"], c["scale"], c["n_levels"], c["fdim"], c["hidden"], num_poses=2,
+                       init_stddev=1e-2)
+    torch.manual_seed(0)
+    net = GridNet(cfg, device=dev).to(dev)
+    for k in range(2):
+        net.set_initial_kf_pose(k, torch.eye(3), torch.zeros(3, 1), kf_key=f"KF{k}")
+    net.unlock_feature()
+    net.lock_pose()
+    n = 4096
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([1.8, 0.9, 1.8])
+    mi = {"coords_frame": x[None].to(dev), "sample_frame_ids": torch.randint(0, 2, (1, n, 1), generator=g).to(dev),
+          "weights": torch.ones(1, n, 1, device=dev)}
+    gt = {"sdf": (torch.rand(1, n, 1, generator=g) * 0.2 - 0.1).to(dev), "sdf_valid": torch.ones(1, n, 1, device=dev),
+          "sdf_signs": torch.zeros(1, n, 1, device=dev)}
+    tcfg = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-2, "epochs": 1, "ckpt_every": -1, "eval_every": -1,
+            "eval_metric": None, "pretrained_model": None, "log_dir": str(tmp_path), "relchange_tol": 0,
+            "max_epochs_in_level": 1000, "grid_training_mode": "joint"}
+    lf = MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
+    tr = GridTrainer(tcfg, net, lf, None, None, dev, torch.float32)
+    poses = list(net.params_for_poses())
+    assert poses and not any(p.requires_grad for p in poses)
+    before = [p.detach().clone() for p in poses]
+    feat0 = net.features[0].feature.detach().clone()
+    for _ in range(3):
+        for p in poses:
+            p.grad = torch.ones_like(p)          # what Tracker.track_window (solver 'adam') leaves behind
+        tr.train_step(mi, gt)
+    assert tr.__dict__.get("_mapping_steps"), "the captured step did not run"
+    for p, q in zip(poses, before):
+        assert torch.equal(p.detach(), q)
+        assert p.grad is None
+    assert not torch.equal(net.features[0].feature.detach(), feat0)      # the grids did train
+
+
+def test_dense_adam_state_round_trips_with_torch_adam():
+    """checkpoints are interchangeable -- a torch.optim.Adam state (the reference's
+    optimizer_state_dict, trainer.py:319-329: 'step' is a float tensor) loads into DenseAdam and steps on; a DenseAdam
+    state loads into torch.optim.Adam (needs weight_decay / amsgrad / maximize in the param group) and steps on; both
+    continue the same trajectory."""
+    from miso_amd.optim import DenseAdam
+    torch.manual_seed(0)
+    grads = [torch.randn(7) for _ in range(4)]
+
+    def run(kinds):
+        p = [torch.nn.Parameter(torch.linspace(-1, 1, 7))]
+        opt, sd = None, None
+        for k, g in zip(kinds, grads):
+            new = (DenseAdam if k == "d" else torch.optim.Adam)(p, lr=1e-2)
+            if sd is not None:
+                new.load_state_dict(sd)
+            opt = new
+            p[0].grad = g.clone()
+            opt.step()
+            sd = opt.state_dict()
+        return p[0].detach().clone()
+
+    ref = run("tttt")
+    for kinds in ("dddd", "dtdt", "tdtd", "ttdd"):
+        torch.testing.assert_close(run(kinds), ref, rtol=0, atol=1e-7)
