@@ -18,6 +18,7 @@
 // So the gradient needs no zero-fill, no atomics, and is bit-reproducible for a given
 // sorted order.  d-feat rows come from sdf_bwd_kernel (dfeat_out); normalised coordinates
 // from sort_scatter_kernel (xn_sorted), so no division is repeated here.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -28,7 +29,8 @@ namespace miso {
 constexpr int PULL_BMAX = 8;      // owned vertices per axis per tile
 constexpr int PULL_ARRW = 192;    // words of byte counters: (8+1)^3 = 729 cells, 3 words per lane
 constexpr int PULL_LIST = 272;    // compacted candidate ids per level
-constexpr int PULL_CAP = 128;     // staged records per group (2 per lane); < 256: counters are bytes
+constexpr int PULL_CAP = 112;     // staged records per group (<= 2 per lane); < 256: counters are bytes.  112: the
+                                  // block kernel fits two workgroups per CU (2 x 79 KB of LDS)
 constexpr int PULL_RB = 4;        // rounds of 64 vertices pulled per pass over the staged records
 constexpr int PULL_MAXL = 4;      // levels swept together (the fused kernels cover <= 4 levels)
 // Heavy tiles.  One wavefront drains one tile serially (~50 ns per swept candidate), so a batch that piles its
@@ -62,6 +64,7 @@ struct PullK {
   int qcap;              // item capacity
   int drain;             // 0: one wavefront per tile, slice 0 + queueing; 1: process the queued slices
   int work0;             // swept candidates per slice
+  int blk_off[PULL_MAXL], blk_cap[PULL_MAXL];   // block kernel: partition of a tile's list pool over the levels
 };
 
 __device__ __forceinline__ int floor_div(int a, int b) {   // b > 0
@@ -120,10 +123,13 @@ __device__ __forceinline__ Brick make_brick(const LevelK& lv, int ta, int tb, in
 // backward.  MODE 1: vertex += (sum_a e_a * d w(corner) / d ix_a) * row with e = gg_x (.) d ix / d x per
 // point -- the grid gradient of the SECOND backward (g_input of gridsample_grad2.grad2_3d,
 // third_party/cuda_gridsample_grad2/gridsample_cuda.cu:462-481); records carry e next to the fracs.
-template <int C, int MODE>
+// BLK: the candidate list holds 16-bit slots of the block-wide survivor table (grad_pull_block_kernel: `blk_list`,
+// `cand_xn`, `cand_p`) instead of point indices in LDS at smem + o_list.
+template <int C, int MODE, bool BLK = false>
 __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, const LevelK& lv, const Brick& b,
                                            float* smem, int o_list, int n, int o_arr, int o_rec, int o_df,
-                                           int lane, int add) {   // add: 0 store, 1 read-add-store, 2 atomic add
+                                           int lane, int add,   // add: 0 store, 1 read-add-store, 2 atomic add
+                                           const uint16_t* blk_list = nullptr, const float4* cand = nullptr) {
   int* ismem = reinterpret_cast<int*>(smem);
   unsigned* arrw = reinterpret_cast<unsigned*>(smem) + o_arr;
   const unsigned char* arrb = reinterpret_cast<const unsigned char*>(arrw);
@@ -164,7 +170,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
         wave_sync_lds();
         // (2a) exact cell of every listed candidate (the sweep's box test is conservative), count
         // per cell; the records stay in registers (<= 3 per lane)
-        constexpr int RPL = PULL_CAP / 64;
+        constexpr int RPL = (PULL_CAP + 63) / 64;
         int rc[RPL], rp[RPL]; float rfx[RPL], rfy[RPL], rfz[RPL];
         constexpr int REC = MODE ? 8 : 4;
 #pragma unroll
@@ -172,8 +178,15 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
           const int i = u * 64 + lane;
           rc[u] = -1;
           if (i < gn) {
-            const int p = ismem[o_list + g0 + i];
-            const float4 c4 = pk.xn[p];
+            int p;
+            float4 c4;
+            if (BLK) {
+              c4 = cand[blk_list[g0 + i]];
+              p = __float_as_int(c4.w);
+            } else {
+              p = ismem[o_list + g0 + i];
+              c4 = pk.xn[p];
+            }
             int i0, j0, k0;
             cell_of(c4.x, lv.X, i0, rfx[u]); cell_of(c4.y, lv.Y, j0, rfy[u]); cell_of(c4.z, lv.Z, k0, rfz[u]);
             const int ci = i0 - (vx0 - 1), cj = j0 - (vy0 - 1), ck = k0 - (vz0 - 1);
@@ -349,6 +362,177 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
 // levels (a candidate's coordinates are loaded once and tested against every level's box).
 // DRAIN = false: one wavefront per tile (slice 0 of a cut tile, queueing the rest); true: the second launch that
 // works off the queued slices -- a separate instantiation so that profiles tell the two apart.
+// One tile, swept by ONE wavefront: the 3x3x3 tile neighbourhood is read row by row, every candidate tested against
+// the catchment box of every pulled level, the hits compacted into per-level LDS lists, the lists binned / pulled /
+// stored by pull_level.  The general path: any grid size, heavy tiles cut into slices (sl of ns; DRAIN: a queued
+// slice, added atomically).  grad_pull_block_kernel below is the fast path for the common case.
+template <int C, int NLV, int MODE, bool DRAIN>
+__device__ __forceinline__ void pull_one_tile(const GridK& g, const PullK& pk, float* smem, int o_list, int o_arr,
+                                              int o_rec, int o_df, int lane, unsigned long long lt_mask, int tile,
+                                              int sl, int ns) {
+  constexpr int PULL_NLV = NLV;
+  int* ismem = reinterpret_cast<int*>(smem);
+  const int T = pk.T;
+  const int ta = tile % T, tb = (tile / T) % T, tc = tile / (T * T);
+  const int tabc[3] = {ta, tb, tc};
+  // catchment box of every level's brick in normalised coordinates: base corner i0 in
+  // [v0-1, v1-1] <=> pos in [v0-1, v1) <=> xn in [(2 v0 - 1)/X - 1, (2 v1 + 1)/X - 1), widened by
+  // a few ulps; and the union of the tile ranges that can hold such points
+  float blo[PULL_NLV][3], bhi[PULL_NLV][3];
+  int t_lo[3] = {T, T, T}, t_hi[3] = {-1, -1, -1};
+  int nverts_all = 0;
+#pragma unroll
+  for (int d = 0; d < PULL_NLV; ++d) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { blo[d][a] = 3e30f; bhi[d][a] = -3e30f; }   // empty box
+    if (d >= pk.nl) continue;
+    const int lvl = pk.lev[d];
+    const LevelK& lv = g.lv[lvl];
+    const Brick b = make_brick(lv, ta, tb, tc, T, pk.bdiv[d]);
+    if (b.nverts == 0 || ((g.ignore_mask >> lvl) & 1u)) continue;
+    nverts_all += b.nverts;
+    const int size[3] = {lv.X, lv.Y, lv.Z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      // the reciprocal is within an ulp of the quotient; the box is widened by ~30 ulps
+      blo[d][a] = (2.0f * b.v0[a] - 1.0f) * pk.inv_size[d][a] - 1.0f - 8e-6f;
+      bhi[d][a] = (2.0f * (b.v0[a] + b.B[a]) + 1.0f) * pk.inv_size[d][a] - 1.0f + 8e-6f;
+      int lo, hi;
+      if (pk.bdiv[d][a]) {   // size = B T: floor((tB - 1) / B) = t - 1, floor((tB + B + 1) / B) = t + 1 (+1 if B = 1)
+        lo = tabc[a] - 1; hi = tabc[a] + (b.B[a] > 1 ? 1 : 2);
+      } else {
+        lo = floor_div((b.v0[a] - 1) * T, size[a]); hi = floor_div((b.v0[a] + b.B[a] + 1) * T, size[a]);
+      }
+      t_lo[a] = min(t_lo[a], max(0, lo));
+      t_hi[a] = max(t_hi[a], min(T - 1, hi));
+    }
+  }
+  int nlist[PULL_NLV];
+#pragma unroll
+  for (int d = 0; d < PULL_NLV; ++d) nlist[d] = 0;
+  unsigned stored = 0;    // bit d: level d's brick has been stored once already
+  bool sweeping = (t_hi[0] >= t_lo[0]) && !(pk.debug & 4);
+  int tz = t_lo[2], ty = t_lo[1];
+  int p_cur = 0, p_end = 0;
+  // bounds of every row of tiles (fixed ty, tz), fetched lane-parallel up front: one memory
+  // round trip per tile instead of a dependent scalar load in front of every row's sweep
+  const int ny = t_hi[1] - t_lo[1] + 1;
+  const int nrows = sweeping ? ny * (t_hi[2] - t_lo[2] + 1) : 0;
+  const bool tabled = nrows <= 64;
+  int rs = 0, re = 0;
+  if (tabled && lane < nrows) {
+    const int ry = t_lo[1] + lane % ny, rz = t_lo[2] + lane / ny;
+    rs = pk.tile_off[(rz * T + ry) * T + t_lo[0]];
+    re = pk.tile_off[(rz * T + ry) * T + t_hi[0] + 1];
+  }
+  if (pk.queue && tabled && sweeping) {
+    if (!DRAIN) {
+      int work = re - rs;
+      for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
+      const int slice = max(pk.work0, 16 * nverts_all);
+      ns = __builtin_amdgcn_readfirstlane(min(PULL_NS_MAX, (work + slice - 1) / slice));
+      if (ns > 1) {
+        int pos = 0;
+        if (lane == 0) pos = atomicAdd(&pk.queue[0], ns - 1);
+        pos = __builtin_amdgcn_readfirstlane(pos);
+        const bool fits = pos + ns - 1 <= pk.qcap;     // else: blank what was reserved, keep the tile whole
+        for (int i = lane; i < ns - 1; i += 64)
+          if (pos + i < pk.qcap) pk.queue[PULL_QHDR + pos + i] = fits ? (tile | ((i + 1) << 12) | (ns << 20)) : -1;
+        if (!fits) ns = 1;
+      }
+    }
+    if (ns > 1) {   // this wavefront's slice of every row range
+      const int len = re - rs;
+      const int a = rs + (int)(((int64_t)len * sl) / ns), b = rs + (int)(((int64_t)len * (sl + 1)) / ns);
+      rs = a; re = b;
+    }
+  }
+  const bool atomic = sl > 0;
+  int ridx = 0;
+  if (sweeping) {
+    if (tabled) {
+      p_cur = __builtin_amdgcn_readlane(rs, 0); p_end = __builtin_amdgcn_readlane(re, 0);
+    } else {
+      p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
+      p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
+    }
+  }
+  bool more = true;
+  while (more) {
+    // ---- (1) sweep: compact the contributing candidates per level (deterministic order) ------
+    while (sweeping) {
+      int room = PULL_LIST;
+#pragma unroll
+      for (int d = 0; d < PULL_NLV; ++d) room = min(room, PULL_LIST - nlist[d]);
+      if (room < 64) break;                     // a list is nearly full: flush first
+      if (p_cur >= p_end) {                     // next (ty, tz) row of tiles
+        if (++ty > t_hi[1]) { ty = t_lo[1]; ++tz; }
+        if (tz > t_hi[2]) { sweeping = false; break; }
+        ++ridx;
+        if (tabled) {
+          p_cur = __builtin_amdgcn_readlane(rs, ridx); p_end = __builtin_amdgcn_readlane(re, ridx);
+        } else {
+          p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
+          p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
+        }
+        continue;
+      }
+      // up to 4 steps (256 candidates) per trip, fixed BEFORE the loads so that all coordinate
+      // loads are in flight together: a row of tiles costs one memory round trip
+      constexpr int UN = 4;
+      const int nstep = __builtin_amdgcn_readfirstlane(min(min(UN, (p_end - p_cur + 63) / 64), room / 64));
+      float4 c4[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int p = p_cur + u * 64 + lane;
+        c4[u] = make_float4(2e30f, 2e30f, 2e30f, 0.f);   // outside every box
+        if (u < nstep && p < p_end) c4[u] = pk.xn[p];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (u >= nstep) continue;    // wave-uniform
+#pragma unroll
+        for (int d = 0; d < PULL_NLV; ++d) {
+          const bool inside = c4[u].x >= blo[d][0] && c4[u].x < bhi[d][0] && c4[u].y >= blo[d][1] &&
+                              c4[u].y < bhi[d][1] && c4[u].z >= blo[d][2] && c4[u].z < bhi[d][2];
+          const unsigned long long m = __ballot(inside);
+          if (inside) ismem[o_list + d * PULL_LIST + nlist[d] + __popcll(m & lt_mask)] = p_cur + u * 64 + lane;
+          nlist[d] = __builtin_amdgcn_readfirstlane(nlist[d] + (int)__popcll(m));
+        }
+      }
+      p_cur += 64 * nstep;
+    }
+    wave_sync_lds();
+    // ---- (2-4) per level: bin, pull, store --------------------------------------------------------
+#pragma unroll 1
+    for (int d = 0; d < pk.nl; ++d) {
+      const int lvl = pk.lev[d];
+      const LevelK& lv = g.lv[lvl];
+      const Brick b = make_brick(lv, ta, tb, tc, T, pk.bdiv[d]);
+      if (b.nverts == 0) continue;
+      int n = 0;
+#pragma unroll
+      for (int e = 0; e < PULL_NLV; ++e) n = (e == d) ? nlist[e] : n;
+      // mid-sweep flush: only the level whose list is (nearly) full is processed; the others keep
+      // collecting, so a fine level's brick is normally pulled and stored once per tile
+      if (sweeping && PULL_LIST - n >= 64) continue;
+      const bool first = !((stored >> d) & 1u);
+      if (n == 0 && (!first || atomic)) continue;
+      pull_level<C, MODE>(g, pk, lv, b, smem, o_list + d * PULL_LIST, n, o_arr, o_rec, o_df, lane,
+                    atomic ? 2 : ((first && pk.overwrite) ? 0 : 1));
+      stored |= 1u << d;
+#pragma unroll
+      for (int e = 0; e < PULL_NLV; ++e) nlist[e] = (e == d) ? 0 : nlist[e];
+    }
+    more = sweeping;
+  }
+  (void)tabc;
+}
+
+// One wavefront per spatial tile.  The 3x3x3 tile neighbourhood is swept ONCE for all pulled
+// levels (a candidate's coordinates are loaded once and tested against every level's box).
+// DRAIN = false: one wavefront per tile (slice 0 of a cut tile, queueing the rest); true: the second launch that
+// works off the queued slices -- a separate instantiation so that profiles tell the two apart.
 template <int C, int NLV, int MODE, bool DRAIN>
 __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   constexpr int PULL_NLV = NLV;   // levels swept together
@@ -361,7 +545,6 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARRW + PULL_CAP * REC + PULL_CAP * C;
   const int o_list = wave * PER_WAVE, o_arr = o_list + PULL_NLV * PULL_LIST, o_rec = o_arr + PULL_ARRW,
             o_df = o_rec + PULL_CAP * REC;
-  int* ismem = reinterpret_cast<int*>(smem);
   const int T = pk.T, ntiles = T * T * T;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
@@ -384,160 +567,7 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
       if (it < 0) continue;
       tile = it & 0xfff; sl = (it >> 12) & 0xff; ns = (it >> 20) & 0xff;   // sl < ns <= 255
     }
-    const int ta = tile % T, tb = (tile / T) % T, tc = tile / (T * T);
-    const int tabc[3] = {ta, tb, tc};
-    // catchment box of every level's brick in normalised coordinates: base corner i0 in
-    // [v0-1, v1-1] <=> pos in [v0-1, v1) <=> xn in [(2 v0 - 1)/X - 1, (2 v1 + 1)/X - 1), widened by
-    // a few ulps; and the union of the tile ranges that can hold such points
-    float blo[PULL_NLV][3], bhi[PULL_NLV][3];
-    int t_lo[3] = {T, T, T}, t_hi[3] = {-1, -1, -1};
-    int nverts_all = 0;
-#pragma unroll
-    for (int d = 0; d < PULL_NLV; ++d) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { blo[d][a] = 3e30f; bhi[d][a] = -3e30f; }   // empty box
-      if (d >= pk.nl) continue;
-      const int lvl = pk.lev[d];
-      const LevelK& lv = g.lv[lvl];
-      const Brick b = make_brick(lv, ta, tb, tc, T, pk.bdiv[d]);
-      if (b.nverts == 0 || ((g.ignore_mask >> lvl) & 1u)) continue;
-      nverts_all += b.nverts;
-      const int size[3] = {lv.X, lv.Y, lv.Z};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        // the reciprocal is within an ulp of the quotient; the box is widened by ~30 ulps
-        blo[d][a] = (2.0f * b.v0[a] - 1.0f) * pk.inv_size[d][a] - 1.0f - 8e-6f;
-        bhi[d][a] = (2.0f * (b.v0[a] + b.B[a]) + 1.0f) * pk.inv_size[d][a] - 1.0f + 8e-6f;
-        int lo, hi;
-        if (pk.bdiv[d][a]) {   // size = B T: floor((tB - 1) / B) = t - 1, floor((tB + B + 1) / B) = t + 1 (+1 if B = 1)
-          lo = tabc[a] - 1; hi = tabc[a] + (b.B[a] > 1 ? 1 : 2);
-        } else {
-          lo = floor_div((b.v0[a] - 1) * T, size[a]); hi = floor_div((b.v0[a] + b.B[a] + 1) * T, size[a]);
-        }
-        t_lo[a] = min(t_lo[a], max(0, lo));
-        t_hi[a] = max(t_hi[a], min(T - 1, hi));
-      }
-    }
-    int nlist[PULL_NLV];
-#pragma unroll
-    for (int d = 0; d < PULL_NLV; ++d) nlist[d] = 0;
-    unsigned stored = 0;    // bit d: level d's brick has been stored once already
-    bool sweeping = (t_hi[0] >= t_lo[0]) && !(pk.debug & 4);
-    int tz = t_lo[2], ty = t_lo[1];
-    int p_cur = 0, p_end = 0;
-    // bounds of every row of tiles (fixed ty, tz), fetched lane-parallel up front: one memory
-    // round trip per tile instead of a dependent scalar load in front of every row's sweep
-    const int ny = t_hi[1] - t_lo[1] + 1;
-    const int nrows = sweeping ? ny * (t_hi[2] - t_lo[2] + 1) : 0;
-    const bool tabled = nrows <= 64;
-    int rs = 0, re = 0;
-    if (tabled && lane < nrows) {
-      const int ry = t_lo[1] + lane % ny, rz = t_lo[2] + lane / ny;
-      rs = pk.tile_off[(rz * T + ry) * T + t_lo[0]];
-      re = pk.tile_off[(rz * T + ry) * T + t_hi[0] + 1];
-    }
-    if (pk.queue && tabled && sweeping) {
-      if (!DRAIN) {
-        int work = re - rs;
-        for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
-        const int slice = max(pk.work0, 16 * nverts_all);
-        ns = __builtin_amdgcn_readfirstlane(min(PULL_NS_MAX, (work + slice - 1) / slice));
-        if (ns > 1) {
-          int pos = 0;
-          if (lane == 0) pos = atomicAdd(&pk.queue[0], ns - 1);
-          pos = __builtin_amdgcn_readfirstlane(pos);
-          const bool fits = pos + ns - 1 <= pk.qcap;     // else: blank what was reserved, keep the tile whole
-          for (int i = lane; i < ns - 1; i += 64)
-            if (pos + i < pk.qcap) pk.queue[PULL_QHDR + pos + i] = fits ? (tile | ((i + 1) << 12) | (ns << 20)) : -1;
-          if (!fits) ns = 1;
-        }
-      }
-      if (ns > 1) {   // this wavefront's slice of every row range
-        const int len = re - rs;
-        const int a = rs + (int)(((int64_t)len * sl) / ns), b = rs + (int)(((int64_t)len * (sl + 1)) / ns);
-        rs = a; re = b;
-      }
-    }
-    const bool atomic = sl > 0;
-    int ridx = 0;
-    if (sweeping) {
-      if (tabled) {
-        p_cur = __builtin_amdgcn_readlane(rs, 0); p_end = __builtin_amdgcn_readlane(re, 0);
-      } else {
-        p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
-        p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
-      }
-    }
-    bool more = true;
-    while (more) {
-      // ---- (1) sweep: compact the contributing candidates per level (deterministic order) ------
-      while (sweeping) {
-        int room = PULL_LIST;
-#pragma unroll
-        for (int d = 0; d < PULL_NLV; ++d) room = min(room, PULL_LIST - nlist[d]);
-        if (room < 64) break;                     // a list is nearly full: flush first
-        if (p_cur >= p_end) {                     // next (ty, tz) row of tiles
-          if (++ty > t_hi[1]) { ty = t_lo[1]; ++tz; }
-          if (tz > t_hi[2]) { sweeping = false; break; }
-          ++ridx;
-          if (tabled) {
-            p_cur = __builtin_amdgcn_readlane(rs, ridx); p_end = __builtin_amdgcn_readlane(re, ridx);
-          } else {
-            p_cur = pk.tile_off[(tz * T + ty) * T + t_lo[0]];
-            p_end = pk.tile_off[(tz * T + ty) * T + t_hi[0] + 1];
-          }
-          continue;
-        }
-        // up to 4 steps (256 candidates) per trip, fixed BEFORE the loads so that all coordinate
-        // loads are in flight together: a row of tiles costs one memory round trip
-        constexpr int UN = 4;
-        const int nstep = __builtin_amdgcn_readfirstlane(min(min(UN, (p_end - p_cur + 63) / 64), room / 64));
-        float4 c4[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          const int p = p_cur + u * 64 + lane;
-          c4[u] = make_float4(2e30f, 2e30f, 2e30f, 0.f);   // outside every box
-          if (u < nstep && p < p_end) c4[u] = pk.xn[p];
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          if (u >= nstep) continue;    // wave-uniform
-#pragma unroll
-          for (int d = 0; d < PULL_NLV; ++d) {
-            const bool inside = c4[u].x >= blo[d][0] && c4[u].x < bhi[d][0] && c4[u].y >= blo[d][1] &&
-                                c4[u].y < bhi[d][1] && c4[u].z >= blo[d][2] && c4[u].z < bhi[d][2];
-            const unsigned long long m = __ballot(inside);
-            if (inside) ismem[o_list + d * PULL_LIST + nlist[d] + __popcll(m & lt_mask)] = p_cur + u * 64 + lane;
-            nlist[d] = __builtin_amdgcn_readfirstlane(nlist[d] + (int)__popcll(m));
-          }
-        }
-        p_cur += 64 * nstep;
-      }
-      wave_sync_lds();
-      // ---- (2-4) per level: bin, pull, store --------------------------------------------------------
-#pragma unroll 1
-      for (int d = 0; d < pk.nl; ++d) {
-        const int lvl = pk.lev[d];
-        const LevelK& lv = g.lv[lvl];
-        const Brick b = make_brick(lv, ta, tb, tc, T, pk.bdiv[d]);
-        if (b.nverts == 0) continue;
-        int n = 0;
-#pragma unroll
-        for (int e = 0; e < PULL_NLV; ++e) n = (e == d) ? nlist[e] : n;
-        // mid-sweep flush: only the level whose list is (nearly) full is processed; the others keep
-        // collecting, so a fine level's brick is normally pulled and stored once per tile
-        if (sweeping && PULL_LIST - n >= 64) continue;
-        const bool first = !((stored >> d) & 1u);
-        if (n == 0 && (!first || atomic)) continue;
-        pull_level<C, MODE>(g, pk, lv, b, smem, o_list + d * PULL_LIST, n, o_arr, o_rec, o_df, lane,
-                      atomic ? 2 : ((first && pk.overwrite) ? 0 : 1));
-        stored |= 1u << d;
-#pragma unroll
-        for (int e = 0; e < PULL_NLV; ++e) nlist[e] = (e == d) ? 0 : nlist[e];
-      }
-      more = sweeping;
-    }
-    (void)tabc;
+    pull_one_tile<C, NLV, MODE, DRAIN>(g, pk, smem, o_list, o_arr, o_rec, o_df, lane, lt_mask, tile, sl, ns);
   }
   if (DRAIN) {   // the last workgroup out rewinds the queue for the next launch
     __syncthreads();
@@ -545,6 +575,179 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
       __threadfence();
       if (atomicAdd(&pk.queue[2], 1) == (int)gridDim.x - 1) { pk.queue[0] = 0; pk.queue[2] = 0; }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path: one WORKGROUP (8 wavefronts) per 2x2x2 block of tiles.
+//
+// The per-tile kernel above is bound by the serial chain of one tile: ten dependent memory round trips of the sweep
+// (row table, then nine tile rows one after the other), and 27 x 64 candidates tested against every level's box
+// to find the ~430 (point, level) pairs that matter.  Eight neighbouring tiles share most of their neighbourhoods:
+// the union is 4x4x4 tiles (8 tile-loads per tile instead of 27), so the workgroup
+//   (1) sweeps the union ONCE, cooperatively: 16 rows of tiles, two per wavefront, all coordinate loads of a wave
+//       in flight together (one round trip); a candidate outside the block's widest catchment box (3/4 of them)
+//       is dropped after six compares, the survivors (~1000) are compacted into an LDS table {xn, index};
+//   (2) routes the survivors: densely re-read from the table (125 per wavefront), for every level the exact cell,
+//       from it the one-to-eight tiles of the block whose bricks it touches (integer compares against the block's
+//       first vertex: no box test per tile, no division), appended to that (tile, level)'s list of 16-bit table slots;
+//   (3) lets wavefront w bin / pull / store tile w from its three lists (pull_level, reading the coordinates from
+//       the LDS table instead of global memory).
+// Taken when 2 | T and T divides every pulled level's size (bricks are (size/T)^3; else the per-tile kernel).  A block
+// whose union holds more than BLK_MAX_UNION candidates, or whose survivor table or a list overflows (a crowded
+// batch), runs the per-tile routine for its eight tiles -- heavy-tile slicing included -- in the same launch.
+constexpr int BLK_WAVES = 8;
+constexpr int BLK_CAND = 1152;        // survivor table (uniform cfg-2 batch: ~1000 per block, sigma ~31)
+constexpr int BLK_POOL = 704;         // 16-bit list slots per tile, split over the levels by the launcher in
+                                      // proportion to their catchment volumes (uniform cfg-2: 91 / 125 / 218 used)
+constexpr int BLK_UN = 8;             // 64-candidate steps in flight per wavefront
+
+template <int C, int NLV, int MODE>
+__global__ __launch_bounds__(512, 4) void grad_pull_block_kernel(GridK g, PullK pk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int REC = MODE ? 8 : 4;
+  // LDS (words): survivor table {xn.x, xn.y, xn.z, index} | lists | counters | per-wave staging.  The per-tile
+  // fallback reuses table + lists as its per-wave index lists (NLV * PULL_LIST ints per wave).
+  constexpr int O_LISTS = BLK_CAND * 4;
+  constexpr int O_CNT = O_LISTS + BLK_WAVES * BLK_POOL / 2;
+  constexpr int O_STAGE = O_CNT + 32;
+  constexpr int STAGE = PULL_ARRW + PULL_CAP * REC + PULL_CAP * C;
+  static_assert(BLK_WAVES * NLV * PULL_LIST <= O_CNT, "fallback lists must fit the table + list area");
+  float4* cand = reinterpret_cast<float4*>(smem);        // .w = the point's sorted index (bits)
+  uint16_t* lists = reinterpret_cast<uint16_t*>(reinterpret_cast<int*>(smem) + O_LISTS);
+  int* cnt = reinterpret_cast<int*>(smem) + O_CNT;       // [tile * NLV + level] list lengths, [24] survivors, [25] overflow
+  const int o_arr = O_STAGE + wave * STAGE, o_rec = o_arr + PULL_ARRW, o_df = o_rec + PULL_CAP * REC;
+  const int T = pk.T, nb = T / 2;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  for (int blk = blockIdx.x; blk < nb * nb * nb; blk += gridDim.x) {
+    const int bx = blk % nb, by = (blk / nb) % nb, bz = blk / (nb * nb);
+    if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+    // ---- (1) cooperative sweep of the 4x4x4 tile union, (2) routing -------------------------------------------
+    const int tx0 = max(2 * bx - 1, 0), tx1 = min(2 * bx + 2, T - 1);
+    const int ty0 = max(2 * by - 1, 0), ny = min(2 * by + 2, T - 1) - ty0 + 1;
+    const int tz0 = max(2 * bz - 1, 0), nz = min(2 * bz + 2, T - 1) - tz0 + 1;
+    const int nrows = ny * nz;
+    // the widest catchment box of the block over the pulled levels (axis-wise), cf. pull_one_tile
+    float ulo[3] = {3e30f, 3e30f, 3e30f}, uhi[3] = {-3e30f, -3e30f, -3e30f};
+    const int b3[3] = {bx, by, bz};
+#pragma unroll
+    for (int d = 0; d < NLV; ++d) {
+      if (d >= pk.nl || ((g.ignore_mask >> pk.lev[d]) & 1u)) continue;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int B = pk.bdiv[d][a], v0 = 2 * b3[a] * B;
+        ulo[a] = fminf(ulo[a], (2.0f * v0 - 1.0f) * pk.inv_size[d][a] - 1.0f - 8e-6f);
+        uhi[a] = fmaxf(uhi[a], (2.0f * (v0 + 2 * B) + 1.0f) * pk.inv_size[d][a] - 1.0f + 8e-6f);
+      }
+    }
+    int rs[2], re[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = wave + r * BLK_WAVES;
+      rs[r] = re[r] = 0;
+      if (row < nrows) {
+        const int ry = ty0 + row % ny, rz = tz0 + row / ny;
+        rs[r] = pk.tile_off[(rz * T + ry) * T + tx0];
+        re[r] = pk.tile_off[(rz * T + ry) * T + tx1 + 1];
+      }
+    }
+    __syncthreads();       // counters are zero
+    const bool forced = (pk.debug & 8) != 0;
+#pragma unroll 1
+    for (int r = 0; r < 2 && !forced; ++r) {
+#pragma unroll 1
+      for (int p0 = rs[r]; p0 < re[r]; p0 += 64 * BLK_UN) {
+        if (cnt[25]) break;            // a crowded block: the table or a list is full already
+        const int nstep = __builtin_amdgcn_readfirstlane(min(BLK_UN, (re[r] - p0 + 63) / 64));
+        float4 c4[BLK_UN];
+#pragma unroll
+        for (int u = 0; u < BLK_UN; ++u) {
+          const int p = p0 + u * 64 + lane;
+          c4[u] = make_float4(2e30f, 2e30f, 2e30f, 0.f);
+          if (u < nstep && p < re[r]) c4[u] = pk.xn[p];
+        }
+#pragma unroll
+        for (int u = 0; u < BLK_UN; ++u) {
+          if (u >= nstep) continue;
+          const bool in = c4[u].x >= ulo[0] && c4[u].x < uhi[0] && c4[u].y >= ulo[1] && c4[u].y < uhi[1] &&
+                          c4[u].z >= ulo[2] && c4[u].z < uhi[2];
+          const unsigned long long m = __ballot(in);
+          if (m == 0ull) continue;
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&cnt[24], (int)__popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          const int slot = base + (int)__popcll(m & lt_mask);
+          if (in) {
+            if (slot < BLK_CAND) cand[slot] = make_float4(c4[u].x, c4[u].y, c4[u].z, __int_as_float(p0 + u * 64 + lane));
+            else cnt[25] = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (2) route the survivors, densely re-read from the table: for every level the exact cell, from it the tiles
+    // of the block whose bricks it touches ----------------------------------------------------------------------
+    if (!forced && cnt[25] == 0 && !(pk.debug & 32)) {
+      const int ncand = cnt[24];
+#pragma unroll 1
+      for (int s0 = wave * 64; s0 < ncand; s0 += 64 * BLK_WAVES) {
+        const int slot = s0 + lane;
+        const bool live = slot < ncand;
+        const float4 c4 = live ? cand[slot] : make_float4(2e30f, 2e30f, 2e30f, 0.f);
+#pragma unroll
+        for (int d = 0; d < NLV; ++d) {
+          if (d >= pk.nl || ((g.ignore_mask >> pk.lev[d]) & 1u)) continue;
+          const LevelK& lv = g.lv[pk.lev[d]];
+          int i0[3]; float fr;
+          cell_of(c4.x, lv.X, i0[0], fr); cell_of(c4.y, lv.Y, i0[1], fr); cell_of(c4.z, lv.Z, i0[2], fr);
+          // per axis: which of the block's two tiles own vertex i0 / i0 + 1 (brick of tile l: [v0 + l B, v0 + (l+1) B))
+          unsigned m3[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const int B = pk.bdiv[d][a], rel = i0[a] - 2 * b3[a] * B;      // vertex i0 relative to the block's first
+            unsigned mm = 0;
+            if (rel >= 0 && rel < 2 * B) mm |= (rel >= B) ? 2u : 1u;
+            if (rel + 1 >= 0 && rel + 1 < 2 * B) mm |= (rel + 1 >= B) ? 2u : 1u;
+            m3[a] = mm;
+          }
+          unsigned m8 = ((m3[2] & 1u ? 0x0Fu : 0u) | (m3[2] & 2u ? 0xF0u : 0u)) &
+                        ((m3[1] & 1u ? 0x33u : 0u) | (m3[1] & 2u ? 0xCCu : 0u)) &
+                        ((m3[0] & 1u ? 0x55u : 0u) | (m3[0] & 2u ? 0xAAu : 0u));
+          if (!live) m8 = 0;
+          while (m8) {
+            const int t = __ffs((int)m8) - 1;
+            m8 &= m8 - 1;
+            const int pos = atomicAdd(&cnt[t * NLV + d], 1);
+            if (pos < pk.blk_cap[d]) lists[t * BLK_POOL + pk.blk_off[d] + pos] = (uint16_t)slot;
+            else cnt[25] = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const bool fallback = forced || cnt[25] != 0;
+    const int ta = 2 * bx + (wave & 1), tb = 2 * by + ((wave >> 1) & 1), tc = 2 * bz + (wave >> 2);
+    if (fallback) {
+      // crowded block: the per-tile routine (own sweep, slicing) for this wavefront's tile
+      pull_one_tile<C, NLV, MODE, false>(g, pk, smem, wave * (NLV * PULL_LIST), o_arr, o_rec, o_df, lane, lt_mask,
+                                         (tc * T + tb) * T + ta, 0, 1);
+    } else if (!(pk.debug & 16)) {
+      // ---- (3) wavefront w: tile w of the block -----------------------------------------------------------------
+      // finest level first: its brick is most of the bytes this tile writes (64 of 73 MB at cfg-2), and stores need
+      // no wait -- they drain to HBM while the coarser levels are binned and pulled
+#pragma unroll 1
+      for (int d = pk.nl - 1; d >= 0; --d) {
+        const LevelK& lv = g.lv[pk.lev[d]];
+        const Brick b = make_brick(lv, ta, tb, tc, T, pk.bdiv[d]);
+        if (b.nverts == 0) continue;
+        const int n = __builtin_amdgcn_readfirstlane(cnt[wave * NLV + d]);
+        pull_level<C, MODE, true>(g, pk, lv, b, smem, 0, n, o_arr, o_rec, o_df, lane, pk.overwrite ? 0 : 1,
+                                  lists + wave * BLK_POOL + pk.blk_off[d], cand);
+      }
+    }
+    __syncthreads();   // the next block reuses the table, the lists and the counters
   }
 }
 
@@ -599,6 +802,7 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   if (blocks > 2048u) blocks = 2048u;
   void (*k)(GridK, PullK) = nullptr;
   void (*kd)(GridK, PullK) = nullptr;
+  void (*kb)(GridK, PullK) = nullptr;
 #define PICK(c, n)                                                                            \
   if (C == c && pk.nl == n) {                                                                 \
     k = ggx ? grad_pull_kernel<c, n, 1, false> : grad_pull_kernel<c, n, 0, false>;            \
@@ -606,12 +810,49 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   }
   PICK(8, 1) PICK(8, 2) PICK(8, 3) PICK(8, 4) PICK(4, 1) PICK(4, 2) PICK(4, 3) PICK(4, 4)
 #undef PICK
+#define PICKB(c, n) \
+  if (C == c && pk.nl == n) kb = ggx ? grad_pull_block_kernel<c, n, 1> : grad_pull_block_kernel<c, n, 0>;
+  PICKB(8, 1) PICKB(8, 2) PICKB(8, 3) PICKB(4, 1) PICKB(4, 2) PICKB(4, 3)
+#undef PICKB
   if (!k) return hipErrorInvalidValue;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // block kernel (one workgroup per 2x2x2 tiles): bricks must be (size / T)^3 for every pulled level
+  bool block_ok = (T % 2 == 0) && kb != nullptr && !getenv("MISO_PULL_NO_BLOCK");
+  for (int d = 0; d < pk.nl; ++d)
+    for (int a = 0; a < 3; ++a) block_ok = block_ok && pk.bdiv[d][a] > 0;
+  if (block_ok) {
+    const int rec = ggx ? 8 : 4;
+    // a tile's list pool, split in proportion to the catchment volume ((B+1)/B)^3 of each level's brick
+    double w[PULL_MAXL], wsum = 0.0;
+    for (int d = 0; d < pk.nl; ++d) {
+      w[d] = 1.0;
+      for (int a = 0; a < 3; ++a) w[d] *= (double)(pk.bdiv[d][a] + 1) / (double)pk.bdiv[d][a];
+      wsum += w[d];
+    }
+    int off = 0;
+    for (int d = 0; d < pk.nl; ++d) {
+      pk.blk_off[d] = off;
+      pk.blk_cap[d] = (d + 1 == pk.nl) ? BLK_POOL - off : ((int)(BLK_POOL * w[d] / wsum) & ~1);
+      off += pk.blk_cap[d];
+    }
+    const size_t words = (size_t)BLK_CAND * 4 + (size_t)BLK_WAVES * BLK_POOL / 2 + 32 +
+                         (size_t)BLK_WAVES * (PULL_ARRW + PULL_CAP * rec + PULL_CAP * C);
+    const size_t blds = words * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
     if (e != hipSuccess) return e;
+    const int nb = T / 2;
+    if (getenv("MISO_PULL_OCC")) {   // dev
+      int nblk = 0;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)kb, 512, blds);
+      fprintf(stderr, "grad_pull_block_kernel: %zu B LDS, %d workgroups per CU\n", blds, nblk);
+    }
+    kb<<<(unsigned)(nb * nb * nb), 512, blds, s>>>(g, pk);
+  } else {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    k<<<blocks, 256, lds, s>>>(g, pk);
   }
-  k<<<blocks, 256, lds, s>>>(g, pk);
   if (pk.queue) {
     pk.drain = 1;
     unsigned dblocks = 1024;
