@@ -1,0 +1,316 @@
+"""BASELINE.json configs 3, 4 and 5 at their FULL shapes against the CPU oracle (these shapes were timed
+and cross-checked HIP-vs-HIP only).  The oracle side is oracle/ref_torch.py (stock ATen ops arranged as the reference)
+plus torch.optim.Adam on the host; sizes are chosen so that each test finishes in well under a minute of CPU work.
+
+  cfg-3  ScanNet submap: 40x20x40 / 200x100x200, C = 4, decoder 8-64-64-1, 540 000 clustered samples per step
+         (configs/rgbd/scannet.yaml:11-25,70,107-110) through GridTrainer.train_step -- dense wave scatter for the
+         coarse level, atomic fallback for the fine one, heavy-tile slicing -- for 3 Adam steps.
+  cfg-4  align_submaps, 8 ScanNet-shaped submaps / 28 pairs: the fused alignment loop vs the oracle loop.
+  cfg-5  Newer College: the real 2-level grid 20x120x120 / 100x600x600 (144 M floats in the fine level,
+         configs/lidar/ncd_quad.yaml:22-24) with 6 144 samples, and the 4-level C = 8 variant BASELINE names.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _decoder(F_, H, seed=0):
+    torch.manual_seed(seed)
+    lin = [torch.nn.Linear(F_, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    return [l.weight.detach().clone() for l in lin], [l.bias.detach().clone() for l in lin]
+
+
+def _gridnet(bound, base_cell, scale, n_levels, C, H, ws, bs, seed=0):
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    cfg = gc.model_cfg(bound, base_cell, scale, n_levels, C, H, init_stddev=1e-2)
+    torch.manual_seed(seed)
+    net = GridNet(cfg, device=DEV).to(DEV)
+    sd = {}
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        sd[f"network.{2 * i}.weight"], sd[f"network.{2 * i}.bias"] = w, b
+    net.decoder.load_state_dict(sd)
+    net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+    net.unlock_feature()
+    net.lock_pose()
+    return net
+
+
+def _trainer(net, tmp_path, lr, lossf):
+    from miso_amd.grid_opt.trainer import GridTrainer
+    tcfg = {"verbose": False, "optimizer": "adam", "learning_rate": lr, "epochs": 1, "ckpt_every": -1, "eval_every": -1,
+            "eval_metric": None, "pretrained_model": None, "log_dir": str(tmp_path), "relchange_tol": 0,
+            "max_epochs_in_level": 1000, "grid_training_mode": "joint"}
+    return GridTrainer(tcfg, net, lossf, None, None, DEV, torch.float32)
+
+
+def _train_both(net, tmp_path, x, sdf_t, sign, steps, lr, weight_fs, trunc):
+    """`steps` iterations of GridTrainer.train_step on the GPU and of (oracle forward, loss, autograd, torch Adam) on
+    the host from the same start.  Returns per-step losses of both and the final features of both."""
+    import miso_amd.grid_opt.loss as L
+    n = x.shape[0]
+    feats0 = [f.feature.detach().cpu().contiguous().clone() for f in net.features]
+    ws = [net.decoder.network[i].weight.detach().cpu() for i in (0, 2, 4)]
+    bs = [net.decoder.network[i].bias.detach().cpu() for i in (0, 2, 4)]
+    bound = net.bound.detach().cpu()
+    mi = {"coords_frame": x[None].to(DEV), "sample_frame_ids": torch.zeros(1, n, 1, dtype=torch.int64, device=DEV),
+          "weights": torch.ones(1, n, 1, device=DEV)}
+    gt = {"sdf": sdf_t[None].to(DEV), "sdf_valid": torch.ones(1, n, 1, device=DEV), "sdf_signs": sign[None].to(DEV)}
+    lossf = L.MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=weight_fs, trunc_dist=trunc)
+    tr = _trainer(net, tmp_path, lr, lossf)
+    gpu_losses = [float(tr.train_step(mi, gt)) for _ in range(steps)]
+    assert tr.__dict__.get("_mapping_steps"), "the captured mapping step did not run"
+    # host
+    fc = [f.clone().requires_grad_(True) for f in feats0]
+    opt = torch.optim.Adam(fc, lr=lr)
+    cpu_losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        pred = R.sdf_stock(fc, bound, x, ws, bs)
+        loss = R.miso_loss_regression(pred, sdf_t, None, None, "L1")
+        if weight_fs > 0:
+            loss = loss + weight_fs * R.miso_loss_free_space(pred, sdf_t, sign, trunc)
+        loss.backward()
+        opt.step()
+        cpu_losses.append(float(loss))
+    tr.host_optimizer, tr.host_params = opt, fc
+    return gpu_losses, cpu_losses, [f.feature.detach().cpu() for f in net.features], [f.detach() for f in fc], tr
+
+
+def _check_training(gpu_losses, cpu_losses, fg, fc, lr):
+    for a, b in zip(gpu_losses, cpu_losses):
+        assert abs(a - b) <= 2e-5 * abs(b), (gpu_losses, cpu_losses)
+    for a, b in zip(fg, fc):
+        d = (a - b).abs()
+        # Adam normalises the gradient: an element moves by <= lr per step whatever the size of its gradient, so a
+        # rounding-level difference in a near-zero gradient component shows as a fraction of lr, not of the value
+        assert d.max().item() <= 0.05 * lr, d.max().item()
+        assert d.mean().item() <= 1e-4 * lr, d.mean().item()
+
+
+def test_cfg3_scannet_submap_training_steps_vs_cpu_oracle(tmp_path):
+    bound = [[-10.0, 10.0], [-5.0, 5.0], [-10.0, 10.0]]
+    ws, bs = _decoder(8, 64)
+    net = _gridnet(bound, 0.5, 5, 2, 4, 64, ws, bs)
+    assert [tuple(f.feature.shape) for f in net.features] == [(1, 4, 40, 20, 40), (1, 4, 200, 100, 200)]
+    n = 540000
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([6.0, 2.5, 6.0])       # the occupied part of the bound
+    k = n // 4                                                                        # depth samples crowd near a camera
+    x[:k] = torch.randn(k, 3, generator=g) * torch.tensor([0.5, 0.3, 0.5]) + torch.tensor([2.0, -1.0, -3.0])
+    sdf_t = torch.rand(n, 1, generator=g) * 0.2 - 0.1
+    sign = (torch.rand(n, 1, generator=g) < 0.3).float()
+    gl, cl, fg, fc, tr = _train_both(net, tmp_path, x, sdf_t, sign, steps=3, lr=1e-3, weight_fs=0.1, trunc=0.15)
+    _check_training(gl, cl, fg, fc, 1e-3)
+    step = next(iter(tr._mapping_steps.values()))
+    assert step.sorted is not None          # binned step: dense wave scatter / pull / atomic fallback per level
+
+
+def test_cfg5_newer_college_real_grid_training_steps_vs_cpu_oracle(tmp_path):
+    """6 144 samples into a 120x120x20 m bound: 0.1 % of the 144 M-float fine level ever sees a gradient.  Dense Adam
+    semantics all the same: parameters, both moments and the step count equal torch.optim.Adam on the WHOLE level,
+    and exactly the chunks a gradient has reached are flagged active."""
+    bound = [[-60.0, 60.0], [-60.0, 60.0], [-5.0, 15.0]]
+    ws, bs = _decoder(8, 64)
+    net = _gridnet(bound, 1.0, 5, 2, 4, 64, ws, bs)
+    assert [tuple(f.feature.shape) for f in net.features] == [(1, 4, 20, 120, 120), (1, 4, 100, 600, 600)]
+    n = 6144
+    g = torch.Generator().manual_seed(6)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([25.0, 25.0, 4.0]) + torch.tensor([5.0, -8.0, 2.0])
+    sdf_t = torch.rand(n, 1, generator=g) * 0.2 - 0.1
+    sign = (torch.rand(n, 1, generator=g) < 0.3).float()
+    gl, cl, fg, fc, tr = _train_both(net, tmp_path, x, sdf_t, sign, steps=3, lr=1e-3, weight_fs=0.1, trunc=0.15)
+    _check_training(gl, cl, fg, fc, 1e-3)
+    # optimiser state of the fine level against torch's (which stepped all 144 M elements)
+    from miso_amd import _lib
+    p = net.features[1].feature
+    st = tr.optimizer.state[p]
+    assert st["step"] == 3
+    m_gpu = st["exp_avg"].detach().cpu()
+    flags = st["active"].cpu().bool()
+    flat_m = m_gpu.permute(0, 2, 3, 4, 1).reshape(-1)                             # physical (channels-last) order
+    nz_chunks = torch.zeros_like(flags)
+    nzc = (flat_m != 0).nonzero().squeeze(1) // _lib.ADAM_CHUNK
+    nz_chunks[nzc] = True
+    assert torch.equal(nz_chunks & ~flags, torch.zeros_like(flags))               # every moving element lies in a flagged chunk
+    assert 0 < int(flags.sum()) < 0.05 * flags.numel()                            # measured: 3.4 % of the chunks
+    ref_state = tr.host_optimizer.state[tr.host_params[1]]
+    assert int(ref_state["step"]) == 3
+    for key in ("exp_avg", "exp_avg_sq"):
+        a, b = st[key].detach().cpu(), ref_state[key]
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item(), key
+        assert torch.equal(a == 0, b == 0)                                        # the same elements have ever moved
+    inactive = ~flags.repeat_interleave(_lib.ADAM_CHUNK)[: flat_m.numel()]
+    assert float(flat_m[inactive].abs().max()) == 0.0                             # never stepped: moments exactly zero
+
+
+def test_cfg5_four_level_variant_training_steps_vs_cpu_oracle(tmp_path):
+    """BASELINE config 5 as worded: a 4-level C = 8 grid (decoder 32-64-64-1) over the Newer College bound, sized to
+    fit (cells 4 / 2 / 1 / 0.5 m: 30x30x5 ... 240x240x40), 6 144 streaming-LiDAR-sized batches."""
+    bound = [[-60.0, 60.0], [-60.0, 60.0], [-5.0, 15.0]]
+    ws, bs = _decoder(32, 64)
+    net = _gridnet(bound, 4.0, 2, 4, 8, 64, ws, bs)
+    assert [tuple(f.feature.shape)[2:] for f in net.features] == [(5, 30, 30), (10, 60, 60), (20, 120, 120), (40, 240, 240)]
+    n = 6144
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([25.0, 25.0, 4.0]) + torch.tensor([5.0, -8.0, 2.0])
+    sdf_t = torch.rand(n, 1, generator=g) * 0.2 - 0.1
+    sign = (torch.rand(n, 1, generator=g) < 0.3).float()
+    gl, cl, fg, fc, _ = _train_both(net, tmp_path, x, sdf_t, sign, steps=3, lr=1e-3, weight_fs=0.1, trunc=0.15)
+    _check_training(gl, cl, fg, fc, 1e-3)
+
+
+def test_cfg4_eight_submaps_alignment_vs_oracle_loop():
+    """align_submaps at its full shape: 8 ScanNet-shaped submaps, all 28 pairs.  Level 0 (32 000 vertices per
+    submap): three Adam iterations of the fused loop against the oracle loop (tests/oracle_backend.AlignPlan -- the
+    reference's generic_align_multiple_submaps restated with autograd, itself pinned to the reference's trajectory on
+    the 3-submap golden atlas).  Level 1 (4 M vertices per submap): the pose gradients and losses of one iteration for
+    two pairs against the oracle in fp32 and fp64 (a full level-1 oracle iteration over 28 pairs is minutes of CPU)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from bench import scannet_atlas
+    import oracle_backend
+    from miso_amd import ops
+    import miso_amd.grid_opt.align.miso as AM
+    atlas = scannet_atlas(DEV, 8)
+    atlas.precompute_coordinates_for_alignment()
+    S = atlas.num_submaps
+    pairs = [(a, b) for a in range(S) for b in range(a + 1, S)]
+    R0 = torch.stack(list(atlas.R_world_submap_list))
+    t0 = torch.stack(list(atlas.t_world_submap_list))
+    prm0 = torch.cat((torch.cat([p.detach().reshape(1, 3) for p in atlas.rotation_corrections]),
+                      torch.cat([p.detach().reshape(1, 3) for p in atlas.translation_corrections])), 1)
+
+    def host(inputs):
+        out = []
+        for pr in inputs:
+            q = dict(pr)
+            for k in ("coords", "feats_src", "gate_pts"):
+                q[k] = None if pr[k] is None else pr[k].detach().cpu()
+            q["feats_dst"] = [f.detach().cpu().contiguous() for f in pr["feats_dst"]]
+            out.append(q)
+        return out
+
+    kw = dict(loss_type="L2", align_weight=3000.0, lr=1e-2, ring_iters=3)
+    # ---- level 0, all 28 pairs, 3 iterations ----------------------------------------------------------------------
+    inp = AM.latent_pair_inputs(atlas, pairs, level=0, fdim=4, check_intersection=True)
+    plan = ops.AlignPlan(R0, t0, inp, **kw)
+    ref = oracle_backend.AlignPlan(R0.cpu(), t0.cpu(), host(inp), **kw)
+    plan.params.copy_(prm0)
+    ref.params.copy_(prm0.cpu())
+    for it in range(3):
+        plan.iteration_a()
+        ref.iteration_a()
+        f_gpu, f_ref = plan.flat.cpu(), ref.flat
+        assert abs(f_gpu[-1] - f_ref[-1]) <= 5e-5 * abs(f_ref[-1]), (it, f_gpu[-1], f_ref[-1])
+        torch.testing.assert_close(plan.pair_losses.cpu(), ref.pair_losses, rtol=1e-4, atol=1e-3)
+        scale = f_ref[:-1].abs().max().item()
+        assert (f_gpu[:-1] - f_ref[:-1]).abs().max().item() <= 5e-4 * scale, it
+        plan.iteration_b()
+        ref.iteration_b()
+        torch.testing.assert_close(plan.params.cpu(), ref.params, rtol=0, atol=2e-4)
+    gated = int((plan.pair_losses.cpu() == 0).sum())
+    assert 0 < gated < len(pairs)               # the lattice has pairs that do not overlap: the gate is exercised
+    # ---- level 1, two pairs, one iteration, against the oracle in fp32 AND fp64 ----------------------------------------
+    # The rotation gradient is a difference of large sums (the antisymmetric part of sum_i (R g_i) p_i^T over ~1e6
+    # in-bound vertices with |p| up to 10 m): in fp32 it is conditioned to ~2e-3 of its largest component whoever
+    # computes it.  Measured (tools/align_precision_check.py): reference arithmetic (torch fp32) vs fp64 2.2e-3, HIP vs
+    # fp64 3.5e-3, HIP vs torch fp32 1.8e-3.  So the bar is: as close to the exact value as the reference's own fp32.
+    some = [(0, 1), (2, 3)]
+    inp = AM.latent_pair_inputs(atlas, some, level=1, fdim=4, check_intersection=True)
+    assert all(p["coords"].shape[0] == 4000000 for p in inp)
+    plan = ops.AlignPlan(R0, t0, inp, **kw)
+    plan.params.copy_(prm0)
+    plan.iteration_a()
+    f_gpu = plan.flat.cpu().double()
+
+    def oracle(dt):
+        cast = []
+        for pr in host(inp):
+            q = dict(pr)
+            for k in ("coords", "feats_src", "gate_pts"):
+                q[k] = pr[k].to(dt)
+            q["feats_dst"] = [f.to(dt) for f in pr["feats_dst"]]
+            cast.append(q)
+        ref = oracle_backend.AlignPlan(R0.cpu().to(dt), t0.cpu().to(dt), cast, **kw)
+        ref.params, ref.flat, ref.pair_losses = prm0.cpu().to(dt), ref.flat.to(dt), ref.pair_losses.to(dt)
+        ref.iteration_a()
+        return ref.flat.double(), ref.pair_losses.double()
+
+    (f32, l32), (f64, l64) = oracle(torch.float32), oracle(torch.float64)
+    torch.testing.assert_close(plan.pair_losses.cpu().double(), l64, rtol=2e-5, atol=0)
+    scale = f64[:-1].abs().max().item()
+    err_hip = (f_gpu - f64)[:-1].abs().max().item() / scale
+    err_ref = (f32 - f64)[:-1].abs().max().item() / scale
+    assert err_hip <= max(2.5 * err_ref, 1e-4), (err_hip, err_ref)
+    assert err_hip <= 1e-2
+
+
+def test_full_size_cfg2_gradient_outliers_are_relu_ties():
+    """BASELINE cfg-2 at full size (262 144 points): the grid gradient of the binned step against the CPU oracle,
+    in the MAX norm.  Two fp32 implementations of the decoder gate a ReLU differently only where its pre-activation
+    lies within rounding of zero; such a point changes the gradient of the (few) vertices it touches by O(1 %).  So:
+    (1) census -- the points with a pre-activation within 2e-6 of zero (fp64 oracle) are counted and must be rare;
+    (2) with exactly those points masked out of the loss on both sides the gradients agree to 2e-4 in the max norm;
+    (3) unmasked, every vertex whose gradient differs by more than that is a corner of one of those points."""
+    from miso_amd import ops
+    from miso_amd.step import MappingStep
+    case = gc.CASES["cfg2"]
+    n = 262144
+    gen = torch.Generator().manual_seed(77)
+    x = torch.rand(n, 3, generator=gen) * 2 - 1
+    target = torch.rand(n, 1, generator=gen) * 0.2 - 0.1
+    bound = torch.tensor(case["bound"], dtype=torch.float32)
+    shapes = [gc.grid_shape(case["bound"], c, case["fdim"]) for c in gc.level_cells(case)]
+    feats = [torch.randn(s, generator=gen) * 1e-2 for s in shapes]
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in gc.make_decoder(case).items()}
+    ws, bs = R.decoder_params(sd)
+    # (1) census in fp64
+    with torch.no_grad():
+        f64 = R.encode_stock([f.double() for f in feats], bound.double(), x.double())
+        pre1 = f64 @ ws[0].double().T + bs[0].double()
+        pre2 = torch.relu(pre1) @ ws[1].double().T + bs[1].double()
+        near = torch.minimum(pre1.abs().min(dim=1).values, pre2.abs().min(dim=1).values) < 2e-6
+    n_near = int(near.sum())
+    assert n_near < 1e-3 * n, n_near                 # measured: a few dozen of 262 144
+    valid = (~near).float().unsqueeze(1)
+
+    def host(valid_mask):
+        fc = [f.clone().requires_grad_(True) for f in feats]
+        pred = R.sdf_stock(fc, bound, x, ws, bs)
+        loss = R.miso_loss_regression(pred, target, valid_mask, None, "L1")
+        return torch.autograd.grad(loss, fc)
+
+    meta = ops.GridMeta.from_bound(bound)
+    fd = [f.to(DEV).contiguous(memory_format=torch.channels_last_3d) for f in feats]
+    pack = ops.DecoderPack([w.to(DEV) for w in ws], [b.to(DEV) for b in bs])
+
+    def device(valid_mask):
+        step = MappingStep(fd, meta, pack, n, "L1", 1.0, 0.0, 0.0, use_graph=False)
+        step.set_batch(x.to(DEV), target.to(DEV), valid_mask.to(DEV), torch.zeros(n, 1, device=DEV),
+                       torch.ones(n, 1, device=DEV))
+        step.run()
+        torch.cuda.synchronize()
+        return [g.cpu() for g in step.grads]
+
+    # (2) ties masked out: tight in the max norm
+    for a, b in zip(device(valid), host(valid)):
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+    # (3) unmasked: outliers only at the corners of tie points
+    ones = torch.ones(n, 1)
+    g_dev, g_ref = device(ones), host(ones)
+    xs = x[near]
+    for l, (a, b) in enumerate(zip(g_dev, g_ref)):
+        bad = ((a - b).abs() > 2e-4 * b.abs().max()).any(dim=1, keepdim=True)           # (1,1,Z,Y,X) vertices
+        if not bool(bad.any()):
+            continue
+        probe = torch.zeros_like(feats[l][:, :1]).requires_grad_(True)                   # which vertices do tie points touch?
+        R.encode_stock([probe], bound, xs).sum().backward()
+        touched = probe.grad != 0
+        assert bool((bad & ~touched).sum() == 0), f"level {l}: a gradient outlier away from every ReLU tie"

@@ -794,6 +794,91 @@ def gen_encoder(GridNet, gc):
     print("[encoder] ok", {k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
 
 
+def gen_second_order(GridNet, rloss, risdf, gc):
+    """The branches of the reference's losses that differentiate a spatial gradient obtained with create_graph=True
+    (loss_isdf.py:99-150 eik / grad / smooth; loss.py:638-665 miso_loss_eikonal with grad_method 'autograd' and
+    'finitediff'), on a GridNet built with second_order_grid_sample=True (grid_modules.py:63-66).
+
+    The loss code that runs here is the REFERENCE's.  Its sampling op for this configuration is the CUDA extension
+    third_party/cuda_gridsample_grad2 (cuda_gridsample.grid_sample_3d), which can be neither built nor run in this
+    container, and ATen has no double backward for grid_sampler_3d; so a module named ``cuda_gridsample``
+    backed by the oracle's any-order restatement (oracle.ref_torch.trilinear_gather: equal to ATen to first order,
+    gradgradcheck'ed in fp64, tests/test_oracle_golden.py) stands in for it.  The random perturbation of the
+    smoothness term (torch.randn_like, loss_isdf.py:143) is replaced by a recorded draw."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import ref_torch as R
+    shim = types.ModuleType("cuda_gridsample")
+
+    def grid_sample_3d(input, grid, padding_mode="zeros", align_corners=True):
+        _, do, ho, wo, _ = grid.shape
+        out = R.trilinear_gather(input, grid.reshape(-1, 3), align_corners, padding_mode)
+        return out.transpose(0, 1).reshape(1, input.shape[1], do, ho, wo)
+
+    shim.grid_sample_3d = grid_sample_3d
+    shim.grid_sample_2d = None
+    sys.modules["cuda_gridsample"] = shim
+    case = dict(gc.CASES["small"])
+    cfg = gc.model_cfg(case["bound"], case["base_cell"], case["scale"], case["n_levels"], case["fdim"], case["hidden"],
+                       second_order=True)
+    net = GridNet(cfg, device="cpu")
+    with torch.no_grad():
+        for l, f in enumerate(gc.make_features(case)):
+            net.features[l].feature.copy_(T(f))
+    net.decoder.load_state_dict({k: T(v) for k, v in gc.make_decoder(case).items()})
+    net.unlock_feature()
+    assert net.features[0].grid_sample_func is grid_sample_3d
+    rs = np.random.RandomState(4242)
+    n_rays, per_ray = 96, 5
+    n = n_rays * per_ray
+    b = np.asarray(case["bound"], dtype=np.float32)
+    pts = (b[:, 0] + (b[:, 1] - b[:, 0]) * rs.uniform(0.03, 0.97, size=(n, 3))).astype(np.float32)
+    unit = lambda a: (a / np.linalg.norm(a, axis=-1, keepdims=True)).astype(np.float32)
+    normals = unit(rs.standard_normal((1, n_rays, 3)))
+    grad_vec = unit(rs.standard_normal((1, n_rays, per_ray - 1, 3)))
+    grad_vec[0, ::7, 1, :] = np.nan                       # rows the reference replaces by the surface normal (:126-127)
+    bounds = np.abs(0.2 * rs.standard_normal((1, n, 1))).astype(np.float32)
+    noise = rs.standard_normal((1, n, 3)).astype(np.float32)
+    out = dict(coords=pts, normals=normals, grad_vec=grad_vec.copy(), bounds=bounds, noise=noise,
+               n_rays=np.int64(n_rays), per_ray=np.int64(per_ray))
+    real_randn_like = torch.randn_like
+    for tag, kw in (("eik", dict(eik_weight=50.0)),
+                    ("grad", dict(grad_weight=0.02)),
+                    ("all", dict(eik_weight=50.0, grad_weight=0.02, smooth_weight=0.1)),
+                    ("allL2", dict(eik_weight=50.0, grad_weight=0.02, smooth_weight=0.1, loss_type="L2"))):
+        il = risdf.iSDFLoss("grid_net", trunc_weight=5.0, trunc_distance=0.15, eik_apply_dist=0.1, smooth_std=0.05,
+                            slam_mode=False, **kw)
+        for p_ in net.parameters():
+            p_.grad = None
+        mi = {"coords": T(pts)[None].clone(), "normals": T(normals).clone()}
+        gt = {"sdf": T(bounds).clone(), "grad_vec": T(grad_vec).clone()}
+        torch.randn_like = lambda t, *a, **k: T(noise).clone()
+        try:
+            d = il.compute(net, mi, gt)
+        finally:
+            torch.randn_like = real_randn_like
+        sum(v.mean() for v in d.values()).backward()
+        for k_, v in d.items():
+            out[f"isdf_{tag}_{k_}"] = np.float64(v.item())
+        for l in range(case["n_levels"]):
+            out[f"isdf_{tag}_gfeat{l}"] = net.features[l].feature.grad.numpy().copy()
+        out[f"isdf_{tag}_gcoords"] = mi["coords"].grad.numpy().copy()
+    # miso_loss_eikonal, both gradient methods (configs/rgbd/scannet.yaml:45-49 ships 'finitediff')
+    sdf_t = (0.12 * rs.standard_normal((n, 1))).astype(np.float32)
+    out["eik_gt_sdf"] = sdf_t
+    for method in ("autograd", "finitediff"):
+        for p_ in net.parameters():
+            p_.grad = None
+        val = rloss.miso_loss_eikonal(model=net, coords_world=T(pts), gt_sdf=T(sdf_t), eik_trunc_dist=0.1,
+                                      grad_method=method, finite_diff_eps=1e-2)
+        val.backward()
+        out[f"eik_{method}"] = np.float64(val.item())
+        for l in range(case["n_levels"]):
+            out[f"eik_{method}_gfeat{l}"] = net.features[l].feature.grad.numpy().copy()
+    np.savez_compressed(gc.golden_path("second_order"), **out)
+    print("[second_order]", {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
+
+
 def main():
     import_reference()
     import golden_cases as gc
@@ -810,7 +895,7 @@ def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
-    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra", "geometry", "formats", "encoder"]
+    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra", "geometry", "formats", "encoder", "second_order"]
     for name in which:
         if name in gc.CASES:
             gen_encode_decode(name, GridNet, rloss, gc)
@@ -834,6 +919,8 @@ def main():
             gen_encoder(GridNet, gc)
         elif name == "extra":
             gen_extra(GridNet, GridAtlas, miso, rtrainer, gc)
+        elif name == "second_order":
+            gen_second_order(GridNet, rloss, risdf, gc)
 
 
 if __name__ == "__main__":
