@@ -883,8 +883,11 @@ def test_mapping_eikonal_term_matches_reference(device_backend, method):
     ref = float(g[f"eik_{method}"])
     assert abs(val.item() - ref) <= 2e-5 * abs(ref)
     grads = [net.features[l].feature.grad.clone() for l in range(case["n_levels"])]
+    # central differences divide fp32 SDF values by 2 eps = 0.02: a 1e-8 difference between two fp32 evaluation orders
+    # of the decoder becomes 5e-7 in the spatial gradient and enters every feature gradient
+    rtol = 1e-3 if method == "finitediff" else 2e-4
     for l in range(case["n_levels"]):
-        close(grads[l], T(g[f"eik_{method}_gfeat{l}"]), 2e-4, 1e-7)
+        close(grads[l], T(g[f"eik_{method}_gfeat{l}"]), rtol, 1e-7)
     # through the loss class: sdf + weight_eik * eik (+ free space), one keyframe at the identity
     net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
     net.lock_pose()

@@ -734,14 +734,12 @@ def test_full_size_training_step_vs_cpu_oracle_cfg2():
     d = (step.sdf.cpu() - pred.detach()).abs()
     assert d.max().item() <= 1e-5 and d.mean().item() <= 1e-6
     assert abs(step.loss.sum().item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
-    # Gradients: 262 144 points x 128 hidden units make a handful of ReLU pre-activations land within
-    # fp32 rounding of zero, where the two implementations may gate differently (a ~1 % change of that
-    # point's contribution, visible where a fine vertex is fed by a single point).  So: tight in the
-    # Euclidean norm, loose in the max norm.
+    # Gradients in the Euclidean norm here; in the MAX norm -- with the census of the ReLU pre-activations that land
+    # within fp32 rounding of zero, where two implementations may gate differently -- in
+    # tests/test_config_shapes.py::test_full_size_cfg2_gradient_outliers_are_relu_ties
     for a, b in zip(step.grads, gref):
         a = a.cpu()
         assert ((a - b).double().norm() / b.double().norm()).item() < 5e-4
-        assert relerr(a, b) < 3e-2
 
 
 @pytest.mark.parametrize("lt", ["L2", "L1"])
