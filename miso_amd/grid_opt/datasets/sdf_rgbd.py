@@ -233,3 +233,26 @@ class PosedSdfRgbd(SubmapDataset):
 
     def __getitem__(self, index):
         return self.getitem_sdf(index)
+
+    def compute_scene_obb(self):
+        """Bounding box of one batch of samples in the world frame (reference :495-515 returns Open3D's minimal
+        oriented box of the voxel-down-sampled cloud; callers use its centre to aim a viewer).  Here: the
+        axis-aligned box, with the accessors the demo calls."""
+        model_input, _ = self.__getitem__(0)
+        ids = model_input['sample_frame_ids'][:, 0].to(self.device)
+        n = int(model_input.get('live_rows', torch.tensor(ids.shape[0])).item())
+        x = model_input['coords_frame'][:n]
+        world = torch.einsum('nij,nj->ni', self._R_gt_dev[ids[:n]], x) + self._t_gt_dev[ids[:n], :, 0]
+        lo, hi = world.min(dim=0).values.cpu().numpy(), world.max(dim=0).values.cpu().numpy()
+        return AxisAlignedBox(lo, hi)
+
+
+class AxisAlignedBox:
+    def __init__(self, lo, hi):
+        self.min_bound, self.max_bound = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+
+    def get_center(self):
+        return 0.5 * (self.min_bound + self.max_bound)
+
+    def get_extent(self):
+        return self.max_bound - self.min_bound

@@ -13,6 +13,8 @@ import os
 import numpy as np
 import torch
 
+import miso_amd.grid_opt.utils.utils as utils   # noqa: F401  (the demos reach `utils` through `from ...utils_sdf import *`)
+
 logger = logging.getLogger(__name__)
 
 

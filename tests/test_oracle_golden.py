@@ -97,7 +97,11 @@ def test_gather_gradgradcheck():
     assert torch.autograd.gradgradcheck(fn, (inp, xn))
 
 
-def test_so3_and_pose_goldens():
+def test_so3_and_pose_goldens_parity_unpinned_vs_pytorch3d():
+    """NOT a pin against pytorch3d (absent from the image, an unpinned git dependency upstream): the golden came from
+    the reference run on tools/ref_shims/pytorch3d, a restatement of the same recalled formula as oracle.so3_exp_map
+    and miso_amd.so3 -- three copies, so a shared mistake would be invisible here.  The independent check is
+    test_so3_exp_map_equals_the_matrix_exponential below."""
     g = _load("so3")
     R0 = T(gc.rodrigues([0.2, 0.1, -0.3]).astype(np.float32))
     t0 = torch.tensor([[1.0], [2.0], [3.0]])
@@ -110,6 +114,34 @@ def test_so3_and_pose_goldens():
         torch.testing.assert_close(Rn.detach(), T(g[f"R_{i}"]), rtol=0, atol=1e-7)
         torch.testing.assert_close(tn, T(g[f"t_{i}"]))
         torch.testing.assert_close(dr.grad, T(g[f"gdr_{i}"]), rtol=1e-5, atol=1e-6)
+
+
+def test_so3_exp_map_equals_the_matrix_exponential():
+    """Independent of the recalled Rodrigues formula: so3_exp_map(w) = expm(hat(w)) (torch.linalg.matrix_exp, a Pade /
+    Taylor evaluation) for |w|^2 >= eps = 1e-4, where the angle clamp is inactive -- values and the gradient w.r.t. w,
+    for the oracle's restatement and the product's (miso_amd.so3, plain torch, runs on CPU).  Below the clamp the
+    function is by construction NOT the exponential (theta is held at 0.01): there the first-order behaviour is
+    checked instead: R(w) = I + (sin .01 / .01) hat(w) + O(|w|^2)."""
+    from miso_amd import so3 as P
+    for mod in (R, P):
+        for w in ([0.3, -0.2, 0.1], [1.2, 0.4, -0.9], [0.02, 0.0, 0.0], [-2.0, 1.0, 2.0], [0.006, -0.006, 0.006]):
+            v = torch.tensor([w], dtype=torch.float64, requires_grad=True)
+            assert float((v * v).sum()) >= 1e-4
+            E = mod.so3_exp_map(v)[0]
+            M = torch.linalg.matrix_exp(mod.hat(v)[0])
+            torch.testing.assert_close(E, M, rtol=0, atol=1e-9)
+            wgt = torch.arange(9, dtype=torch.float64).reshape(3, 3) / 10
+            ga, = torch.autograd.grad((E * wgt).sum(), v, retain_graph=True)
+            gb, = torch.autograd.grad((M * wgt).sum(), v)
+            torch.testing.assert_close(ga, gb, rtol=0, atol=1e-8)
+            torch.testing.assert_close(E @ E.T, torch.eye(3, dtype=torch.float64), rtol=0, atol=1e-12)
+        # hat: [v]_x u = v x u
+        a, b = torch.tensor([[0.3, -1.2, 0.7]], dtype=torch.float64), torch.tensor([0.5, 0.1, -0.4], dtype=torch.float64)
+        torch.testing.assert_close(mod.hat(a)[0] @ b, torch.linalg.cross(a[0], b))
+        # inside the clamp: linear in w with slope sin(0.01) / 0.01
+        v = torch.tensor([[2e-3, -1e-3, 5e-4]], dtype=torch.float64)
+        lin = torch.eye(3, dtype=torch.float64) + (np.sin(0.01) / 0.01) * mod.hat(v)[0]
+        assert (mod.so3_exp_map(v)[0] - lin).abs().max().item() < 3e-6      # the K^2 term: |w|^2 / 2
 
 
 def test_pairwise_latent_matches_reference():
