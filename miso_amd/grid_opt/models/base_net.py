@@ -23,6 +23,17 @@ class BaseNet(nn.Module):
             self.device = self.bound.device
         return out
 
+    # device-side caches (ctypes structs with raw pointers, pose tables, vertex tables) are rebuilt on demand and must
+    # not travel with ``torch.save(model)`` -- the whole-module pickle the demos exchange (demo/build_submaps.py:141)
+    _TRANSIENT = ('_pose_cache', '_vertex_cache', '_align_src_cache', '_align_grid_cache', '_align_plan_const',
+                  '_kf_pose_cache', '_kf_table')
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            state.pop(k, None)
+        return state
+
     def forward(self, x: torch.Tensor):
         raise NotImplementedError
 

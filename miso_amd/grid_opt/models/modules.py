@@ -41,6 +41,11 @@ class MLPNet(nn.Module):
     def is_frozen(self) -> bool:
         return not any(p.requires_grad for p in self.parameters())
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_pack', None)          # packed weights (ctypes struct + device buffer): rebuilt on demand
+        return state
+
     def decoder_pack(self):
         """Packed weights for the fused encode+decode kernels, or None if the decoder
         cannot take that path (trainable weights, non-ReLU activation)."""

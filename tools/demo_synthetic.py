@@ -93,7 +93,8 @@ def create_configs(args, dataset):
         "tracking": {"solver": "adam", "learning_rate": 1e-3, "loss_type": "L1", "trunc_dist": 0.15, "gm_scale_sdf": 0.1,
                      "lm_lambda": 1e-4, "lm_max_iter": 10, "lm_tol_deg": 0.01, "lm_tol_m": 0.001, "verbose": False,
                      "disable": True},
-        "mapping": {"learning_rate": 1e-3, "loss_type": "L1", "weight_sdf": 1.0, "weight_eik": 0.0, "weight_fs": 0.1,
+        # (the reference maps with lr 1e-3 on top of its pretrained decoder; a random frozen decoder needs larger steps)
+        "mapping": {"learning_rate": 1e-2, "loss_type": "L1", "weight_sdf": 1.0, "weight_eik": 0.0, "weight_fs": 0.1,
                     "trunc_dist": 0.15, "finite_diff_eps": 0.03, "grad_method": "finitediff", "eik_trunc_dist": 0.024,
                     "verbose": False, "max_replay_frames": 10, "max_replay_freq": 10, "gm_scale_sdf": 0.1,
                     "disable": True},
