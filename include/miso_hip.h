@@ -310,6 +310,13 @@ typedef struct {
   int64_t ld_feats, n;
   const float* gate_coords; /* (gate_n,3) or NULL */
   int64_t gate_n;
+  /* The gate vertices as a lattice instead (GridAtlas.check_submap_intersection tests ALL voxel centres of the source's
+   * finest level, FeatureGrid.vertex_positions: a meshgrid of three per-axis tables): gate_axis[a] = the gate_dims[a]
+   * coordinates along axis a (x, y, z), vertex index (k ny + j) nx + i.  When gate_axis[0] != NULL the kernel forms the
+   * positions from the tables (same values, same arithmetic, same count) and gate_coords is not read: the gate of a
+   * 4 M-vertex level costs no HBM traffic instead of 48 MB per pair and iteration.  gate_n must equal nx ny nz. */
+  const float* gate_axis[3];
+  int32_t gate_dims[3];
   int32_t src, dst;         /* submap indices */
 } miso_align_pair_t;
 
@@ -318,7 +325,7 @@ typedef struct {
   int32_t loss_type;         /* 1 = L1 (row-wise 2-norm), 2 = L2 */
   int32_t ring_iters, save_poses;
   int32_t vec4;              /* set by miso_align_plan_build */
-  int64_t max_n, max_gate_n; /* set by miso_align_plan_build */
+  int64_t max_n, max_gate_n, max_gate_rows; /* set by miso_align_plan_build */
   float align_weight, overlap_thresh;
   float reg_weight, reg_thresh_rad, reg_thresh_m; /* grid_atlas_pose_trust_region_loss, base.py:20-27; 0 = off */
   float rel_change_thresh;

@@ -73,13 +73,14 @@ class RaySampling(C.Structure):
 class AlignPair(C.Structure):
     _fields_ = [("dst_grid", Grid), ("coords_src", C.c_void_p), ("feats_src", C.c_void_p),
                 ("ld_feats", C.c_int64), ("n", C.c_int64), ("gate_coords", C.c_void_p), ("gate_n", C.c_int64),
+                ("gate_axis", C.c_void_p * 3), ("gate_dims", C.c_int32 * 3),
                 ("src", C.c_int32), ("dst", C.c_int32)]
 
 
 class Align(C.Structure):
     _fields_ = [("n_submaps", C.c_int32), ("n_pairs", C.c_int32), ("loss_type", C.c_int32),
                 ("ring_iters", C.c_int32), ("save_poses", C.c_int32), ("vec4", C.c_int32),
-                ("max_n", C.c_int64), ("max_gate_n", C.c_int64),
+                ("max_n", C.c_int64), ("max_gate_n", C.c_int64), ("max_gate_rows", C.c_int64),
                 ("align_weight", C.c_float), ("overlap_thresh", C.c_float),
                 ("reg_weight", C.c_float), ("reg_thresh_rad", C.c_float), ("reg_thresh_m", C.c_float),
                 ("rel_change_thresh", C.c_float),

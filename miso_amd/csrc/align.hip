@@ -138,37 +138,69 @@ __device__ __forceinline__ void so3_exp_backward(const float w_[3], const double
   for (int q = 0; q < 3; ++q) gw[q] = a * veeG[q] + b * veeM[q] + (da * gk + db * gkk) * w[q];
 }
 
-__global__ __launch_bounds__(64) void align_epilogue_a_kernel(AlignK k) {
+constexpr int EPI_A_THREADS = 256;
+constexpr int EPI_A_PAIRS = 512;      // pairs staged in LDS per pass (S <= 64 => at most 2016 pairs: 4 passes)
+
+__global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK k) {
   const int32_t* ctrl = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl);
   if (ctrl[CTRL_STOPPED]) return;
   const float* out = k.state + k.L.out;
   const float* cnt = k.state + k.L.cnt;
   const float* pose = k.state + k.L.pose;
   float* flat = k.state + k.L.flat;
-  for (int s = threadIdx.x; s < k.S; s += blockDim.x) {
-    double gR[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, gt[3] = {0., 0., 0.};
-    for (int p = 0; p < k.P; ++p) {
+  float* pl = k.state + k.L.pair_loss;
+  // Pass structure: (1) one thread per pair normalises it -- loss value, overlap gate, the scale of its cotangents --
+  // into LDS (the descriptors live in global memory: read in parallel, not P times in a row by every submap's
+  // thread); (2) one thread per submap sums the cotangents of its pairs IN LIST ORDER (deterministic) and pulls
+  // them back through R0 Exp(dr).
+  __shared__ float s_sc[EPI_A_PAIRS], s_loss[EPI_A_PAIRS];
+  __shared__ int s_src[EPI_A_PAIRS], s_dst[EPI_A_PAIRS];
+  __shared__ float s_total;
+  double gR[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, gt[3] = {0., 0., 0.};
+  float total = 0.0f;
+  const int s = threadIdx.x;      // submap of this thread in pass (2) (S <= 64 < EPI_A_THREADS)
+  for (int p0 = 0; p0 < k.P; p0 += EPI_A_PAIRS) {
+    const int np = min(EPI_A_PAIRS, k.P - p0);
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+      const int p = p0 + i;
       const AlignPairK& d = k.plan[p];
-      if (d.src != s && d.dst != s) continue;
       const float* o = out + 24 * p;
       const float denom = fmaxf(o[1], 1.0f) * (k.loss_type == 2 ? d.n_ch : 1.0f);
       const float val = o[0] / denom;
       const bool finite = (val == val) && !isinf(val);          // nan_to_num passes no gradient otherwise
       const float gate = d.gate_p ? ((cnt[p] / (float)d.gate_n) > k.overlap_thresh ? 1.0f : 0.0f) : 1.0f;
-      if (!finite || gate == 0.0f) continue;
-      const double sc = (double)k.align_weight / (double)denom;
-      const float* Rd = pose + 12 * d.dst;
-      const double h[3] = {(double)Rd[0] * o[2] + (double)Rd[1] * o[3] + (double)Rd[2] * o[4],
-                           (double)Rd[3] * o[2] + (double)Rd[4] * o[3] + (double)Rd[5] * o[4],
-                           (double)Rd[6] * o[2] + (double)Rd[7] * o[3] + (double)Rd[8] * o[4]};
-      if (d.src == s) {
-        for (int i = 0; i < 9; ++i) gR[i] += o[14 + i] * sc;
-        for (int i = 0; i < 3; ++i) gt[i] += h[i] * sc;
-      } else {
-        for (int i = 0; i < 9; ++i) gR[i] += o[5 + i] * sc;
-        for (int i = 0; i < 3; ++i) gt[i] -= h[i] * sc;
+      s_sc[i] = (finite && gate != 0.0f) ? k.align_weight / denom : 0.0f;
+      const float v = gate != 0.0f ? nan_to_num_f(val) * k.align_weight : 0.0f;
+      s_loss[i] = v;
+      pl[p] = v;
+      s_src[i] = d.src; s_dst[i] = d.dst;
+    }
+    __syncthreads();
+    if (s < k.S) {
+      for (int i = 0; i < np; ++i) {
+        const bool is_src = s_src[i] == s, is_dst = s_dst[i] == s;
+        const float scf = s_sc[i];
+        if (!(is_src || is_dst) || scf == 0.0f) continue;
+        const double sc = (double)scf;
+        const float* o = out + 24 * (p0 + i);
+        const float* Rd = pose + 12 * s_dst[i];
+        const double h[3] = {(double)Rd[0] * o[2] + (double)Rd[1] * o[3] + (double)Rd[2] * o[4],
+                             (double)Rd[3] * o[2] + (double)Rd[4] * o[3] + (double)Rd[5] * o[4],
+                             (double)Rd[6] * o[2] + (double)Rd[7] * o[3] + (double)Rd[8] * o[4]};
+        if (is_src) {
+          for (int q = 0; q < 9; ++q) gR[q] += o[14 + q] * sc;
+          for (int q = 0; q < 3; ++q) gt[q] += h[q] * sc;
+        } else {
+          for (int q = 0; q < 9; ++q) gR[q] += o[5 + q] * sc;
+          for (int q = 0; q < 3; ++q) gt[q] -= h[q] * sc;
+        }
       }
     }
+    if (threadIdx.x == 0)      // pair losses in list order (the reference sums its loss dict in insertion order)
+      for (int i = 0; i < np; ++i) total += s_loss[i];
+    __syncthreads();
+  }
+  if (s < k.S) {
     const float* R0 = k.R0 + 9 * s;
     double G[9];
     for (int i = 0; i < 3; ++i)
@@ -179,20 +211,8 @@ __global__ __launch_bounds__(64) void align_epilogue_a_kernel(AlignK k) {
     so3_exp_backward(w, G, gw);
     for (int i = 0; i < 3; ++i) { flat[6 * s + i] = (float)gw[i]; flat[6 * s + 3 + i] = (float)gt[i]; }
   }
-  if (threadIdx.x == 0) {     // pair losses in list order (the reference sums its loss dict in insertion order)
-    float* pl = k.state + k.L.pair_loss;
-    float total = 0.0f;
-    for (int p = 0; p < k.P; ++p) {
-      const AlignPairK& d = k.plan[p];
-      const float* o = out + 24 * p;
-      const float denom = fmaxf(o[1], 1.0f) * (k.loss_type == 2 ? d.n_ch : 1.0f);
-      const float gate = d.gate_p ? ((cnt[p] / (float)d.gate_n) > k.overlap_thresh ? 1.0f : 0.0f) : 1.0f;
-      const float v = gate != 0.0f ? nan_to_num_f(o[0] / denom) * k.align_weight : 0.0f;
-      pl[p] = v;
-      total += v;
-    }
-    flat[6 * k.S] = total;
-  }
+  if (threadIdx.x == 0) flat[6 * k.S] = total;
+  (void)s_total;
 }
 
 __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
@@ -267,15 +287,16 @@ __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
 }
 
 hipError_t launch_pair_batch(const AlignPairK*, int, int64_t, int64_t, bool, const float*, int, float*, float*,
-                             const int32_t*, hipStream_t);
+                             const int32_t*, int64_t, hipStream_t);
 
-hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, bool vec4, hipStream_t s) {
+hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, int64_t max_gate_rows, bool vec4,
+                          hipStream_t s) {
   align_prologue_kernel<<<1, 256, 0, s>>>(k);
   const int32_t* stopped = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl) + CTRL_STOPPED;
   hipError_t e = launch_pair_batch(k.plan, k.P, max_n, max_gate_n, vec4, k.state + k.L.pose, k.loss_type,
-                                   k.state + k.L.out, k.state + k.L.cnt, stopped, s);
+                                   k.state + k.L.out, k.state + k.L.cnt, stopped, max_gate_rows, s);
   if (e != hipSuccess) return e;
-  align_epilogue_a_kernel<<<1, 64, 0, s>>>(k);
+  align_epilogue_a_kernel<<<1, EPI_A_THREADS, 0, s>>>(k);
   return hipGetLastError();
 }
 

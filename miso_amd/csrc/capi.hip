@@ -52,7 +52,7 @@ hipError_t launch_adam_active(float*, float*, float*, float*, unsigned char*, in
                               int, const float*, hipStream_t);
 hipError_t launch_mapping_loss(int, float, float, float, const float*, const float*, const float*,
                                const float*, const float*, int64_t, float*, float*, float*, hipStream_t);
-hipError_t launch_align_a(const AlignK&, int64_t, int64_t, bool, hipStream_t);
+hipError_t launch_align_a(const AlignK&, int64_t, int64_t, int64_t, bool, hipStream_t);
 hipError_t launch_align_b(const AlignK&, hipStream_t);
 }  // namespace miso
 
@@ -521,7 +521,7 @@ int miso_align_plan_build(const miso_align_pair_t* pairs, miso_align_t* cfg, voi
   if (cfg->n_pairs > 0 && (!pairs || !plan_host)) return MISO_E_BADARG;
   AlignPairK* out = reinterpret_cast<AlignPairK*>(plan_host);
   bool v4_all = true;
-  int64_t max_n = 0, max_gate = 0;
+  int64_t max_n = 0, max_gate = 0, max_rows = 0;
   for (int p = 0; p < cfg->n_pairs; ++p) {
     const miso_align_pair_t& in = pairs[p];
     if (in.src < 0 || in.src >= cfg->n_submaps || in.dst < 0 || in.dst >= cfg->n_submaps || in.src == in.dst)
@@ -538,6 +538,20 @@ int miso_align_plan_build(const miso_align_pair_t* pairs, miso_align_t* cfg, voi
     v4_all = v4_all && v4;
     d.p = in.coords_src; d.fsrc = in.feats_src; d.ld = in.ld_feats; d.n = in.n;
     d.gate_p = in.gate_n > 0 ? in.gate_coords : nullptr; d.gate_n = in.gate_n;
+    if (in.gate_n > 0 && in.gate_axis[0]) {
+      if (!in.gate_axis[1] || !in.gate_axis[2]) return MISO_E_BADARG;
+      int64_t prod = 1;
+      for (int a = 0; a < 3; ++a) {
+        if (in.gate_dims[a] < 1) return MISO_E_BADARG;
+        d.gate_ax[a] = in.gate_axis[a]; d.gate_dim[a] = in.gate_dims[a];
+        prod *= in.gate_dims[a];
+      }
+      if (prod != in.gate_n) return MISO_E_BADARG;
+      d.gate_p = in.gate_axis[0];      // non-null marks the gate as on; the lattice path does not read it as points
+      if ((int64_t)in.gate_dims[1] * in.gate_dims[2] > max_rows) max_rows = (int64_t)in.gate_dims[1] * in.gate_dims[2];
+    } else if (in.gate_n > 0 && !in.gate_coords) {
+      return MISO_E_BADARG;
+    }
     d.src = in.src; d.dst = in.dst; d.n_ch = (float)d.g.F;
     if (in.n > max_n) max_n = in.n;
     if (d.gate_p && in.gate_n > max_gate) max_gate = in.gate_n;
@@ -545,6 +559,7 @@ int miso_align_plan_build(const miso_align_pair_t* pairs, miso_align_t* cfg, voi
   cfg->vec4 = v4_all ? 1 : 0;
   cfg->max_n = max_n;
   cfg->max_gate_n = max_gate;
+  cfg->max_gate_rows = max_rows;
   return MISO_OK;
 }
 
@@ -580,7 +595,7 @@ int miso_align_iteration_a(const miso_align_t* cfg, void* stream) {
   AlignK k;
   int rc = align_k(cfg, &k);
   if (rc) return rc;
-  return (int)launch_align_a(k, cfg->max_n, cfg->max_gate_n, cfg->vec4 != 0, (hipStream_t)stream);
+  return (int)launch_align_a(k, cfg->max_n, cfg->max_gate_n, cfg->max_gate_rows, cfg->vec4 != 0, (hipStream_t)stream);
 }
 
 int miso_align_iteration_b(const miso_align_t* cfg, void* stream) {

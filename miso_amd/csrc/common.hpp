@@ -129,9 +129,12 @@ struct AlignPairK {
   int64_t ld, n;
   const float* gate_p;  // (gate_n,3) finest-level source vertices for the overlap gate, or nullptr: always on
   int64_t gate_n;
+  // the same vertices as a lattice (preferred: nothing to read but three short tables): vertex (i,j,k), index
+  // (k ny + j) nx + i, sits at (gate_ax[0][i], gate_ax[1][j], gate_ax[2][k]); gate_n = nx ny nz
+  const float* gate_ax[3];
+  int32_t gate_dim[3];
   int32_t src, dst;
   float n_ch;           // channels compared (the L2 mean divides by count * n_ch)
-  int32_t _pad;
 };
 
 // One torch.optim.Adam update (amsgrad=False, weight_decay=0) as torch forms it op by op; shared by adam.hip

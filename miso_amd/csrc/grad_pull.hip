@@ -842,7 +842,7 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
     const int nb = T / 2;
     if (getenv("MISO_PULL_OCC")) {   // dev
       int nblk = 0;
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)kb, 512, blds);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)kb, 512, blds);
       fprintf(stderr, "grad_pull_block_kernel: %zu B LDS, %d workgroups per CU\n", blds, nblk);
     }
     kb<<<(unsigned)(nb * nb * nb), 512, blds, s>>>(g, pk);

@@ -208,15 +208,61 @@ __global__ __launch_bounds__(256) void overlap_count_kernel(const float* __restr
 }
 
 // The overlap gate of every pair of the plan in one launch (blockIdx.y = pair); cnt_all (P) zeroed by the prologue.
+// Lattice form (gate_ax): a workgroup takes GATE_ROWS (j,k) rows of the source's finest level, a thread walks along
+// x; the vertex positions come from the three per-axis tables (the values FeatureGrid.vertex_positions builds the
+// meshgrid from), so nothing but 3 x a few hundred floats is read, and the arithmetic per vertex is the point-list
+// path's.
+constexpr int GATE_ROWS = 64;
+
 __global__ __launch_bounds__(256) void overlap_count_batch_kernel(const AlignPairK* __restrict__ plan,
                                                                  const float* __restrict__ pose_all,
                                                                  float* __restrict__ cnt_all,
                                                                  const int32_t* __restrict__ stopped) {
   if (stopped && *stopped) return;
   const AlignPairK& d = plan[blockIdx.y];
-  if (!d.gate_p || (int64_t)blockIdx.x * blockDim.x >= d.gate_n) return;
-  overlap_count_body(pose_all + 12 * d.src, pose_all + 12 * d.dst, d.gate_p, d.gate_n, d.g.bmin[0], d.g.bmin[1],
-                     d.g.bmin[2], d.g.bmax[0], d.g.bmax[1], d.g.bmax[2], cnt_all + blockIdx.y, blockIdx.x, gridDim.x);
+  if (!d.gate_p) return;
+  if (!d.gate_ax[0]) {
+    if ((int64_t)blockIdx.x * blockDim.x >= d.gate_n) return;
+    overlap_count_body(pose_all + 12 * d.src, pose_all + 12 * d.dst, d.gate_p, d.gate_n, d.g.bmin[0], d.g.bmin[1],
+                       d.g.bmin[2], d.g.bmax[0], d.g.bmax[1], d.g.bmax[2], cnt_all + blockIdx.y, blockIdx.x, gridDim.x);
+    return;
+  }
+  const int nx = d.gate_dim[0], ny = d.gate_dim[1], nz = d.gate_dim[2];
+  const int nrows = ny * nz;
+  const int row0 = blockIdx.x * GATE_ROWS;
+  if (row0 >= nrows) return;
+  const float* ps = pose_all + 12 * d.src;
+  const float* pd = pose_all + 12 * d.dst;
+  float Rs[9], ts[3], Rd[9], td[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Rs[i] = ps[i]; Rd[i] = pd[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { ts[i] = ps[9 + i]; td[i] = pd[9 + i]; }
+  const float b0 = d.g.bmin[0], b1 = d.g.bmin[1], b2 = d.g.bmin[2], B0 = d.g.bmax[0], B1 = d.g.bmax[1], B2 = d.g.bmax[2];
+  float cnt = 0.0f;
+  const int rend = min(row0 + GATE_ROWS, nrows);
+  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
+    const float px = d.gate_ax[0][i];
+    int j = row0 % ny, k = row0 / ny;
+    for (int row = row0; row < rend; ++row) {
+      const float py = d.gate_ax[1][j], pz = d.gate_ax[2][k];      // wave-uniform
+      const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
+                          Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
+      const float e[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
+      const float q0 = Rd[0] * e[0] + Rd[3] * e[1] + Rd[6] * e[2], q1 = Rd[1] * e[0] + Rd[4] * e[1] + Rd[7] * e[2],
+                  q2 = Rd[2] * e[0] + Rd[5] * e[1] + Rd[8] * e[2];
+      if (q0 >= b0 && q0 <= B0 && q1 >= b1 && q1 <= B1 && q2 >= b2 && q2 <= B2) cnt += 1.0f;
+      if (++j == ny) { j = 0; ++k; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (red[0] + red[1]) + (red[2] + red[3]);
+    if (v != 0.0f) atomic_add_f32(cnt_all + blockIdx.y, v);
+  }
 }
 
 hipError_t launch_overlap_count(const float* pose, const float* p, int64_t n, const float* bmin, const float* bmax,
@@ -247,11 +293,14 @@ hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, cons
 // The pair stage of one fused alignment iteration (align.hip): overlap counts, then the pair residuals.
 hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t max_n, int64_t max_gate_n, bool vec4,
                              const float* pose_all, int loss_type, float* out_all, float* cnt_all,
-                             const int32_t* stopped, hipStream_t s) {
+                             const int32_t* stopped, int64_t max_gate_rows, hipStream_t s) {
   if (n_pairs <= 0) return hipSuccess;
   if (max_gate_n > 0) {
     unsigned blocks = (unsigned)((max_gate_n + 2047) / 2048);
     if (blocks > 512u) blocks = 512u;
+    // lattice gates: one workgroup per GATE_ROWS rows (point-list gates grid-stride whatever the block count)
+    const unsigned lat = (unsigned)((max_gate_rows + GATE_ROWS - 1) / GATE_ROWS);
+    if (lat > blocks) blocks = lat;
     overlap_count_batch_kernel<<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, cnt_all, stopped);
   }
   if (max_n > 0) {

@@ -178,7 +178,8 @@ def latent_pair_inputs(grid_atlas: GridAtlas, pairs, level: int, fdim=4, check_i
                         feats_src=_src_features(grid_atlas, src_id, level, coords, nlv),
                         feats_dst=[g.feature.detach() for g in sub_to.features[:nlv]],
                         meta_dst=sub_to.features[0].grid_meta(sub_to.ignore_level_[:nlv]),
-                        gate_pts=grid_atlas._finest_vertices(src_id) if check_intersection else None))
+                        gate_pts=grid_atlas._finest_vertices(src_id) if check_intersection else None,
+                        gate_dims=tuple(int(v) for v in reversed(sub_from.features[-1].feature.shape[2:]))))
     return out
 
 

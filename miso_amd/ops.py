@@ -812,7 +812,9 @@ class AlignPlan:
 
     R0 (S,3,3) / t0 (S,3,1): base poses.  pairs: dicts with ``src``, ``dst``, ``coords`` (n,3), ``feats_src``
     (n, >= F), ``feats_dst`` (list of level tensors, levels 0..level), ``meta_dst`` (GridMeta) and ``gate_pts``
-    ((m,3) finest-level vertices of src, or None: no overlap gate)."""
+    ((m,3) finest-level vertices of src, or None: no overlap gate) with, optionally, ``gate_dims`` = (nx, ny, nz) when
+    those vertices are FeatureGrid.vertex_positions' meshgrid -- the gate then reads three short tables instead of m
+    points."""
 
     def __init__(self, R0, t0, pairs, *, loss_type="L2", align_weight=3000.0, overlap_thresh=1e-2, lr=1e-2,
                  betas=(0.9, 0.999), eps=1e-8, reg_weight=0.0, reg_thresh_rad=1.0, reg_thresh_m=1.0,
@@ -848,6 +850,15 @@ class AlignPlan:
                 gate = gate.detach().contiguous()
                 _require_hip(gate)
                 d.gate_coords, d.gate_n = gate.data_ptr(), gate.shape[0]
+                dims = pr.get("gate_dims")           # (nx, ny, nz): the points are a z-major meshgrid of three tables
+                if dims is not None:
+                    nx, ny, nz = (int(v) for v in dims)
+                    assert nx * ny * nz == gate.shape[0]
+                    axes = (gate[:nx, 0].contiguous(), gate[::nx][:ny, 1].contiguous(),
+                            gate[::nx * ny][:nz, 2].contiguous())
+                    for a in range(3):
+                        d.gate_axis[a], d.gate_dims[a] = axes[a].data_ptr(), (nx, ny, nz)[a]
+                    gate = (gate, axes)
             d.src, d.dst = int(pr["src"]), int(pr["dst"])
             self._keep.append((feats_dst, coords, fsrc, gate))
         nbytes = int(lib.miso_align_plan_bytes(P))

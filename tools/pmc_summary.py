@@ -42,13 +42,15 @@ for k, d in acc.items():
     out[k] = {"FETCH_SIZE_KiB_avg": f, "WRITE_SIZE_KiB_avg": w, "launches_sampled": len(d.get("FETCH_SIZE", [])),
               "hbm_bytes_per_launch": (2 * f + w) * 1024,
               "note": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halving, KiB units)"}
-    # fp32 MFMA busy share: SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs of the chip (256 CUs x 4), in shader
-    # cycles; GRBM_GUI_ACTIVE = cycles the kernel kept the GPU busy (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+    # fp32 MFMA busy share.  SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs of the chip, in shader cycles
+    # (checked: sdf_fwd_kernel issues 4096 chunks x 176 v_mfma_f32_32x32x2_f32 x 64 cycles = 46.14 M, the counter reads
+    # 46.14 M); GRBM_GUI_ACTIVE is summed over the 8 XCDs (it reads ~8 x duration x clock).  So the share of the
+    # kernel's SIMD-cycles spent issuing MFMAs is busy / (active / 8 * 1024).
     busy, act = d.get("SQ_VALU_MFMA_BUSY_CYCLES"), d.get("GRBM_GUI_ACTIVE")
     if busy and act:
         b, a = sum(busy) / len(busy), sum(act) / len(act)
         out[k].update({"SQ_VALU_MFMA_BUSY_CYCLES_avg": b, "GRBM_GUI_ACTIVE_avg": a,
-                       "mfma_busy_frac": b / (a * 1024.0) if a else None})
+                       "mfma_busy_frac": b / (a / 8.0 * 1024.0) if a else None})
 sys.path.insert(0, os.getcwd())
 try:
     from miso_amd.csrc_hash import source_hash
