@@ -44,16 +44,49 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
 #pragma unroll
   for (int i = 0; i < 23; ++i) acc[i] = 0.0f;
 
-  for (int64_t idx = (int64_t)bx * blockDim.x + threadIdx.x; idx < k.n; idx += (int64_t)nbx * blockDim.x) {
+  // Two passes per chunk, per wavefront.  Under a perturbed pose only a fraction of a source submap lands inside the
+  // destination (cfg-4: 21 % of the level-1 vertices), and the heavy part -- 8 corner gathers per level, the source
+  // features, ~300 flops -- runs for the whole wavefront whenever one lane is inside.  So pass 1 only transforms and
+  // tests PAIR_K x 64 consecutive vertices and compacts the in-bound ones into a per-wave LDS list (ballot + prefix:
+  // a deterministic order, no block barrier); pass 2 walks that list with all lanes busy.
+  constexpr int PAIR_K = 8;
+  __shared__ uint16_t s_in[4][PAIR_K * 64];
+  const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (lane_ == 0) ? 0ull : (~0ull >> (64 - lane_));
+  const int64_t chunk = (int64_t)blockDim.x * PAIR_K;
+  for (int64_t c0 = (int64_t)bx * chunk; c0 < k.n; c0 += (int64_t)nbx * chunk) {
+    const int64_t w0 = c0 + (int64_t)wave_ * (PAIR_K * 64);
+    int n_in = 0;
+#pragma unroll
+    for (int u = 0; u < PAIR_K; ++u) {
+      const int64_t i = w0 + u * 64 + lane_;
+      bool inb = false;
+      if (i < k.n) {
+        const float px = k.p[i * 3 + 0], py = k.p[i * 3 + 1], pz = k.p[i * 3 + 2];
+        const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
+                            Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
+        const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
+        const float q[3] = {Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
+                            Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2]};
+        inb = q[0] >= g.bmin[0] && q[0] <= g.bmax[0] && q[1] >= g.bmin[1] && q[1] <= g.bmax[1] &&
+              q[2] >= g.bmin[2] && q[2] <= g.bmax[2];
+      }
+      const unsigned long long m = __ballot(inb);
+      if (inb) s_in[wave_][n_in + (int)__popcll(m & lt_mask)] = (uint16_t)(u * 64 + lane_);
+      n_in += (int)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = lane_; e < n_in; e += 64) {
+    const int64_t idx = w0 + s_in[wave_][e];
+    // the same arithmetic as pass 1 (three loads from L2 and 30 flops are cheaper than carrying q through LDS)
     const float px = k.p[idx * 3 + 0], py = k.p[idx * 3 + 1], pz = k.p[idx * 3 + 2];
     const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
                         Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
     const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
     const float q[3] = {Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
                         Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2]};
-    const bool inb = q[0] >= g.bmin[0] && q[0] <= g.bmax[0] && q[1] >= g.bmin[1] && q[1] <= g.bmax[1] &&
-                     q[2] >= g.bmin[2] && q[2] <= g.bmax[2];
-    if (!inb) continue;
     const float* fs = k.fsrc + idx * k.ld;
     // pass 1: residual norm (needed by L1 before the derivative weights are known)
     float term = 0.0f, gq[3] = {0.f, 0.f, 0.f};
@@ -129,6 +162,8 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) { acc[5 + a * 3 + b] += d[a] * gq[b]; acc[14 + a * 3 + b] += h[a] * pp[b]; }
+    }
+    __builtin_amdgcn_wave_barrier();      // the list is rewritten by the next chunk's pass 1
   }
   // block reduction: wave shuffles, then one atomic per value per block
   __shared__ float red[4][24];
@@ -161,7 +196,7 @@ __global__ __launch_bounds__(256) void pair_latent_batch_kernel(const AlignPairK
                                                                const int32_t* __restrict__ stopped) {
   if (stopped && *stopped) return;
   const AlignPairK& d = plan[blockIdx.y];
-  if ((int64_t)blockIdx.x * blockDim.x >= d.n) return;
+  if ((int64_t)blockIdx.x * blockDim.x * 8 >= d.n) return;
   PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y};
   pair_latent_body<VEC4>(d.g, pose_all + 12 * d.src, pose_all + 12 * d.dst, k, blockIdx.x, gridDim.x);
 }
@@ -283,7 +318,7 @@ hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, cons
   hipError_t e = launch_zero_words(out, 24, s);
   if (e != hipSuccess || n == 0) return e;
   PairK k{pose, p, fsrc, ld, n, loss_type, out};
-  unsigned blocks = (unsigned)((n + 255) / 256);
+  unsigned blocks = (unsigned)((n + 2047) / 2048);      // a workgroup takes 256 x PAIR_K vertices per trip
   if (blocks > 2048u) blocks = 2048u;
   if (vec4) pair_latent_kernel<true><<<blocks, 256, 0, s>>>(g, k);
   else pair_latent_kernel<false><<<blocks, 256, 0, s>>>(g, k);
@@ -304,7 +339,7 @@ hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t ma
     overlap_count_batch_kernel<<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, cnt_all, stopped);
   }
   if (max_n > 0) {
-    unsigned blocks = (unsigned)((max_n + 255) / 256);
+    unsigned blocks = (unsigned)((max_n + 2047) / 2048);
     if (blocks > 2048u) blocks = 2048u;
     if (vec4) pair_latent_batch_kernel<true><<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
     else pair_latent_batch_kernel<false><<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
