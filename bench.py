@@ -206,8 +206,9 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
             return time.perf_counter() - t0
 
         run(4)                                      # warm-up (plan build, source features cached)
-        t_a, t_b = min(run(iters), run(iters)), min(run(3 * iters), run(3 * iters))
-        per_it = (t_b - t_a) / (2 * iters)
+        # wall time of a run = plan set-up (host) + iterations: the difference of a long and a short run is iterations only
+        t_a, t_b = min(run(iters), run(iters), run(iters)), min(run(6 * iters), run(6 * iters))
+        per_it = (t_b - t_a) / (5 * iters)
         nv = sum(atlas.coordinates_for_alignment(a, level).shape[0] for a in range(S) for b in range(a + 1, S))
         C_ = SCANNET_CFG["grid"]["feature_dim"]
         rec = {"source_vertices_per_iteration": nv, "ms_per_iteration": per_it * 1e3,
