@@ -241,10 +241,12 @@ int miso_grad_pull_dx(const miso_grid_t* grid, const miso_sorted_t* sorted, int6
  * gathers the contributions to the vertices it owns and writes them once, without atomics.
  * Levels the pull cannot own (more than 8 vertices per tile and axis, non-default sampling
  * flags) keep the atomic scatter. */
-/* Levels (bit l) whose gradient miso_sdf_bwd_sorted scatters from the MFMA pass by the dense wave walk instead of
- * leaving them to the pull: coarse levels (a tile owns <= 3 vertices per axis) of a batch that averages >= 100
- * points per tile ($MISO_DENSE_MIN).  n = batch size.  Informational: the entry point decides by itself. */
-uint32_t miso_sdf_bwd_dense_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n);
+/* Levels (bit l) whose gradient miso_sdf_bwd_sorted forms by the matrix-core push instead of the pull (grad_pull.hip:
+ * per run of tile-sorted samples a (samples x 25)^T (samples x 5 C) product on v_mfma_f32_32x32x2_f32, added to the
+ * zero-filled level with atomics): a batch that averages >= 100 samples per tile ($MISO_DENSE_MIN), 4 or 8 channels,
+ * and every tile's samples within 5 vertices per axis (a tile owns <= 3).  n = batch size.  Informational: the entry
+ * point decides by itself. */
+uint32_t miso_sdf_bwd_push_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n);
 int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n);
 int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,

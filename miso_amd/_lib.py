@@ -130,7 +130,7 @@ SIGNATURES = {
     "miso_encode_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p]),
     "miso_grad_pull_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32]),
-    "miso_sdf_bwd_dense_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32, C.c_int64]),
+    "miso_sdf_bwd_push_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32, C.c_int64]),
     "miso_sdf_bwd_workspace_floats": (C.c_int64, [C.POINTER(Grid), C.c_int64]),
     "miso_sdf_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted),
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

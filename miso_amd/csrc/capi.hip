@@ -24,9 +24,11 @@ hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, 
                        hipStream_t);
 hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, const float*, int64_t, int64_t, int,
                               float*, hipStream_t);
+hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
-                            uint32_t, int, const float*, int32_t*, int64_t, hipStream_t);
+                            uint32_t, int, const float*, int32_t*, int64_t, hipStream_t, uint32_t push_mask, int64_t n);
+uint32_t plan_push(const GridK&, int, int64_t, uint32_t);
 int64_t pull_queue_ints(int64_t);
 hipError_t launch_rigid_by_index(const float*, const float*, const int64_t*, const float*, int64_t, int32_t, int, float*,
                                  hipStream_t);
@@ -58,7 +60,6 @@ hipError_t launch_align_b(const AlignK&, hipStream_t);
 
 using namespace miso;
 
-static uint32_t plan_dense(const GridK& g, int T, int64_t n, uint32_t pull);
 
 namespace {
 
@@ -297,31 +298,34 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   uint32_t pull = 0;
   if (sorted && sorted->xn_sorted && workspace && want_grid && ((uintptr_t)workspace & 15u) == 0)
     pull = plan_grad_pull(g, sorted->tiles_per_axis);
-  const uint32_t dense = (pull && sorted) ? plan_dense(g, sorted->tiles_per_axis, n, pull) : 0u;
-  pull &= ~dense;
+  // coarse levels under a crowd: the matrix-core push (grad_pull.hip; its d-feat rows go through the workspace like a
+  // pulled level's, so it stays in `pull`)
+  const uint32_t push = (pull && sorted) ? plan_push(g, sorted->tiles_per_axis, n, pull) : 0u;
   hipStream_t st = (hipStream_t)stream;
   if (overwrite) {
-    // levels that are still scattered with atomics start from zero; pulled levels need no fill
+    // levels that are scattered or pushed with atomics start from zero; pulled levels need no fill
     for (int l = 0; l < g.n_levels; ++l) {
       const LevelK& lv = g.lv[l];
-      if (!lv.grad || ((pull >> l) & 1u)) continue;
+      if (!lv.grad || (((pull & ~push) >> l) & 1u)) continue;
       size_t span = (size_t)(lv.C - 1) * lv.sC + (size_t)(lv.X - 1) * lv.sX + (size_t)(lv.Y - 1) * lv.sY +
                     (size_t)(lv.Z - 1) * lv.sZ + 1;
-      hipError_t e = hipMemsetAsync(lv.grad, 0, span * sizeof(float), st);
+      // (a kernel, not hipMemsetAsync: memset nodes of a captured graph that is replayed back to back with other
+      // launches in between now and then fill with garbage on ROCm 7.2 -- see loss.hip:zero_words_kernel)
+      hipError_t e = launch_zero_fill(lv.grad, (int64_t)span, st);
       if (e != hipSuccess) return (int)e;
     }
   }
   if (n == 0 && !pull) return MISO_OK;
   if (n > 0) {
     rc = (int)launch_sdf_bwd(C, L, H, NH, gp, packed, x, n, grad_sdf, relu_mask, grad_x, want_grid, perm,
-                             pull ? workspace : nullptr, pull | (dense << 16),
+                             pull ? workspace : nullptr, pull,
                              sorted && (grid->flags & MISO_F_GRAD_SDF_SORTED), st);
     if (rc) return rc;
   }
   if (!pull) return MISO_OK;
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace,
                                g.F, nullptr, pull, overwrite ? 1 : 0, nullptr, sorted->pull_queue,
-                               sorted->pull_queue_ints, st);
+                               sorted->pull_queue_ints, st, push, n);
 }
 
 int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
@@ -404,21 +408,6 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
 }
 
 // levels (with a gradient requested) the owner-computes pull covers for this grid
-// Coarse levels under a crowd: a tile owns at most 3 vertices per axis and holds on average >= MISO_DENSE_MIN
-// points (default 100).  The pull would cut such tiles into atomic slices, each sweeping 27 tiles; the fused
-// backward walks the chunk's vertex box instead (sdf_fused.hip, "dense wave scatter").  Subset of `pull`.
-static uint32_t plan_dense(const GridK& g, int T, int64_t n, uint32_t pull) {
-  static const int dense_min = [] { const char* e = getenv("MISO_DENSE_MIN"); return e ? atoi(e) : 100; }();
-  uint32_t dense = 0;
-  if (dense_min <= 0 || n < (int64_t)dense_min * T * T * T) return 0;
-  for (int l = 0; l < g.n_levels && l < 16; ++l) {
-    const LevelK& lv = g.lv[l];
-    if (((pull >> l) & 1u) && (lv.X + T - 1) / T <= 3 && (lv.Y + T - 1) / T <= 3 && (lv.Z + T - 1) / T <= 3)
-      dense |= 1u << l;
-  }
-  return dense;
-}
-
 static int pull_plan(const miso_grid_t* grid, int32_t tiles_per_axis, GridK* g, int* C, uint32_t* mask) {
   bool v4;
   int rc = convert_grid(grid, g, false, &v4);
@@ -433,10 +422,10 @@ static int pull_plan(const miso_grid_t* grid, int32_t tiles_per_axis, GridK* g, 
   return MISO_OK;
 }
 
-uint32_t miso_sdf_bwd_dense_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n) {
+uint32_t miso_sdf_bwd_push_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n) {
   GridK g; int C; uint32_t mask;
   if (pull_plan(grid, tiles_per_axis, &g, &C, &mask)) return 0;
-  return plan_dense(g, tiles_per_axis, n, mask);
+  return plan_push(g, tiles_per_axis, n, mask);
 }
 
 uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis) {
@@ -462,7 +451,7 @@ static int grad_pull_impl(const miso_grid_t* grid, const miso_sorted_t* sorted, 
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, dfeat, ld_d,
                                rows_in_caller_order ? sorted->perm : nullptr, pull,
                                (grid->flags & MISO_F_GRAD_OVERWRITE) ? 1 : 0, gg_x, sorted->pull_queue,
-                               sorted->pull_queue_ints, (hipStream_t)stream);
+                               sorted->pull_queue_ints, (hipStream_t)stream, 0u, n);
 }
 
 int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,

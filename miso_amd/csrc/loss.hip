@@ -73,6 +73,26 @@ __global__ void zero_words_kernel(uint32_t* __restrict__ p, int n) {
   if (i < n) p[i] = 0u;
 }
 
+// Large buffers (a level's gradient before an atomic scatter), for the same reason: 16 B per lane, grid-stride.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, int64_t n) {
+  const int64_t head = min(n, (int64_t)((16 - ((uintptr_t)p & 15u)) & 15u) >> 2);   // floats up to 16-B alignment
+  const int64_t n4 = (n - head) >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p + head);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t < head) p[t] = 0.0f;
+  const int64_t tail = head + 4 * n4 + t;
+  if (tail < n) p[tail] = 0.0f;
+}
+
+hipError_t launch_zero_fill(float* p, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int64_t want = (n / 4 + 255) / 256;
+  const unsigned blocks = (unsigned)max((int64_t)1, min(want, (int64_t)256 * 16));
+  zero_fill_kernel<<<blocks, 256, 0, s>>>(p, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_zero_words(void* p, int n_words, hipStream_t s) {
   if (n_words <= 0) return hipSuccess;
   zero_words_kernel<<<(n_words + 255) / 256, 256, 0, s>>>(reinterpret_cast<uint32_t*>(p), n_words);

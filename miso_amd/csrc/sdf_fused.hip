@@ -407,48 +407,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
 // gradients and/or grad_x.  Lane (hi, l&31) holds, for tile t, point 32t+(l&31):
 //   C == 8: channels 4hi..4hi+3 of level j>>2      (registers j = 4*level + c)
 //   C == 4: channels 0..3 of level 2*(j>>2) + hi   (registers j = 4*g + c)
-// ---- dense wave scatter (coarse levels under a crowd of points) --------------------------------------
-// The 64 points of a tile-sorted chunk sit in one or two tiles; at a coarse level their cells span a box of a
-// few dozen vertices.  Instead of 8 atomic rows per point (or the owner-computes sweep, which makes 27 tiles
-// look at every point and is cut into atomic slices when a tile is crowded), the wave walks the box once:
-// every lane evaluates its point's hat weight at the vertex, the C channel products are summed over the wave
-// by a halving butterfly (C values per lane -> 1 after log2 C exchanges, then an all-reduce inside the lane
-// group), and ONE C-wide atomic adds the vertex' total.  Every point is read once; atomic requests drop from
-// 4 * 64 per chunk and level to the number of touched vertices.
-constexpr int DENSE_MAX_BOX = 160;   // vertices; larger boxes (chunks spread over far-apart tiles) fall back
-
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-// in: v[c] per lane.  out: every lane holds the wave total of channel lane / (64 / C).
-template <int C>
-__device__ __forceinline__ float wave_sum_channels(float (&v)[C], int lane) {
-  int bit = 32;
-#pragma unroll
-  for (int n = C; n > 1; n >>= 1, bit >>= 1) {
-    const bool up = (lane & bit) != 0;
-#pragma unroll
-    for (int i = 0; i < n / 2; ++i) {
-      const float keep = up ? v[n / 2 + i] : v[i];
-      const float send = up ? v[i] : v[n / 2 + i];
-      v[i] = keep + __shfl_xor(send, bit, 64);
-    }
-  }
-#pragma unroll
-  for (; bit > 0; bit >>= 1) v[0] += __shfl_xor(v[0], bit, 64);
-  return v[0];
-}
-
-// DENSE: the dense wave scatter is compiled in (its own instantiation: the plain one keeps its registers)
-template <int C, int L, int H, int NH, bool WANT_GRID, bool WANT_X, bool DENSE = false>
+template <int C, int L, int H, int NH, bool WANT_GRID, bool WANT_X>
 __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(GridK g, const float* __restrict__ packed,
                                                         const float* __restrict__ x, int64_t n,
                                                         const float* __restrict__ gsdf,
@@ -483,9 +442,6 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
   // allocated per wave -- 50 KB per workgroup instead of 74, i.e. three workgroups per CU
   float* wave_lds = smem + ((nb + H + 3) / 4) * 4 + wave * ((debug & 32) ? 64 * FP : WAVE_LDS);
   const int64_t nchunks = (n + 63) / 64;
-  // defer_mask: bits 0..15 levels left to the pull, bits 16..31 levels scattered here by the dense wave walk
-  const uint32_t dense_mask = DENSE ? (defer_mask >> 16) : 0u;
-  defer_mask &= 0xffffu;
   // levels whose gradient is scattered from this kernel (binned training defers all of them to the
   // pull: then no per-point cell records are formed at all)
   uint32_t scatter_mask = 0;
@@ -615,59 +571,15 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
             *reinterpret_cast<float4*>(dst + row * F + col) = *reinterpret_cast<const float4*>(dF + row * FP + col);
         }
       }
-      uint32_t dense_done = 0;      // wave-uniform: levels this chunk has scattered densely
-      if (DENSE && (dense_mask & scatter_mask)) {
-        const int64_t p = chunk * 64 + lane;
-        const bool valid = p < n;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) load_point(g, x, p, px, py, pz);
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-          if (!((dense_mask & scatter_mask) >> l & 1u)) continue;
-          const LevelK& lv = g.lv[l];
-          Cell c = make_cell(axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags),
-                             axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags),
-                             axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags), lv);
-          // box of the vertices the chunk's cells touch, clipped to the grid
-          const int big = 1 << 30;
-          const int x0 = max(wave_min_i(valid ? c.i0 : big), 0), x1 = min(wave_max_i(valid ? c.i0 + 1 : -big), lv.X - 1);
-          const int y0 = max(wave_min_i(valid ? c.j0 : big), 0), y1 = min(wave_max_i(valid ? c.j0 + 1 : -big), lv.Y - 1);
-          const int z0 = max(wave_min_i(valid ? c.k0 : big), 0), z1 = min(wave_max_i(valid ? c.k0 + 1 : -big), lv.Z - 1);
-          if (x1 < x0 || y1 < y0 || z1 < z0) { dense_done |= 1u << l; continue; }       // nothing inside the grid
-          if ((int64_t)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > DENSE_MAX_BOX) continue;   // row-major atomics below
-          dense_done |= 1u << l;
-          float dv[C];
-#pragma unroll
-          for (int cc = 0; cc < C; ++cc) dv[cc] = valid ? dF[lane * FP + l * C + cc] : 0.0f;
-          for (int vz = z0; vz <= z1; ++vz) {
-            const float wz = (vz == c.k0) ? c.wz[0] : ((vz == c.k0 + 1) ? c.wz[1] : 0.0f);
-            if (__ballot(wz != 0.0f) == 0ull) continue;            // no point of the chunk next to this plane
-            for (int vy = y0; vy <= y1; ++vy) {
-              const float wyz = wz * ((vy == c.j0) ? c.wy[0] : ((vy == c.j0 + 1) ? c.wy[1] : 0.0f));
-              if (__ballot(wyz != 0.0f) == 0ull) continue;         // ... nor to this row
-              for (int vx = x0; vx <= x1; ++vx) {
-                const float w = wyz * ((vx == c.i0) ? c.wx[0] : ((vx == c.i0 + 1) ? c.wx[1] : 0.0f));
-                if (__ballot(w != 0.0f) == 0ull) continue;
-                float t[C];
-#pragma unroll
-                for (int cc = 0; cc < C; ++cc) t[cc] = w * dv[cc];
-                const float tot = wave_sum_channels<C>(t, lane);
-                const float mine = __shfl(tot, (lane & (C - 1)) * (64 / C), 64);   // lane j < C: channel j
-                if (lane < C && !(debug & 1)) atomic_add_f32(lv.grad + vz * lv.sZ + vy * lv.sY + vx * lv.sX + lane, mine);
-              }
-            }
-          }
-        }
-      }
       constexpr int LPR = 2 * C, SLOTS = 64 / LPR;
       const int slot = lane / LPR, dx = (lane / C) & 1, ch = lane % C;
 #pragma unroll 1
-      for (int pg = 0; pg < ((scatter_mask & ~dense_done) ? 64 / SLOTS : 0); ++pg) {
+      for (int pg = 0; pg < (scatter_mask ? 64 / SLOTS : 0); ++pg) {
         const int pt = pg * SLOTS + slot;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
           const LevelK& lv = g.lv[l];
-          if (!lv.grad || ((g.ignore_mask >> l) & 1u) || ((defer_mask >> l) & 1u) || ((dense_done >> l) & 1u)) continue;
+          if (!lv.grad || ((g.ignore_mask >> l) & 1u) || ((defer_mask >> l) & 1u)) continue;
           const int* r = rec + (pt * L + l) * REC;
           const int4 r0 = *reinterpret_cast<const int4*>(r);
           const int4 r1 = *reinterpret_cast<const int4*>(r + 4);
@@ -783,7 +695,7 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   PackLayout pl(C * L, H, NH);
   constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4, WAVE_LDS = 64 * FP + 64 * L * 8;
   bool lean = want_grid && !gx && dfeat_out != nullptr;      // every gradient level deferred to the pull?
-  for (int l = 0; l < L && lean; ++l)        // (bits 16.. of defer_mask name densely scattered levels: not deferred)
+  for (int l = 0; l < L && lean; ++l)
     if (g.lv[l].grad && !((g.ignore_mask >> l) & 1u) && !((defer_mask >> l) & 1u)) lean = false;
   static const bool no_lean = getenv("MISO_BWD_NO_LEAN") != nullptr;      // dev
   if (no_lean) lean = false;
@@ -800,10 +712,8 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   if (lean) debug |= 32;
   void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*, const int*, int,
             float*, uint32_t) =
-      (want_grid && gx) ? ((defer_mask >> 16) ? sdf_bwd_kernel<C, L, H, NH, true, true, true>
-                                              : sdf_bwd_kernel<C, L, H, NH, true, true>)
-      : want_grid       ? ((defer_mask >> 16) ? sdf_bwd_kernel<C, L, H, NH, true, false, true>
-                                              : sdf_bwd_kernel<C, L, H, NH, true, false>)
+      (want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true>
+      : want_grid       ? sdf_bwd_kernel<C, L, H, NH, true, false>
                         : sdf_bwd_kernel<C, L, H, NH, false, true>;
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;

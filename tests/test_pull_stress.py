@@ -159,17 +159,17 @@ def test_heavy_tiles_are_cut_and_summed_exactly(shape, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [0, 1, 2])
-def test_dense_wave_scatter_matches_pull_and_atomics(seed, monkeypatch):
-    """the dense wave scatter of coarse levels (forced on with MISO_DENSE_MIN=1 before the library
-    reads the knob is not possible in-process, so the crowd is real): a batch that averages >= 100 points per tile
-    on a two-level ScanNet-like grid takes the dense path for the coarse level; its gradients equal the unsorted
-    atomic path's to fp32 summation-order tolerance."""
+@pytest.mark.parametrize("seed,C", [(0, 4), (1, 4), (2, 4), (3, 8)])
+def test_dense_wave_scatter_matches_pull_and_atomics(seed, C, monkeypatch):
+    """the matrix-core push of coarse levels under a crowd (the knob MISO_DENSE_MIN is read once by the
+    library, so the crowd is real): a batch that averages >= 100 points per tile on a two-level ScanNet-like grid
+    pushes both levels; the gradients equal the unsorted atomic path's to fp32 summation-order tolerance."""
     from miso_amd import ops
     torch.manual_seed(seed)
     dev = "cuda:0"
-    C, H = 4, 64
-    sizes = [(8, 5, 8), (40, 25, 40)]                     # (X, Y, Z): coarse bricks <= 3 per axis at 16^3 tiles
+    H = 64
+    # (X, Y, Z): coarse bricks <= 3 per axis at 16^3 tiles (<= 2 with 8 channels: the tiny-brick kernel's register budget)
+    sizes = [(8, 5, 8), (40, 25, 40)] if C == 4 else [(8, 5, 8), (32, 20, 27)]
     feats = [(torch.randn(1, C, z, y, x, device=dev) * 1e-2).contiguous(memory_format=torch.channels_last_3d)
              for (x, y, z) in sizes]
     meta = ops.GridMeta.from_bound([[-2.0, 2.0], [-1.0, 1.5], [-2.0, 2.0]])
@@ -182,8 +182,9 @@ def test_dense_wave_scatter_matches_pull_and_atomics(seed, monkeypatch):
     import ctypes
     from miso_amd import _lib
     grid = ops._fill_grid(feats, meta, grads=[torch.zeros_like(f) for f in feats])
-    assert _lib.load().miso_sdf_bwd_dense_levels(ctypes.byref(grid), 16, n) == 0b11      # both levels walk densely
-    assert _lib.load().miso_sdf_bwd_dense_levels(ctypes.byref(grid), 16, 64 * 4096) == 0  # a thin batch: the pull
+    # both levels (regions of <= 5 vertices per axis and tile) go through the matrix-core push
+    assert _lib.load().miso_sdf_bwd_push_levels(ctypes.byref(grid), 16, n) == 0b11
+    assert _lib.load().miso_sdf_bwd_push_levels(ctypes.byref(grid), 16, 64 * 4096) == 0
     sdf, mask = ops.sdf_fwd_raw(x, feats, meta, pack, True)
     want = [torch.zeros_like(f) for f in feats]
     ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask, False, [True, True], want)
@@ -194,3 +195,45 @@ def test_dense_wave_scatter_matches_pull_and_atomics(seed, monkeypatch):
     for a, b in zip(got, want):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-12      # thousands of fp32 terms per coarse vertex, in two orders
+
+
+@pytest.mark.gpu
+def test_captured_step_replayed_back_to_back_between_eager_launches():
+    """The captured mapping step replayed 60 times with no host sync and eager launches in between (set_batch's copies,
+    the loss sum, Adam), the way GridTrainer drives it.  Regression: the zero-fill of the atomically scattered levels
+    was a hipMemsetAsync node, which under exactly this pattern filled with garbage now and then on ROCm 7.2 -- the
+    gradients gained non-zeros all over the level and Adam's active-chunk flags went to 100 %.  It is a kernel now."""
+    from miso_amd import ops
+    from miso_amd.step import MappingStep
+    torch.manual_seed(0)
+    dev, C, H, n = "cuda:0", 4, 64, 540000
+    sizes = [(40, 20, 40), (200, 100, 200)]                                  # ScanNet (cfg-3): push + atomics
+    meta = ops.GridMeta.from_bound([[-10., 10.], [-5., 5.], [-10., 10.]])
+    lin = [torch.nn.Linear(2 * C, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.data.to(dev) for l in lin], [l.bias.data.to(dev) for l in lin])
+    x = (torch.rand(n, 3, device=dev) * 2 - 1) * torch.tensor([6.0, 2.5, 6.0], device=dev)
+    tgt = torch.rand(n, 1, device=dev) * 0.2 - 0.1
+    one, zero = torch.ones(n, 1, device=dev), torch.zeros(n, 1, device=dev)
+    feats = [(torch.randn(1, C, z, y, xx, device=dev) * 1e-2).contiguous(memory_format=torch.channels_last_3d)
+             for (xx, y, z) in sizes]
+    st = MappingStep(feats, meta, pack, n, "L1", 1.0, 0.1, 0.15, use_graph=True, sort=True, keep_sdf=False)
+    st.set_batch(x, tgt, one, zero, one)
+    for _ in range(3):
+        st.run()
+    torch.cuda.synchronize()
+    support = [(g != 0) for g in st.grads]
+    m, v = [torch.zeros_like(f) for f in feats], [torch.zeros_like(f) for f in feats]
+    act = [ops.adam_active_flags(f) for f in feats]
+    for it in range(60):
+        xw = x * 1.0
+        st.set_batch(xw, tgt, one, zero, one)
+        del xw
+        st.run()
+        tot = st.loss.sum()
+        for f, g, mm, vv, a in zip(feats, st.grads, m, v, act):
+            ops.adam_active_(f, g, mm, vv, a, it + 1, 1e-3, 0.9, 0.999, 1e-8, zero_grad=False, guard=tot.reshape(1))
+    torch.cuda.synchronize()
+    for g, s, a in zip(st.grads, support, act):
+        assert torch.isfinite(g).all()
+        assert not (g != 0)[~s].any()                   # nothing outside the vertices the batch can touch
+        assert float(a.float().mean()) < 0.5            # and Adam still skips the empty part of the bound

@@ -48,11 +48,25 @@ for captured in (True, False):
     tr = GridTrainer(tcfg, net, lossf, None, None, dev, torch.float32)
     for _ in range(5):
         tr.train_step(*batch)
+        if os.environ.get("SHOW_ACTIVE"):
+            torch.cuda.synchronize()
+            print("   step", _, [(float((p_.grad != 0).float().mean()), int(torch.isnan(p_.grad).sum()), float(p_.grad.abs().max()))
+                                 for p_ in tr.optimizer.state if p_.grad is not None and p_.dim() == 5])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     iters = 50
     for _ in range(iters):
         tr.train_step(*batch)
+        if os.environ.get("SHOW_ACTIVE") == "2" and _ % 5 == 0:
+            torch.cuda.synchronize()
+            print("   step", _, [(float((p_.grad != 0).float().mean()), int(torch.isnan(p_.grad).sum()), float(p_.grad.abs().max()))
+                                 for p_ in tr.optimizer.state if p_.grad is not None and p_.dim() == 5])
     torch.cuda.synchronize()
+    if os.environ.get("SHOW_ACTIVE"):
+        for prm, st in tr.optimizer.state.items():
+            if "active" in st:
+                print("  param", tuple(prm.shape), "active chunks", float(st["active"].float().mean()),
+                      "nonzero exp_avg", float((st["exp_avg"] != 0).float().mean()),
+                      "nonzero grad", float((prm.grad != 0).float().mean()) if prm.grad is not None else None)
     print(f"train_step N={n} captured={captured}: {(time.perf_counter() - t0) / iters * 1e6:.0f} us per step "
           f"({n / ((time.perf_counter() - t0) / iters) / 1e6:.0f} Mpts/s incl. Adam over all levels)")
