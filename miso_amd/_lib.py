@@ -36,7 +36,8 @@ E_TOOLARGE = 2003
 class Level(C.Structure):
     _fields_ = [("data", C.c_void_p), ("grad", C.c_void_p),
                 ("C", C.c_int32), ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
-                ("sC", C.c_int64), ("sZ", C.c_int64), ("sY", C.c_int64), ("sX", C.c_int64)]
+                ("sC", C.c_int64), ("sZ", C.c_int64), ("sY", C.c_int64), ("sX", C.c_int64),
+                ("grad_touched", C.c_void_p)]
 
 
 class Grid(C.Structure):
@@ -130,6 +131,9 @@ SIGNATURES = {
     "miso_encode_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p]),
     "miso_grad_pull_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32]),
+    "miso_adam_touched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int, C.c_void_p,
+                                    C.c_void_p]),
     "miso_sdf_bwd_push_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32, C.c_int64]),
     "miso_sdf_bwd_workspace_floats": (C.c_int64, [C.POINTER(Grid), C.c_int64]),
     "miso_sdf_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted),

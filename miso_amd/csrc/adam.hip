@@ -116,6 +116,107 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
   }
 }
 
+// The same step driven by flags instead of by reading the gradient (miso_adam_touched): the scatter kernels set
+// touched[c] when they put a non-zero into chunk c (common.hpp:touch_chunk), so a chunk is stepped iff
+// active[c] | touched[c].  One wavefront looks at ADAM_FPW chunks' flag bytes at a time (lane = chunk), then walks
+// the set bits of the ballot, all lanes on one chunk and ADAM_UN chunks in flight as above.  A 144 M-float level (Newer College, fine)
+// whose batch wrote a few thousand chunks costs its 1.1 MB of flags instead of a 576 MB gradient scan (150 us).
+// flag bytes a wavefront looks at per round: few enough that a level whose chunks are all moving (the coarse ones) still
+// spreads over the chip -- with 64, the 4 500 chunks of a 1.1 M-float level were 18 workgroups walking 64 chunks each
+constexpr int ADAM_FPW = 16;
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_touched_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          unsigned char* __restrict__ active,
+                                                          unsigned char* __restrict__ touched, int64_t n,
+                                                          AdamScalars a, const float* __restrict__ guard) {
+  const int lane = threadIdx.x & 63;
+  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK, nfull = n / ADAM_CHUNK;
+  for (int64_t c0 = wave * ADAM_FPW; c0 < nchunks; c0 += nwaves * ADAM_FPW) {
+    const int64_t mine = c0 + lane;
+    unsigned char act = 0, tch = 0;
+    if (lane < ADAM_FPW && mine < nchunks) { act = active[mine]; tch = touched[mine]; }
+    if (tch) {
+      touched[mine] = 0;
+      if (!act && !skip) active[mine] = 1;
+    }
+    unsigned long long todo = __ballot((act | tch) != 0);
+    const unsigned long long was_touched = __ballot(tch != 0);
+    // the common case first, branch-free: ADAM_UN whole chunks in flight (all loads issued before the first use)
+    while (!skip && __popcll(todo) >= ADAM_UN && c0 + 63 - __builtin_clzll(todo) < nfull) {
+      int64_t ii[ADAM_UN];
+      bool tt[ADAM_UN];
+      float4 gg[ADAM_UN], pp[ADAM_UN], mm[ADAM_UN], vv[ADAM_UN];
+#pragma unroll
+      for (int u = 0; u < ADAM_UN; ++u) {
+        const int b = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        tt[u] = (was_touched >> b) & 1ull;
+        ii[u] = (c0 + b) * ADAM_CHUNK + lane * 4;
+        gg[u] = *reinterpret_cast<const float4*>(g + ii[u]);
+        pp[u] = *reinterpret_cast<float4*>(p + ii[u]); mm[u] = *reinterpret_cast<float4*>(m + ii[u]);
+        vv[u] = *reinterpret_cast<float4*>(v + ii[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < ADAM_UN; ++u) {
+        adam_one(pp[u].x, gg[u].x, mm[u].x, vv[u].x, a); adam_one(pp[u].y, gg[u].y, mm[u].y, vv[u].y, a);
+        adam_one(pp[u].z, gg[u].z, mm[u].z, vv[u].z, a); adam_one(pp[u].w, gg[u].w, mm[u].w, vv[u].w, a);
+        *reinterpret_cast<float4*>(p + ii[u]) = pp[u];
+        *reinterpret_cast<float4*>(m + ii[u]) = mm[u];
+        *reinterpret_cast<float4*>(v + ii[u]) = vv[u];
+        if (ZERO && tt[u]) *reinterpret_cast<float4*>(g + ii[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    while (todo) {
+      // up to ADAM_UN chunks in flight, as in adam_active_kernel
+      int64_t cc[ADAM_UN];
+      bool tt[ADAM_UN], full[ADAM_UN];
+      float4 gg[ADAM_UN], pp[ADAM_UN], mm[ADAM_UN], vv[ADAM_UN];
+#pragma unroll
+      for (int u = 0; u < ADAM_UN; ++u) {
+        cc[u] = -1; tt[u] = false; full[u] = false;
+        if (todo) {
+          const int b = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          cc[u] = c0 + b;
+          tt[u] = (was_touched >> b) & 1ull;
+          full[u] = cc[u] < nfull;
+        }
+        if (full[u] && !skip) {
+          const int64_t i = cc[u] * ADAM_CHUNK + lane * 4;
+          gg[u] = *reinterpret_cast<const float4*>(g + i);
+          pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
+          vv[u] = *reinterpret_cast<float4*>(v + i);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < ADAM_UN; ++u) {
+        if (cc[u] < 0) continue;                       // wave-uniform
+        if (full[u]) {
+          const int64_t i = cc[u] * ADAM_CHUNK + lane * 4;
+          if (!skip) {
+            adam_one(pp[u].x, gg[u].x, mm[u].x, vv[u].x, a); adam_one(pp[u].y, gg[u].y, mm[u].y, vv[u].y, a);
+            adam_one(pp[u].z, gg[u].z, mm[u].z, vv[u].z, a); adam_one(pp[u].w, gg[u].w, mm[u].w, vv[u].w, a);
+            *reinterpret_cast<float4*>(p + i) = pp[u];
+            *reinterpret_cast<float4*>(m + i) = mm[u];
+            *reinterpret_cast<float4*>(v + i) = vv[u];
+          }
+          if (ZERO && tt[u]) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {   // the ragged last chunk, element-wise
+          for (int64_t i = cc[u] * ADAM_CHUNK + lane; i < n; i += 64) {
+            if (!skip) adam_one(p[i], g[i], m[i], v[i], a);
+            if (ZERO) g[i] = 0.0f;
+          }
+        }
+      }
+    }
+  }
+}
+
 static AdamScalars adam_scalars(double lr, double b1, double b2, double eps, int step) {
   const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   AdamScalars a;
@@ -138,6 +239,19 @@ hipError_t launch_adam_active(float* p, float* g, float* m, float* v, unsigned c
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (zero_grad) adam_active_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard);
   else adam_active_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard);
+  return hipGetLastError();
+}
+
+hipError_t launch_adam_touched(float* p, float* g, float* m, float* v, unsigned char* active, unsigned char* touched,
+                               int64_t n, double lr, double b1, double b2, double eps, int step, int zero_grad,
+                               const float* guard, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const AdamScalars a = adam_scalars(lr, b1, b2, eps, step);
+  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
+  int64_t blocks = (nchunks + 4 * ADAM_FPW - 1) / (4 * ADAM_FPW);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (zero_grad) adam_touched_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, touched, n, a, guard);
+  else adam_touched_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, touched, n, a, guard);
   return hipGetLastError();
 }
 

@@ -25,6 +25,8 @@ hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, 
 hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, const float*, int64_t, int64_t, int,
                               float*, hipStream_t);
 hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
+hipError_t launch_adam_touched(float*, float*, float*, float*, unsigned char*, unsigned char*, int64_t, double, double,
+                               double, double, int, int, const float*, hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
                             uint32_t, int, const float*, int32_t*, int64_t, hipStream_t, uint32_t push_mask, int64_t n);
@@ -91,6 +93,7 @@ int convert_grid(const miso_grid_t* in, GridK* out, bool need_data, bool* vec4) 
     if (span >= ((int64_t)1 << 31)) return MISO_E_TOOLARGE;
     LevelK& d = out->lv[l];
     d.data = s.data; d.grad = s.grad; d.gg = nullptr;
+    d.touched = s.grad ? s.grad_touched : nullptr;
     d.C = s.C; d.X = s.X; d.Y = s.Y; d.Z = s.Z;
     d.sC = (int32_t)s.sC; d.sX = (int32_t)s.sX; d.sY = (int32_t)s.sY; d.sZ = (int32_t)s.sZ;
     d.foff = foff;
@@ -668,6 +671,17 @@ int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_s
     return MISO_E_BADARG;
   return (int)launch_adam_active(param, grad, exp_avg, exp_avg_sq, active, numel, lr, beta1, beta2, eps, step,
                                  zero_grad, guard, (hipStream_t)stream);
+}
+
+int miso_adam_touched(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active, uint8_t* touched,
+                      int64_t numel, double lr, double beta1, double beta2, double eps, int32_t step, int zero_grad,
+                      const float* guard, void* stream) {
+  if (numel < 0 || step < 1 || (numel > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !active || !touched)))
+    return MISO_E_BADARG;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15u)
+    return MISO_E_BADARG;
+  return (int)launch_adam_touched(param, grad, exp_avg, exp_avg_sq, active, touched, numel, lr, beta1, beta2, eps,
+                                  step, zero_grad, guard, (hipStream_t)stream);
 }
 
 int miso_rigid_by_index(const float* R, const float* t, const int64_t* idx, const float* x, int64_t n, int32_t n_poses,

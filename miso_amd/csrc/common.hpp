@@ -12,6 +12,7 @@ struct LevelK {
   const float* data;
   float* grad;
   const float* gg;  // cotangent-of-grad grid (second order), or nullptr
+  unsigned char* touched;  // miso_level_t.grad_touched: one byte per 256 floats of `grad`, or nullptr
   int32_t C, Z, Y, X;
   int32_t sC, sZ, sY, sX;  // element strides, validated < 2^31 on the host
   int32_t foff;            // first output column of this level
@@ -118,6 +119,12 @@ __device__ __forceinline__ Cell make_cell(const Axis& ax, const Axis& ay, const 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   // hardware fp32 add at L2 (global_atomic_add_f32, no return value)
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// miso_level_t.grad_touched: a non-zero went into grad[off] (element offset from lv.grad)
+static_assert(MISO_ADAM_CHUNK == 256, "touch_chunk shifts by 8");
+__device__ __forceinline__ void touch_chunk(const LevelK& lv, int64_t off) {
+  if (lv.touched) lv.touched[off >> 8] = 1;
 }
 
 // One (src, dst) pair of a fused alignment iteration, as the batched kernels of pair_latent.hip read it from the

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(GridK g, const float* _
             float* t = lv.grad + off[k] + ch;
             atomic_add_f32(t + 0, gv.x * w[k]); atomic_add_f32(t + 1, gv.y * w[k]);
             atomic_add_f32(t + 2, gv.z * w[k]); atomic_add_f32(t + 3, gv.w * w[k]);
+            touch_chunk(lv, off[k] + ch);
           }
         }
       }
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(GridK g, const float* _
         if (lv.grad) {
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            if (inb[k]) atomic_add_f32(lv.grad + cb + off[k], gv * w[k]);
+            if (inb[k]) { atomic_add_f32(lv.grad + cb + off[k], gv * w[k]); touch_chunk(lv, cb + off[k]); }
         }
       }
     }
@@ -235,7 +236,10 @@ __global__ __launch_bounds__(256) void encode_bwd2_kernel(GridK g, const float* 
             ax_ += gv[e] * (g2[e] * dwx[k] + val[e] * cx[k]);
             ay_ += gv[e] * (g2[e] * dwy[k] + val[e] * cy[k]);
             az_ += gv[e] * (g2[e] * dwz[k] + val[e] * cz[k]);
-            if (lv.grad && inb[k] && ggx) atomic_add_f32(lv.grad + off[k] + ch + e, gwd[k] * gv[e]);
+            if (lv.grad && inb[k] && ggx) {
+              atomic_add_f32(lv.grad + off[k] + ch + e, gwd[k] * gv[e]);
+              if (e == 0) touch_chunk(lv, off[k] + ch);
+            }
           }
         }
 #pragma unroll
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void encode_bwd2_kernel(GridK g, const float* 
           ax_ += gv * (g2 * dwx[k] + val * cx[k]);
           ay_ += gv * (g2 * dwy[k] + val * cy[k]);
           az_ += gv * (g2 * dwz[k] + val * cz[k]);
-          if (lv.grad && inb[k] && ggx) atomic_add_f32(lv.grad + cb + off[k], gwd[k] * gv);
+          if (lv.grad && inb[k] && ggx) { atomic_add_f32(lv.grad + cb + off[k], gwd[k] * gv); touch_chunk(lv, cb + off[k]); }
         }
         ggout[lv.foff + ch] = ggv;
       }

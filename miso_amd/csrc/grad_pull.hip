@@ -340,6 +340,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
 #pragma unroll
       for (int c = 0; c < C; c += 4) {
         float4 v = make_float4(acc[r][c], acc[r][c + 1], acc[r][c + 2], acc[r][c + 3]);
+        if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) touch_chunk(lv, (int64_t)(dst + c - lv.grad));
         if (add_eff == 2) {   // a queued slice: other wavefronts add to the same brick
           if (v.x != 0.0f) atomic_add_f32(dst + c, v.x);
           if (v.y != 0.0f) atomic_add_f32(dst + c + 1, v.y);
@@ -920,8 +921,11 @@ __global__ __launch_bounds__(64 * PUSH_WAVES) void grad_push_mfma_kernel(GridK g
         const int row = 8 * (r >> 2) + 4 * half + (r & 3);
         const int vx = r0[0] + row % 5, vy = r0[1] + row / 5;
         const float v = acc[nb][r];
-        if (col_ok && row < 25 && v != 0.0f && vx >= 0 && vx < lv.X && vy >= 0 && vy < lv.Y && !(pk.debug & 64))
-          atomic_add_f32(colp + (int64_t)vy * lv.sY + (int64_t)vx * lv.sX, v);
+        if (col_ok && row < 25 && v != 0.0f && vx >= 0 && vx < lv.X && vy >= 0 && vy < lv.Y && !(pk.debug & 64)) {
+          float* dst = colp + (int64_t)vy * lv.sY + (int64_t)vx * lv.sX;
+          atomic_add_f32(dst, v);
+          touch_chunk(lv, (int64_t)(dst - lv.grad));
+        }
         acc[nb][r] = 0.0f;
       }
     }

@@ -593,8 +593,10 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int dy = q & 1, dz = q >> 1;
-            if (((fl >> (2 + dy)) & 1) && ((fl >> (4 + dz)) & 1) && !(debug & 1))
+            if (((fl >> (2 + dy)) & 1) && ((fl >> (4 + dz)) & 1) && !(debug & 1)) {
               atomic_add_f32(base + dy * lv.sY + dz * lv.sZ, v * ((wx * wy[dy]) * wz[dz]));
+              if (ch == 0) touch_chunk(lv, r0.x + dx * lv.sX + dy * lv.sY + dz * lv.sZ);   // C floats: one chunk
+            }
           }
         }
       }

@@ -183,7 +183,9 @@ class Trainer(object):
         clear = step.sorted is None
         # NaN guard (reference :213-219) on the device: the optimizer's kernels leave everything alone if the
         # loss is NaN and the host hears about it one step later -- no read-back between backward and step
-        self.optimizer.step(clear_grads=clear, guard=total)
+        # the step's scatter kernels flagged the 256-float chunks they wrote: Adam reads the flags, not the gradient
+        self.optimizer.step(clear_grads=clear, guard=total,
+                            touched={id(f): t for f, t, nd in zip(feats, step.touched, need) if nd})
         return total
 
     def train_step(self, model_input, gt):

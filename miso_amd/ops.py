@@ -67,7 +67,9 @@ def _ptr(t: Optional[torch.Tensor]):
 
 def _fill_grid(features: Sequence[torch.Tensor], meta: GridMeta,
                grads: Optional[Sequence[Optional[torch.Tensor]]] = None,
-               data: bool = True) -> _lib.Grid:
+               data: bool = True, touched: Optional[Sequence[Optional[torch.Tensor]]] = None) -> _lib.Grid:
+    """touched: per level, the uint8 flags of adam_active_flags() that the scatter kernels set where they put a
+    non-zero into ``grads[l]`` (miso_level_t.grad_touched) -- the gradient must then be a dense storage."""
     if not 1 <= len(features) <= _lib.MAX_LEVELS:
         raise ValueError(f"1..{_lib.MAX_LEVELS} levels supported, got {len(features)}")
     g = _lib.Grid()
@@ -85,8 +87,17 @@ def _fill_grid(features: Sequence[torch.Tensor], meta: GridMeta,
         if gr is not None:
             assert gr.shape == f.shape and gr.stride() == f.stride(), "grad must share the feature layout"
             lv.grad = gr.data_ptr()
+            tc = None if touched is None else touched[l]
+            if tc is not None:
+                assert tc.dtype == torch.uint8 and tc.numel() * _lib.ADAM_CHUNK >= gr.numel() and tc.is_contiguous()
+                assert gr.is_contiguous() or gr.is_contiguous(memory_format=torch.channels_last_3d), \
+                    "touched flags index the gradient's dense storage"
+                lv.grad_touched = tc.data_ptr()
+            else:
+                lv.grad_touched = 0
         else:
             lv.grad = 0
+            lv.grad_touched = 0
         lv.C, lv.Z, lv.Y, lv.X = f.shape[1], f.shape[2], f.shape[3], f.shape[4]
         lv.sC, lv.sZ, lv.sY, lv.sX = f.stride(1), f.stride(2), f.stride(3), f.stride(4)
     return g
@@ -465,10 +476,11 @@ def sdf_fwd_raw(x, features, meta, pack: DecoderPack, want_mask: bool, out=None,
 
 
 def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f, grads=None,
-                sorted_batch: Optional[SortedBatch] = None, overwrite: bool = False, gsdf_sorted: bool = False):
+                sorted_batch: Optional[SortedBatch] = None, overwrite: bool = False, gsdf_sorted: bool = False,
+                touched: Optional[Sequence[Optional[torch.Tensor]]] = None):
     """overwrite (binned path only): the gradients are written, not accumulated -- ``grads``
     need no zero-fill (MISO_F_GRAD_OVERWRITE).  gsdf_sorted (binned path only): ``gsdf`` is in
-    the binned order (sdf_fwd_loss_raw), not the caller's."""
+    the binned order (sdf_fwd_loss_raw), not the caller's.  touched: see _fill_grid / adam_active_."""
     _require_hip(x, gsdf, *features)
     m, packed = pack.get()
     x = x.contiguous()
@@ -479,7 +491,7 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
         alloc = torch.empty_like if overwrite else torch.zeros_like
         grads = [alloc(f) if nf else None for f, nf in zip(features, need_f)]
     gx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
-    g = _fill_grid(features, meta, grads)
+    g = _fill_grid(features, meta, grads, touched=touched)
     if overwrite:
         g.flags |= _lib.F_GRAD_OVERWRITE
     if gsdf_sorted:
@@ -612,14 +624,24 @@ def adam_active_flags(param) -> torch.Tensor:
 
 
 def adam_active_(param, grad, exp_avg, exp_avg_sq, active, step: int, lr: float, beta1: float = 0.9,
-                 beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = False, guard: Optional[torch.Tensor] = None):
+                 beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = False, guard: Optional[torch.Tensor] = None,
+                 touched: Optional[torch.Tensor] = None):
     """adam_dense_ that skips the chunks that cannot move (miso_adam_active): bit-identical results, 4 B per
     element + 28 B per element of the chunks a gradient has ever reached.  guard: device scalar (the step's loss);
-    if it is NaN the launch leaves parameters, moments and flags alone (the reference's NaN guard on the device)."""
+    if it is NaN the launch leaves parameters, moments and flags alone (the reference's NaN guard on the device).
+    touched: the flags the scatter kernels left for this gradient (sdf_bwd_raw(touched=...)): the launch then reads
+    them instead of the gradient (miso_adam_touched) and clears them -- only valid when nothing but those kernels
+    wrote the gradient since the last step."""
     _require_hip(param, grad, exp_avg, exp_avg_sq, guard)
     for t in (grad, exp_avg, exp_avg_sq):
         assert t.shape == param.shape and t.stride() == param.stride(), "Adam state must share the param layout"
     assert active.dtype == torch.uint8 and active.numel() * _lib.ADAM_CHUNK >= param.numel()
+    if touched is not None:
+        assert touched.dtype == torch.uint8 and touched.numel() == active.numel() and touched.is_contiguous()
+        _lib.check(_lib.load().miso_adam_touched(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(active),
+                                                 _ptr(touched), param.numel(), lr, beta1, beta2, eps, step,
+                                                 int(zero_grad), _ptr(guard), _stream(param)), "miso_adam_touched")
+        return
     _lib.check(_lib.load().miso_adam_active(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(active),
                                             param.numel(), lr, beta1, beta2, eps, step, int(zero_grad),
                                             _ptr(guard), _stream(param)), "miso_adam_active")

@@ -70,10 +70,13 @@ class DenseAdam(torch.optim.Optimizer):
             st.pop('active', None)
 
     @torch.no_grad()
-    def step(self, closure=None, clear_grads=False, guard=None):
+    def step(self, closure=None, clear_grads=False, guard=None, touched=None):
         """clear_grads: leave every .grad zeroed (in the same pass for the big tensors), for callers that
         accumulate into persistent gradient buffers and would otherwise memset them before the next backward.
-        guard: device scalar; NaN => nothing is updated (see the module docstring)."""
+        guard: device scalar; NaN => nothing is updated (see the module docstring).
+        touched: {id(param): uint8 flags} left by the scatter kernels for that parameter's .grad
+        (MappingStep.touched): the step finds the chunks to move from the flags instead of reading the gradient.
+        Only for gradients written by nothing but those kernels since the last step."""
         self.resolve_guard()
         if guard is not None and not guard.is_cuda:
             if bool(torch.isnan(guard)):                  # host tensors: the plain check
@@ -114,7 +117,8 @@ class DenseAdam(torch.optim.Optimizer):
                         if t > 1:
                             st['active'].fill_(1)
                     ops.adam_active_(p, g, m, v, st['active'], t, lr, b1, b2, eps, zero_grad=clear_grads,
-                                     guard=None if guard is None else guard.detach().reshape(1))
+                                     guard=None if guard is None else guard.detach().reshape(1),
+                                     touched=None if touched is None else touched.get(id(p)))
                     # the kernel wrote through raw pointers: tell autograd / version-keyed caches (DecoderPack)
                     torch.autograd.graph.increment_version(p)
                     continue

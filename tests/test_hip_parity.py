@@ -952,3 +952,61 @@ def test_align_plan_rejects_bad_arguments():
     assert lib.miso_align_plan_build(None, C.byref(cfg), None) == _lib.E_BADARG
     assert lib.miso_align_state_layout(65, 1, 0, 0, None) == 0
     assert lib.miso_align_plan_bytes(-1) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["unsorted", "sorted_thin", "sorted_crowd"])
+def test_adam_touched_flags_equal_gradient_scan(path):
+    """miso_adam_touched (Adam driven by the flags the scatter kernels leave in miso_level_t.grad_touched) against
+    miso_adam_active (Adam that reads the gradient to find what moved): parameters, both moments, the active flags and
+    the cleared gradients bit for bit over four steps with different batches, one of them with a NaN loss guard; the
+    flags are all cleared afterwards.  unsorted: float atomics from the decoder backward, gradients cleared by Adam.
+    sorted_thin: owner-computes pull (overwrite).  sorted_crowd: matrix-core push + atomics of a fine level."""
+    from miso_amd import ops
+    torch.manual_seed(3)
+    C, H = 4, 64
+    sizes = [(40, 25, 40), (130, 70, 130)]
+    meta = ops.GridMeta.from_bound([[-2.0, 2.0], [-1.0, 1.5], [-2.0, 2.0]])
+    lin = [torch.nn.Linear(2 * C, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.data.to(DEV) for l in lin], [l.bias.data.to(DEV) for l in lin])
+    n = {"unsorted": 3000, "sorted_thin": 70000, "sorted_crowd": 100 * 4096 + 5}[path]
+    f0 = [(torch.randn(1, C, z, y, x, device=DEV) * 1e-2).contiguous(memory_format=torch.channels_last_3d)
+          for (x, y, z) in sizes]
+    # two Adam states fed the SAME gradients (float atomics do not sum in a reproducible order): A scans them,
+    # B reads the flags
+    featsA, featsB = [f.clone() for f in f0], [f.clone() for f in f0]
+    mA, vA = [torch.zeros_like(f) for f in f0], [torch.zeros_like(f) for f in f0]
+    mB, vB = [torch.zeros_like(f) for f in f0], [torch.zeros_like(f) for f in f0]
+    actA, actB = [ops.adam_active_flags(f) for f in f0], [ops.adam_active_flags(f) for f in f0]
+    tch = [ops.adam_active_flags(f) for f in f0]
+    grads = [torch.zeros_like(f) for f in f0]
+    gen = torch.Generator().manual_seed(11)
+    zero = path == "unsorted"
+    for t in range(4):
+        # batches wander: chunks wake up at different steps
+        ctr = torch.tensor([-1.0 + 0.5 * t, 0.1 * t, 0.3 * t - 0.5])
+        x = ((torch.rand(n, 3, generator=gen) - 0.5) * torch.tensor([1.2, 0.8, 1.0]) + ctr).to(DEV)
+        gs = (torch.randn(n, 1, generator=gen) / n).to(DEV)
+        guard = torch.tensor([float("nan") if t == 2 else 1.0], device=DEV)
+        if path == "unsorted":
+            _, mask = ops.sdf_fwd_raw(x, featsB, meta, pack, True)
+            ops.sdf_bwd_raw(x, featsB, meta, pack, gs, mask, False, [True, True], grads, touched=tch)
+        else:
+            sb = ops.SortedBatch(n, DEV).sort(x, meta)
+            _, mask = ops.sdf_fwd_raw(x, featsB, meta, pack, True, sorted_batch=sb)
+            ops.sdf_bwd_raw(x, featsB, meta, pack, gs, mask, False, [True, True], grads, sorted_batch=sb,
+                            overwrite=True, touched=tch)
+        for g, tc in zip(grads, tch):            # every non-zero gradient lies in a flagged chunk
+            nz = (torch.as_strided(g, (g.numel(),), (1,)) != 0).nonzero().reshape(-1)      # storage order
+            assert bool(tc[nz // 256].all()) and int(tc.sum()) > 0
+        gA = [g.clone() for g in grads]
+        for i in range(2):
+            ops.adam_active_(featsA[i], gA[i], mA[i], vA[i], actA[i], t + 1, 1e-3, zero_grad=zero, guard=guard)
+            ops.adam_active_(featsB[i], grads[i], mB[i], vB[i], actB[i], t + 1, 1e-3, zero_grad=zero, guard=guard,
+                             touched=tch[i])
+        assert all(int(tc.sum()) == 0 for tc in tch)
+        for a, b in zip(featsA + mA + vA + actA + gA, featsB + mB + vB + actB + grads):
+            assert torch.equal(a, b)
+        if zero:
+            assert all(bool((g == 0).all()) for g in grads)
+    assert 0 < float(actB[-1].float().mean()) < 0.9      # some chunks never woke up
