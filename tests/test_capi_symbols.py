@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from miso_amd import _lib
     # sizes implied by the C declarations (LP64)
-    assert ctypes.sizeof(_lib.Level) == 8 + 8 + 4 * 4 + 8 * 4
+    assert ctypes.sizeof(_lib.Level) == 8 + 8 + 4 * 4 + 8 * 4 + 8      # ... + grad_touched
     assert ctypes.sizeof(_lib.Grid) == 4 + 4 + 12 + 12 + 4 + 4 + 8 * ctypes.sizeof(_lib.Level)
     assert ctypes.sizeof(_lib.Mlp) == 16 + 8 * 4 + 8 * 4
 
