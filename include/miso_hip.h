@@ -458,6 +458,22 @@ int miso_adam_touched(float* param, float* grad, float* exp_avg, float* exp_avg_
                       uint8_t* touched, int64_t numel, double lr, double beta1, double beta2, double eps,
                       int32_t step /* 1-based */, int zero_grad, const float* guard, void* stream);
 
+/* Adam inside a captured HIP graph.  The bias corrections change every step but the arguments of a captured launch do
+ * not, so a captured step reads them from the device: `table` (device, table_len rows of 6 floats) holds the step
+ * scalars of steps 1..table_len exactly as miso_adam_active computes them on the host -- filled by
+ * miso_adam_scalars_table (a HOST function writing a HOST buffer; upload it) -- and `step` (device int32) the 1-based
+ * count of the step being taken.  Steps past the table use its last row (choose table_len so that beta^table_len
+ * has left fp32: the rows no longer change).  miso_adam_bump, once per step and in front of the level launches:
+ * step += 1 unless *guard is NaN (the reference's NaN guard skips optimizer.step(), grid_opt/trainer.py:213-219, so
+ * the count must not move).  miso_adam_step_dev = miso_adam_active (touched == NULL) / miso_adam_touched with the
+ * scalars of table[*step - 1]: bit-identical to the launch-by-launch step. */
+int miso_adam_scalars_table(double lr, double beta1, double beta2, double eps, int32_t first_step, int32_t count,
+                            float* host_out /* count x 6 */);
+int miso_adam_bump(int32_t* step, const float* guard /* or NULL */, void* stream);
+int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
+                       uint8_t* touched /* or NULL */, int64_t numel, const float* table, int32_t table_len,
+                       const int32_t* step, int zero_grad, const float* guard, void* stream);
+
 /* --- per-keyframe rigid map of a sample batch ---------------------------------
  * y[i] = R[idx[i]] x[i] + t[idx[i]] (transpose = 0) or R[idx[i]]^T x[i] (+ t if given; transpose = 1: the cotangent
  * of x).  R (n_poses x 9, row-major 3x3), t (n_poses x 3) or NULL, idx (n) int64 clamped into [0, n_poses),
@@ -466,6 +482,20 @@ int miso_adam_touched(float* param, float* grad, float* exp_avg, float* exp_avg_
  * (grid_opt/utils/utils_geometry.py:214-225). */
 int miso_rigid_by_index(const float* R, const float* t, const int64_t* idx, const float* x, int64_t n,
                         int32_t n_poses, int transpose, float* y, void* stream);
+
+/* The input side of one mapping step in one launch (MisoLossMapping.world_coords, grid_opt/loss.py:763-774, plus
+ * the label layout of miso_sdf_fwd_sorted_loss / miso_mapping_loss_rows): k = table[clamp(frame_ids[i], 0,
+ * table_len - 1)] clamped into [0, n_poses), coords_world[i] = R[k] coords_frame[i] + t[k] (operation order of
+ * miso_rigid_by_index), loss_rows[i] = {target[i], valid[i], sign[i], weight[i]} (valid / sign / weight may be NULL:
+ * 1 / 0 / 1).  table: int64 keyframe-id -> pose-index (device).  loss_rows 16-B aligned. */
+int miso_mapping_batch(const float* R, const float* t, int32_t n_poses, const int64_t* table, int64_t table_len,
+                       const int64_t* frame_ids, const float* coords_frame, const float* target, const float* valid,
+                       const float* sign, const float* weight, int64_t n, float* coords_world, float* loss_rows,
+                       void* stream);
+
+/* miso_mapping_loss over interleaved label rows {target, valid, sign, weight} (N,4), 16-B aligned. */
+int miso_mapping_loss_rows(int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* pred,
+                           const float* loss_rows, int64_t n, float* grad_pred, float* loss_out, void* stream);
 
 /* --- marching cubes on the dense SDF volume ------------------------------------
  * Replaces mcubes.marching_cubes(u, threshold) as called by extract_geometry

@@ -131,6 +131,16 @@ SIGNATURES = {
     "miso_encode_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p]),
     "miso_grad_pull_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32]),
+    "miso_adam_scalars_table": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                          C.c_void_p]),
+    "miso_adam_bump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "miso_mapping_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "miso_mapping_loss_rows": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_adam_touched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int, C.c_void_p,
                                     C.c_void_p]),

@@ -4,10 +4,27 @@
 // batch did not touch, exactly like the reference.  HBM-bound: 16 B read +
 // 12 B written per element (+4 B when the gradient is cleared in the same pass).
 #include <math.h>
+#include <string.h>
 
 #include "common.hpp"
 
 namespace miso {
+
+// Step scalars from the device, for a step captured in a HIP graph (the bias corrections change every step, kernel
+// arguments of a captured launch do not): table[t - 1] = the AdamScalars of step t as the host computes them
+// (miso_adam_scalars_table: same code, so the captured step is bit-identical to the launch-by-launch one), step[0] =
+// the 1-based step count, advanced by adam_bump_kernel in front of the launches of a step.  table == nullptr: the
+// by-value scalars are used.
+struct AdamDevK {
+  const AdamScalars* table;
+  const int32_t* step;
+  int32_t table_len;
+};
+
+// step += 1 unless the step's loss is NaN (the reference skips optimizer.step() then: its step count does not move)
+__global__ void adam_bump_kernel(int32_t* step, const float* __restrict__ guard) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(guard != nullptr && !(guard[0] == guard[0]))) step[0] += 1;
+}
 
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -48,7 +65,9 @@ template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p, float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v,
                                                          unsigned char* __restrict__ active, int64_t n,
-                                                         AdamScalars a, const float* __restrict__ guard) {
+                                                         AdamScalars a, const float* __restrict__ guard,
+                                                         AdamDevK dev) {
+  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];     // a captured step: see AdamDevK
   const int lane = threadIdx.x & 63;
   // guard (optional, device): the step's loss.  NaN => the reference skips backward and optimizer step
   // (grid_opt/trainer.py:213-219); here the launch leaves parameters, moments and flags alone (and still clears
@@ -130,7 +149,9 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(float* __restrict__ p
                                                           float* __restrict__ m, float* __restrict__ v,
                                                           unsigned char* __restrict__ active,
                                                           unsigned char* __restrict__ touched, int64_t n,
-                                                          AdamScalars a, const float* __restrict__ guard) {
+                                                          AdamScalars a, const float* __restrict__ guard,
+                                                          AdamDevK dev) {
+  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];
   const int lane = threadIdx.x & 63;
   const bool skip = guard != nullptr && !(guard[0] == guard[0]);
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -229,29 +250,45 @@ static AdamScalars adam_scalars(double lr, double b1, double b2, double eps, int
   return a;
 }
 
+hipError_t launch_adam_bump(int32_t* step, const float* guard, hipStream_t s) {
+  adam_bump_kernel<<<1, 64, 0, s>>>(step, guard);
+  return hipGetLastError();
+}
+
+void adam_scalars_table(double lr, double b1, double b2, double eps, int first_step, int count, float* out) {
+  static_assert(sizeof(AdamScalars) == 6 * sizeof(float), "table rows are 6 floats");
+  for (int i = 0; i < count; ++i) {
+    const AdamScalars a = adam_scalars(lr, b1, b2, eps, first_step + i);
+    memcpy(out + 6 * (size_t)i, &a, sizeof(a));
+  }
+}
+
 hipError_t launch_adam_active(float* p, float* g, float* m, float* v, unsigned char* active, int64_t n, double lr,
                               double b1, double b2, double eps, int step, int zero_grad, const float* guard,
-                              hipStream_t s) {
+                              hipStream_t s, const float* table, const int32_t* step_dev, int table_len) {
   if (n == 0) return hipSuccess;
   const AdamScalars a = adam_scalars(lr, b1, b2, eps, step);
+  const AdamDevK dev{reinterpret_cast<const AdamScalars*>(table), step_dev, table_len};
   const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
   int64_t blocks = (nchunks + 4 * ADAM_UN - 1) / (4 * ADAM_UN);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (zero_grad) adam_active_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard);
-  else adam_active_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard);
+  if (zero_grad) adam_active_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard, dev);
+  else adam_active_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard, dev);
   return hipGetLastError();
 }
 
 hipError_t launch_adam_touched(float* p, float* g, float* m, float* v, unsigned char* active, unsigned char* touched,
                                int64_t n, double lr, double b1, double b2, double eps, int step, int zero_grad,
-                               const float* guard, hipStream_t s) {
+                               const float* guard, hipStream_t s, const float* table, const int32_t* step_dev,
+                               int table_len) {
   if (n == 0) return hipSuccess;
   const AdamScalars a = adam_scalars(lr, b1, b2, eps, step);
+  const AdamDevK dev{reinterpret_cast<const AdamScalars*>(table), step_dev, table_len};
   const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
   int64_t blocks = (nchunks + 4 * ADAM_FPW - 1) / (4 * ADAM_FPW);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (zero_grad) adam_touched_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, touched, n, a, guard);
-  else adam_touched_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, touched, n, a, guard);
+  if (zero_grad) adam_touched_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, touched, n, a, guard, dev);
+  else adam_touched_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, touched, n, a, guard, dev);
   return hipGetLastError();
 }
 

@@ -26,7 +26,14 @@ hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, co
                               float*, hipStream_t);
 hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
 hipError_t launch_adam_touched(float*, float*, float*, float*, unsigned char*, unsigned char*, int64_t, double, double,
-                               double, double, int, int, const float*, hipStream_t);
+                               double, double, int, int, const float*, hipStream_t, const float*, const int32_t*, int);
+hipError_t launch_adam_bump(int32_t*, const float*, hipStream_t);
+void adam_scalars_table(double, double, double, double, int, int, float*);
+hipError_t launch_mapping_batch(const float*, const float*, int32_t, const int64_t*, int64_t, const int64_t*,
+                                const float*, const float*, const float*, const float*, const float*, int64_t, float*,
+                                float*, hipStream_t);
+hipError_t launch_mapping_loss_rows(int, float, float, float, const float*, const float*, int64_t, float*, float*,
+                                    hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
                             uint32_t, int, const float*, int32_t*, int64_t, hipStream_t, uint32_t push_mask, int64_t n);
@@ -53,7 +60,7 @@ int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
                        hipStream_t);
 hipError_t launch_adam_active(float*, float*, float*, float*, unsigned char*, int64_t, double, double, double, double, int,
-                              int, const float*, hipStream_t);
+                              int, const float*, hipStream_t, const float*, const int32_t*, int);
 hipError_t launch_mapping_loss(int, float, float, float, const float*, const float*, const float*,
                                const float*, const float*, int64_t, float*, float*, float*, hipStream_t);
 hipError_t launch_align_a(const AlignK&, int64_t, int64_t, int64_t, bool, hipStream_t);
@@ -670,7 +677,7 @@ int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_s
   if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15u)
     return MISO_E_BADARG;
   return (int)launch_adam_active(param, grad, exp_avg, exp_avg_sq, active, numel, lr, beta1, beta2, eps, step,
-                                 zero_grad, guard, (hipStream_t)stream);
+                                 zero_grad, guard, (hipStream_t)stream, nullptr, nullptr, 0);
 }
 
 int miso_adam_touched(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active, uint8_t* touched,
@@ -681,7 +688,54 @@ int miso_adam_touched(float* param, float* grad, float* exp_avg, float* exp_avg_
   if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15u)
     return MISO_E_BADARG;
   return (int)launch_adam_touched(param, grad, exp_avg, exp_avg_sq, active, touched, numel, lr, beta1, beta2, eps,
-                                  step, zero_grad, guard, (hipStream_t)stream);
+                                  step, zero_grad, guard, (hipStream_t)stream, nullptr, nullptr, 0);
+}
+
+int miso_adam_scalars_table(double lr, double beta1, double beta2, double eps, int32_t first_step, int32_t count,
+                            float* host_out) {
+  if (first_step < 1 || count < 0 || (count > 0 && !host_out)) return MISO_E_BADARG;
+  adam_scalars_table(lr, beta1, beta2, eps, first_step, count, host_out);
+  return MISO_OK;
+}
+
+int miso_adam_bump(int32_t* step, const float* guard, void* stream) {
+  if (!step) return MISO_E_BADARG;
+  return (int)launch_adam_bump(step, guard, (hipStream_t)stream);
+}
+
+int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active, uint8_t* touched,
+                       int64_t numel, const float* table, int32_t table_len, const int32_t* step, int zero_grad,
+                       const float* guard, void* stream) {
+  if (numel < 0 || table_len < 1 || !table || !step ||
+      (numel > 0 && (!param || !grad || !exp_avg || !exp_avg_sq || !active)))
+    return MISO_E_BADARG;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15u)
+    return MISO_E_BADARG;
+  if (touched)
+    return (int)launch_adam_touched(param, grad, exp_avg, exp_avg_sq, active, touched, numel, 1e-3, 0.9, 0.999, 1e-8, 1,
+                                    zero_grad, guard, (hipStream_t)stream, table, step, table_len);
+  return (int)launch_adam_active(param, grad, exp_avg, exp_avg_sq, active, numel, 1e-3, 0.9, 0.999, 1e-8, 1, zero_grad,
+                                 guard, (hipStream_t)stream, table, step, table_len);
+}
+
+int miso_mapping_batch(const float* R, const float* t, int32_t n_poses, const int64_t* table, int64_t table_len,
+                       const int64_t* frame_ids, const float* coords_frame, const float* target, const float* valid,
+                       const float* sign, const float* weight, int64_t n, float* coords_world, float* loss_rows,
+                       void* stream) {
+  if (n < 0 || n_poses < 1 || table_len < 1 || !R || !t || !table) return MISO_E_BADARG;
+  if (n > 0 && (!frame_ids || !coords_frame || !target || !coords_world || !loss_rows)) return MISO_E_BADARG;
+  if (((uintptr_t)loss_rows & 15u) != 0) return MISO_E_BADARG;
+  return (int)launch_mapping_batch(R, t, n_poses, table, table_len, frame_ids, coords_frame, target, valid, sign, weight,
+                                   n, coords_world, loss_rows, (hipStream_t)stream);
+}
+
+int miso_mapping_loss_rows(int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* pred,
+                           const float* loss_rows, int64_t n, float* grad_pred, float* loss_out, void* stream) {
+  if ((loss_type != 1 && loss_type != 2) || n < 0 || !loss_out || (n > 0 && (!pred || !loss_rows || !grad_pred)))
+    return MISO_E_BADARG;
+  if (((uintptr_t)loss_rows & 15u) != 0) return MISO_E_BADARG;
+  return (int)launch_mapping_loss_rows(loss_type, weight_sdf, weight_fs, trunc_dist, pred, loss_rows, n, grad_pred,
+                                       loss_out, (hipStream_t)stream);
 }
 
 int miso_rigid_by_index(const float* R, const float* t, const int64_t* idx, const float* x, int64_t n, int32_t n_poses,

@@ -65,6 +65,34 @@ __global__ __launch_bounds__(256) void mapping_loss_kernel(MapLossK p, const flo
   }
 }
 
+// The same loss over interleaved label rows {target, valid, sign, weight} (the (N,4) layout MappingStep keeps for the
+// binned forward): one 16-B load per point instead of four strided column copies in front of the launch.
+__global__ __launch_bounds__(256) void mapping_loss_rows_kernel(MapLossK p, const float* __restrict__ pred,
+                                                               const float4* __restrict__ rows, int64_t n,
+                                                               float* __restrict__ gpred, float* __restrict__ loss_out) {
+  const float inv_n = 1.0f / (float)n;
+  float s_sdf = 0.f, s_fs = 0.f;
+  const bool want_fs = p.w_fs > 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float4 r = rows[i];
+    float g, gf;
+    map_loss_one(p, pred[i], r.x, r.w, r.y == 1.0f, want_fs && r.z == 1.0f, g, gf, s_sdf, s_fs);
+    gpred[i] = (g + gf) * inv_n;
+  }
+  for (int o = 32; o > 0; o >>= 1) { s_sdf += __shfl_down(s_sdf, o); s_fs += __shfl_down(s_fs, o); }
+  __shared__ float red[2][4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = s_sdf; red[1][wave] = s_fs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    float b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    atomic_add_f32(loss_out + 0, p.w_sdf * a * inv_n);
+    atomic_add_f32(loss_out + 1, p.w_fs * b * inv_n);
+  }
+}
+
 // Small accumulators are cleared by a kernel, not by hipMemsetAsync: inside a captured HIP graph the 8-byte memset
 // node in front of the atomics of mapping_loss_kernel left garbage in the two sums now and then (seen on ROCm 7.2
 // with the unsorted trainer step replayed back to back: the loss read 0xFEFE.. / NaN while every input was finite).
@@ -116,6 +144,17 @@ hipError_t launch_mapping_loss(int loss_type, float w_sdf, float w_fs, float tru
   if (blocks > 64u) blocks = 64u;
   if (vec) mapping_loss_kernel<true><<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, gpred_fs, loss_out);
   else mapping_loss_kernel<false><<<blocks, 256, 0, s>>>(p, pred, targ, valid, sign, weight, n, gpred, gpred_fs, loss_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_mapping_loss_rows(int loss_type, float w_sdf, float w_fs, float trunc, const float* pred,
+                                    const float* rows, int64_t n, float* gpred, float* loss_out, hipStream_t s) {
+  hipError_t e = launch_zero_words(loss_out, 2, s);
+  if (e != hipSuccess || n == 0) return e;
+  MapLossK p{loss_type, w_sdf, w_fs, trunc};
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 64u) blocks = 64u;
+  mapping_loss_rows_kernel<<<blocks, 256, 0, s>>>(p, pred, reinterpret_cast<const float4*>(rows), n, gpred, loss_out);
   return hipGetLastError();
 }
 

@@ -36,7 +36,48 @@ __global__ __launch_bounds__(256) void rigid_by_index_kernel(const float* __rest
   y[3 * i + 2] = o[2];
 }
 
+// One launch in front of a captured mapping step: the batch's frame ids looked up in the keyframe table
+// (MisoLossMapping.world_coords: table[clamp(id)] -> pose index), the rigid map above, and the four label columns
+// interleaved into the (N,4) rows the fused forward / the loss kernel read -- what the trainer otherwise does with a
+// clamp, an index, rigid_by_index, and a cat (or four strided copies).
+__global__ __launch_bounds__(256) void mapping_batch_kernel(const float* __restrict__ R, const float* __restrict__ t,
+                                                            int32_t K, const int64_t* __restrict__ table,
+                                                            int64_t table_len, const int64_t* __restrict__ frame_ids,
+                                                            const float* __restrict__ x, const float* __restrict__ target,
+                                                            const float* __restrict__ valid,
+                                                            const float* __restrict__ sign,
+                                                            const float* __restrict__ weight, int64_t n,
+                                                            float* __restrict__ y, float4* __restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int64_t f = frame_ids[i];
+  f = f < 0 ? 0 : (f >= table_len ? table_len - 1 : f);
+  int64_t k = table[f];
+  k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+  const float* r = R + k * 9;
+  const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float s = __fmul_rn(a, r[3 * j]);
+    s = __fmaf_rn(b, r[3 * j + 1], s);
+    s = __fmaf_rn(c, r[3 * j + 2], s);
+    y[3 * i + j] = __fadd_rn(s, t[k * 3 + j]);
+  }
+  rows[i] = make_float4(target[i], valid ? valid[i] : 1.0f, sign ? sign[i] : 0.0f, weight ? weight[i] : 1.0f);
+}
+
 }  // namespace
+
+hipError_t launch_mapping_batch(const float* R, const float* t, int32_t K, const int64_t* table, int64_t table_len,
+                                const int64_t* frame_ids, const float* x, const float* target, const float* valid,
+                                const float* sign, const float* weight, int64_t n, float* y, float* rows,
+                                hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  mapping_batch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(R, t, K, table, table_len, frame_ids, x, target,
+                                                                   valid, sign, weight, n, y,
+                                                                   reinterpret_cast<float4*>(rows));
+  return hipGetLastError();
+}
 
 hipError_t launch_rigid_by_index(const float* R, const float* t, const int64_t* idx, const float* x, int64_t n,
                                  int32_t K, int transpose, float* y, hipStream_t s) {

@@ -58,7 +58,9 @@ def _require_hip(*tensors):
 
 
 def _stream(t: torch.Tensor):
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    # (torch.cuda.current_stream(...).cuda_stream builds a Stream object: 7 us a call; this is the raw handle)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(t.device.index if t.device.index is not None
+                                                         else torch.cuda.current_device()))
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -647,6 +649,64 @@ def adam_active_(param, grad, exp_avg, exp_avg_sq, active, step: int, lr: float,
                                             _ptr(guard), _stream(param)), "miso_adam_active")
 
 
+class AdamDeviceStep:
+    """What a captured step needs to take Adam steps without new kernel arguments (miso_adam_step_dev): the table of
+    per-step scalars (computed by the library's own host code, so the captured step equals the launch-by-launch one
+    bit for bit) and the step count on the device.  ``count`` mirrors the device value on the host."""
+    MAX_ROWS = 1 << 21
+
+    def __init__(self, lr: float, beta1: float, beta2: float, eps: float, device, count: int = 0):
+        import math
+        self.hyper = (float(lr), float(beta1), float(beta2), float(eps))
+        bmax = max(beta1, beta2)
+        # rows until beta^t has left fp32 (the scalars no longer change): 20 700 for beta2 = 0.999
+        rows = 64 if bmax <= 0 else int(math.ceil(math.log(1e-9) / math.log(bmax))) + 64 if bmax < 1 else None
+        if rows is None or rows > self.MAX_ROWS:
+            raise ValueError(f"betas {beta1, beta2}: the step-scalar table would need {rows} rows")
+        host = torch.empty((rows, 6), dtype=torch.float32)
+        _lib.check(_lib.load().miso_adam_scalars_table(lr, beta1, beta2, eps, 1, rows, C.c_void_p(host.data_ptr())),
+                   "miso_adam_scalars_table")
+        self.table = host.to(device)
+        self.rows = rows
+        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+        self.set_count(count)
+
+    def set_count(self, count: int):
+        self.count = int(count)
+        self.step.fill_(self.count)
+
+    def bump(self, guard: Optional[torch.Tensor]):
+        """step += 1 on the device unless ``guard`` (device scalar) is NaN; the host mirror is the caller's business."""
+        _lib.check(_lib.load().miso_adam_bump(_ptr(self.step), _ptr(guard), _stream(self.step)), "miso_adam_bump")
+
+    def step_(self, param, grad, exp_avg, exp_avg_sq, active, touched=None, zero_grad=False, guard=None):
+        _require_hip(param, grad, exp_avg, exp_avg_sq, guard)
+        _lib.check(_lib.load().miso_adam_step_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(active),
+                                                  _ptr(touched), param.numel(), _ptr(self.table), self.rows,
+                                                  _ptr(self.step), int(zero_grad), _ptr(guard), _stream(param)),
+                   "miso_adam_step_dev")
+
+
+def mapping_batch(R, t, table, frame_ids, coords_frame, target, valid, sign, weight, x_out, rows_out):
+    """The input side of a mapping step in one launch (miso_mapping_batch): keyframe lookup, frame -> world map and
+    the interleaved label rows, written into the step's static buffers ``x_out`` (N,3) / ``rows_out`` (N,4)."""
+    n = x_out.shape[0]
+    col = lambda c: None if c is None else c.reshape(-1)
+    cols = [col(c) for c in (frame_ids, target, valid, sign, weight)]
+    cf = coords_frame.reshape(-1, 3)
+    for c in cols[1:]:
+        if c is not None and not (c.dtype == torch.float32 and c.is_cuda and c.is_contiguous() and c.numel() == n):
+            raise ValueError("mapping_batch wants fp32 contiguous device columns of the batch's length")
+    if not (cols[0].dtype == torch.int64 and cols[0].is_contiguous() and cols[0].numel() == n and cf.is_contiguous()
+            and cf.dtype == torch.float32 and cf.shape[0] == n and table.dtype == torch.int64):
+        raise ValueError("mapping_batch: frame ids int64 (N,), coords fp32 (N,3)")
+    R, t = R.detach(), t.detach()
+    assert R.is_contiguous() and t.is_contiguous() and R.dtype == torch.float32 and t.dtype == torch.float32
+    _lib.check(_lib.load().miso_mapping_batch(_ptr(R), _ptr(t), R.shape[0], _ptr(table), table.numel(), _ptr(cols[0]),
+                                              _ptr(cf), _ptr(cols[1]), _ptr(cols[2]), _ptr(cols[3]), _ptr(cols[4]), n,
+                                              _ptr(x_out), _ptr(rows_out), _stream(x_out)), "miso_mapping_batch")
+
+
 # --------------------------------------------------------------------------- #
 # mapping loss (value + gradient w.r.t. the prediction)
 # --------------------------------------------------------------------------- #
@@ -671,6 +731,18 @@ def mapping_loss_raw(pred, target, valid, sign, weight, loss_type: str, weight_s
                                              _ptr(target), _ptr(valid), _ptr(sign), _ptr(weight), n,
                                              _ptr(grad_pred), _ptr(grad_pred_fs), _ptr(loss_out),
                                              _stream(pred)), "miso_mapping_loss")
+    return loss_out, grad_pred
+
+
+def mapping_loss_rows_raw(pred, rows, loss_type: str, weight_sdf: float, weight_fs: float, trunc_dist: float,
+                          grad_pred, loss_out):
+    """mapping_loss_raw over the interleaved label rows {target, valid, sign, weight} (N,4) of MappingStep."""
+    _require_hip(pred, rows, grad_pred, loss_out)
+    assert rows.is_contiguous() and rows.shape == (pred.shape[0], 4) and pred.is_contiguous() and grad_pred.is_contiguous()
+    _lib.check(_lib.load().miso_mapping_loss_rows(_LOSS_TYPES[loss_type], weight_sdf, weight_fs,
+                                                  0.0 if trunc_dist is None else trunc_dist, _ptr(pred), _ptr(rows),
+                                                  pred.shape[0], _ptr(grad_pred), _ptr(loss_out), _stream(pred)),
+               "miso_mapping_loss_rows")
     return loss_out, grad_pred
 
 

@@ -33,22 +33,31 @@ class DenseAdam(torch.optim.Optimizer):
                                       foreach=None, capturable=False, differentiable=False, fused=None,
                                       decoupled_weight_decay=False))
         self.skipped_steps = 0
-        self._pending = None          # (pinned loss copy, event, states stepped under that guard, device scalar)
-        self._guard_host = None       # one pinned float + one event, reused: a guard is resolved before the next
+        self._pending = []            # guarded steps not yet accounted for: [pinned loss copy, event, states, device scalar]
+        self._guard_slots = []        # pinned floats + events, reused
 
-    def resolve_guard(self):
-        """Account for the last guarded step: if its loss was NaN the device skipped it -- take the step counts back."""
+    def resolve_guard(self, block=True):
+        """Account for guarded steps whose loss has arrived: if it was NaN the device skipped the step -- take the step
+        counts back.  block=True waits for every pending one (the launch-by-launch path computes the next step's bias
+        corrections from the count, so it must be right); block=False looks only at those that have completed (a
+        captured step counts on the device).  Returns the number of steps found skipped."""
         pending = self.__dict__.get('_pending')
-        if pending is None:
-            return
-        host, event, states, _src = pending
-        self._pending = None
-        event.synchronize()
-        if bool(torch.isnan(host[0])):
-            for st in states:
-                st['step'] -= 1
-            self.skipped_steps += 1
-            logger.warning("Loss is nan! Skip backward step.")
+        skipped = 0
+        while pending:
+            host, event, states, _src = pending[0]
+            if block:
+                event.synchronize()
+            elif not event.query():
+                break
+            pending.pop(0)
+            self.__dict__.setdefault('_guard_slots', []).append((host, event))
+            if bool(torch.isnan(host[0])):
+                for st in states:
+                    st['step'] -= 1
+                skipped += 1
+                logger.warning("Loss is nan! Skip backward step.")
+        self.skipped_steps = self.__dict__.get('skipped_steps', 0) + skipped
+        return skipped
 
     def state_dict(self):
         self.resolve_guard()
@@ -137,13 +146,23 @@ class DenseAdam(torch.optim.Optimizer):
                 if clear_grads:
                     g.zero_()
         if guard is not None and stepped:
-            if self._guard_host is None:
-                self._guard_host = (torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event())
-            host, event = self._guard_host
-            src = guard.detach().reshape(1)
-            host.copy_(src, non_blocking=True)
-            event.record()
-            # the device scalar stays referenced until the copy has been consumed: a caller that drops the loss
-            # right away would hand its block back to the allocator while the asynchronous copy may still read it
-            self._pending = (host, event, stepped, src)
+            self.note_guarded_step(guard, stepped)
         return loss
+
+    def note_guarded_step(self, guard, stepped):
+        """A step guarded by the device scalar ``guard`` has been launched for the states ``stepped`` (their 'step'
+        already counts it): remember to take the count back if the guard turns out NaN (resolve_guard)."""
+        pending = self.__dict__.setdefault('_pending', [])        # (an unpickled optimizer has no such attributes)
+        slots = self.__dict__.setdefault('_guard_slots', [])
+        if len(pending) >= 8:
+            self.resolve_guard(block=True)        # a bounded number of guards in flight
+        if slots:
+            host, event = slots.pop()
+        else:
+            host, event = torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event()
+        src = guard.detach().reshape(1)
+        host.copy_(src, non_blocking=True)
+        event.record()
+        # the device scalar stays referenced until the copy has been consumed: a caller that drops the loss
+        # right away would hand its block back to the allocator while the asynchronous copy may still read it
+        pending.append((host, event, stepped, src))

@@ -25,13 +25,19 @@ class MappingStep:
                  trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
                  sort: Optional[bool] = None, need_levels: Optional[Sequence[bool]] = None,
                  keep_sdf: bool = True, padded: bool = False, grads_cleared_by_optimizer: bool = False,
-                 share_grads: Optional[Sequence[Optional[torch.Tensor]]] = None):
+                 share_grads: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                 adam_device: Optional["ops.AdamDeviceStep"] = None,
+                 adam_state: Optional[Sequence[Optional[tuple]]] = None):
         """padded: the batch buffers hold ``n_points`` rows of which only ``self.live_rows`` (one int32 on the
         device, set through set_batch) are live, the rest neutral padding (valid = sign = weight = 0); the loss
         means divide by the live count.  Lets a sampler with a data-dependent row count (depth holes) feed ONE
         captured graph.
         grads_cleared_by_optimizer: the caller's optimizer leaves the gradient buffers zeroed after its step
         (DenseAdam.step(clear_grads=True)), so the small-batch path does not memset them before scattering.
+        adam_device + adam_state: the optimizer step INSIDE the captured sequence -- per level (exp_avg, exp_avg_sq,
+        active) tensors of the caller's optimizer state (they stay the caller's: checkpoints, resets) and the
+        device-side step scalars of ops.AdamDeviceStep; ``self.total`` (0-d) then holds the step's loss, which also
+        guards the step against NaN.  The caller mirrors the step count (adam_device.count / its state['step']).
         need_levels: which levels get a gradient (default all) -- the coarse-to-fine schedule of
         GridTrainer optimises one level at a time.  keep_sdf: also leave the predicted SDF of the batch
         in ``self.sdf`` (caller order); a training loop only needs the loss and the gradients, and on
@@ -95,8 +101,13 @@ class MappingStep:
             for g in self.grads:
                 if g is not None:
                     g.zero_()
+        self.adam_device, self.adam_state = adam_device, adam_state
+        if adam_device is not None:
+            assert adam is None and adam_state is not None and len(adam_state) == len(self.features)
+            assert all((st is not None) == nd for st, nd in zip(adam_state, need))
+        self.total = torch.zeros((), **f32)
         self._graph = None
-        self._use_graph = use_graph and adam is None  # the Adam step count changes per call
+        self._use_graph = use_graph and adam is None  # the Adam step count changes per call (adam_device: on the device)
 
     def set_batch(self, x, target, valid=None, sign=None, weight=None, live_rows=None):
         if self.live_rows is not None:
@@ -141,13 +152,18 @@ class MappingStep:
             _, mask = ops.sdf_fwd_raw(self.x, self.features, self.meta, self.pack, True, out=self.sdf,
                                       mask=getattr(self, "_mask", None))
             self._mask = mask
-            if getattr(self, "_cols", None) is None:
-                self._cols = [torch.empty((self.n, 1), device=self.x.device) for _ in range(4)]
-            for c, src in zip(self._cols, (self.target, self.valid, self.sign, self.weight)):
-                c.copy_(src)          # mapping_loss_raw takes unit-stride columns
-            ops.mapping_loss_raw(self.sdf, *self._cols, lt, ws, wf, td, self.gpred, self._loss)
+            ops.mapping_loss_rows_raw(self.sdf, self.aux, lt, ws, wf, td, self.gpred, self._loss)
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
                             self.need_levels, self.grads, touched=self.touched)
+        if self.adam_device is not None:
+            src = self.loss_slots.view(-1) if self.sorted is not None else self._loss
+            torch.sum(src, dim=0, out=self.total)
+            self.adam_device.bump(self.total)
+            for p, g, st, tch in zip(self.features, self.grads, self.adam_state, self.touched):
+                if g is None:
+                    continue
+                self.adam_device.step_(p, g, st[0], st[1], st[2], touched=tch, zero_grad=self.sorted is None,
+                                       guard=self.total)
         if self.adam is not None:
             self.t += 1
             for p, g, m, v, act, tch in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq, self.active,

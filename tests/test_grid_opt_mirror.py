@@ -899,3 +899,91 @@ def test_mapping_eikonal_term_matches_reference(device_backend, method):
                            eik_trunc_dist=0.1, grad_method=method, finite_diff_eps=1e-2)
     d = lf.compute(net, mi, gt)
     assert set(d) == {"sdf_L1", "eik"} and abs(d["eik"].item() - 0.5 * ref) <= 2e-5 * ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 70000])
+def test_fast_captured_step_equals_the_checked_one(n, tmp_path):
+    """GridTrainer's fast plan (batch written by one launch, optimizer inside the graph replay, step scalars and step
+    count on the device, NaN guards resolved without waiting) against the checked captured path (fast_captured_step
+    off): identical features / Adam moments / step counts over 12 steps of changing batches, one of which has a NaN
+    label (the reference skips backward and optimizer.step(): nothing moves, the count does not advance); then the
+    plan lets go when something it baked in changes (learning rate; a pose unlocked) and the results still agree;
+    and the optimizer state round-trips through state_dict.  n = 4096: atomic scatter; 70000: binned path."""
+    from miso_amd.grid_opt.loss import MisoLossMapping
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    from miso_amd.grid_opt.trainer import GridTrainer
+    dev = "cuda:0"
+    c = gc.ATLAS
+    # 16 x 8 x 16 and 64 x 32 x 64 vertices, 4 channels: both levels big enough for the optimizer's kernel path
+    cfg = gc.model_cfg(c["bound"], 0.25, 4, 2, c["fdim"], c["hidden"], num_poses=2, init_stddev=1e-2)
+    g = torch.Generator().manual_seed(2)
+    batches = []
+    for b in range(4):
+        x = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([1.8, 0.9, 1.8]) * (0.5 + 0.15 * b)
+        mi = {"coords_frame": x[None].to(dev), "sample_frame_ids": torch.randint(0, 2, (1, n, 1), generator=g).to(dev),
+              "weights": (torch.rand(1, n, 1, generator=g) + 0.5).to(dev)}
+        gt = {"sdf": (torch.rand(1, n, 1, generator=g) * 0.2 - 0.1).to(dev),
+              "sdf_valid": (torch.rand(1, n, 1, generator=g) > 0.1).float().to(dev),
+              "sdf_signs": (torch.rand(1, n, 1, generator=g) > 0.6).float().to(dev)}
+        batches.append((mi, gt))
+    bad = ({k: v.clone() for k, v in batches[1][0].items()}, {k: v.clone() for k, v in batches[1][1].items()})
+    bad[1]["sdf"][0, 7, 0] = float("nan")
+
+    def run(fast):
+        torch.manual_seed(0)
+        net = GridNet(cfg, device=dev).to(dev)
+        R1 = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+        net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+        net.set_initial_kf_pose(1, R1, torch.tensor([[0.1], [-0.05], [0.02]]), kf_key="KF1")
+        net.unlock_feature()
+        net.lock_pose()
+        tcfg = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-2, "epochs": 1, "ckpt_every": -1,
+                "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": str(tmp_path),
+                "relchange_tol": 0, "max_epochs_in_level": 1000, "grid_training_mode": "joint",
+                "fast_captured_step": fast}
+        lf = MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
+        tr = GridTrainer(tcfg, net, lf, None, None, dev, torch.float32)
+        losses, used_fast = [], 0
+        for it in range(12):
+            mi, gt = bad if it == 6 else batches[it % 4]
+            losses.append(tr.train_step(mi, gt))
+            used_fast += tr.__dict__.get("_fast_plan") is not None
+        torch.cuda.synchronize()
+        feats = [f.feature for f in net.features]
+        snap = lambda: ([f.detach().clone() for f in feats]
+                        + [tr.optimizer.state[f][k].clone() for f in feats for k in ("exp_avg", "exp_avg_sq")])
+        out = {"after12": snap(), "losses": torch.stack([l.detach().reshape(()) for l in losses]).cpu()}
+        tr.optimizer.resolve_guard()
+        out["steps12"] = [tr.optimizer.state[f]["step"] for f in feats]
+        out["skipped"] = tr.optimizer.skipped_steps
+        out["used_fast"] = used_fast
+        # a change the plan baked in: the learning rate
+        for grp in tr.optimizer.param_groups:
+            grp["lr"] = 3e-3
+        for it in range(3):
+            tr.train_step(*batches[it])
+        out["after_lr"] = snap()
+        # state dict round trip, then on
+        sd = tr.optimizer.state_dict()
+        tr.optimizer.load_state_dict(sd)
+        for it in range(3):
+            tr.train_step(*batches[it])
+        tr.optimizer.resolve_guard()
+        out["after_reload"] = snap()
+        out["steps_end"] = [tr.optimizer.state[f]["step"] for f in feats]
+        return out
+
+    a, b = run(False), run(True)
+    assert a["used_fast"] == 0 and b["used_fast"] >= 9
+    assert a["steps12"] == b["steps12"] == [11] * len(a["steps12"]) and a["skipped"] == b["skipped"] == 1
+    assert a["steps_end"] == b["steps_end"] == [17] * len(a["steps_end"])
+    assert torch.isnan(a["losses"][6]) and torch.isnan(b["losses"][6])
+    fin = torch.ones(12, dtype=torch.bool)
+    fin[6] = False
+    torch.testing.assert_close(a["losses"][fin], b["losses"][fin], rtol=2e-5, atol=1e-8)
+    for key in ("after12", "after_lr", "after_reload"):
+        for ta, tb in zip(a[key], b[key]):
+            # float atomics / slot sums reorder: same tolerance the captured-vs-eager trainer tests use
+            scale = ta.abs().max().item()
+            assert (ta - tb).abs().max().item() <= 2e-4 * scale + 1e-9, key
