@@ -44,10 +44,12 @@ __global__ __launch_bounds__(256) void mapping_batch_kernel(const float* __restr
                                                             int32_t K, const int64_t* __restrict__ table,
                                                             int64_t table_len, const int64_t* __restrict__ frame_ids,
                                                             const float* __restrict__ x, const float* __restrict__ target,
-                                                            const float* __restrict__ valid,
+                                                            const void* __restrict__ valid,
                                                             const float* __restrict__ sign,
                                                             const float* __restrict__ weight, int64_t n,
-                                                            float* __restrict__ y, float4* __restrict__ rows) {
+                                                            float* __restrict__ y, float4* __restrict__ rows,
+                                                            int64_t s_target, int64_t s_valid, int64_t s_sign,
+                                                            int64_t s_weight, int valid_is_bool) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   int64_t f = frame_ids[i];
@@ -63,19 +65,26 @@ __global__ __launch_bounds__(256) void mapping_batch_kernel(const float* __restr
     s = __fmaf_rn(c, r[3 * j + 2], s);
     y[3 * i + j] = __fadd_rn(s, t[k * 3 + j]);
   }
-  rows[i] = make_float4(target[i], valid ? valid[i] : 1.0f, sign ? sign[i] : 0.0f, weight ? weight[i] : 1.0f);
+  float v = 1.0f;
+  if (valid)
+    v = valid_is_bool ? (reinterpret_cast<const unsigned char*>(valid)[i * s_valid] ? 1.0f : 0.0f)
+                      : reinterpret_cast<const float*>(valid)[i * s_valid];
+  rows[i] = make_float4(target[i * s_target], v, sign ? sign[i * s_sign] : 0.0f, weight ? weight[i * s_weight] : 1.0f);
 }
 
 }  // namespace
 
 hipError_t launch_mapping_batch(const float* R, const float* t, int32_t K, const int64_t* table, int64_t table_len,
-                                const int64_t* frame_ids, const float* x, const float* target, const float* valid,
+                                const int64_t* frame_ids, const float* x, const float* target, const void* valid,
                                 const float* sign, const float* weight, int64_t n, float* y, float* rows,
-                                hipStream_t s) {
+                                const int64_t* strides, int valid_is_bool, hipStream_t s) {
   if (n == 0) return hipSuccess;
+  const int64_t one[4] = {1, 1, 1, 1};
+  const int64_t* st = strides ? strides : one;
   mapping_batch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(R, t, K, table, table_len, frame_ids, x, target,
                                                                    valid, sign, weight, n, y,
-                                                                   reinterpret_cast<float4*>(rows));
+                                                                   reinterpret_cast<float4*>(rows), st[0], st[1], st[2],
+                                                                   st[3], valid_is_bool);
   return hipGetLastError();
 }
 

@@ -689,21 +689,36 @@ class AdamDeviceStep:
 
 def mapping_batch(R, t, table, frame_ids, coords_frame, target, valid, sign, weight, x_out, rows_out):
     """The input side of a mapping step in one launch (miso_mapping_batch): keyframe lookup, frame -> world map and
-    the interleaved label rows, written into the step's static buffers ``x_out`` (N,3) / ``rows_out`` (N,4)."""
+    the interleaved label rows, written into the step's static buffers ``x_out`` (N,3) / ``rows_out`` (N,4).  The
+    label columns may be strided views ((N,1) slices of a row-major block); ``valid`` may be a bool mask.
+    Raises ValueError for layouts the launch does not take."""
     n = x_out.shape[0]
-    col = lambda c: None if c is None else c.reshape(-1)
-    cols = [col(c) for c in (frame_ids, target, valid, sign, weight)]
+    strides = (C.c_int64 * 4)(1, 1, 1, 1)
+
+    def col(c, i, dtypes=(torch.float32,)):
+        if c is None:
+            return None
+        if c.dim() == 2 and c.shape[1] == 1:
+            c = c[:, 0]
+        if not (c.dim() == 1 and c.shape[0] == n and c.is_cuda and c.dtype in dtypes and (n < 2 or c.stride(0) >= 0)):
+            raise ValueError("mapping_batch wants device columns (N,) or (N,1) of the batch's length")
+        strides[i] = c.stride(0) if n > 1 else 1
+        return c
+
+    cols = [col(target, 0), col(valid, 1, (torch.float32, torch.bool)), col(sign, 2), col(weight, 3)]
+    if target is None:
+        raise ValueError("mapping_batch needs the target column")
+    fid = frame_ids.reshape(-1)
     cf = coords_frame.reshape(-1, 3)
-    for c in cols[1:]:
-        if c is not None and not (c.dtype == torch.float32 and c.is_cuda and c.is_contiguous() and c.numel() == n):
-            raise ValueError("mapping_batch wants fp32 contiguous device columns of the batch's length")
-    if not (cols[0].dtype == torch.int64 and cols[0].is_contiguous() and cols[0].numel() == n and cf.is_contiguous()
-            and cf.dtype == torch.float32 and cf.shape[0] == n and table.dtype == torch.int64):
+    if not (fid.dtype == torch.int64 and fid.is_contiguous() and fid.numel() == n and cf.is_contiguous()
+            and cf.dtype == torch.float32 and cf.shape[0] == n and table.dtype == torch.int64 and fid.is_cuda):
         raise ValueError("mapping_batch: frame ids int64 (N,), coords fp32 (N,3)")
     R, t = R.detach(), t.detach()
-    assert R.is_contiguous() and t.is_contiguous() and R.dtype == torch.float32 and t.dtype == torch.float32
-    _lib.check(_lib.load().miso_mapping_batch(_ptr(R), _ptr(t), R.shape[0], _ptr(table), table.numel(), _ptr(cols[0]),
-                                              _ptr(cf), _ptr(cols[1]), _ptr(cols[2]), _ptr(cols[3]), _ptr(cols[4]), n,
+    if not (R.is_contiguous() and t.is_contiguous() and R.dtype == torch.float32 and t.dtype == torch.float32):
+        raise ValueError("mapping_batch: poses fp32 contiguous")
+    _lib.check(_lib.load().miso_mapping_batch(_ptr(R), _ptr(t), R.shape[0], _ptr(table), table.numel(), _ptr(fid),
+                                              _ptr(cf), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]), _ptr(cols[3]),
+                                              strides, int(valid is not None and cols[1].dtype == torch.bool), n,
                                               _ptr(x_out), _ptr(rows_out), _stream(x_out)), "miso_mapping_batch")
 
 
