@@ -698,7 +698,9 @@ def main():
         kernels_us["sdf_bwd_kernel(MFMA pass)"] = t_bwd - t_pull
         # algorithmic bytes of the pull: the gradient of 8 corners x C channels per level, counted
         # once as a write (SURVEY 8d backward figure without the 4 B of dL/dsdf the MFMA pass reads)
-        dom = ("grad_pull_kernel", t_pull, 32 * L * C)
+        # (at cfg-2 the pull is grad_pull_block_kernel -- one workgroup per 2x2x2 tiles -- followed by the drain launch
+        # of grad_pull_kernel for sliced tiles, which finds an empty queue on this uniform batch)
+        dom = ("grad_pull_block_kernel", t_pull, 32 * L * C)
     if t_fwd > dom[1]:
         dom = ("sdf_fwd_kernel", t_fwd, b_fwd)
     achieved = N_POINTS * dom[2] / (dom[1] * 1e-6) / 1e9
@@ -716,7 +718,11 @@ def main():
         except Exception:
             continue
         if js.get("_meta", {}).get("source_hash") == source_hash():
-            traffic = js.get(dom[0], {}).get("hbm_bytes_per_launch")
+            if dom[0] == "grad_pull_block_kernel":      # kernel_us covers both launches of the pull: so does the traffic
+                parts = [v.get("hbm_bytes_per_launch") for k, v in js.items() if k.startswith("grad_pull") and isinstance(v, dict)]
+                traffic = sum(p for p in parts if p is not None) if parts else None
+            else:
+                traffic = js.get(dom[0], {}).get("hbm_bytes_per_launch")
             mfma_pmc = {k: v["mfma_busy_frac"] for k, v in js.items() if isinstance(v, dict) and "mfma_busy_frac" in v}
             pmc_note = f"{os.path.basename(pmc)} (kernel sources {source_hash()}, commit {js['_meta'].get('commit')})"
             break
@@ -733,9 +739,9 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                 "traffic_source": pmc_note, "algorithmic_bytes_per_point": dom[2], "kernel_us": dom[1],
                 "mfma_frac": mfma}
-    if dom[0] == "grad_pull_kernel":
-        roofline["launches"] = ("grad_pull_kernel<..,false> + its drain launch <..,true> (slices of over-full tiles; "
-                                "finds an empty queue on this uniform batch, ~2 us); kernel_us covers both")
+    if dom[0] == "grad_pull_block_kernel":
+        roofline["launches"] = ("grad_pull_block_kernel + the drain launch grad_pull_kernel<..,true> (slices of over-full "
+                                "tiles; finds an empty queue on this uniform batch, ~3 us); kernel_us and traffic cover both")
 
     out = {
         "metric": "3D point-samples/sec (encode+decode fwd+bwd), 262144-pt batch",

@@ -340,7 +340,8 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
 #pragma unroll
       for (int c = 0; c < C; c += 4) {
         float4 v = make_float4(acc[r][c], acc[r][c + 1], acc[r][c + 2], acc[r][c + 3]);
-        if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) touch_chunk(lv, (int64_t)(dst + c - lv.grad));
+        if (lv.touched && (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f))
+          lv.touched[(dst + c - lv.grad) >> 8] = 1;
         if (add_eff == 2) {   // a queued slice: other wavefronts add to the same brick
           if (v.x != 0.0f) atomic_add_f32(dst + c, v.x);
           if (v.y != 0.0f) atomic_add_f32(dst + c + 1, v.y);
