@@ -75,6 +75,9 @@ extern "C" {
 #define MISO_F_COORDS_NORMALIZED 4u /* x is already in [-1,1]: skip normalize_coordinates */
 #define MISO_F_GRAD_SDF_SORTED 16u  /* miso_sdf_bwd_sorted: grad_sdf is in the binned order (what
                                        miso_sdf_fwd_sorted_loss writes), not the caller's */
+#define MISO_F_GRAD_ZEROED 32u      /* with MISO_F_GRAD_OVERWRITE: the levels miso_sdf_bwd_sorted ADDS to with atomics
+                                       (miso_sdf_bwd_scattered_levels) are zero on entry -- e.g. cleared by the Adam
+                                       launch that consumed them (zero_grad) -- so the library skips its fill */
 #define MISO_F_GRAD_OVERWRITE 8u    /* miso_sdf_bwd_sorted: level[l].grad = sum instead of += (the library
                                        clears what it still scatters; the caller never zero-fills) */
 
@@ -252,6 +255,11 @@ int miso_grad_pull_dx(const miso_grid_t* grid, const miso_sorted_t* sorted, int6
  * and every tile's samples within 5 vertices per axis (a tile owns <= 3).  n = batch size.  Informational: the entry
  * point decides by itself. */
 uint32_t miso_sdf_bwd_push_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n);
+/* Levels (bit l, among those with a grad pointer) that miso_sdf_bwd_sorted forms by ADDING with atomics -- the decoder
+ * pass's scatter for levels the pull cannot own, and the push -- as opposed to the pull's plain stores.  With
+ * MISO_F_GRAD_OVERWRITE these are the levels the call zero-fills first, unless MISO_F_GRAD_ZEROED says they are
+ * zero already. */
+uint32_t miso_sdf_bwd_scattered_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n);
 int64_t miso_sdf_bwd_workspace_floats(const miso_grid_t* grid, int64_t n);
 int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const miso_sorted_t* sorted, int64_t n, const float* grad_sdf,

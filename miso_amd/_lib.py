@@ -26,6 +26,7 @@ F_PAD_BORDER = 2
 F_COORDS_NORMALIZED = 4
 F_GRAD_OVERWRITE = 8
 F_GRAD_SDF_SORTED = 16
+F_GRAD_ZEROED = 32
 LOSS_SLOTS = 512
 
 E_BADARG = 2001
@@ -144,6 +145,7 @@ SIGNATURES = {
     "miso_adam_touched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int, C.c_void_p,
                                     C.c_void_p]),
+    "miso_sdf_bwd_scattered_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32, C.c_int64]),
     "miso_sdf_bwd_push_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32, C.c_int64]),
     "miso_sdf_bwd_workspace_floats": (C.c_int64, [C.POINTER(Grid), C.c_int64]),
     "miso_sdf_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted),

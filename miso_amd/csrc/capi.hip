@@ -78,12 +78,12 @@ enum Need { NEED_DATA = 1, NEED_GRAD_OPT = 2 };
 int convert_grid(const miso_grid_t* in, GridK* out, bool need_data, bool* vec4) {
   if (!in || in->n_levels < 1 || in->n_levels > MISO_MAX_LEVELS) return MISO_E_BADARG;
   if (in->flags & ~(MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER | MISO_F_COORDS_NORMALIZED | MISO_F_GRAD_OVERWRITE |
-                    MISO_F_GRAD_SDF_SORTED))
+                    MISO_F_GRAD_SDF_SORTED | MISO_F_GRAD_ZEROED))
     return MISO_E_BADARG;
   memset(out, 0, sizeof(*out));
   out->n_levels = in->n_levels;
   out->ignore_mask = in->ignore_mask;
-  out->flags = in->flags & ~(MISO_F_GRAD_OVERWRITE | MISO_F_GRAD_SDF_SORTED);   // host-side flags
+  out->flags = in->flags & ~(MISO_F_GRAD_OVERWRITE | MISO_F_GRAD_SDF_SORTED | MISO_F_GRAD_ZEROED);   // host-side flags
   for (int a = 0; a < 3; ++a) { out->bmin[a] = in->bound_min[a]; out->bmax[a] = in->bound_max[a]; out->gscale[a] = 1.0f; }
   out->xstride = 3;
   static const uint32_t tune = [] { const char* e = getenv("MISO_TUNE"); return e ? (uint32_t)atoi(e) : 0u; }();
@@ -312,7 +312,7 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   // pulled level's, so it stays in `pull`)
   const uint32_t push = (pull && sorted) ? plan_push(g, sorted->tiles_per_axis, n, pull) : 0u;
   hipStream_t st = (hipStream_t)stream;
-  if (overwrite) {
+  if (overwrite && !(grid->flags & MISO_F_GRAD_ZEROED)) {
     // levels that are scattered or pushed with atomics start from zero; pulled levels need no fill
     for (int l = 0; l < g.n_levels; ++l) {
       const LevelK& lv = g.lv[l];
@@ -430,6 +430,16 @@ static int pull_plan(const miso_grid_t* grid, int32_t tiles_per_axis, GridK* g, 
     if (g->lv[l].C != *C) return MISO_OK;
   *mask = plan_grad_pull(*g, tiles_per_axis);
   return MISO_OK;
+}
+
+uint32_t miso_sdf_bwd_scattered_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n) {
+  GridK g; int C; uint32_t mask;
+  if (pull_plan(grid, tiles_per_axis, &g, &C, &mask)) return 0;
+  const uint32_t owned = mask & ~plan_push(g, tiles_per_axis, n, mask);
+  uint32_t out = 0;
+  for (int l = 0; l < g.n_levels; ++l)
+    if (g.lv[l].grad && !((owned >> l) & 1u)) out |= 1u << l;
+  return out;
 }
 
 uint32_t miso_sdf_bwd_push_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n) {

@@ -479,10 +479,12 @@ def sdf_fwd_raw(x, features, meta, pack: DecoderPack, want_mask: bool, out=None,
 
 def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f, grads=None,
                 sorted_batch: Optional[SortedBatch] = None, overwrite: bool = False, gsdf_sorted: bool = False,
-                touched: Optional[Sequence[Optional[torch.Tensor]]] = None):
+                touched: Optional[Sequence[Optional[torch.Tensor]]] = None, zeroed: bool = False):
     """overwrite (binned path only): the gradients are written, not accumulated -- ``grads``
     need no zero-fill (MISO_F_GRAD_OVERWRITE).  gsdf_sorted (binned path only): ``gsdf`` is in
-    the binned order (sdf_fwd_loss_raw), not the caller's.  touched: see _fill_grid / adam_active_."""
+    the binned order (sdf_fwd_loss_raw), not the caller's.  touched: see _fill_grid / adam_active_.
+    zeroed (with overwrite): the levels the call adds to with atomics (sdf_bwd_scattered_levels) are zero already --
+    the Adam launch that consumed them cleared them -- so the library's fill is skipped (MISO_F_GRAD_ZEROED)."""
     _require_hip(x, gsdf, *features)
     m, packed = pack.get()
     x = x.contiguous()
@@ -496,6 +498,8 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
     g = _fill_grid(features, meta, grads, touched=touched)
     if overwrite:
         g.flags |= _lib.F_GRAD_OVERWRITE
+        if zeroed:
+            g.flags |= _lib.F_GRAD_ZEROED
     if gsdf_sorted:
         assert sorted_batch is not None
         g.flags |= _lib.F_GRAD_SDF_SORTED
@@ -508,6 +512,13 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
         _lib.check(_lib.load().miso_sdf_bwd(C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _ptr(gsdf),
                                             _ptr(mask), _ptr(gx), _stream(x)), "miso_sdf_bwd")
     return gx, grads
+
+
+def sdf_bwd_scattered_levels(features, meta, grads, n: int) -> int:
+    """Bit l set: sdf_bwd_raw(sorted_batch=..., overwrite=True) forms level l's gradient by adding with atomics (and
+    zero-fills it first) rather than by the pull's plain stores (miso_sdf_bwd_scattered_levels)."""
+    g = _fill_grid(features, meta, grads, data=False)
+    return int(_lib.load().miso_sdf_bwd_scattered_levels(C.byref(g), SortedBatch.TILES, n))
 
 
 def sdf_mask_words(pack: DecoderPack) -> int:

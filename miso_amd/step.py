@@ -106,6 +106,14 @@ class MappingStep:
             assert adam is None and adam_state is not None and len(adam_state) == len(self.features)
             assert all((st is not None) == nd for st, nd in zip(adam_state, need))
         self.total = torch.zeros((), **f32)
+        # binned step with the optimizer inside: the levels the backward ADDS to (atomic scatter, push) are cleared by
+        # the Adam launch that consumes them instead of by a fill in front of every backward (64 MB at the ScanNet shape)
+        self._adam_clears = 0
+        if adam_device is not None and self.sorted is not None:
+            self._adam_clears = ops.sdf_bwd_scattered_levels(self.features, meta, self.grads, self.n)
+            for l, g in enumerate(self.grads):
+                if g is not None and (self._adam_clears >> l) & 1:
+                    g.zero_()
         self._graph = None
         self._use_graph = use_graph and adam is None  # the Adam step count changes per call (adam_device: on the device)
 
@@ -147,7 +155,7 @@ class MappingStep:
                                  sdf_out=self.sdf if self.keep_sdf else None, n_live=self.live_rows)
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, self._mask, False,
                             self.need_levels, self.grads, sorted_batch=self.sorted, overwrite=True, gsdf_sorted=True,
-                            touched=self.touched)
+                            touched=self.touched, zeroed=self.adam_device is not None)
         else:
             _, mask = ops.sdf_fwd_raw(self.x, self.features, self.meta, self.pack, True, out=self.sdf,
                                       mask=getattr(self, "_mask", None))
@@ -159,11 +167,11 @@ class MappingStep:
             src = self.loss_slots.view(-1) if self.sorted is not None else self._loss
             torch.sum(src, dim=0, out=self.total)
             self.adam_device.bump(self.total)
-            for p, g, st, tch in zip(self.features, self.grads, self.adam_state, self.touched):
+            for l, (p, g, st, tch) in enumerate(zip(self.features, self.grads, self.adam_state, self.touched)):
                 if g is None:
                     continue
-                self.adam_device.step_(p, g, st[0], st[1], st[2], touched=tch, zero_grad=self.sorted is None,
-                                       guard=self.total)
+                self.adam_device.step_(p, g, st[0], st[1], st[2], touched=tch, guard=self.total,
+                                       zero_grad=self.sorted is None or bool((self._adam_clears >> l) & 1))
         if self.adam is not None:
             self.t += 1
             for p, g, m, v, act, tch in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq, self.active,
