@@ -243,11 +243,19 @@ __global__ __launch_bounds__(256) void overlap_count_kernel(const float* __restr
 }
 
 // The overlap gate of every pair of the plan in one launch (blockIdx.y = pair); cnt_all (P) zeroed by the prologue.
-// Lattice form (gate_ax): a workgroup takes GATE_ROWS (j,k) rows of the source's finest level, a thread walks along
-// x; the vertex positions come from the three per-axis tables (the values FeatureGrid.vertex_positions builds the
-// meshgrid from), so nothing but 3 x a few hundred floats is read, and the arithmetic per vertex is the point-list
-// path's.
-constexpr int GATE_ROWS = 64;
+// Lattice form (gate_ax): the source's finest level is a lattice whose vertex positions come from three per-axis
+// tables (the values FeatureGrid.vertex_positions builds the meshgrid from), and the map into the destination frame is
+// affine, so along a lattice row (fixed j, k) every face of the destination bound cuts the row at one point: the
+// in-bound vertices of a row are one index interval.  A lane takes a row, solves the six inequalities for the interval
+// in fp32, and then decides with the EXACT per-vertex arithmetic of the point-list path (the reference's op order)
+// only where rounding could matter -- the two vertices either side of each interval end; the vertices strictly
+// between are counted without being evaluated, provided the analytic map leaves them GATE_SLACK inside every face
+// (else, and for rows nearly parallel to a face they nearly touch, the whole row is evaluated exactly, all lanes of
+// the wavefront on it).  Same count as evaluating every vertex (tests compare the two), at ~1/15 of the instructions:
+// the gate of 28 pairs x 4 M vertices took 147 us of a 210 us level-0 alignment iteration.
+constexpr int GATE_ROWS = 256;          // rows (lanes) per workgroup
+constexpr float GATE_SLACK = 2e-3f;     // metres; fp32 rounding of the map is ~1e-5 at 100 m
+constexpr float GATE_ERR = 2e-4f;       // metres: bound on the rounding of one mapped coordinate, generous
 
 __global__ __launch_bounds__(256) void overlap_count_batch_kernel(const AlignPairK* __restrict__ plan,
                                                                  const float* __restrict__ pose_all,
@@ -273,22 +281,93 @@ __global__ __launch_bounds__(256) void overlap_count_batch_kernel(const AlignPai
   for (int i = 0; i < 9; ++i) { Rs[i] = ps[i]; Rd[i] = pd[i]; }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { ts[i] = ps[9 + i]; td[i] = pd[9 + i]; }
-  const float b0 = d.g.bmin[0], b1 = d.g.bmin[1], b2 = d.g.bmin[2], B0 = d.g.bmax[0], B1 = d.g.bmax[1], B2 = d.g.bmax[2];
+  const float lo[3] = {d.g.bmin[0], d.g.bmin[1], d.g.bmin[2]}, hi[3] = {d.g.bmax[0], d.g.bmax[1], d.g.bmax[2]};
+  const float* __restrict__ ax = d.gate_ax[0];
+  // the exact test of one vertex: the arithmetic of overlap_count_body / the reference's tensor ops
+  auto inside = [&](float px, float py, float pz) -> bool {
+    const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
+                        Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
+    const float e[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
+    const float q0 = Rd[0] * e[0] + Rd[3] * e[1] + Rd[6] * e[2], q1 = Rd[1] * e[0] + Rd[4] * e[1] + Rd[7] * e[2],
+                q2 = Rd[2] * e[0] + Rd[5] * e[1] + Rd[8] * e[2];
+    return q0 >= lo[0] && q0 <= hi[0] && q1 >= lo[1] && q1 <= hi[1] && q2 >= lo[2] && q2 <= hi[2];
+  };
+  const int lane = threadIdx.x & 63;
+  const int row = row0 + threadIdx.x;
+  const bool live = row < nrows;
+  const int j = live ? row % ny : 0, k = live ? row / ny : 0;
+  const float py = d.gate_ax[1][j], pz = d.gate_ax[2][k];
   float cnt = 0.0f;
-  const int rend = min(row0 + GATE_ROWS, nrows);
-  for (int i = threadIdx.x; i < nx; i += blockDim.x) {
-    const float px = d.gate_ax[0][i];
-    int j = row0 % ny, k = row0 / ny;
-    for (int row = row0; row < rend; ++row) {
-      const float py = d.gate_ax[1][j], pz = d.gate_ax[2][k];      // wave-uniform
-      const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
-                          Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
-      const float e[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
-      const float q0 = Rd[0] * e[0] + Rd[3] * e[1] + Rd[6] * e[2], q1 = Rd[1] * e[0] + Rd[4] * e[1] + Rd[7] * e[2],
-                  q2 = Rd[2] * e[0] + Rd[5] * e[1] + Rd[8] * e[2];
-      if (q0 >= b0 && q0 <= B0 && q1 >= b1 && q1 <= B1 && q2 >= b2 && q2 <= B2) cnt += 1.0f;
-      if (++j == ny) { j = 0; ++k; }
+  bool whole = false;                     // this lane's row needs every vertex evaluated
+  if (live) {
+    if (nx <= 8) {
+      for (int i = 0; i < nx; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
+    } else {
+      // q_c(px) = alpha_c px + beta_c;  interval of px with all six faces satisfied
+      const float x0 = ax[0], x1 = ax[nx - 1];
+      float pxl = x0, pxh = x1;           // the row itself
+      float unc = 0.0f;                   // how far (in px) rounding can move an interval end: GATE_ERR / |alpha|
+      bool empty = false;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float al = Rd[c] * Rs[0] + Rd[3 + c] * Rs[3] + Rd[6 + c] * Rs[6];
+        const float be = Rd[c] * (Rs[1] * py + Rs[2] * pz + ts[0] - td[0]) +
+                         Rd[3 + c] * (Rs[4] * py + Rs[5] * pz + ts[1] - td[1]) +
+                         Rd[6 + c] * (Rs[7] * py + Rs[8] * pz + ts[2] - td[2]);
+        // across the row q_c moves by |al| (x1 - x0): a row that hardly moves against this face pair is decided by
+        // beta alone -- clearly inside both faces, clearly outside one, or too close to call
+        if (fabsf(al) * (x1 - x0) < GATE_SLACK) {
+          if (be < lo[c] - 2.0f * GATE_SLACK || be > hi[c] + 2.0f * GATE_SLACK) empty = true;
+          else if (!(be > lo[c] + 2.0f * GATE_SLACK && be < hi[c] - 2.0f * GATE_SLACK)) whole = true;
+          continue;
+        }
+        const float a = (lo[c] - be) / al, b = (hi[c] - be) / al;
+        pxl = fmaxf(pxl, fminf(a, b));
+        pxh = fminf(pxh, fmaxf(a, b));
+        unc = fmaxf(unc, GATE_ERR / fabsf(al));
+      }
+      pxl -= unc; pxh += unc;
+      if (!(pxl == pxl) || !(pxh == pxh)) whole = true;          // NaN poses: let the exact path decide
+      if (!whole && !empty && pxl <= pxh + 4.0f * (x1 - x0) / (float)(nx - 1)) {
+        // index estimates from the mean spacing (the tables are linspace-like; the tests around the ends absorb +-1)
+        const float inv_dx = (float)(nx - 1) / (x1 - x0);
+        int il = (int)floorf((pxl - x0) * inv_dx), ih = (int)ceilf((pxh - x0) * inv_dx);
+        il = max(il - 2, 0); ih = min(ih + 2, nx - 1);           // first / last vertex that could be in bound
+        if (ih - il < 12) {
+          for (int i = il; i <= ih; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
+        } else {
+          // vertices il .. il+4 and ih-4 .. ih exactly; il+5 .. ih-5 counted if the analytic map keeps both ends of
+          // that stretch GATE_SLACK inside every face (q is linear in px, so everything between is at least as deep)
+          const int a0 = il + 5, a1 = ih - 5;
+          bool deep = true;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float al = Rd[c] * Rs[0] + Rd[3 + c] * Rs[3] + Rd[6 + c] * Rs[6];
+            const float be = Rd[c] * (Rs[1] * py + Rs[2] * pz + ts[0] - td[0]) +
+                             Rd[3 + c] * (Rs[4] * py + Rs[5] * pz + ts[1] - td[1]) +
+                             Rd[6 + c] * (Rs[7] * py + Rs[8] * pz + ts[2] - td[2]);
+            const float qa = al * ax[a0] + be, qb = al * ax[a1] + be;
+            deep = deep && fminf(qa, qb) >= lo[c] + GATE_SLACK && fmaxf(qa, qb) <= hi[c] - GATE_SLACK;
+          }
+          if (!deep) {
+            whole = true;
+          } else {
+            for (int i = il; i < a0; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
+            for (int i = a1 + 1; i <= ih; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
+            cnt += (float)(a1 - a0 + 1);
+          }
+        }
+      }
+      if (whole) cnt = 0.0f;
     }
+  }
+  // rows that need every vertex: one at a time, all lanes of the wavefront along x
+  unsigned long long todo = __ballot(whole);
+  while (todo) {
+    const int src = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const float ry = __shfl(py, src, 64), rz = __shfl(pz, src, 64);
+    for (int i = lane; i < nx; i += 64) cnt += inside(ax[i], ry, rz) ? 1.0f : 0.0f;
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
   __shared__ float red[4];

@@ -976,9 +976,16 @@ class AlignPlan:
                     assert nx * ny * nz == gate.shape[0]
                     axes = (gate[:nx, 0].contiguous(), gate[::nx][:ny, 1].contiguous(),
                             gate[::nx * ny][:nz, 2].contiguous())
-                    for a in range(3):
-                        d.gate_axis[a], d.gate_dims[a] = axes[a].data_ptr(), (nx, ny, nz)[a]
-                    gate = (gate, axes)
+                    # the lattice gate walks rows along x by index arithmetic: the x table must be an increasing,
+                    # evenly spaced one (FeatureGrid.vertex_positions: a linspace) -- checked once, here
+                    xs = axes[0].double().cpu()
+                    even = nx < 2 or bool(((xs[1:] - xs[:-1]) > 0).all() and
+                                          ((xs - torch.linspace(float(xs[0]), float(xs[-1]), nx, dtype=torch.float64)).abs()
+                                           <= 0.25 * float(xs[-1] - xs[0]) / (nx - 1)).all())
+                    if even:
+                        for a in range(3):
+                            d.gate_axis[a], d.gate_dims[a] = axes[a].data_ptr(), (nx, ny, nz)[a]
+                        gate = (gate, axes)
             d.src, d.dst = int(pr["src"]), int(pr["dst"])
             self._keep.append((feats_dst, coords, fsrc, gate))
         nbytes = int(lib.miso_align_plan_bytes(P))
@@ -1010,6 +1017,11 @@ class AlignPlan:
     @property
     def pair_out(self) -> torch.Tensor:
         return self._view(2, 24 * self.P).view(self.P, 24)
+
+    @property
+    def overlap_counts(self) -> torch.Tensor:
+        """(P,) number of gate vertices of src inside dst's bound as of the last iteration_a (float-valued integers)."""
+        return self._view(3, self.P)
 
     @property
     def pair_losses(self) -> torch.Tensor:

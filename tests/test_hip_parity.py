@@ -7,6 +7,8 @@ reference's own tests allow nondet_tol=1e-5, test3d.py:149):
   sdf       mean|d| <= 1e-5 (BASELINE north-star), max|d| <= 1e-5
   gradients rel. error <= 1e-4 (+ small absolute floor)
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -1010,3 +1012,77 @@ def test_adam_touched_flags_equal_gradient_scan(path):
         if zero:
             assert all(bool((g == 0).all()) for g in grads)
     assert 0 < float(actB[-1].float().mean()) < 0.9      # some chunks never woke up
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["small", "scannet"])
+def test_lattice_overlap_gate_counts_equal_the_point_list_gate(case):
+    """The overlap gate of the fused alignment iteration in its lattice form (a lane per lattice row solves for the
+    in-bound index interval and evaluates the reference's per-vertex arithmetic only around the interval ends) must
+    count exactly what the point-list form counts by evaluating every vertex: identity and axis-swapping rotations
+    (rows exactly parallel to faces), translations that put vertices ON faces, small and large rotations, no overlap
+    at all, containment, a NaN pose.  scannet: the real lattice (200 x 100 x 200 vertices of a 20 x 10 x 20 m bound,
+    0.1 m cells) under poses like those of neighbouring submaps."""
+    from miso_amd import ops
+    from miso_amd.so3 import so3_exp_map
+    torch.manual_seed(5)
+    if case == "small":
+        nx, ny, nz = 40, 18, 30
+        bound = [[-2.0, 2.0], [-0.9, 0.9], [-1.5, 1.5]]
+        rots = [torch.zeros(3), torch.tensor([0.0, 0.0, math.pi / 2]), torch.tensor([math.pi / 2, 0.0, 0.0]),
+                torch.tensor([0.0, 1e-4, 0.0]), torch.tensor([0.02, -0.01, 0.03]), torch.tensor([0.4, 0.2, -0.7]),
+                torch.tensor([1.2, -2.0, 0.6]), torch.tensor([0.0, math.pi, 0.0]), torch.randn(3), torch.zeros(3)]
+        trans = [torch.zeros(3), torch.tensor([0.05, 0.0, 0.0]), torch.tensor([3.95, 0.0, 0.0]), torch.tensor([0.0, 1.75, 0.0]),
+                 torch.tensor([10.0, 0.0, 0.0]), torch.tensor([0.3, -0.2, 0.1]), torch.tensor([1.0, 0.9, -1.5]),
+                 torch.tensor([-2.0, 0.0, 2.95]), torch.randn(3), torch.zeros(3)]      # the last one coincides with the first
+    else:
+        nx, ny, nz = 200, 100, 200
+        bound = [[-10.0, 10.0], [-5.0, 5.0], [-10.0, 10.0]]
+        rots = [torch.zeros(3), torch.tensor([0.0, 0.3, 0.0]), torch.tensor([0.01, -0.5, 0.02]), torch.tensor([0.0, 1e-5, 0.0]),
+                torch.tensor([0.0, math.pi / 2, 0.0]), torch.randn(3) * 0.2, torch.randn(3) * 0.05, torch.zeros(3)]
+        trans = [torch.zeros(3), torch.tensor([6.0, 0.2, -3.0]), torch.tensor([-8.0, 0.0, 7.5]), torch.tensor([0.1, 0.0, 0.0]),
+                 torch.tensor([19.9, 0.0, 0.0]), torch.randn(3) * 4, torch.randn(3) * 4, torch.tensor([35.0, 0.0, 0.0])]
+    half = [(b[1] - b[0]) / (2 * n) for b, n in zip(bound, (nx, ny, nz))]
+    axes = [torch.linspace(b[0] + h, b[1] - h, n) for b, h, n in zip(bound, half, (nx, ny, nz))]
+    zz, yy, xx = torch.meshgrid(axes[2], axes[1], axes[0], indexing="ij")          # z-major, x fastest
+    pts = torch.stack([xx, yy, zz], dim=-1).reshape(-1, 3).to(DEV)
+    S = len(rots)
+    R0 = so3_exp_map(torch.stack(rots)).to(DEV)
+    t0 = torch.stack(trans).reshape(S, 3, 1).to(DEV)
+    C_ = 4
+    feat = (torch.randn(1, C_, 6, 5, 8) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    meta = ops.GridMeta.from_bound(bound)
+    coords = pts[:64].contiguous()
+    fsrc = torch.randn(64, C_, device=DEV)
+    pairs = [(a, b) for a in range(S) for b in range(S) if a != b]
+    counts = {}
+    for lattice in (False, True):
+        descr = [dict(src=a, dst=b, coords=coords, feats_src=fsrc, feats_dst=[feat], meta_dst=meta, gate_pts=pts,
+                      **({"gate_dims": (nx, ny, nz)} if lattice else {})) for a, b in pairs]
+        plan = ops.AlignPlan(R0, t0, descr, loss_type="L2")
+        plan.iteration_a()
+        counts[lattice] = plan.overlap_counts.clone().cpu()
+        if lattice:      # a NaN pose: both forms must agree there too (nothing in bound)
+            plan.params[3, 0] = float("nan")
+            plan.iteration_a()
+            nan_lat = plan.overlap_counts.clone().cpu()
+        else:
+            plan.params[3, 0] = float("nan")
+            plan.iteration_a()
+            nan_pts = plan.overlap_counts.clone().cpu()
+    assert torch.equal(counts[True], counts[False]), (counts[True] - counts[False]).abs().max()
+    assert torch.equal(nan_lat, nan_pts)
+    c = counts[True]
+    assert (c == 0).any() and ((c > 0) & (c < nx * ny * nz)).sum() > 20
+    if case == "small":
+        assert (c == nx * ny * nz).any()
+    # and the reference's own formulation, on the host in fp32 (transform_points_to -> transfrom_points_from ->
+    # coords_in_bound, grid_atlas.py:405-420), for a few pairs
+    P = pts.cpu()
+    b = torch.tensor(bound)
+    for idx in (0, 7, 19, 33, 52, 80) if case == "small" else (0, 9, 23, 41):
+        a_, b_ = pairs[idx]
+        w = P @ R0[a_].cpu().T + t0[a_].cpu().reshape(1, 3)
+        q = (w - t0[b_].cpu().reshape(1, 3)) @ R0[b_].cpu()
+        ref = int(((q >= b[:, 0]) & (q <= b[:, 1])).all(dim=1).sum())
+        assert abs(int(c[idx]) - ref) <= max(2, int(2e-4 * ref)), (idx, int(c[idx]), ref)     # matmul order differs
