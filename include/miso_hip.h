@@ -370,6 +370,39 @@ int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const flo
                       const float* sdf, const float* target, int64_t n, int loss_type, float gm_scale,
                       float* out, void* stream);
 
+/* --- one whole Levenberg-Marquardt step of the keyframe tracker (Tracker.lm_step, grid_opt/slam/tracker.py:148-212)
+ * R = R_base so3_exp_map(rot_correction), t = t_base + trans_correction (GridNet.updated_kf_pose); samples into the
+ * submap frame; SDF and its spatial gradient by the fused forward / coordinate backward; J, H = J^T W J + lm_lambda I,
+ * g = J^T W r as in miso_lm_normal_eq; delta = solve(H, -g) (LU with partial pivoting, fp32); the two corrections
+ * += delta IN PLACE.  What the reference settles with host round trips is counted on the device instead and handed
+ * back in info (8 floats, device): {|delta_R| rad, |delta_t|, |g|, rows inside the grid bound, rows kept by the
+ * truncation filter |target| < trunc_dist (trunc_dist < 0: all), kept rows whose frame id != keyframe_id, kept rows
+ * whose validity != 1, 0} -- fov_overlap = info[3] / info[4]; the reference asserts info[5] == info[6] == 0.
+ * Filtered rows take no part in anything, as if removed.  loss_type 2 = L2, 3 = Geman-McClure (gm_scale).
+ * The grid needs `data` only (no grad pointers).  Scratch, all device: pose 12, coords_world 3N, sdf N, grad 3N floats,
+ * ones N floats holding 1.0, relu_mask N * miso_sdf_mask_words words, sums 36 floats. */
+typedef struct {
+  const float* coords_frame;       /* (N,3) samples in the keyframe frame */
+  const float* target;             /* measured SDF, element stride stride_target */
+  const void* valid;               /* float (== 1 means valid) or, with valid_is_bool, one byte per row; or NULL */
+  const int64_t* frame_ids;        /* or NULL */
+  int64_t stride_target, stride_valid, stride_frame_ids;
+  int32_t valid_is_bool;
+  int64_t n;
+  int64_t keyframe_id;
+  float trunc_dist;
+  const float* R_base;             /* 9 */
+  const float* t_base;             /* 3 */
+  float* rot_correction;           /* 3, updated */
+  float* trans_correction;         /* 3, updated */
+  int32_t loss_type;
+  float gm_scale, lm_lambda;
+  float* pose; float* coords_world; float* sdf; float* grad; const float* ones; uint32_t* relu_mask; float* sums;
+  float* info;
+} miso_lm_track_t;
+int miso_lm_track_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const miso_lm_track_t* args,
+                       void* stream);
+
 /* --- mapping loss (value + d/d pred) --------------------------------------
  * loss_type 1 = L1, 2 = L2.  pred/target (N); valid/sign/weight (N) or NULL
  * (= all valid / no free-space rows / unit weights).  Writes grad_pred (N) =

@@ -41,6 +41,17 @@ class Level(C.Structure):
                 ("grad_touched", C.c_void_p)]
 
 
+class LmTrack(C.Structure):
+    _fields_ = [("coords_frame", C.c_void_p), ("target", C.c_void_p), ("valid", C.c_void_p), ("frame_ids", C.c_void_p),
+                ("stride_target", C.c_int64), ("stride_valid", C.c_int64), ("stride_frame_ids", C.c_int64),
+                ("valid_is_bool", C.c_int32), ("n", C.c_int64), ("keyframe_id", C.c_int64), ("trunc_dist", C.c_float),
+                ("R_base", C.c_void_p), ("t_base", C.c_void_p), ("rot_correction", C.c_void_p),
+                ("trans_correction", C.c_void_p), ("loss_type", C.c_int32), ("gm_scale", C.c_float),
+                ("lm_lambda", C.c_float), ("pose", C.c_void_p), ("coords_world", C.c_void_p), ("sdf", C.c_void_p),
+                ("grad", C.c_void_p), ("ones", C.c_void_p), ("relu_mask", C.c_void_p), ("sums", C.c_void_p),
+                ("info", C.c_void_p)]
+
+
 class Grid(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("ignore_mask", C.c_uint32),
                 ("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3),
@@ -132,6 +143,7 @@ SIGNATURES = {
     "miso_encode_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p]),
     "miso_grad_pull_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32]),
+    "miso_lm_track_step": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(LmTrack), C.c_void_p]),
     "miso_adam_scalars_table": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                           C.c_void_p]),
     "miso_adam_bump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

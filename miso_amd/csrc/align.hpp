@@ -25,4 +25,20 @@ struct AlignK {
   AlignLayout L;
 };
 
+// so3_exp_map(log_rot, eps = 1e-4) of pytorch3d as restated in miso_amd/so3.py, fp32, same op order
+__device__ __forceinline__ void so3_exp(const float w[3], float E[9]) {
+#pragma clang fp contract(off)
+  const float sq = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
+  const float ang = sqrtf(fmaxf(sq, 1e-4f));
+  const float a = sinf(ang) / ang, b = (1.0f - cosf(ang)) / (ang * ang);
+  const float K[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+  float KK[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) KK[i * 3 + j] = (K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j]) + K[i * 3 + 2] * K[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) E[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + a * K[i] + b * KK[i];
+}
+
 }  // namespace miso

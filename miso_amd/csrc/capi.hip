@@ -28,6 +28,8 @@ hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
 hipError_t launch_adam_touched(float*, float*, float*, float*, unsigned char*, unsigned char*, int64_t, double, double,
                                double, double, int, int, const float*, hipStream_t, const float*, const int32_t*, int);
 hipError_t launch_adam_bump(int32_t*, const float*, hipStream_t);
+hipError_t launch_lm_track_head(const LmTrackK&, hipStream_t);
+hipError_t launch_lm_track_tail(const LmTrackK&, const float*, const float*, int, float, hipStream_t);
 void adam_scalars_table(double, double, double, double, int, int, float*);
 hipError_t launch_mapping_batch(const float*, const float*, int32_t, const int64_t*, int64_t, const int64_t*,
                                 const float*, const float*, const void*, const float*, const float*, int64_t, float*,
@@ -623,6 +625,40 @@ int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const flo
   if (loss_type == 3 && !(gm_scale > 0.0f)) return MISO_E_BADARG;
   return (int)launch_lm_normal_eq(coords_frame, R_frame, grad_sdf_x, sdf, target, n, loss_type, gm_scale, out,
                                   (hipStream_t)stream);
+}
+
+int miso_lm_track_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const miso_lm_track_t* a,
+                       void* stream) {
+  if (!a || a->n < 0 || !a->R_base || !a->t_base || !a->rot_correction || !a->trans_correction || !a->pose || !a->sums ||
+      !a->info)
+    return MISO_E_BADARG;
+  if (a->n > 0 && (!a->coords_frame || !a->target || !a->coords_world || !a->sdf || !a->grad || !a->ones || !a->relu_mask))
+    return MISO_E_BADARG;
+  if (a->stride_target < 0 || a->stride_valid < 0 || a->stride_frame_ids < 0) return MISO_E_BADARG;
+  if (a->loss_type != 2 && a->loss_type != 3) return MISO_E_UNSUPPORTED;
+  if (a->loss_type == 3 && !(a->gm_scale > 0.0f)) return MISO_E_BADARG;
+  if (!grid) return MISO_E_BADARG;
+  for (int l = 0; l < grid->n_levels && l < MISO_MAX_LEVELS; ++l)
+    if (grid->level[l].grad) return MISO_E_BADARG;      // the step wants d sdf / d x only
+  LmTrackK k;
+  memset(&k, 0, sizeof(k));
+  k.x = a->coords_frame; k.gt = a->target; k.valid = a->valid; k.frame_ids = a->frame_ids;
+  k.s_gt = a->stride_target; k.s_valid = a->stride_valid; k.s_fid = a->stride_frame_ids;
+  k.valid_is_bool = a->valid_is_bool; k.n = a->n; k.kf = a->keyframe_id; k.trunc = a->trunc_dist;
+  k.Rwk = a->R_base; k.twk = a->t_base; k.dr = a->rot_correction; k.dt = a->trans_correction;
+  k.pose = a->pose; k.xw = a->coords_world; k.sums = a->sums; k.info = a->info;
+  for (int i = 0; i < 3; ++i) { k.bmin[i] = grid->bound_min[i]; k.bmax[i] = grid->bound_max[i]; }
+  k.lm_lambda = a->lm_lambda;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = (int)launch_lm_track_head(k, st);
+  if (rc) return rc;
+  if (a->n > 0) {
+    rc = sdf_fwd_impl(grid, mlp, packed, a->coords_world, a->n, a->sdf, a->relu_mask, nullptr, stream);
+    if (rc) return rc;
+    rc = sdf_bwd_impl(grid, mlp, packed, a->coords_world, a->n, a->ones, a->relu_mask, a->grad, nullptr, nullptr, stream);
+    if (rc) return rc;
+  }
+  return (int)launch_lm_track_tail(k, a->grad, a->sdf, a->loss_type, a->gm_scale, st);
 }
 
 int64_t miso_pull_queue_ints(int64_t n) { return n < 0 ? 0 : pull_queue_ints(n); }

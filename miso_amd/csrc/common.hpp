@@ -121,6 +121,28 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One Levenberg-Marquardt step of the tracker on the device (lm.hip)
+struct LmTrackK {
+  const float* x;            // (N,3) samples in the keyframe frame
+  const float* gt;           // (N) measured SDF, element stride s_gt
+  const void* valid;         // (N) validity (float or bool), stride s_valid, or nullptr
+  const int64_t* frame_ids;  // (N), stride s_fid, or nullptr
+  int64_t s_gt, s_valid, s_fid;
+  int valid_is_bool;
+  int64_t n, kf;
+  float trunc;
+  const float* Rwk;          // 9: base rotation of the keyframe
+  const float* twk;          // 3
+  float* dr;                 // 3: rotation correction (axis-angle), updated by the solve
+  float* dt;                 // 3
+  float* pose;               // scratch 12: R (row-major), t
+  float* xw;                 // scratch (N,3): samples in the submap frame
+  float* sums;               // scratch 36: 32 of lm_normal_eq + {rows kept, in bound, wrong frame id, invalid}
+  float* info;               // out 8: |dR| (rad), |dt|, |g|, in bound, kept, wrong frame id, invalid, 0
+  float bmin[3], bmax[3];
+  float lm_lambda;
+};
+
 // miso_level_t.grad_touched: a non-zero went into grad[off] (element offset from lv.grad)
 static_assert(MISO_ADAM_CHUNK == 256, "touch_chunk shifts by 8");
 __device__ __forceinline__ void touch_chunk(const LevelK& lv, int64_t off) {

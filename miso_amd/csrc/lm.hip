@@ -9,6 +9,7 @@
 // block-reduced sums (upper triangle of H, g, sum w r^2, count).  lambda*I and the 6x6 solve
 // stay with the caller (they are 36 floats).
 #include "common.hpp"
+#include "align.hpp"
 
 namespace miso {
 
@@ -17,7 +18,9 @@ struct LmK {
   const float* R;      // device, 9 floats row-major: keyframe -> submap rotation
   const float* grad;   // (N,3) d sdf / d x_submap
   const float* sdf;    // (N) predicted
-  const float* gt;     // (N) measured
+  const float* gt;     // (N) measured, element stride s_gt
+  int64_t s_gt;
+  float trunc;         // >= 0: only rows with |gt| < trunc count (the tracker's SDF truncation filter); < 0: all rows
   int64_t n;
   int loss_type;       // 2 = L2, 3 = GM
   float gm_scale;
@@ -42,7 +45,9 @@ __global__ __launch_bounds__(256) void lm_normal_eq_kernel(LmK k) {
     J[1] = c0 * R[1] + c1 * R[4] + c2 * R[7];
     J[2] = c0 * R[2] + c1 * R[5] + c2 * R[8];
     J[3] = g0; J[4] = g1; J[5] = g2;
-    const float r = k.sdf[i] - k.gt[i];
+    const float gti = k.gt[i * k.s_gt];
+    if (k.trunc >= 0.0f && !(fabsf(gti) < k.trunc)) continue;
+    const float r = k.sdf[i] - gti;
     float w = 1.0f;
     if (k.loss_type == 3) { const float d = k.gm_scale + r * r; w = k.gm_scale / (d * d); }
     int o = 0;
@@ -76,10 +81,145 @@ hipError_t launch_lm_normal_eq(const float* x, const float* R, const float* grad
                                int64_t n, int loss_type, float gm_scale, float* out, hipStream_t s) {
   hipError_t e = launch_zero_words(out, 32, s);
   if (e != hipSuccess || n == 0) return e;
-  LmK k{x, R, grad, sdf, gt, n, loss_type, gm_scale, out};
+  LmK k{x, R, grad, sdf, gt, 1, -1.0f, n, loss_type, gm_scale, out};
   unsigned blocks = (unsigned)((n + 255) / 256);
   if (blocks > 128u) blocks = 128u;      // <= 128 same-address atomics per sum
   lm_normal_eq_kernel<<<blocks, 256, 0, s>>>(k);
+  return hipGetLastError();
+}
+
+// ---- one whole Levenberg-Marquardt step of the tracker on the device (Tracker.lm_step, tracker.py:148-212) -----------
+// pose of the keyframe from its corrections -> samples into the submap frame (+ the bookkeeping the reference does
+// with host round trips: the truncation filter, the frame-id / validity asserts, the field-of-view overlap) -> [SDF
+// and its spatial gradient: the fused forward / coordinate backward, launched by the caller between the two halves]
+// -> normal equations -> damped 6x6 solve -> pose corrections updated in place -> eight floats for the host.
+__global__ void lm_pose_kernel(LmTrackK k) {
+  const int t = threadIdx.x;
+  if (t < 36) k.sums[t] = 0.0f;
+  if (t == 0) {
+    const float w[3] = {k.dr[0], k.dr[1], k.dr[2]};
+    float E[9];
+    so3_exp(w, E);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        k.pose[i * 3 + j] = (k.Rwk[i * 3] * E[j] + k.Rwk[i * 3 + 1] * E[3 + j]) + k.Rwk[i * 3 + 2] * E[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) k.pose[9 + i] = k.twk[i] + k.dt[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void lm_transform_kernel(LmTrackK k) {
+  float R[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = k.pose[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = k.pose[9 + i];
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = k.x[3 * i], b = k.x[3 * i + 1], cc = k.x[3 * i + 2];
+    float y[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {      // transform_points_to: the row-times-matrix order of rigid.hip
+      float s = __fmul_rn(a, R[3 * j]);
+      s = __fmaf_rn(b, R[3 * j + 1], s);
+      s = __fmaf_rn(cc, R[3 * j + 2], s);
+      y[j] = __fadd_rn(s, t[j]);
+      k.xw[3 * i + j] = y[j];
+    }
+    const float g = k.gt[i * k.s_gt];
+    if (k.trunc >= 0.0f && !(fabsf(g) < k.trunc)) continue;
+    c[0] += 1.0f;
+    if (y[0] >= k.bmin[0] && y[0] <= k.bmax[0] && y[1] >= k.bmin[1] && y[1] <= k.bmax[1] && y[2] >= k.bmin[2] &&
+        y[2] <= k.bmax[2])
+      c[1] += 1.0f;
+    if (k.frame_ids && k.frame_ids[i * k.s_fid] != k.kf) c[2] += 1.0f;
+    if (k.valid) {
+      const bool ok = k.valid_is_bool ? reinterpret_cast<const unsigned char*>(k.valid)[i * k.s_valid] != 0
+                                      : reinterpret_cast<const float*>(k.valid)[i * k.s_valid] == 1.0f;
+      if (!ok) c[3] += 1.0f;
+    }
+  }
+  __shared__ float red[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v = c[q];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (v != 0.0f) atomic_add_f32(k.sums + 32 + threadIdx.x, v);      // integer-valued: exact below 2^24
+  }
+}
+
+// H delta = -g with H = J^T W J + lambda I: LU with partial pivoting in fp32 (what torch.linalg.solve does for a
+// general 6x6), then the corrections move in place and the host gets its eight numbers.
+__global__ void lm_solve_kernel(LmTrackK k) {
+  if (threadIdx.x != 0) return;
+  float A[6][7];
+  int o = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) { A[a][b] = k.sums[o]; A[b][a] = k.sums[o]; ++o; }
+  float gn = 0.0f;
+  for (int a = 0; a < 6; ++a) {
+    A[a][a] += k.lm_lambda;
+    A[a][6] = -k.sums[21 + a];
+    gn += k.sums[21 + a] * k.sums[21 + a];
+  }
+  for (int c = 0; c < 6; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (fabsf(A[r][c]) > fabsf(A[p][c])) p = r;
+    if (p != c)
+      for (int j = 0; j < 7; ++j) { const float tmp = A[c][j]; A[c][j] = A[p][j]; A[p][j] = tmp; }
+    const float inv = 1.0f / A[c][c];
+    for (int r = c + 1; r < 6; ++r) {
+      const float f = A[r][c] * inv;
+      for (int j = c; j < 7; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  float d[6];
+  for (int r = 5; r >= 0; --r) {
+    float v = A[r][6];
+    for (int j = r + 1; j < 6; ++j) v -= A[r][j] * d[j];
+    d[r] = v / A[r][r];
+  }
+  // (the reference asserts on frame ids and validity before it touches the pose: leave it alone if they fail)
+  if (k.sums[34] == 0.0f && k.sums[35] == 0.0f)
+    for (int i = 0; i < 3; ++i) { k.dr[i] += d[i]; k.dt[i] += d[3 + i]; }
+  k.info[0] = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+  k.info[1] = sqrtf((d[3] * d[3] + d[4] * d[4]) + d[5] * d[5]);
+  k.info[2] = sqrtf(gn);
+  k.info[3] = k.sums[33];
+  k.info[4] = k.sums[32];
+  k.info[5] = k.sums[34];
+  k.info[6] = k.sums[35];
+  k.info[7] = 0.0f;
+}
+
+hipError_t launch_lm_track_head(const LmTrackK& k, hipStream_t s) {
+  lm_pose_kernel<<<1, 64, 0, s>>>(k);
+  if (k.n > 0) {
+    unsigned blocks = (unsigned)((k.n + 255) / 256);
+    if (blocks > 128u) blocks = 128u;
+    lm_transform_kernel<<<blocks, 256, 0, s>>>(k);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_lm_track_tail(const LmTrackK& k, const float* grad, const float* sdf, int loss_type, float gm_scale,
+                                hipStream_t s) {
+  if (k.n > 0) {
+    LmK q{k.x, k.pose, grad, sdf, k.gt, k.s_gt, k.trunc, k.n, loss_type, gm_scale, k.sums};
+    unsigned blocks = (unsigned)((k.n + 255) / 256);
+    if (blocks > 128u) blocks = 128u;
+    lm_normal_eq_kernel<<<blocks, 256, 0, s>>>(q);
+  }
+  lm_solve_kernel<<<1, 64, 0, s>>>(k);
   return hipGetLastError();
 }
 

@@ -36,14 +36,21 @@ class MLPNet(nn.Module):
 
     # -- glue to the fused HIP path ------------------------------------------------
     def linears(self):
-        return [m for m in self.network if isinstance(m, nn.Linear)]
+        lin = self.__dict__.get('_linears')
+        if lin is None:        # the layer set is fixed at construction; walking nn.Module containers costs ~20 us a call
+            lin = self.__dict__['_linears'] = [m for m in self.network if isinstance(m, nn.Linear)]
+        return lin
 
     def is_frozen(self) -> bool:
-        return not any(p.requires_grad for p in self.parameters())
+        ps = self.__dict__.get('_param_list')
+        if ps is None:
+            ps = self.__dict__['_param_list'] = list(self.parameters())
+        return not any(p.requires_grad for p in ps)
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        state.pop('_pack', None)          # packed weights (ctypes struct + device buffer): rebuilt on demand
+        for k in ('_pack', '_linears', '_param_list'):      # packed weights (ctypes struct + device buffer) and the
+            state.pop(k, None)                             # cached layer / parameter lists: rebuilt on demand
         return state
 
     def decoder_pack(self):

@@ -83,6 +83,40 @@ class Tracker:
                 break
         self.latest_fov_overlap = info['fov_overlap']
 
+    def _lm_step_on_device(self, optimize_kf, coords_frame, frame_ids, gt_sdf, gt_valid):
+        """The step below as one library call and one host synchronisation (ops.LmTrackStep) when the model takes the
+        fused decoder path; None otherwise.  The reference's op-by-op version waits for the device eight times per
+        step (nonzero, two asserts, the overlap count, the solve, three norms): 1.08 ms per step at 16 384 samples of
+        which the GPU works for under 0.1 ms."""
+        if not coords_frame.is_cuda or self.loss_type not in ('L2', 'GM') or not hasattr(self.grid, '_fused_decoder'):
+            return None
+        pack = self.grid._fused_decoder()
+        if pack is None or coords_frame.shape[0] == 0:
+            return None
+        from miso_amd import ops
+        n = coords_frame.shape[0]
+        step = self.__dict__.get('_lm_dev')
+        if step is None or step.n != n or step.pose.device != coords_frame.device:
+            step = self.__dict__['_lm_dev'] = ops.LmTrackStep(n, coords_frame.device, pack)
+        grid = self.grid
+        kf = grid.pose_key_to_id(f'KF{optimize_kf}')
+        feats = [g.feature for g in grid.features]
+        meta = grid.features[0].grid_meta(grid.ignore_level_)
+        dr, dt = grid.rotation_corrections.data[kf], grid.translation_corrections.data[kf]
+        try:
+            out = step(feats, meta, pack, coords_frame.contiguous(), gt_sdf, gt_valid, frame_ids, optimize_kf,
+                       self.trunc_dist, grid.Rwk[kf], grid.twk[kf], dr, dt, self.loss_type, self.gm_scale_sdf,
+                       self.lm_lambda)
+        except ValueError:
+            return None
+        torch.autograd.graph.increment_version(grid.rotation_corrections)      # written through raw pointers:
+        torch.autograd.graph.increment_version(grid.translation_corrections)   # pose caches key on the versions
+        d_r, d_t, g_norm, n_in, n_keep, bad_frame, invalid = out[:7]
+        assert bad_frame == 0
+        assert invalid == 0, "Only valid SDFs should be used for tracking."
+        return {'delta_R_deg': math.degrees(d_r), 'delta_t_norm': d_t, 'grad_norm': g_norm,
+                'fov_overlap': float(n_in) / n_keep}
+
     def residual_weights(self, r: torch.Tensor):
         if self.loss_type == 'L2':
             return torch.ones_like(r)
@@ -98,6 +132,9 @@ class Tracker:
         coords_frame = model_input['coords_frame'][0]
         frame_ids = model_input['sample_frame_ids'][0]
         gt_sdf, gt_valid = gt['sdf'][0], gt['sdf_valid'][0]
+        info = self._lm_step_on_device(optimize_kf, coords_frame, frame_ids, gt_sdf, gt_valid)
+        if info is not None:
+            return info
         if self.trunc_dist is not None:
             keep = torch.nonzero(torch.abs(gt_sdf[:, 0]) < self.trunc_dist, as_tuple=False).squeeze(1)
             coords_frame, frame_ids = coords_frame[keep], frame_ids[keep]

@@ -379,20 +379,8 @@ class Trainer(object):
 
     @staticmethod
     def _batches(loader):
-        """What ``for batch in loader`` yields for a single-process DataLoader, without building a DataLoader iterator
-        per epoch (0.1 ms; the reference's datasets have ONE item per epoch, grid_opt/datasets/sdf_rgbd.py, so that is
-        per training step).  The iterator's draw of a base seed from the loader's generator is kept, so random streams
-        line up with a plain loop."""
-        simple = (isinstance(loader, torch.utils.data.DataLoader) and loader.num_workers == 0 and not loader.pin_memory
-                  and loader.batch_sampler is not None and loader.collate_fn is not None
-                  and not isinstance(loader.dataset, torch.utils.data.IterableDataset))
-        if not simple:
-            yield from loader
-            return
-        torch.empty((), dtype=torch.int64).random_(generator=loader.generator)      # _BaseDataLoaderIter's base seed
-        dataset, collate = loader.dataset, loader.collate_fn
-        for indices in loader.batch_sampler:
-            yield collate([dataset[i] for i in indices])
+        from .utils.utils import iter_batches
+        return iter_batches(loader)
 
     def train_epoch(self, epoch):
         # model.train() walks every submodule (65 us on a 100-keyframe GridNet) and an epoch here is ONE step: skip the

@@ -1093,6 +1093,72 @@ def lm_normal_eq(coords_frame, R_frame, grad_world, sdf_pred, sdf_gt, loss_type=
     return H, out[21:27].reshape(6, 1), out[27]
 
 
+class LmTrackStep:
+    """One Levenberg-Marquardt step of the keyframe tracker as ONE library call and ONE host synchronisation
+    (miso_lm_track_step): pose from the corrections, samples into the submap frame, fused SDF forward + coordinate
+    backward, normal equations, damped solve, corrections updated in place; the truncation filter, the frame-id /
+    validity checks and the field-of-view count that the reference settles with host round trips come back as
+    counters.  Scratch is sized for ``n`` rows and reused."""
+
+    def __init__(self, n: int, device, pack: DecoderPack):
+        self.n = int(n)
+        f32 = dict(device=device, dtype=torch.float32)
+        mw = sdf_mask_words(pack)
+        self.pose = torch.empty(12, **f32)
+        self.xw = torch.empty((self.n, 3), **f32)
+        self.sdf = torch.empty(self.n, **f32)
+        self.grad = torch.empty((self.n, 3), **f32)
+        self.ones = torch.ones(self.n, **f32)
+        self.mask = torch.empty(((self.n + 63) // 64) * 64 * mw, device=device, dtype=torch.int32)
+        self.sums = torch.empty(36, **f32)
+        self.info = torch.empty(8, **f32)
+        self.info_host = torch.empty(8, dtype=torch.float32, pin_memory=True)
+
+    def __call__(self, features, meta: GridMeta, pack: DecoderPack, coords_frame, target, valid, frame_ids, keyframe_id,
+                 trunc_dist, R_base, t_base, rot_correction, trans_correction, loss_type: str, gm_scale: float,
+                 lm_lambda: float):
+        """-> [|delta_R| rad, |delta_t|, |g|, rows in bound, rows kept, wrong frame ids, invalid rows, 0] (host floats).
+        rot_correction / trans_correction: 3-float views of the pose parameters, updated in place."""
+        n = self.n
+
+        def col(c, dtypes):
+            if c is None:
+                return None, 1
+            if c.dim() == 2 and c.shape[1] == 1:
+                c = c[:, 0]
+            if not (c.dim() == 1 and c.shape[0] == n and c.is_cuda and c.dtype in dtypes):
+                raise ValueError("LmTrackStep wants device columns (N,) or (N,1) of the batch's length")
+            return c, (c.stride(0) if n > 1 else 1)
+
+        a = _lib.LmTrack()
+        cf = coords_frame.detach()
+        if not (cf.shape == (n, 3) and cf.is_contiguous() and cf.dtype == torch.float32 and cf.is_cuda):
+            raise ValueError("LmTrackStep: coords fp32 contiguous (N,3) on the device")
+        tg, a.stride_target = col(target, (torch.float32,))
+        vl, a.stride_valid = col(valid, (torch.float32, torch.bool))
+        fi, a.stride_frame_ids = col(frame_ids, (torch.int64,))
+        for t_ in (R_base, t_base, rot_correction, trans_correction):
+            assert t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
+        assert R_base.numel() == 9 and t_base.numel() == 3 and rot_correction.numel() == 3 and trans_correction.numel() == 3
+        m, packed = pack.get()
+        g = _fill_grid([f.detach() for f in features], meta)
+        a.coords_frame, a.target, a.valid, a.frame_ids = cf.data_ptr(), tg.data_ptr(), 0 if vl is None else vl.data_ptr(), \
+            0 if fi is None else fi.data_ptr()
+        a.valid_is_bool = int(vl is not None and vl.dtype == torch.bool)
+        a.n, a.keyframe_id = n, int(keyframe_id)
+        a.trunc_dist = -1.0 if trunc_dist is None else float(trunc_dist)
+        a.R_base, a.t_base = R_base.data_ptr(), t_base.data_ptr()
+        a.rot_correction, a.trans_correction = rot_correction.data_ptr(), trans_correction.data_ptr()
+        a.loss_type, a.gm_scale, a.lm_lambda = {"L2": 2, "GM": 3}[loss_type], float(gm_scale), float(lm_lambda)
+        a.pose, a.coords_world, a.sdf, a.grad = self.pose.data_ptr(), self.xw.data_ptr(), self.sdf.data_ptr(), self.grad.data_ptr()
+        a.ones, a.relu_mask, a.sums, a.info = self.ones.data_ptr(), self.mask.data_ptr(), self.sums.data_ptr(), self.info.data_ptr()
+        _lib.check(_lib.load().miso_lm_track_step(C.byref(g), C.byref(m), _ptr(packed), C.byref(a), _stream(cf)),
+                   "miso_lm_track_step")
+        self.info_host.copy_(self.info, non_blocking=True)
+        torch.cuda.current_stream(cf.device).synchronize()
+        return self.info_host.tolist()
+
+
 # --------------------------------------------------------------------------- #
 # sample generation: posed depth frames -> SDF training rows
 # --------------------------------------------------------------------------- #

@@ -987,3 +987,75 @@ def test_fast_captured_step_equals_the_checked_one(n, tmp_path):
             # float atomics / slot sums reorder: same tolerance the captured-vs-eager trainer tests use
             scale = ta.abs().max().item()
             assert (ta - tb).abs().max().item() <= 2e-4 * scale + 1e-9, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lt", ["GM", "L2"])
+def test_lm_step_on_device_equals_the_op_by_op_step(lt, monkeypatch):
+    """Tracker.lm_step as one library call (miso_lm_track_step: one host synchronisation) against the op-by-op version
+    (eight synchronisations): four consecutive steps from the same start give the same info and the same pose
+    corrections, with the truncation filter active, a bool validity mask, label columns that are strided views, and
+    samples outside the bound; wrong frame ids / invalid rows raise the reference's assertions and leave the pose
+    alone."""
+    from miso_amd.grid_opt.slam.tracker import Tracker
+    dev = "cuda:0"
+    case = gc.CASES["small"]
+    g = G("tracker")
+    pts = T(gc.make_points(case))
+    n = pts.shape[0]
+    gen = torch.Generator().manual_seed(3)
+    pts = pts * 1.15                                            # some leave the bound
+    lab = torch.stack([T(g["sdf"])[:, 0] * (1.0 + 0.5 * torch.rand(n, generator=gen)), torch.ones(n), torch.zeros(n),
+                       torch.ones(n)], dim=1).to(dev)            # (n,4) block: columns are strided views
+
+    def make(valid_dtype=torch.bool, frame=1, bad_valid=False):
+        net = make_gridnet(case, dev, num_poses=2, optimize_pose=True)
+        net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+        net.set_initial_kf_pose(1, T(g["R0"]), T(g["t0"]), kf_key="KF1")
+        valid = (lab[:, 1:2] > 0) if valid_dtype == torch.bool else lab[:, 1:2]
+        if bad_valid:
+            valid = valid.clone()
+            valid[5] = 0
+        fid = torch.full((n, 1), frame, dtype=torch.int64, device=dev)
+
+        class DS(torch.utils.data.Dataset):
+            def select_keyframes(self, kfs):
+                pass
+
+            def __len__(self):
+                return 1
+
+            def __getitem__(self, i):
+                return ({"coords_frame": pts.to(dev), "sample_frame_ids": fid, "weights": lab[:, 3:4]},
+                        {"sdf": lab[:, 0:1], "sdf_valid": valid, "sdf_signs": lab[:, 2:3]})
+
+        cfg = {"device": dev, "train": {},
+               "tracking": {"learning_rate": 1e-3, "verbose": False, "gm_scale_sdf": 0.1, "lm_lambda": 5.0,
+                            "lm_max_iter": 3, "lm_tol_deg": 0.0, "lm_tol_m": 0.0, "loss_type": lt,
+                            "trunc_dist": 0.12, "solver": "lm"}}
+        return net, Tracker(net, DS(), cfg)
+
+    res = {}
+    for fused in (False, True):
+        net, trk = make()
+        if not fused:
+            monkeypatch.setattr(Tracker, "_lm_step_on_device", lambda self, *a: None)
+        else:
+            monkeypatch.undo()
+        infos = [trk.lm_step(1) for _ in range(4)]
+        assert (trk.__dict__.get("_lm_dev") is not None) == fused
+        res[fused] = (infos, net.rotation_corrections.detach().clone(), net.translation_corrections.detach().clone())
+    for a, b in zip(res[False][0], res[True][0]):
+        for key in a:
+            assert abs(a[key] - b[key]) <= 2e-4 * abs(a[key]) + 1e-7, (key, a[key], b[key])
+    assert 0.0 < res[True][0][0]["fov_overlap"] < 1.0
+    close(res[True][1], res[False][1], 2e-4, 1e-7)
+    close(res[True][2], res[False][2], 2e-4, 1e-7)
+    # the reference's assertions, without having moved the pose
+    for kw in (dict(frame=0), dict(bad_valid=True)):
+        net, trk = make(**kw)
+        before = (net.rotation_corrections.detach().clone(), net.translation_corrections.detach().clone())
+        with pytest.raises(AssertionError):
+            trk.lm_step(1)
+        assert torch.equal(net.rotation_corrections.detach(), before[0])
+        assert torch.equal(net.translation_corrections.detach(), before[1])
