@@ -403,6 +403,29 @@ typedef struct {
 int miso_lm_track_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const miso_lm_track_t* args,
                        void* stream);
 
+/* --- one Adam iteration of the tracker's pose refinement (Tracker.track_window with MisoLossTracking: tracker.py:95-118,
+ * loss.py:517-586, one Trainer step incl. its NaN guard) without a host round trip.  `s` as for miso_lm_track_step
+ * (inputs, base pose, the two corrections -- updated by the Adam step --, scratch; s.ones and s.loss_type are not used;
+ * s.info[0] receives the loss).  resid = valid && |target| < trunc ? sdf - target : 0; loss = weight_sdf * mean over
+ * ALL rows of resid^2 (2) | |resid| (1) | w resid^2 with w = c / (c + resid^2)^2 held constant (3).  The gradient
+ * reaches the keyframe's six correction numbers through x_world = R x + t and R = R_base so3_exp_map(dr); Adam with the
+ * step scalars of adam_table (miso_adam_scalars_table) and the moments in `state` (device: 12 floats m, v, then int32
+ * {steps taken, steps skipped for a NaN loss, iterations}; zero it when a window starts -- the reference builds a new
+ * optimizer per window).  loss_ring[i] = loss of iteration i. */
+typedef struct {
+  miso_lm_track_t s;
+  int32_t loss_type;
+  float weight_sdf, gm_scale;
+  float* grad_pred;              /* scratch N */
+  const float* adam_table;
+  int32_t adam_table_len;
+  float* state;
+  float* loss_ring;
+  int32_t ring_len;
+} miso_track_adam_t;
+int miso_track_adam_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const miso_track_adam_t* args,
+                         void* stream);
+
 /* --- mapping loss (value + d/d pred) --------------------------------------
  * loss_type 1 = L1, 2 = L2.  pred/target (N); valid/sign/weight (N) or NULL
  * (= all valid / no free-space rows / unit weights).  Writes grad_pred (N) =

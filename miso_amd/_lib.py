@@ -52,6 +52,12 @@ class LmTrack(C.Structure):
                 ("info", C.c_void_p)]
 
 
+class TrackAdam(C.Structure):
+    _fields_ = [("s", LmTrack), ("loss_type", C.c_int32), ("weight_sdf", C.c_float), ("gm_scale", C.c_float),
+                ("grad_pred", C.c_void_p), ("adam_table", C.c_void_p), ("adam_table_len", C.c_int32),
+                ("state", C.c_void_p), ("loss_ring", C.c_void_p), ("ring_len", C.c_int32)]
+
+
 class Grid(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("ignore_mask", C.c_uint32),
                 ("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3),
@@ -143,6 +149,7 @@ SIGNATURES = {
     "miso_encode_bwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p]),
     "miso_grad_pull_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32]),
+    "miso_track_adam_step": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(TrackAdam), C.c_void_p]),
     "miso_lm_track_step": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(LmTrack), C.c_void_p]),
     "miso_adam_scalars_table": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                           C.c_void_p]),

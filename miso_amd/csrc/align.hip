@@ -91,37 +91,6 @@ __device__ __forceinline__ float nan_to_num_f(float v) {
   return v;
 }
 
-// d loss / d w for R = R0 Exp(w), given gR = d loss / d R: G = R0^T gR, Exp = I + a K + b K^2 with
-// a = sin(th)/th, b = (1 - cos th)/th^2, th = sqrt(max(|w|^2, eps)) -- the clamp passes no gradient below eps
-// (torch.clamp backward), so near w = 0 only the a dK and b d(K^2) terms remain.  In double: three values per
-// submap per iteration, and the a', b' differences cancel badly in fp32.
-__device__ __forceinline__ void so3_exp_backward(const float w_[3], const double G[9], double gw[3]) {
-  const double w[3] = {w_[0], w_[1], w_[2]};
-  const float sqf = (w_[0] * w_[0] + w_[1] * w_[1]) + w_[2] * w_[2];
-  const bool live = sqf >= 1e-4f;
-  const double th = sqrt(fmax((double)sqf, 1e-4));
-  const double s = sin(th), c = cos(th);
-  const double a = s / th, b = (1.0 - c) / (th * th);
-  const double K[9] = {0., -w[2], w[1], w[2], 0., -w[0], -w[1], w[0], 0.};
-  double KK[9], M[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) KK[i * 3 + j] = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
-  // M = G K^T + K^T G
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double v = 0.;
-      for (int q = 0; q < 3; ++q) v += G[i * 3 + q] * K[j * 3 + q] + K[q * 3 + i] * G[q * 3 + j];
-      M[i * 3 + j] = v;
-    }
-  double gk = 0., gkk = 0.;
-  for (int i = 0; i < 9; ++i) { gk += G[i] * K[i]; gkk += G[i] * KK[i]; }
-  const double da = live ? (th * c - s) / (th * th) / th : 0.;                     // a'(th) / th
-  const double db = live ? (th * s - 2.0 * (1.0 - c)) / (th * th * th) / th : 0.;  // b'(th) / th
-  const double veeG[3] = {G[7] - G[5], G[2] - G[6], G[3] - G[1]};
-  const double veeM[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
-  for (int q = 0; q < 3; ++q) gw[q] = a * veeG[q] + b * veeM[q] + (da * gk + db * gkk) * w[q];
-}
-
 constexpr int EPI_A_THREADS = 256;
 constexpr int EPI_A_PAIRS = 512;      // pairs staged in LDS per pass (S <= 64 => at most 2016 pairs: 4 passes)
 

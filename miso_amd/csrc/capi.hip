@@ -29,6 +29,8 @@ hipError_t launch_adam_touched(float*, float*, float*, float*, unsigned char*, u
                                double, double, int, int, const float*, hipStream_t, const float*, const int32_t*, int);
 hipError_t launch_adam_bump(int32_t*, const float*, hipStream_t);
 hipError_t launch_lm_track_head(const LmTrackK&, hipStream_t);
+hipError_t launch_track_loss(const TrackAdamK&, hipStream_t);
+hipError_t launch_track_tail(const TrackAdamK&, hipStream_t);
 hipError_t launch_lm_track_tail(const LmTrackK&, const float*, const float*, int, float, hipStream_t);
 void adam_scalars_table(double, double, double, double, int, int, float*);
 hipError_t launch_mapping_batch(const float*, const float*, int32_t, const int64_t*, int64_t, const int64_t*,
@@ -625,6 +627,54 @@ int miso_lm_normal_eq(const float* coords_frame, const float* R_frame, const flo
   if (loss_type == 3 && !(gm_scale > 0.0f)) return MISO_E_BADARG;
   return (int)launch_lm_normal_eq(coords_frame, R_frame, grad_sdf_x, sdf, target, n, loss_type, gm_scale, out,
                                   (hipStream_t)stream);
+}
+
+static int lm_track_args(const miso_grid_t* grid, const miso_lm_track_t* a, LmTrackK* out) {
+  LmTrackK& k = *out;
+  memset(&k, 0, sizeof(k));
+  k.x = a->coords_frame; k.gt = a->target; k.valid = a->valid; k.frame_ids = a->frame_ids;
+  k.s_gt = a->stride_target; k.s_valid = a->stride_valid; k.s_fid = a->stride_frame_ids;
+  k.valid_is_bool = a->valid_is_bool; k.n = a->n; k.kf = a->keyframe_id; k.trunc = a->trunc_dist;
+  k.Rwk = a->R_base; k.twk = a->t_base; k.dr = a->rot_correction; k.dt = a->trans_correction;
+  k.pose = a->pose; k.xw = a->coords_world; k.sums = a->sums; k.info = a->info;
+  for (int i = 0; i < 3; ++i) { k.bmin[i] = grid->bound_min[i]; k.bmax[i] = grid->bound_max[i]; }
+  k.lm_lambda = a->lm_lambda;
+  return MISO_OK;
+}
+
+int miso_track_adam_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const miso_track_adam_t* t,
+                         void* stream) {
+  if (!t || !grid) return MISO_E_BADARG;
+  const miso_lm_track_t* a = &t->s;
+  if (a->n < 0 || !a->R_base || !a->t_base || !a->rot_correction || !a->trans_correction || !a->pose || !a->sums ||
+      !a->info || !t->adam_table || t->adam_table_len < 1 || !t->state || t->ring_len < 0 || (t->ring_len > 0 && !t->loss_ring))
+    return MISO_E_BADARG;
+  if (a->n > 0 && (!a->coords_frame || !a->target || !a->coords_world || !a->sdf || !a->grad || !a->relu_mask || !t->grad_pred))
+    return MISO_E_BADARG;
+  if (a->stride_target < 0 || a->stride_valid < 0 || a->stride_frame_ids < 0) return MISO_E_BADARG;
+  if (t->loss_type < 1 || t->loss_type > 3) return MISO_E_UNSUPPORTED;
+  if (t->loss_type == 3 && !(t->gm_scale > 0.0f)) return MISO_E_BADARG;
+  for (int l = 0; l < grid->n_levels && l < MISO_MAX_LEVELS; ++l)
+    if (grid->level[l].grad) return MISO_E_BADARG;
+  TrackAdamK k;
+  memset(&k, 0, sizeof(k));
+  lm_track_args(grid, a, &k.s);
+  k.loss_type = t->loss_type; k.weight_sdf = t->weight_sdf; k.gm_scale = t->gm_scale;
+  k.gpred = t->grad_pred; k.gx = a->grad; k.sdf = a->sdf;
+  k.table = reinterpret_cast<const AdamScalars*>(t->adam_table); k.table_len = t->adam_table_len;
+  k.state = t->state; k.ring = t->loss_ring; k.ring_len = t->ring_len;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = (int)launch_lm_track_head(k.s, st);
+  if (rc) return rc;
+  if (a->n > 0) {
+    rc = sdf_fwd_impl(grid, mlp, packed, a->coords_world, a->n, a->sdf, a->relu_mask, nullptr, stream);
+    if (rc) return rc;
+    rc = (int)launch_track_loss(k, st);
+    if (rc) return rc;
+    rc = sdf_bwd_impl(grid, mlp, packed, a->coords_world, a->n, t->grad_pred, a->relu_mask, a->grad, nullptr, nullptr, stream);
+    if (rc) return rc;
+  }
+  return (int)launch_track_tail(k, st);
 }
 
 int miso_lm_track_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const miso_lm_track_t* a,

@@ -180,6 +180,22 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p + (a.neg_step_size * m) / denom;            // addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// One Adam iteration of the tracker's pose refinement on the device (lm.hip: miso_track_adam_step)
+struct TrackAdamK {
+  LmTrackK s;
+  int loss_type;             // 1 L1, 2 L2, 3 GM
+  float weight_sdf, gm_scale;
+  float* gpred;              // scratch (N): d loss / d sdf
+  const float* gx;           // (N,3): d loss / d x_world, from the fused coordinate backward
+  const float* sdf;          // (N)
+  const AdamScalars* table;  // step scalars of steps 1..table_len (miso_adam_scalars_table)
+  int table_len;
+  float* state;              // 12 floats m[6] v[6], then int32 {steps taken, skipped, iterations}
+  float* ring;               // loss of iteration i at ring[i], i < ring_len
+  int ring_len;
+};
+
+
 
 // Pointwise mapping loss (grid_opt/loss.py:594-635, :668-700) shared by loss.hip and the fused
 // backward.  g / gf: d(w_sdf * sdf term) / ds and d(w_fs * free-space term) / ds BEFORE the 1/N of

@@ -201,6 +201,114 @@ __global__ void lm_solve_kernel(LmTrackK k) {
   k.info[7] = 0.0f;
 }
 
+// ---- the tracker's Adam solver (Tracker.track_window with MisoLossTracking, tracker.py:95-118 + loss.py:517-586 + the
+// Trainer step) as a launch sequence without a host round trip: pose -> samples into the submap frame -> fused forward
+// -> residual / loss / d loss / d sdf -> fused coordinate backward -> pose cotangents -> so3_exp backward + Adam on the
+// six numbers of the keyframe's corrections.  sums: [0,9) d loss / d R, [9,12) d loss / d t, [12] loss sum.
+__global__ __launch_bounds__(256) void track_loss_kernel(TrackAdamK k) {
+  const LmTrackK& s = k.s;
+  const float inv_n = 1.0f / (float)s.n;
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = s.gt[i * s.s_gt];
+    bool ok = true;
+    if (s.valid)
+      ok = s.valid_is_bool ? reinterpret_cast<const unsigned char*>(s.valid)[i * s.s_valid] != 0
+                           : reinterpret_cast<const float*>(s.valid)[i * s.s_valid] == 1.0f;
+    if (s.trunc >= 0.0f) ok = ok && (fabsf(g) < s.trunc);
+    const float r = ok ? k.sdf[i] - g : 0.0f;        // torch.where(valid == 1, pred - gt, 0)
+    float d;
+    if (k.loss_type == 2) { acc += r * r; d = 2.0f * r; }
+    else if (k.loss_type == 1) { acc += fabsf(r); d = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f); }
+    else { const float q = k.gm_scale + r * r, w = k.gm_scale / (q * q); acc += w * r * r; d = w * 2.0f * r; }
+    k.gpred[i] = ok ? k.weight_sdf * d * inv_n : 0.0f;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (red[0] + red[1]) + (red[2] + red[3]);
+    if (v != 0.0f || v != v) atomic_add_f32(s.sums + 12, k.weight_sdf * v * inv_n);
+  }
+}
+
+__global__ __launch_bounds__(256) void track_reduce_kernel(TrackAdamK k) {
+  const LmTrackK& s = k.s;
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g0 = k.gx[3 * i], g1 = k.gx[3 * i + 1], g2 = k.gx[3 * i + 2];
+    const float x0 = s.x[3 * i], x1 = s.x[3 * i + 1], x2 = s.x[3 * i + 2];
+    acc[0] += g0 * x0; acc[1] += g0 * x1; acc[2] += g0 * x2;      // d loss / d R = sum g x^T   (y = R x + t)
+    acc[3] += g1 * x0; acc[4] += g1 * x1; acc[5] += g1 * x2;
+    acc[6] += g2 * x0; acc[7] += g2 * x1; acc[8] += g2 * x2;
+    acc[9] += g0; acc[10] += g1; acc[11] += g2;
+  }
+  __shared__ float red[4][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    float v = acc[i];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (v != 0.0f || v != v) atomic_add_f32(s.sums + threadIdx.x, v);
+  }
+}
+
+__global__ void track_adam_kernel(TrackAdamK k) {
+  if (threadIdx.x != 0) return;
+  const LmTrackK& s = k.s;
+  int32_t* cnt = reinterpret_cast<int32_t*>(k.state + 12);      // {steps taken, skipped, iterations}
+  const int it = cnt[2];
+  const float loss = s.sums[12];
+  if (it < k.ring_len) k.ring[it] = loss;
+  cnt[2] = it + 1;
+  s.info[0] = loss;
+  if (!(loss == loss)) { cnt[1] += 1; return; }                  // "Loss is nan! Skip backward step."
+  // R = Rwk E(dr):  d loss / d E = Rwk^T (d loss / d R), then through the exponential map (as the alignment epilogue)
+  double G[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      G[i * 3 + j] = (double)s.Rwk[i] * s.sums[j] + (double)s.Rwk[3 + i] * s.sums[3 + j] + (double)s.Rwk[6 + i] * s.sums[6 + j];
+  const float w[3] = {s.dr[0], s.dr[1], s.dr[2]};
+  double gw[3];
+  so3_exp_backward(w, G, gw);
+  const float g6[6] = {(float)gw[0], (float)gw[1], (float)gw[2], s.sums[9], s.sums[10], s.sums[11]};
+  const int t = cnt[0] + 1;
+  cnt[0] = t;
+  const AdamScalars a = k.table[min(t, k.table_len) - 1];
+  float* m = k.state;
+  float* v = k.state + 6;
+  for (int i = 0; i < 3; ++i) {
+    adam_one(s.dr[i], g6[i], m[i], v[i], a);
+    adam_one(s.dt[i], g6[3 + i], m[3 + i], v[3 + i], a);
+  }
+}
+
+hipError_t launch_track_loss(const TrackAdamK& k, hipStream_t st) {
+  if (k.s.n <= 0) return hipSuccess;
+  unsigned blocks = (unsigned)((k.s.n + 255) / 256);
+  if (blocks > 128u) blocks = 128u;
+  track_loss_kernel<<<blocks, 256, 0, st>>>(k);
+  return hipGetLastError();
+}
+
+hipError_t launch_track_tail(const TrackAdamK& k, hipStream_t st) {
+  if (k.s.n > 0) {
+    unsigned blocks = (unsigned)((k.s.n + 255) / 256);
+    if (blocks > 128u) blocks = 128u;
+    track_reduce_kernel<<<blocks, 256, 0, st>>>(k);
+  }
+  track_adam_kernel<<<1, 64, 0, st>>>(k);
+  return hipGetLastError();
+}
+
 hipError_t launch_lm_track_head(const LmTrackK& k, hipStream_t s) {
   lm_pose_kernel<<<1, 64, 0, s>>>(k);
   if (k.n > 0) {

@@ -63,8 +63,77 @@ class Tracker:
         self.dataset.select_keyframes(optimize_kfs)
         cfg_train = deepcopy(self.cfg)['train']
         cfg_train.update(epochs=iterations, learning_rate=self.lr, verbose=self.verbose)
+        if self._track_window_on_device(optimize_kfs, iterations, cfg_train):
+            return
         Trainer(cfg_train, self.grid, self.loss_fn, self.train_loader, None, self.cfg['device'],
                 torch.float32).train()
+
+    def _track_window_on_device(self, optimize_kfs, iterations, cfg_train) -> bool:
+        """The window above for ONE keyframe as `iterations` library calls (ops.TrackAdamWindow) and one host
+        synchronisation at the end: what Trainer.train() does here is, per epoch, one batch, MisoLossTracking through
+        autograd (a unique() with a host read-back, so3_exp_map chains, the rigid map and its backward), a NaN check that
+        reads the loss back, and Adam over the pose tensors of which only this keyframe's six numbers have a gradient --
+        2.3 ms per iteration at 16 384 samples against ~0.1 ms of GPU work.  False: not this configuration, the
+        Trainer runs."""
+        from miso_amd import ops
+        from miso_amd.grid_opt.loss import MisoLossTracking
+        lf, grid = self.loss_fn, self.grid
+        if (len(optimize_kfs) != 1 or type(lf) is not MisoLossTracking or lf.loss_type not in ('L1', 'L2', 'GM')
+                or cfg_train.get('optimizer') != 'adam' or cfg_train.get('eval_every', -1) > 0
+                or cfg_train.get('ckpt_every', -1) > 0 or cfg_train.get('pretrained_model') is not None
+                or not hasattr(grid, '_fused_decoder') or iterations < 1):
+            return False
+        if str(self.cfg['device']).startswith('cpu') or not grid.Rwk.is_cuda:
+            return False
+        pack = grid._fused_decoder()
+        if pack is None:
+            return False
+        kf_key = optimize_kfs[0]
+        kf = grid.pose_key_to_id(f'KF{kf_key}')
+        loader = self.train_loader
+        batches = []
+        win = None
+        feats = [g.feature for g in grid.features]
+        meta = grid.features[0].grid_meta(grid.ignore_level_)
+        dr, dt = grid.rotation_corrections.data[kf], grid.translation_corrections.data[kf]
+        dirs = self.__dict__.setdefault('_log_dirs_made', set())
+        if cfg_train['log_dir'] not in dirs:                    # Trainer.set_logging creates them
+            import os
+            for d in (cfg_train['log_dir'], os.path.join(cfg_train['log_dir'], 'ckpt'),
+                      os.path.join(cfg_train['log_dir'], 'tensorboard')):
+                utils.cond_mkdir(d)
+            dirs.add(cfg_train['log_dir'])
+        grid.train()
+        for epoch in range(iterations):
+            for step_i, (model_input, gt) in enumerate(utils.iter_batches(loader)):
+                model_input, gt = utils.prepare_batch(model_input, gt, self.cfg['device'])
+                coords_frame = model_input['coords_frame'][0]
+                n = coords_frame.shape[0]
+                if win is None:
+                    win = self.__dict__.get('_adam_dev')
+                    if (win is None or win.n != n or win.hyper != (float(self.lr), (0.9, 0.999), 1e-8, int(iterations))
+                            or win.pose.device != coords_frame.device):
+                        win = self.__dict__['_adam_dev'] = ops.TrackAdamWindow(n, coords_frame.device, pack, self.lr,
+                                                                               iterations)
+                    win.reset()
+                elif n != win.n:
+                    raise RuntimeError("tracking batches of one window differ in size")
+                win.step(feats, meta, pack, coords_frame.contiguous(), gt['sdf'][0], gt['sdf_valid'][0],
+                         model_input['sample_frame_ids'][0], kf_key, lf.trunc_dist, grid.Rwk[kf], grid.twk[kf], dr, dt,
+                         lf.loss_type, lf.weight_sdf, lf.gm_scale_sdf)
+                batches.append((epoch, step_i))
+        torch.autograd.graph.increment_version(grid.rotation_corrections)      # written through raw pointers:
+        torch.autograd.graph.increment_version(grid.translation_corrections)   # pose caches key on the versions
+        if win is None:
+            return True
+        losses, steps, skipped = win.finish()
+        for _ in range(skipped):
+            logger.warning("Loss is nan! Skip backward step.")
+        if self.verbose:
+            for (epoch, step_i), loss in zip(batches, losses):
+                if step_i % 10 == 0:
+                    logger.info(f"Train epoch {epoch} step {step_i} | train_loss={loss:.2e}.")
+        return True
 
     def track(self, optimize_kf: int):
         if self.disable:

@@ -1114,11 +1114,8 @@ class LmTrackStep:
         self.info = torch.empty(8, **f32)
         self.info_host = torch.empty(8, dtype=torch.float32, pin_memory=True)
 
-    def __call__(self, features, meta: GridMeta, pack: DecoderPack, coords_frame, target, valid, frame_ids, keyframe_id,
-                 trunc_dist, R_base, t_base, rot_correction, trans_correction, loss_type: str, gm_scale: float,
-                 lm_lambda: float):
-        """-> [|delta_R| rad, |delta_t|, |g|, rows in bound, rows kept, wrong frame ids, invalid rows, 0] (host floats).
-        rot_correction / trans_correction: 3-float views of the pose parameters, updated in place."""
+    def _fill(self, a, coords_frame, target, valid, frame_ids, keyframe_id, trunc_dist, R_base, t_base, rot_correction,
+              trans_correction):
         n = self.n
 
         def col(c, dtypes):
@@ -1130,7 +1127,6 @@ class LmTrackStep:
                 raise ValueError("LmTrackStep wants device columns (N,) or (N,1) of the batch's length")
             return c, (c.stride(0) if n > 1 else 1)
 
-        a = _lib.LmTrack()
         cf = coords_frame.detach()
         if not (cf.shape == (n, 3) and cf.is_contiguous() and cf.dtype == torch.float32 and cf.is_cuda):
             raise ValueError("LmTrackStep: coords fp32 contiguous (N,3) on the device")
@@ -1140,8 +1136,6 @@ class LmTrackStep:
         for t_ in (R_base, t_base, rot_correction, trans_correction):
             assert t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous()
         assert R_base.numel() == 9 and t_base.numel() == 3 and rot_correction.numel() == 3 and trans_correction.numel() == 3
-        m, packed = pack.get()
-        g = _fill_grid([f.detach() for f in features], meta)
         a.coords_frame, a.target, a.valid, a.frame_ids = cf.data_ptr(), tg.data_ptr(), 0 if vl is None else vl.data_ptr(), \
             0 if fi is None else fi.data_ptr()
         a.valid_is_bool = int(vl is not None and vl.dtype == torch.bool)
@@ -1149,14 +1143,66 @@ class LmTrackStep:
         a.trunc_dist = -1.0 if trunc_dist is None else float(trunc_dist)
         a.R_base, a.t_base = R_base.data_ptr(), t_base.data_ptr()
         a.rot_correction, a.trans_correction = rot_correction.data_ptr(), trans_correction.data_ptr()
-        a.loss_type, a.gm_scale, a.lm_lambda = {"L2": 2, "GM": 3}[loss_type], float(gm_scale), float(lm_lambda)
         a.pose, a.coords_world, a.sdf, a.grad = self.pose.data_ptr(), self.xw.data_ptr(), self.sdf.data_ptr(), self.grad.data_ptr()
         a.ones, a.relu_mask, a.sums, a.info = self.ones.data_ptr(), self.mask.data_ptr(), self.sums.data_ptr(), self.info.data_ptr()
+        return cf
+
+    def __call__(self, features, meta: GridMeta, pack: DecoderPack, coords_frame, target, valid, frame_ids, keyframe_id,
+                 trunc_dist, R_base, t_base, rot_correction, trans_correction, loss_type: str, gm_scale: float,
+                 lm_lambda: float):
+        """-> [|delta_R| rad, |delta_t|, |g|, rows in bound, rows kept, wrong frame ids, invalid rows, 0] (host floats).
+        rot_correction / trans_correction: 3-float views of the pose parameters, updated in place."""
+        a = _lib.LmTrack()
+        cf = self._fill(a, coords_frame, target, valid, frame_ids, keyframe_id, trunc_dist, R_base, t_base, rot_correction,
+                        trans_correction)
+        a.loss_type, a.gm_scale, a.lm_lambda = {"L2": 2, "GM": 3}[loss_type], float(gm_scale), float(lm_lambda)
+        m, packed = pack.get()
+        g = _fill_grid([f.detach() for f in features], meta)
         _lib.check(_lib.load().miso_lm_track_step(C.byref(g), C.byref(m), _ptr(packed), C.byref(a), _stream(cf)),
                    "miso_lm_track_step")
         self.info_host.copy_(self.info, non_blocking=True)
         torch.cuda.current_stream(cf.device).synchronize()
         return self.info_host.tolist()
+
+
+class TrackAdamWindow(LmTrackStep):
+    """The tracker's Adam solver on the device (miso_track_adam_step): every iteration is one library call and nothing
+    is read back until ``finish()``.  A window = a fresh optimizer (zero moments, step count 0), like the Trainer the
+    reference builds per Tracker.track_window."""
+
+    def __init__(self, n: int, device, pack: DecoderPack, lr: float, iterations: int, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(n, device, pack)
+        self.iterations = int(iterations)
+        host = torch.empty((max(self.iterations, 1), 6), dtype=torch.float32)
+        _lib.check(_lib.load().miso_adam_scalars_table(lr, betas[0], betas[1], eps, 1, host.shape[0],
+                                                       C.c_void_p(host.data_ptr())), "miso_adam_scalars_table")
+        self.table = host.to(device)
+        self.hyper = (float(lr), tuple(betas), float(eps), self.iterations)
+        self.state = torch.zeros(16, device=device, dtype=torch.float32)
+        self.ring = torch.zeros(max(self.iterations, 1), device=device, dtype=torch.float32)
+        self.gpred = torch.empty(self.n, device=device, dtype=torch.float32)
+
+    def reset(self):
+        self.state.zero_()
+
+    def step(self, features, meta: GridMeta, pack: DecoderPack, coords_frame, target, valid, frame_ids, keyframe_id,
+             trunc_dist, R_base, t_base, rot_correction, trans_correction, loss_type: str, weight_sdf: float,
+             gm_scale: float):
+        t = _lib.TrackAdam()
+        cf = self._fill(t.s, coords_frame, target, valid, frame_ids, keyframe_id, trunc_dist, R_base, t_base,
+                        rot_correction, trans_correction)
+        t.loss_type, t.weight_sdf, t.gm_scale = {"L1": 1, "L2": 2, "GM": 3}[loss_type], float(weight_sdf), float(gm_scale)
+        t.grad_pred, t.adam_table, t.adam_table_len = self.gpred.data_ptr(), self.table.data_ptr(), self.table.shape[0]
+        t.state, t.loss_ring, t.ring_len = self.state.data_ptr(), self.ring.data_ptr(), self.ring.shape[0]
+        m, packed = pack.get()
+        g = _fill_grid([f.detach() for f in features], meta)
+        _lib.check(_lib.load().miso_track_adam_step(C.byref(g), C.byref(m), _ptr(packed), C.byref(t), _stream(cf)),
+                   "miso_track_adam_step")
+
+    def finish(self):
+        """One synchronisation: (losses of the iterations run, Adam steps taken, steps skipped for a NaN loss)."""
+        cnt = self.state[12:15].view(torch.int32).cpu().tolist()
+        return self.ring[:cnt[2]].cpu().tolist(), cnt[0], cnt[1]
 
 
 # --------------------------------------------------------------------------- #

@@ -1059,3 +1059,75 @@ def test_lm_step_on_device_equals_the_op_by_op_step(lt, monkeypatch):
             trk.lm_step(1)
         assert torch.equal(net.rotation_corrections.detach(), before[0])
         assert torch.equal(net.translation_corrections.detach(), before[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lt", ["L1", "L2", "GM"])
+def test_track_window_on_device_equals_the_trainer_window(lt, monkeypatch, tmp_path, caplog):
+    """Tracker.track_window (the 'adam' solver of configs/rgbd/scannet.yaml) as library calls without a host round trip
+    (miso_track_adam_step) against the Trainer + MisoLossTracking + autograd + DenseAdam window it replaces: the same
+    pose corrections after 8 iterations from the same start, with a truncation filter, a bool validity mask with holes,
+    strided label columns and samples outside the bound; other keyframes' corrections do not move; a NaN loss (NaN
+    features) skips every step and says so."""
+    import logging
+    from miso_amd.grid_opt.slam.tracker import Tracker
+    dev = "cuda:0"
+    case = gc.CASES["small"]
+    g = G("tracker")
+    pts = (T(gc.make_points(case)) * 1.1).to(dev)
+    n = pts.shape[0]
+    gen = torch.Generator().manual_seed(4)
+    lab = torch.stack([T(g["sdf"])[:, 0] * (1.0 + 0.5 * torch.rand(n, generator=gen)),
+                       (torch.rand(n, generator=gen) > 0.1).float()], dim=1).to(dev)
+    fid = torch.ones(n, 1, dtype=torch.int64, device=dev)
+
+    def run(fused, nan_feats=False):
+        net = make_gridnet(case, dev, num_poses=3, optimize_pose=True)
+        net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+        net.set_initial_kf_pose(1, T(g["R0"]), T(g["t0"]), kf_key="KF1")
+        net.set_initial_kf_pose(2, torch.eye(3), torch.ones(3, 1) * 0.1, kf_key="KF2")
+        with torch.no_grad():
+            net.rotation_corrections[1] += torch.tensor([0.02, -0.01, 0.015], device=dev)
+            net.rotation_corrections[2] += 0.3
+        if nan_feats:
+            with torch.no_grad():
+                net.features[0].feature.fill_(float("nan"))
+
+        class DS(torch.utils.data.Dataset):
+            def select_keyframes(self, kfs):
+                pass
+
+            def __len__(self):
+                return 1
+
+            def __getitem__(self, i):
+                sdf = lab[:, 0:1]
+                return ({"coords_frame": pts, "sample_frame_ids": fid, "weights": torch.ones(n, 1, device=dev)},
+                        {"sdf": sdf, "sdf_valid": lab[:, 1:2] > 0, "sdf_signs": torch.zeros(n, 1, device=dev)})
+
+        cfg = {"device": dev,
+               "train": {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 1, "ckpt_every": -1,
+                         "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": str(tmp_path)},
+               "tracking": {"learning_rate": 2e-3, "verbose": False, "gm_scale_sdf": 0.1, "lm_lambda": 5.0,
+                            "lm_max_iter": 3, "lm_tol_deg": 0.0, "lm_tol_m": 0.0, "loss_type": lt,
+                            "trunc_dist": 0.15, "solver": "adam"}}
+        trk = Tracker(net, DS(), cfg)
+        if not fused:
+            monkeypatch.setattr(Tracker, "_track_window_on_device", lambda self, *a: False)
+        else:
+            monkeypatch.undo()
+        trk.track_window([1], iterations=8)
+        assert (trk.__dict__.get("_adam_dev") is not None) == fused
+        return net.rotation_corrections.detach().clone(), net.translation_corrections.detach().clone()
+
+    ref, got = run(False), run(True)
+    assert (got[0][1] - torch.tensor([0.02, -0.01, 0.015], device=dev)).abs().max() > 5e-3      # it did move
+    # Adam normalises the gradient: after 8 steps of 2e-3 the two paths may differ by a fraction of one step
+    assert (ref[0] - got[0]).abs().max().item() <= 2e-4 and (ref[1] - got[1]).abs().max().item() <= 2e-4
+    for k in (0, 2):                                   # the locked keyframes
+        assert torch.equal(got[0][k], ref[0][k]) and torch.equal(got[1][k], ref[1][k])
+    with caplog.at_level(logging.WARNING):
+        ref_n, got_n = run(False, nan_feats=True), run(True, nan_feats=True)
+    assert sum("Loss is nan" in r.getMessage() for r in caplog.records) == 16          # 8 skipped steps each
+    assert torch.equal(ref_n[0], got_n[0]) and torch.equal(ref_n[1], got_n[1])          # nothing moved
+    assert torch.allclose(got_n[0][1], torch.tensor([0.02, -0.01, 0.015], device=dev))
