@@ -94,9 +94,68 @@ class _FastMappingPlan:
         self.step, self.dev, self.states, self.mine = step, dev, states, mine
         self.feats, self.need, self.pack, self.n, self.padded = list(feats), tuple(need), pack, n, padded
         self.dec_params = list(model.decoder.parameters())
-        self.other_params = [p for g in opt.param_groups for p in g['params'] if not any(p is f for f in mine)]
-        self.sig = self.signature(trainer)
+        self.hyper = (lr, (b1, b2), eps)
+        self.bind(trainer, states)
+        # kept with the model: the SLAM loop builds a new trainer (new optimizers) for every Mapper.mapping call, a few
+        # iterations each -- a later trainer over the same grids adopts the plan (adopt()) instead of paying for a
+        # new step, a new capture and a new plan every time
+        plans = model.__dict__.setdefault('_fast_plans', [])
+        plans.append(self)
+        del plans[:-8]
         return self
+
+    def bind(self, trainer, states):
+        import weakref
+        opt = trainer.optimizer
+        self.states = states
+        self.opt_ref = weakref.ref(opt)
+        self.other_params = [p for g in opt.param_groups for p in g['params'] if not any(p is f for f in self.mine)]
+        self.sig = self.signature(trainer)
+
+    @classmethod
+    def adopt(cls, trainer, n, padded):
+        """A plan built by an earlier trainer of the same model that fits this trainer's (fresh) optimizer: same grids,
+        same levels to train, same loss and Adam hyper-parameters.  The optimizer's state for those levels becomes the
+        plan's buffers, zeroed -- what a new torch.optim.Adam starts from."""
+        from miso_amd.grid_opt.loss import MisoLossMappingBase
+        opt, lf, model = trainer.optimizer, trainer.loss_func, trainer.model
+        plans = model.__dict__.get('_fast_plans')
+        if not plans or type(opt) is not DenseAdam or opt._optimizer_step_pre_hooks or opt._optimizer_step_post_hooks:
+            return None
+        if not (isinstance(lf, MisoLossMappingBase) and type(lf).compute is MisoLossMappingBase.compute):
+            return None
+        for plan in reversed(plans):
+            if plan.n != n or plan.padded != padded:
+                continue
+            old = plan.opt_ref()
+            if old is not None and old is not opt:
+                continue                              # still serving a live optimizer
+            feats = plan.feats
+            opt_params = {id(p) for group in opt.param_groups for p in group['params']}
+            need = tuple(id(f) in opt_params and f.requires_grad for f in feats)
+            if need != plan.need:
+                continue
+            groups = [g for g in opt.param_groups if any(any(p is f for f in plan.mine) for p in g['params'])]
+            if {(g['lr'], tuple(g['betas']), g['eps']) for g in groups} != {plan.hyper}:
+                continue
+            states = [opt.state[f] for f in plan.mine]
+            fresh = all(not st for st in states)
+            if not fresh and old is not opt:
+                continue                              # an optimizer with a history of its own: not ours to replace
+            if fresh:
+                for st, (m, v, act) in zip(states, [a for a in plan.step.adam_state if a is not None]):
+                    m.zero_(); v.zero_(); act.zero_()
+                    st.update(step=0, exp_avg=m, exp_avg_sq=v, active=act)
+                plan.dev.set_count(0)
+            saved = (plan.states, plan.opt_ref, plan.other_params, plan.sig)
+            plan.bind(trainer, states)
+            # everything else the capture baked in must still hold (loss scalars, flags, decoder weights ...): compare the
+            # new signature with the old one field by field except for the optimizer's identity and state addresses
+            if plan.sig[1:16] != saved[3][1:16]:
+                plan.states, plan.opt_ref, plan.other_params, plan.sig = saved
+                continue
+            return plan
+        return None
 
     def signature(self, trainer):
         """Everything the capture baked in, cheap to read: compared before every replay."""
@@ -252,7 +311,18 @@ class Trainer(object):
             total = fast.run(self, model_input, gt)
             if total is not None:
                 return total
-            self._fast_plan = None            # something changed: the checked path below rebuilds what is needed
+            self._fast_plan = None            # something changed (e.g. the coordinate schedule moved to another optimizer)
+        if (self.cfg.get('fast_captured_step', True) and '_fast_plans' in model.__dict__
+                and self.__dict__.get('_adopt_failed') != id(self.optimizer)):
+            # a plan an earlier trainer of this model left behind (Mapper.mapping builds a trainer per call)
+            cf = model_input['coords_frame'][0]
+            fast = _FastMappingPlan.adopt(self, cf.shape[0], model_input.get('live_rows') is not None)
+            if fast is not None:
+                total = fast.run(self, model_input, gt)
+                if total is not None:
+                    self._fast_plan = fast
+                    return total
+            self._adopt_failed = id(self.optimizer)     # until the optimizer changes
         if not (isinstance(lf, MisoLossMappingBase) and type(lf).compute is MisoLossMappingBase.compute):
             return None
         if lf.loss_type not in ('L1', 'L2') or lf.weight_eik > 0 or lf.use_stability or lf.weight_clip > 0:
@@ -270,8 +340,11 @@ class Trainer(object):
         feats = [g.feature for g in model.features]
         opt_params = {id(p) for group in self.optimizer.param_groups for p in group['params']}
         need = tuple(id(f) in opt_params and f.requires_grad for f in feats)
-        if not any(need) or any(f.requires_grad and not nd for f, nd in zip(feats, need)):
-            return None      # a feature grid would receive a gradient that no optimizer consumes: keep autograd's view
+        if not any(need):
+            return None
+        # (a level that requires grad but is not in the active optimizer -- the coordinate schedule trains one level at
+        # a time -- gets no gradient here.  Autograd would accumulate one that nothing consumes: the level's own
+        # optimizer starts with zero_grad() when its turn comes, trainer.py:206.  Parameters are the same either way.)
         n = coords_frame.shape[0]
         live = model_input.get('live_rows')          # padded batch (datasets with padded=True): count on the device
         ignore = tuple(bool(v) for v in model.ignore_level_)

@@ -1131,3 +1131,83 @@ def test_track_window_on_device_equals_the_trainer_window(lt, monkeypatch, tmp_p
     assert sum("Loss is nan" in r.getMessage() for r in caplog.records) == 16          # 8 skipped steps each
     assert torch.equal(ref_n[0], got_n[0]) and torch.equal(ref_n[1], got_n[1])          # nothing moved
     assert torch.allclose(got_n[0][1], torch.tensor([0.02, -0.01, 0.015], device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["coordinate+joint", "joint"])
+def test_mapper_calls_adopt_the_fast_plan(mode, tmp_path):
+    """The SLAM loop builds a new GridTrainer (new optimizers, fresh Adam state) for every Mapper.mapping call.  With
+    fast_captured_step the plan an earlier call left with the model is adopted by the next trainer -- its optimizer's
+    state becomes the plan's zeroed buffers -- instead of paying for a new step, capture and plan per call.  Three calls
+    of 8 iterations (coordinate schedule: 3 per level, then joint) must leave the same features as the checked path,
+    which builds everything anew each time; and from the second call on every step but none must go through a plan."""
+    from miso_amd.grid_opt.slam.mapper import Mapper
+    import miso_amd.grid_opt.trainer as TR
+    dev = "cuda:0"
+    c = gc.ATLAS
+    cfg_m = gc.model_cfg(c["bound"], 0.25, 4, 2, c["fdim"], c["hidden"], num_poses=2, init_stddev=1e-2)
+    n = 20000
+    g = torch.Generator().manual_seed(6)
+    batches = []
+    for b in range(3):
+        x = ((torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([1.8, 0.9, 1.8])).to(dev)
+        batches.append(({"coords_frame": x, "sample_frame_ids": torch.randint(0, 2, (n, 1), generator=g).to(dev),
+                         "weights": torch.ones(n, 1, device=dev)},
+                        {"sdf": (torch.rand(n, 1, generator=g) * 0.2 - 0.1).to(dev), "sdf_valid": torch.ones(n, 1, device=dev),
+                         "sdf_signs": (torch.rand(n, 1, generator=g) > 0.5).float().to(dev)}))
+
+    def run(fast):
+        torch.manual_seed(0)
+        from miso_amd.grid_opt.models.grid_net import GridNet
+        net = GridNet(cfg_m, device=dev).to(dev)
+        net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+        net.set_initial_kf_pose(1, torch.eye(3), torch.tensor([[0.1], [0.0], [-0.05]]), kf_key="KF1")
+        state = {"i": 0}
+
+        class DS(torch.utils.data.Dataset):
+            def select_keyframes(self, kfs):
+                pass
+
+            def __len__(self):
+                return 1
+
+            def __getitem__(self, i):
+                state["i"] += 1
+                return batches[state["i"] % 3]
+
+        cfg = {"device": dev,
+               "train": {"trainer": "base", "verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 50,
+                         "ckpt_every": -1, "eval_every": -1, "pretrained_model": None, "log_dir": str(tmp_path),
+                         "relchange_tol": 0, "max_epochs_in_level": 100, "grid_training_mode": mode,
+                         "fast_captured_step": fast},
+               "mapping": {"learning_rate": 5e-3, "loss_type": "L1", "weight_sdf": 1.0, "weight_eik": 0.0, "weight_fs": 0.1,
+                           "trunc_dist": 0.15, "finite_diff_eps": 0.01, "grad_method": "finitediff",
+                           "eik_trunc_dist": 0.024, "verbose": False}}
+        mp = Mapper(net, DS(), cfg)
+        runs = []
+        orig = TR._FastMappingPlan.run
+
+        def counting(self, *a, **k):
+            out = orig(self, *a, **k)
+            runs.append(out is not None)
+            return out
+
+        TR._FastMappingPlan.run = counting
+        try:
+            per_call = []
+            for _ in range(3):
+                before = sum(runs)
+                mp.mapping([0, 1], iterations=8, level_iterations=3)
+                per_call.append(sum(runs) - before)
+        finally:
+            TR._FastMappingPlan.run = orig
+        torch.cuda.synchronize()
+        return [f.feature.detach().clone() for f in net.features], per_call
+
+    ref, calls_ref = run(False)
+    got, calls = run(True)
+    assert calls_ref == [0, 0, 0]
+    assert calls[1] == 8 and calls[2] == 8, calls            # every step of the later calls through an adopted plan
+    for a, b in zip(ref, got):
+        scale = a.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-9
