@@ -42,6 +42,7 @@ class Tracker:
             self.loss_fn = MisoLossTracking(weight_sdf=1.0, loss_type=self.loss_type, trunc_dist=self.trunc_dist,
                                             gm_scale_sdf=self.gm_scale_sdf)
         self.disable = bool(t.get('disable', False))
+        self.fused = bool(t.get('fused', True))      # the device-side LM step / Adam window (ours; not a reference key)
         self.latest_fov_overlap = 1.0
 
     def initialize_window(self, head_kf, tail_kf):
@@ -78,7 +79,7 @@ class Tracker:
         from miso_amd import ops
         from miso_amd.grid_opt.loss import MisoLossTracking
         lf, grid = self.loss_fn, self.grid
-        if (len(optimize_kfs) != 1 or type(lf) is not MisoLossTracking or lf.loss_type not in ('L1', 'L2', 'GM')
+        if (not self.fused or len(optimize_kfs) != 1 or type(lf) is not MisoLossTracking or lf.loss_type not in ('L1', 'L2', 'GM')
                 or cfg_train.get('optimizer') != 'adam' or cfg_train.get('eval_every', -1) > 0
                 or cfg_train.get('ckpt_every', -1) > 0 or cfg_train.get('pretrained_model') is not None
                 or not hasattr(grid, '_fused_decoder') or iterations < 1):
@@ -157,7 +158,8 @@ class Tracker:
         fused decoder path; None otherwise.  The reference's op-by-op version waits for the device eight times per
         step (nonzero, two asserts, the overlap count, the solve, three norms): 1.08 ms per step at 16 384 samples of
         which the GPU works for under 0.1 ms."""
-        if not coords_frame.is_cuda or self.loss_type not in ('L2', 'GM') or not hasattr(self.grid, '_fused_decoder'):
+        if (not self.fused or not coords_frame.is_cuda or self.loss_type not in ('L2', 'GM')
+                or not hasattr(self.grid, '_fused_decoder')):
             return None
         pack = self.grid._fused_decoder()
         if pack is None or coords_frame.shape[0] == 0:

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Wall time of System.run on the synthetic lidar room of tests/test_datasets.py (7 keyframes, two submaps; LM or Adam
+tracking, coordinate+joint mapping), with the round-2 fast paths on and off (dev)."""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_cases as gc  # noqa: E402
+from test_datasets import _room_scan  # noqa: E402
+from miso_amd.grid_opt.datasets.sdf_3d_lidar import PosedSdf3DLidar  # noqa: E402
+from miso_amd.grid_opt.models.grid_atlas import GridAtlas  # noqa: E402
+from miso_amd.grid_opt.slam.system import System  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def run(solver, fast):
+    rs = np.random.RandomState(3)
+    F = 7
+    poses_gt = np.tile(np.eye(4), (F, 1, 1))
+    for f in range(F):
+        poses_gt[f, :3, :3] = gc.rodrigues([0.0, 0.0, 0.05 * f])
+        poses_gt[f, :3, 3] = [-3.0 + 1.0 * f, 0.3 * f, 1.5]
+    bias = np.eye(4)
+    bias[:3, :3] = gc.rodrigues([0.0, 0.0, 0.016])
+    bias[:3, 3] = [0.09, -0.06, 0.02]
+    poses_init = poses_gt.copy()
+    for f in range(1, F):
+        poses_init[f] = poses_init[f - 1] @ (np.linalg.inv(poses_gt[f - 1]) @ poses_gt[f]) @ bias
+    scans = [_room_scan(poses_gt[f, :3, :3], poses_gt[f, :3, 3], 6000, rs) for f in range(F)]
+    common = dict(trunc_dist=0.5, min_dist_ratio=0.5, crop=False, device=DEV)
+    ds_track = PosedSdf3DLidar.from_frames(scans, poses_gt, poses_init, frame_samples=4096, frame_batchsize=4096,
+                                           near_surface_n=0, free_space_n=0, behind_surface_n=0, **common)
+    ds_map = PosedSdf3DLidar.from_frames(scans, poses_gt, poses_init, frame_samples=4096, frame_batchsize=1024,
+                                         near_surface_n=4, near_surface_std=0.25, free_space_n=2, behind_surface_n=1,
+                                         **common)
+    log = tempfile.mkdtemp()
+    cfg = {"device": DEV,
+           "model": gc.model_cfg([[-25.0, 25.0], [-25.0, 25.0], [-4.0, 8.0]], 2.0, 4, 2, 4, 64, num_poses=F, init_stddev=0.0),
+           "tracking": dict(solver=solver, learning_rate=1e-3, loss_type="GM" if solver == "lm" else "L1", trunc_dist=None,
+                            gm_scale_sdf=0.3, lm_lambda=1e-4, lm_max_iter=10, lm_tol_deg=0.01, lm_tol_m=0.001,
+                            verbose=False, fused=fast),
+           "mapping": dict(learning_rate=2e-2, loss_type="L2", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.5,
+                           trunc_dist=0.5, finite_diff_eps=0.5, grad_method="finitediff", eik_trunc_dist=0.5,
+                           verbose=False, max_replay_frames=5, max_replay_freq=10, gm_scale_sdf=0.3),
+           # (the adam solver indexes the submap's pose slots with the global keyframe id, as the reference does: one submap)
+           "system": dict(init_odom="external", submap_size=5 if solver == "lm" else 8, submap_local_bound=[[-25, 25], [-25, 25], [-4, 8]],
+                          submap_fov_thresh=0.0, save_submap_mesh=False, log_dir=log),
+           "train": {"trainer": "base", "verbose": False, "optimizer": "adam", "learning_rate": 2e-2, "epochs": 50,
+                     "ckpt_every": -1, "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": log,
+                     "relchange_tol": 0, "max_epochs_in_level": 100, "grid_training_mode": "coordinate+joint",
+                     "fast_captured_step": fast}}
+    torch.manual_seed(0)
+    atlas = GridAtlas(cfg["model"], device=DEV).to(DEV)
+    T0 = torch.tensor(poses_gt[0], dtype=torch.float32)
+    system = System(atlas, ds_track, ds_map, cfg, R_world_origin=T0[:3, :3], t_world_origin=T0[:3, 3:], verbose=False)
+    system.init_iterations, system.kf_iterations = 150, 40
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    system.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    err = []
+    for f in range(1, 5):
+        _, t = atlas.updated_kf_pose_in_world(f)
+        err.append(float(np.linalg.norm(t.detach().cpu().numpy().reshape(3) - poses_gt[f, :3, 3])))
+    return dt, err
+
+
+for solver in ("lm", "adam"):
+    for fast in (False, True):
+        run(solver, fast)                      # warm (allocations, first captures)
+        dt, err = run(solver, fast)
+        print(f"System.run solver={solver} fast_paths={fast}: {dt * 1e3:.0f} ms for 7 keyframes "
+              f"({dt / 7 * 1e3:.0f} ms per keyframe); tracked translation error {['%.2f' % e for e in err]} m")
