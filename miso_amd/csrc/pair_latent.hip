@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void overlap_count_batch_kernel(const AlignPai
       if (!whole && !empty && pxl <= pxh + 4.0f * (x1 - x0) / (float)(nx - 1)) {
         // index estimates from the mean spacing (the tables are linspace-like; the tests around the ends absorb +-1)
         const float inv_dx = (float)(nx - 1) / (x1 - x0);
-        int il = (int)floorf((pxl - x0) * inv_dx), ih = (int)ceilf((pxh - x0) * inv_dx);
+        // (clamped while still floats: a far-away interval end must not overflow the conversion)
+        int il = (int)fminf(fmaxf(floorf((pxl - x0) * inv_dx), -4.0f), (float)nx + 4.0f);
+        int ih = (int)fminf(fmaxf(ceilf((pxh - x0) * inv_dx), -4.0f), (float)nx + 4.0f);
         il = max(il - 2, 0); ih = min(ih + 2, nx - 1);           // first / last vertex that could be in bound
         if (ih - il < 12) {
           for (int i = il; i <= ih; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
