@@ -100,38 +100,44 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
         Axis az = axis_coord(q[2], g.bmin[2], g.bmax[2], lv.Z, g.flags);
         const bool ign = (g.ignore_mask >> l) & 1u;
         Cell c = make_cell(ax, ay, az, lv);
-        int off[8]; float wt[8], dwx[8], dwy[8], dwz[8];
+        // Corner values with zeros outside the grid (padding_mode = zeros), then the trilinear value and its three
+        // derivatives by a lerp tree along x, y, z -- the same polynomial as sum_k v_k w_k with w = (wx wy) wz and its
+        // derivative weights, without 32 weight registers per level live next to the 32 corner values: the kernel is
+        // bound by the latency of its gathers and ran at two wavefronts per SIMD (225 VGPRs) with the weight form.
+        int off[8];
+        bool inb8[8];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           const int dx = kk & 1, dy = (kk >> 1) & 1, dz = kk >> 2;
-          const bool in = c.inx[dx] && c.iny[dy] && c.inz[dz] && !ign;
-          const float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
-          wt[kk] = in ? (c.wx[dx] * c.wy[dy]) * c.wz[dz] : 0.0f;
-          dwx[kk] = in ? sx * c.wy[dy] * c.wz[dz] : 0.0f;
-          dwy[kk] = in ? sy * c.wx[dx] * c.wz[dz] : 0.0f;
-          dwz[kk] = in ? sz * c.wx[dx] * c.wy[dy] : 0.0f;
-          off[kk] = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+          inb8[kk] = c.inx[dx] && c.iny[dy] && c.inz[dz] && !ign;
+          off[kk] = inb8[kk] ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
         }
+        const float fx = c.wx[1], fy = c.wy[1], fz = c.wz[1];      // weight of the upper corner along each axis
         float ax_ = 0.f, ay_ = 0.f, az_ = 0.f;
         for (int ch = 0; ch < lv.C; ch += (VEC4 ? 4 : 1)) {
           float v[8][4];
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) {
             if (VEC4) {
-              const float4 t = *reinterpret_cast<const float4*>(lv.data + off[kk] + ch);
+              float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (inb8[kk]) t = *reinterpret_cast<const float4*>(lv.data + off[kk] + ch);
               v[kk][0] = t.x; v[kk][1] = t.y; v[kk][2] = t.z; v[kk][3] = t.w;
             } else {
-              v[kk][0] = lv.data[(int64_t)ch * lv.sC + off[kk]];
+              v[kk][0] = inb8[kk] ? lv.data[(int64_t)ch * lv.sC + off[kk]] : 0.0f;
             }
           }
 #pragma unroll
           for (int e = 0; e < (VEC4 ? 4 : 1); ++e) {
-            float fto = 0.f, gxs = 0.f, gys = 0.f, gzs = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-              fto += v[kk][e] * wt[kk];
-              gxs += v[kk][e] * dwx[kk]; gys += v[kk][e] * dwy[kk]; gzs += v[kk][e] * dwz[kk];
-            }
+            // along x: value and d/dx on the four (y,z) edges
+            const float d00 = v[1][e] - v[0][e], d10 = v[3][e] - v[2][e], d01 = v[5][e] - v[4][e], d11 = v[7][e] - v[6][e];
+            const float a00 = v[0][e] + fx * d00, a10 = v[2][e] + fx * d10, a01 = v[4][e] + fx * d01, a11 = v[6][e] + fx * d11;
+            // along y
+            const float e0 = a10 - a00, e1 = a11 - a01;
+            const float b0 = a00 + fy * e0, b1 = a01 + fy * e1;
+            const float gx0 = d00 + fy * (d10 - d00), gx1 = d01 + fy * (d11 - d01);
+            // along z
+            const float fto = b0 + fz * (b1 - b0);
+            const float gxs = gx0 + fz * (gx1 - gx0), gys = e0 + fz * (e1 - e0), gzs = b1 - b0;
             const float r = fs[lv.foff + ch + e] - fto;
             ss += r * r;
             if (pass == 1) {
@@ -182,7 +188,7 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
 }
 
 template <bool VEC4>
-__global__ __launch_bounds__(256) void pair_latent_kernel(GridK g, PairK k) {
+__global__ __launch_bounds__(256, 4) void pair_latent_kernel(GridK g, PairK k) {
   pair_latent_body<VEC4>(g, k.pose, k.pose + 12, k, blockIdx.x, gridDim.x);
 }
 
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void pair_latent_kernel(GridK g, PairK k) {
 // levels, source vertices and features) is read from the device-resident plan, the two poses from the (S,12)
 // table the prologue kernel of align.hip wrote.  out_all: (P,24), zeroed by that prologue.
 template <bool VEC4>
-__global__ __launch_bounds__(256) void pair_latent_batch_kernel(const AlignPairK* __restrict__ plan,
+__global__ __launch_bounds__(256, 4) void pair_latent_batch_kernel(const AlignPairK* __restrict__ plan,
                                                                const float* __restrict__ pose_all, int loss_type,
                                                                float* __restrict__ out_all,
                                                                const int32_t* __restrict__ stopped) {

@@ -1208,6 +1208,10 @@ def test_mapper_calls_adopt_the_fast_plan(mode, tmp_path):
     got, calls = run(True)
     assert calls_ref == [0, 0, 0]
     assert calls[1] == 8 and calls[2] == 8, calls            # every step of the later calls through an adopted plan
+    # 24 Adam steps of 5e-3 each.  Typically the two runs agree to 5e-8; now and then a handful of elements whose
+    # gradient is within rounding of zero part by whole steps (measured: 6 of 524 288 elements by 2 x lr) -- the binned
+    # batch's order inside a tile is not reproducible, Adam's normalisation turns the sign of a 1e-12 gradient into a
+    # full step.  A wrong state adoption (stale moments, flags, step count) moves every trained element instead.
     for a, b in zip(ref, got):
-        scale = a.abs().max().item()
-        assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-9
+        d = (a - b).abs()
+        assert d.mean().item() <= 1e-6 and (d > 1e-5).float().mean().item() <= 1e-4, (d.max().item(), d.mean().item())
