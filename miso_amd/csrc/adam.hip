@@ -192,46 +192,28 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(float* __restrict__ p
         if (ZERO && tt[u]) *reinterpret_cast<float4*>(g + ii[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    while (todo) {
-      // up to ADAM_UN chunks in flight, as in adam_active_kernel
-      int64_t cc[ADAM_UN];
-      bool tt[ADAM_UN], full[ADAM_UN];
-      float4 gg[ADAM_UN], pp[ADAM_UN], mm[ADAM_UN], vv[ADAM_UN];
-#pragma unroll
-      for (int u = 0; u < ADAM_UN; ++u) {
-        cc[u] = -1; tt[u] = false; full[u] = false;
-        if (todo) {
-          const int b = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          cc[u] = c0 + b;
-          tt[u] = (was_touched >> b) & 1ull;
-          full[u] = cc[u] < nfull;
+    while (todo) {      // what is left (fewer than ADAM_UN chunks, the ragged last one, a skipped step): one at a time
+      const int b = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int64_t c = c0 + b;
+      const bool tt = (was_touched >> b) & 1ull;
+      if (c < nfull) {
+        const int64_t i = c * ADAM_CHUNK + lane * 4;
+        if (!skip) {
+          float4 gg = *reinterpret_cast<const float4*>(g + i);
+          float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i);
+          float4 vv = *reinterpret_cast<float4*>(v + i);
+          adam_one(pp.x, gg.x, mm.x, vv.x, a); adam_one(pp.y, gg.y, mm.y, vv.y, a);
+          adam_one(pp.z, gg.z, mm.z, vv.z, a); adam_one(pp.w, gg.w, mm.w, vv.w, a);
+          *reinterpret_cast<float4*>(p + i) = pp;
+          *reinterpret_cast<float4*>(m + i) = mm;
+          *reinterpret_cast<float4*>(v + i) = vv;
         }
-        if (full[u] && !skip) {
-          const int64_t i = cc[u] * ADAM_CHUNK + lane * 4;
-          gg[u] = *reinterpret_cast<const float4*>(g + i);
-          pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
-          vv[u] = *reinterpret_cast<float4*>(v + i);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < ADAM_UN; ++u) {
-        if (cc[u] < 0) continue;                       // wave-uniform
-        if (full[u]) {
-          const int64_t i = cc[u] * ADAM_CHUNK + lane * 4;
-          if (!skip) {
-            adam_one(pp[u].x, gg[u].x, mm[u].x, vv[u].x, a); adam_one(pp[u].y, gg[u].y, mm[u].y, vv[u].y, a);
-            adam_one(pp[u].z, gg[u].z, mm[u].z, vv[u].z, a); adam_one(pp[u].w, gg[u].w, mm[u].w, vv[u].w, a);
-            *reinterpret_cast<float4*>(p + i) = pp[u];
-            *reinterpret_cast<float4*>(m + i) = mm[u];
-            *reinterpret_cast<float4*>(v + i) = vv[u];
-          }
-          if (ZERO && tt[u]) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {   // the ragged last chunk, element-wise
-          for (int64_t i = cc[u] * ADAM_CHUNK + lane; i < n; i += 64) {
-            if (!skip) adam_one(p[i], g[i], m[i], v[i], a);
-            if (ZERO) g[i] = 0.0f;
-          }
+        if (ZERO && tt) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {   // the ragged last chunk, element-wise
+        for (int64_t i = c * ADAM_CHUNK + lane; i < n; i += 64) {
+          if (!skip) adam_one(p[i], g[i], m[i], v[i], a);
+          if (ZERO) g[i] = 0.0f;
         }
       }
     }
