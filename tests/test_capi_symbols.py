@@ -76,3 +76,38 @@ def test_argument_validation_without_gpu():
     assert lib.miso_sdf_mask_words(ctypes.byref(m)) == 4
     m.hidden_dim = 48
     assert lib.miso_mlp_packed_floats(ctypes.byref(m)) == 0
+
+
+def test_round2_entry_points_validate_arguments_without_gpu():
+    """The entry points added for the captured trainer step, the tracker and the batch prologue refuse bad arguments
+    before any launch; miso_adam_scalars_table is a host function and can be checked against the formula here."""
+    import math
+    from miso_amd import _lib
+    lib = _lib.load()
+    E = 2001
+    # step scalars: {1 - b1, b2, 1 - b2, -lr / (1 - b1^t), sqrt(1 - b2^t), eps} as torch.optim.Adam computes them
+    host = torch.empty((4, 6), dtype=torch.float32)
+    assert lib.miso_adam_scalars_table(1e-3, 0.9, 0.999, 1e-8, 1, 4, ctypes.c_void_p(host.data_ptr())) == 0
+    for t in range(1, 5):
+        want = [1 - 0.9, 0.999, 1 - 0.999, -(1e-3 / (1 - 0.9 ** t)), math.sqrt(1 - 0.999 ** t), 1e-8]
+        assert torch.allclose(host[t - 1], torch.tensor(want, dtype=torch.float32), rtol=1e-6, atol=0)
+    assert lib.miso_adam_scalars_table(1e-3, 0.9, 0.999, 1e-8, 0, 4, ctypes.c_void_p(host.data_ptr())) == E
+    assert lib.miso_adam_scalars_table(1e-3, 0.9, 0.999, 1e-8, 1, 4, None) == E
+    assert lib.miso_adam_bump(None, None, None) == E
+    assert lib.miso_adam_step_dev(None, None, None, None, None, None, 8, None, 1, None, 0, None, None) == E
+    assert lib.miso_adam_touched(None, None, None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 1, 0, None, None) == E
+    assert lib.miso_adam_touched(None, None, None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0, 0, None, None) == E   # step 0
+    assert lib.miso_mapping_batch(None, None, 1, None, 1, None, None, None, None, None, None, None, 0, 0, None, None, None) == E
+    assert lib.miso_mapping_loss_rows(7, 1.0, 0.0, 0.0, None, None, 0, None, None, None) == E
+    assert lib.miso_mapping_loss_rows(1, 1.0, 0.0, 0.0, None, None, 4, None, None, None) == E
+    assert lib.miso_lm_track_step(None, None, None, None, None) == E
+    assert lib.miso_track_adam_step(None, None, None, None, None) == E
+    a = _lib.LmTrack()
+    g = _lib.Grid()
+    g.n_levels = 1
+    assert lib.miso_lm_track_step(ctypes.byref(g), None, None, ctypes.byref(a), None) == E      # no pose pointers
+    t = _lib.TrackAdam()
+    assert lib.miso_track_adam_step(ctypes.byref(g), None, None, ctypes.byref(t), None) == E
+    # struct sizes the header implies (LP64)
+    assert ctypes.sizeof(_lib.LmTrack) == 4 * 8 + 3 * 8 + 8 + 8 + 8 + 8 + 4 * 8 + 4 + 4 + 4 + 4 + 8 * 8
+    assert ctypes.sizeof(_lib.TrackAdam) == ctypes.sizeof(_lib.LmTrack) + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8
