@@ -237,3 +237,46 @@ def test_captured_step_replayed_back_to_back_between_eager_launches():
         assert torch.isfinite(g).all()
         assert not (g != 0)[~s].any()                   # nothing outside the vertices the batch can touch
         assert float(a.float().mean()) < 0.5            # and Adam still skips the empty part of the bound
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_matrix_core_push_random_shapes_and_clusters(seed):
+    """The push on random level sizes up to 48 per axis (a tile owns <= 3 vertices: regions of <= 5), 4 or 8
+    channels, batches that are part uniform, part tight clusters (thousands of samples in one tile: runs of 512 samples
+    inside one tile, tiles split between runs), part outside the bound -- against the unsorted atomic scatter."""
+    from miso_amd import ops, _lib
+    import ctypes
+    gen = torch.Generator().manual_seed(100 + seed)
+    dev = "cuda:0"
+    C = 4 if seed % 2 == 0 else 8
+    H = 64
+    sizes = [tuple(int(v) for v in torch.randint(8, 49, (3,), generator=gen)) for _ in range(2)]
+    feats = [(torch.randn(1, C, z, y, x, generator=gen) * 1e-2).to(dev).contiguous(memory_format=torch.channels_last_3d)
+             for (x, y, z) in sizes]
+    lo = torch.tensor([-3.0, -1.0, -2.0]) * (1 + seed * 0.3)
+    hi = torch.tensor([2.0, 1.5, 4.0]) * (1 + seed * 0.3)
+    meta = ops.GridMeta.from_bound([[float(a), float(b)] for a, b in zip(lo, hi)])
+    lin = [torch.nn.Linear(2 * C, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.data.to(dev) for l in lin], [l.bias.data.to(dev) for l in lin])
+    n = 100 * 4096 + int(torch.randint(0, 5000, (1,), generator=gen))
+    x = torch.rand(n, 3, generator=gen) * (hi - lo) + lo
+    k = n // 4
+    ctr = torch.rand(3, 3, generator=gen) * (hi - lo) + lo
+    for i in range(3):                                                   # three tight clusters
+        x[i * k // 3:(i + 1) * k // 3] = ctr[i] + torch.randn((i + 1) * k // 3 - i * k // 3, 3, generator=gen) * 0.01 * (hi - lo)
+    x[k:k + 300] = (torch.rand(300, 3, generator=gen) - 0.5) * 4 * (hi - lo) + 0.5 * (hi + lo)     # many outside
+    x = x[torch.randperm(n, generator=gen)].to(dev)
+    gs = (torch.randn(n, 1, generator=gen) / n).to(dev)
+    grid = ops._fill_grid(feats, meta, grads=[torch.zeros_like(f) for f in feats])
+    assert _lib.load().miso_sdf_bwd_push_levels(ctypes.byref(grid), 16, n) == 0b11
+    sdf, mask = ops.sdf_fwd_raw(x, feats, meta, pack, True)
+    want = [torch.zeros_like(f) for f in feats]
+    ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask, False, [True, True], want)
+    sb = ops.SortedBatch(n, dev).sort(x, meta)
+    _, mask_s = ops.sdf_fwd_raw(x, feats, meta, pack, True, sorted_batch=sb)
+    got = [torch.full_like(f, -3.0) for f in feats]
+    ops.sdf_bwd_raw(x, feats, meta, pack, gs, mask_s, False, [True, True], got, sorted_batch=sb, overwrite=True)
+    for a, b in zip(got, want):
+        scale = b.abs().max().item()
+        assert scale > 0 and (a - b).abs().max().item() <= 2e-4 * scale + 1e-12
