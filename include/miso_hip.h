@@ -215,6 +215,12 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
                              float weight_fs, float trunc_dist, const float* loss_inputs, float* sdf,
                              uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots,
                              const int32_t* n_live, void* stream);
+/* The same for an unbinned (small) batch: x (N,3) and loss_inputs in the caller's order, grad_sdf (N) in that order too
+ * (feed it to miso_sdf_bwd).  Replaces miso_sdf_fwd + miso_mapping_loss_rows and the clear of their two sums. */
+int miso_sdf_fwd_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n,
+                      int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* loss_inputs,
+                      float* sdf /* may be NULL */, uint32_t* relu_mask, float* grad_sdf, float* loss_slots,
+                      void* stream);
 /* The owner-computes gradient on its own: rows of d loss / d feats (row pitch ld_d floats,
  * a multiple of 4; 16-B aligned base) -> level[l].grad for every level with a non-NULL grad,
  * written (MISO_F_GRAD_OVERWRITE) or accumulated, without atomics.  Rows are in the binned

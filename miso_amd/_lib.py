@@ -137,6 +137,9 @@ SIGNATURES = {
                                     C.c_float, C.c_void_p, C.c_void_p]),
     "miso_encode_fwd_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_void_p]),
+    "miso_sdf_fwd_loss": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
+                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "miso_sdf_fwd_sorted_loss": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted), C.c_int64,
                                            C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -421,6 +421,22 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
   return sdf_fwd_impl(grid, mlp, packed, nullptr, n, sdf, relu_mask, sorted, stream, &lin);
 }
 
+int miso_sdf_fwd_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n,
+                      int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* loss_inputs,
+                      float* sdf, uint32_t* relu_mask, float* grad_sdf, float* loss_slots, void* stream) {
+  if ((loss_type != 1 && loss_type != 2) || !loss_slots || n < 0 || (n > 0 && (!x || !loss_inputs || !grad_sdf)))
+    return MISO_E_BADARG;
+  if (((uintptr_t)loss_inputs & 15u) != 0) return MISO_E_BADARG;
+  if (n == 0) return (int)launch_zero_words(loss_slots, MISO_LOSS_SLOTS * 2, (hipStream_t)stream);
+  LossInK lin;
+  memset(&lin, 0, sizeof(lin));
+  lin.p.loss_type = loss_type; lin.p.w_sdf = weight_sdf; lin.p.w_fs = weight_fs; lin.p.trunc = trunc_dist;
+  lin.aux = reinterpret_cast<const float4*>(loss_inputs);
+  lin.gsdf_sorted = grad_sdf; lin.loss_out = loss_slots;
+  lin.inv_n = 1.0f / (float)n;
+  return sdf_fwd_impl(grid, mlp, packed, x, n, sdf, relu_mask, nullptr, stream, &lin);
+}
+
 // levels (with a gradient requested) the owner-computes pull covers for this grid
 static int pull_plan(const miso_grid_t* grid, int32_t tiles_per_axis, GridK* g, int* C, uint32_t* mask) {
   bool v4;

@@ -553,6 +553,22 @@ def sdf_fwd_loss_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatc
         _ptr(gsdf_sorted), _ptr(loss_slots), _ptr(n_live), _stream(gsdf_sorted)), "miso_sdf_fwd_sorted_loss")
 
 
+def sdf_fwd_loss_unsorted_raw(x, features, meta, pack: DecoderPack, loss_inputs, mask, gsdf, loss_slots, loss_type="L1",
+                              weight_sdf=1.0, weight_fs=0.0, trunc_dist=0.0, sdf_out=None):
+    """sdf_fwd_loss_raw for an unbinned (small) batch: everything in the caller's order (miso_sdf_fwd_loss)."""
+    _require_hip(x, loss_inputs, gsdf, loss_slots, *features)
+    m, packed = pack.get()
+    n = x.shape[0]
+    assert x.is_contiguous() and loss_inputs.shape == (n, 4) and loss_inputs.is_contiguous()
+    assert gsdf.is_contiguous() and gsdf.numel() == n and loss_slots.is_contiguous()
+    assert loss_slots.numel() == _lib.LOSS_SLOTS * 2
+    g = _fill_grid(features, meta)
+    _lib.check(_lib.load().miso_sdf_fwd_loss(
+        C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _LOSS_TYPES[loss_type], float(weight_sdf), float(weight_fs),
+        float(trunc_dist), _ptr(loss_inputs), _ptr(sdf_out), _ptr(mask), _ptr(gsdf), _ptr(loss_slots), _stream(x)),
+        "miso_sdf_fwd_loss")
+
+
 def grad_pull_raw(features, meta, sorted_batch: SortedBatch, dfeat, grads, overwrite: bool = True,
                   caller_order: bool = False):
     """Grid gradients from d-feat rows (N,F), owner-computes (miso_grad_pull).  Rows are in binned

@@ -157,15 +157,17 @@ class MappingStep:
                             self.need_levels, self.grads, sorted_batch=self.sorted, overwrite=True, gsdf_sorted=True,
                             touched=self.touched, zeroed=self.adam_device is not None)
         else:
-            _, mask = ops.sdf_fwd_raw(self.x, self.features, self.meta, self.pack, True, out=self.sdf,
-                                      mask=getattr(self, "_mask", None))
-            self._mask = mask
-            ops.mapping_loss_rows_raw(self.sdf, self.aux, lt, ws, wf, td, self.gpred, self._loss)
+            # forward + mapping loss in one launch here too (the label rows are read by the forward itself)
+            if getattr(self, "_mask", None) is None:
+                mw = ops.sdf_mask_words(self.pack)
+                self._mask = torch.empty(((self.n + 63) // 64) * 64 * mw, device=self.x.device, dtype=torch.int32)
+            mask = self._mask
+            ops.sdf_fwd_loss_unsorted_raw(self.x, self.features, self.meta, self.pack, self.aux, mask, self.gpred,
+                                          self.loss_slots, lt, ws, wf, td, sdf_out=self.sdf if self.keep_sdf else None)
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
                             self.need_levels, self.grads, touched=self.touched)
         if self.adam_device is not None:
-            src = self.loss_slots.view(-1) if self.sorted is not None else self._loss
-            torch.sum(src, dim=0, out=self.total)
+            torch.sum(self.loss_slots.view(-1), dim=0, out=self.total)
             self.adam_device.bump(self.total)
             for l, (p, g, st, tch) in enumerate(zip(self.features, self.grads, self.adam_state, self.touched)):
                 if g is None:
@@ -185,7 +187,7 @@ class MappingStep:
     @property
     def loss(self) -> torch.Tensor:
         """(2,) = [weight_sdf * sdf term, weight_fs * free-space term] of the last iteration."""
-        return self.loss_slots.sum(dim=0) if self.sorted is not None else self._loss
+        return self.loss_slots.sum(dim=0)
 
     def run(self):
         """Launch one iteration on the current stream (asynchronous)."""
