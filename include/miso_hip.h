@@ -540,6 +540,10 @@ int miso_adam_touched(float* param, float* grad, float* exp_avg, float* exp_avg_
 int miso_adam_scalars_table(double lr, double beta1, double beta2, double eps, int32_t first_step, int32_t count,
                             float* host_out /* count x 6 */);
 int miso_adam_bump(int32_t* step, const float* guard /* or NULL */, void* stream);
+/* total[0] = sum of n_floats floats (the loss slots of miso_sdf_fwd_sorted_loss / miso_sdf_fwd_loss: 2 * MISO_LOSS_SLOTS,
+ * i.e. both terms of the mapping loss) and, with step != NULL, miso_adam_bump(step, total) in the same launch. */
+int miso_loss_total_bump(const float* loss_slots, int32_t n_floats, float* total, int32_t* step /* or NULL */,
+                         void* stream);
 int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
                        uint8_t* touched /* or NULL */, int64_t numel, const float* table, int32_t table_len,
                        const int32_t* step, int zero_grad, const float* guard, void* stream);

@@ -26,6 +26,26 @@ __global__ void adam_bump_kernel(int32_t* step, const float* __restrict__ guard)
   if (threadIdx.x == 0 && blockIdx.x == 0 && !(guard != nullptr && !(guard[0] == guard[0]))) step[0] += 1;
 }
 
+// The step's loss from its per-workgroup slots and the step count in one launch (a captured trainer step needs both
+// between the backward and the Adam launches): total = sum of n floats (pairwise in LDS, a fixed order), then the bump.
+__global__ __launch_bounds__(256) void loss_total_bump_kernel(const float* __restrict__ slots, int n,
+                                                             float* __restrict__ total, int32_t* step) {
+  __shared__ float red[256];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += slots[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float t = red[0];
+    total[0] = t;
+    if (step && t == t) step[0] += 1;
+  }
+}
+
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                   float* __restrict__ m, float* __restrict__ v,
@@ -230,6 +250,11 @@ static AdamScalars adam_scalars(double lr, double b1, double b2, double eps, int
   a.bc2_sqrt = (float)sqrt(bc2);
   a.eps = (float)eps;
   return a;
+}
+
+hipError_t launch_loss_total_bump(const float* slots, int n, float* total, int32_t* step, hipStream_t s) {
+  loss_total_bump_kernel<<<1, 256, 0, s>>>(slots, n, total, step);
+  return hipGetLastError();
 }
 
 hipError_t launch_adam_bump(int32_t* step, const float* guard, hipStream_t s) {

@@ -706,6 +706,12 @@ class AdamDeviceStep:
         """step += 1 on the device unless ``guard`` (device scalar) is NaN; the host mirror is the caller's business."""
         _lib.check(_lib.load().miso_adam_bump(_ptr(self.step), _ptr(guard), _stream(self.step)), "miso_adam_bump")
 
+    def total_and_bump(self, loss_slots: torch.Tensor, total: torch.Tensor):
+        """total (0-d) = loss_slots.sum() and bump(total) in one launch (miso_loss_total_bump)."""
+        assert loss_slots.is_contiguous() and loss_slots.dtype == torch.float32 and total.numel() == 1
+        _lib.check(_lib.load().miso_loss_total_bump(_ptr(loss_slots), loss_slots.numel(), _ptr(total), _ptr(self.step),
+                                                    _stream(self.step)), "miso_loss_total_bump")
+
     def step_(self, param, grad, exp_avg, exp_avg_sq, active, touched=None, zero_grad=False, guard=None):
         _require_hip(param, grad, exp_avg, exp_avg_sq, guard)
         _lib.check(_lib.load().miso_adam_step_dev(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(active),

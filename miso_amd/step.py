@@ -167,8 +167,7 @@ class MappingStep:
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, mask, False,
                             self.need_levels, self.grads, touched=self.touched)
         if self.adam_device is not None:
-            torch.sum(self.loss_slots.view(-1), dim=0, out=self.total)
-            self.adam_device.bump(self.total)
+            self.adam_device.total_and_bump(self.loss_slots, self.total)      # loss sum + step count: one launch
             for l, (p, g, st, tch) in enumerate(zip(self.features, self.grads, self.adam_state, self.touched)):
                 if g is None:
                     continue
