@@ -71,14 +71,15 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(GridK g, const 
   for (int i = threadIdx.x; i < nt; i += blockDim.x) bh[(int64_t)blockIdx.x * nt + i] = hist[i];
 }
 
-// 64 tiles per workgroup, lane = tile; the blocks' histograms are split over the four waves:
+// 64 tiles per workgroup, lane = tile; the blocks' histograms are split over the PREFIX_WAVES waves:
 // bh[b][t] <- sum_{b' < b} bh[b'][t]; count[t] <- column total
-__global__ __launch_bounds__(256) void sort_prefix_kernel(int* __restrict__ bh, int nb, int nt,
-                                                         int* __restrict__ count) {
-  __shared__ int part[4][64];
+constexpr int PREFIX_WAVES = 16;
+__global__ __launch_bounds__(64 * PREFIX_WAVES) void sort_prefix_kernel(int* __restrict__ bh, int nb, int nt,
+                                                                       int* __restrict__ count) {
+  __shared__ int part[PREFIX_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;
-  const int per = (nb + 3) / 4, b0 = wave * per, b1 = min(nb, b0 + per);
+  const int per = (nb + PREFIX_WAVES - 1) / PREFIX_WAVES, b0 = min(nb, wave * per), b1 = min(nb, b0 + per);
   int sum = 0;
   if (t < nt) {
     int b = b0;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void sort_prefix_kernel(int* __restrict__ bh, 
       for (int k = 0; k < 8; ++k) { bh[(int64_t)(b + k) * nt + t] = run; run += v[k]; }
     }
     for (; b < b1; ++b) { int v = bh[(int64_t)b * nt + t]; bh[(int64_t)b * nt + t] = run; run += v; }
-    if (wave == 3) count[t] = run;
+    if (wave == PREFIX_WAVES - 1) count[t] = run;
   }
 }
 
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, con
 }
 
 static inline int sort_blocks(int64_t n) {
-  static const int per = [] { const char* e = getenv("MISO_SORT_PER_BLOCK"); return e ? atoi(e) : 4096; }();
+  static const int per = [] { const char* e = getenv("MISO_SORT_PER_BLOCK"); return e ? atoi(e) : 2048; }();
   int64_t b = (n + per - 1) / per;
   if (b > SORT_MAX_BLOCKS) b = SORT_MAX_BLOCKS;
   if (b < 1) b = 1;
@@ -208,7 +209,7 @@ hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int T, void* w
   int* count = reinterpret_cast<int*>(w);         w += a256(nt * sizeof(int));
   uint16_t* tid = reinterpret_cast<uint16_t*>(w);
   sort_hist_kernel<<<nb, SORT_THREADS, nt * sizeof(int), s>>>(g, x, n, T, seg, bh, tid);
-  sort_prefix_kernel<<<(nt + 63) / 64, 256, 0, s>>>(bh, nb, nt, count);
+  sort_prefix_kernel<<<(nt + 63) / 64, 64 * PREFIX_WAVES, 0, s>>>(bh, nb, nt, count);
   sort_scatter_kernel<<<nb, SORT_THREADS, (nt + 16) * sizeof(int), s>>>(g, x, n, nt, seg, bh, count, tid, xs, xn,
                                                                         perm, tile_off);
   return hipGetLastError();
