@@ -473,3 +473,37 @@ def test_slam_system_tracks_and_maps_lidar_frames(tmp_path):
     # The assertion keeps a factor of two to every measured value: float atomics make the training trajectory differ run
     # to run, and this is a does-tracking-help check, not a tuned threshold.
     assert err_track[-1] < err_odom[-1] and max(err_track) < 0.6, (err_track, err_odom)
+
+
+def test_iter_batches_walks_the_loader_like_its_own_iterator():
+    """utils.iter_batches (what train_epoch / get_batch use instead of building a DataLoader iterator per one-item
+    epoch) yields the same batches in the same order and leaves the global RNG where a plain ``for batch in loader``
+    leaves it -- shuffled and sequential samplers, batch sizes 1 and 3, a loader with its own generator -- and hands
+    anything it does not understand (workers, pinned memory) to the DataLoader itself."""
+    from miso_amd.grid_opt.utils.utils import iter_batches, collate_batch_of_one
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 7
+
+        def __getitem__(self, i):
+            return {"i": torch.tensor([i]), "r": torch.rand(2)}, {"y": torch.tensor([2.0 * i])}
+
+    def run(loader, how):
+        torch.manual_seed(11)
+        out = []
+        for _ in range(3):                                     # three "epochs"
+            it = loader if how == "loader" else iter_batches(loader)
+            for a, b in it:
+                out.append((a["i"].flatten().tolist(), a["r"].flatten().tolist(), b["y"].flatten().tolist()))
+        return out, torch.rand(3).tolist()
+
+    for kw in (dict(shuffle=True, batch_size=1, collate_fn=collate_batch_of_one), dict(shuffle=False, batch_size=3),
+               dict(shuffle=True, batch_size=3, drop_last=True),
+               dict(shuffle=True, batch_size=1, generator=torch.Generator().manual_seed(5))):
+        mk = lambda: torch.utils.data.DataLoader(DS(), num_workers=0, **{k: (torch.Generator().manual_seed(5) if k == "generator" else v)
+                                                                         for k, v in kw.items()})
+        assert run(mk(), "loader") == run(mk(), "iter_batches"), kw
+    # not a single-process plain loader: the DataLoader's own iterator is used
+    dl = torch.utils.data.DataLoader(DS(), batch_size=2, pin_memory=False, num_workers=0)
+    assert len(list(iter_batches(dl))) == 4 and len(list(iter_batches([1, 2, 3]))) == 3
