@@ -563,11 +563,13 @@ int miso_rigid_by_index(const float* R, const float* t, const int64_t* idx, cons
  * miso_rigid_by_index), loss_rows[i] = {target[i], valid[i], sign[i], weight[i]} (valid / sign / weight may be NULL:
  * 1 / 0 / 1).  table: int64 keyframe-id -> pose-index (device).  loss_rows 16-B aligned.
  * col_strides (HOST, 4 element strides of target / valid / sign / weight, or NULL = unit): the columns may be views
- * of a row-major label block; valid_is_bool: `valid` holds one byte per row (a torch.bool mask) instead of floats. */
+ * of a row-major label block; valid_is_bool: `valid` holds one byte per row (a torch.bool mask) instead of floats.
+ * sanitize: torch.nan_to_num on every float read (NaN -> 0, +-inf -> +-FLT_MAX): the trainer's prepare_batch
+ * (grid_opt/utils/utils.py:487-493) folded into the launch. */
 int miso_mapping_batch(const float* R, const float* t, int32_t n_poses, const int64_t* table, int64_t table_len,
                        const int64_t* frame_ids, const float* coords_frame, const float* target, const void* valid,
                        const float* sign, const float* weight, const int64_t* col_strides, int valid_is_bool, int64_t n,
-                       float* coords_world, float* loss_rows, void* stream);
+                       float* coords_world, float* loss_rows, int sanitize, void* stream);
 
 /* miso_mapping_loss over interleaved label rows {target, valid, sign, weight} (N,4), 16-B aligned. */
 int miso_mapping_loss_rows(int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* pred,

@@ -162,7 +162,7 @@ SIGNATURES = {
                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "miso_mapping_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int,
-                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "miso_mapping_loss_rows": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_adam_touched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

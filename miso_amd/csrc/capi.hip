@@ -36,7 +36,7 @@ hipError_t launch_lm_track_tail(const LmTrackK&, const float*, const float*, int
 void adam_scalars_table(double, double, double, double, int, int, float*);
 hipError_t launch_mapping_batch(const float*, const float*, int32_t, const int64_t*, int64_t, const int64_t*,
                                 const float*, const float*, const void*, const float*, const float*, int64_t, float*,
-                                float*, const int64_t*, int, hipStream_t);
+                                float*, const int64_t*, int, int, hipStream_t);
 hipError_t launch_mapping_loss_rows(int, float, float, float, const float*, const float*, int64_t, float*, float*,
                                     hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
@@ -839,7 +839,7 @@ int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg
 int miso_mapping_batch(const float* R, const float* t, int32_t n_poses, const int64_t* table, int64_t table_len,
                        const int64_t* frame_ids, const float* coords_frame, const float* target, const void* valid,
                        const float* sign, const float* weight, const int64_t* col_strides, int valid_is_bool, int64_t n,
-                       float* coords_world, float* loss_rows, void* stream) {
+                       float* coords_world, float* loss_rows, int sanitize, void* stream) {
   if (n < 0 || n_poses < 1 || table_len < 1 || !R || !t || !table) return MISO_E_BADARG;
   if (col_strides)
     for (int i = 0; i < 4; ++i)
@@ -847,7 +847,7 @@ int miso_mapping_batch(const float* R, const float* t, int32_t n_poses, const in
   if (n > 0 && (!frame_ids || !coords_frame || !target || !coords_world || !loss_rows)) return MISO_E_BADARG;
   if (((uintptr_t)loss_rows & 15u) != 0) return MISO_E_BADARG;
   return (int)launch_mapping_batch(R, t, n_poses, table, table_len, frame_ids, coords_frame, target, valid, sign, weight,
-                                   n, coords_world, loss_rows, col_strides, valid_is_bool, (hipStream_t)stream);
+                                   n, coords_world, loss_rows, col_strides, valid_is_bool, sanitize, (hipStream_t)stream);
 }
 
 int miso_mapping_loss_rows(int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* pred,

@@ -49,15 +49,21 @@ __global__ __launch_bounds__(256) void mapping_batch_kernel(const float* __restr
                                                             const float* __restrict__ weight, int64_t n,
                                                             float* __restrict__ y, float4* __restrict__ rows,
                                                             int64_t s_target, int64_t s_valid, int64_t s_sign,
-                                                            int64_t s_weight, int valid_is_bool) {
+                                                            int64_t s_weight, int valid_is_bool, int sanitize) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  // sanitize: torch.nan_to_num on everything read (the trainer's prepare_batch, utils.py:487-493, folded in)
+  auto clean = [&](float v) -> float {
+    if (!sanitize) return v;
+    if (v != v) return 0.0f;
+    return fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+  };
   int64_t f = frame_ids[i];
   f = f < 0 ? 0 : (f >= table_len ? table_len - 1 : f);
   int64_t k = table[f];
   k = k < 0 ? 0 : (k >= K ? K - 1 : k);
   const float* r = R + k * 9;
-  const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+  const float a = clean(x[3 * i]), b = clean(x[3 * i + 1]), c = clean(x[3 * i + 2]);
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     float s = __fmul_rn(a, r[3 * j]);
@@ -68,8 +74,9 @@ __global__ __launch_bounds__(256) void mapping_batch_kernel(const float* __restr
   float v = 1.0f;
   if (valid)
     v = valid_is_bool ? (reinterpret_cast<const unsigned char*>(valid)[i * s_valid] ? 1.0f : 0.0f)
-                      : reinterpret_cast<const float*>(valid)[i * s_valid];
-  rows[i] = make_float4(target[i * s_target], v, sign ? sign[i * s_sign] : 0.0f, weight ? weight[i * s_weight] : 1.0f);
+                      : clean(reinterpret_cast<const float*>(valid)[i * s_valid]);
+  rows[i] = make_float4(clean(target[i * s_target]), v, sign ? clean(sign[i * s_sign]) : 0.0f,
+                        weight ? clean(weight[i * s_weight]) : 1.0f);
 }
 
 }  // namespace
@@ -77,14 +84,14 @@ __global__ __launch_bounds__(256) void mapping_batch_kernel(const float* __restr
 hipError_t launch_mapping_batch(const float* R, const float* t, int32_t K, const int64_t* table, int64_t table_len,
                                 const int64_t* frame_ids, const float* x, const float* target, const void* valid,
                                 const float* sign, const float* weight, int64_t n, float* y, float* rows,
-                                const int64_t* strides, int valid_is_bool, hipStream_t s) {
+                                const int64_t* strides, int valid_is_bool, int sanitize, hipStream_t s) {
   if (n == 0) return hipSuccess;
   const int64_t one[4] = {1, 1, 1, 1};
   const int64_t* st = strides ? strides : one;
   mapping_batch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(R, t, K, table, table_len, frame_ids, x, target,
                                                                    valid, sign, weight, n, y,
                                                                    reinterpret_cast<float4*>(rows), st[0], st[1], st[2],
-                                                                   st[3], valid_is_bool);
+                                                                   st[3], valid_is_bool, sanitize);
   return hipGetLastError();
 }
 

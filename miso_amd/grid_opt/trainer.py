@@ -172,7 +172,7 @@ class _FastMappingPlan:
                       for st in self.states),
                 len(opt._optimizer_step_pre_hooks), len(opt._optimizer_step_post_hooks))
 
-    def run(self, trainer, model_input, gt):
+    def run(self, trainer, model_input, gt, sanitize=False):
         from miso_amd import ops
         opt, model, step = trainer.optimizer, trainer.model, self.step
         coords_frame = model_input['coords_frame'][0]
@@ -194,7 +194,7 @@ class _FastMappingPlan:
             with torch.no_grad():
                 ops.mapping_batch(R_all, t_all.reshape(-1, 3), model.kf_key_index_table('KF'),
                                   model_input['sample_frame_ids'][0], coords_frame, gt['sdf'][0], gt['sdf_valid'][0],
-                                  gt['sdf_signs'][0], model_input['weights'][0], step.x, step.aux)
+                                  gt['sdf_signs'][0], model_input['weights'][0], step.x, step.aux, sanitize=sanitize)
         except (ValueError, AssertionError):
             return None                                       # a batch layout the launch does not take
         if live is not None:
@@ -402,13 +402,27 @@ class Trainer(object):
             self._fast_plan = _FastMappingPlan.build(self, step, feats, need, pack, n, live is not None)
         return total
 
-    def train_step(self, model_input, gt):
+    def train_step(self, model_input, gt, _raw=False):
         """zero_grad -> loss dict -> sum of means -> NaN guard -> backward -> step.
-        Returns the total loss (device scalar)."""
+        Returns the total loss (device scalar).  _raw (train_epoch): the batch has been moved to the device but not
+        been through nan_to_num yet -- the one-replay plan folds that into its first launch, every other path
+        sanitises here."""
         if self.cfg.get('captured_step', True):
+            if _raw:
+                fast = self.__dict__.get('_fast_plan')
+                total = fast.run(self, model_input, gt, sanitize=True) if fast is not None else None
+                if total is not None:
+                    return total
+                from .utils.utils import sanitize_tensor_dict
+                model_input, gt = sanitize_tensor_dict(model_input), sanitize_tensor_dict(gt)
+                if fast is not None:
+                    self._fast_plan = None
             total = self._captured_mapping_step(model_input, gt)
             if total is not None:
                 return total
+        elif _raw:
+            from .utils.utils import sanitize_tensor_dict
+            model_input, gt = sanitize_tensor_dict(model_input), sanitize_tensor_dict(gt)
         self.optimizer.zero_grad()
         loss_dict = self.loss_func.compute(self.model, model_input, gt)
         total = 0.
@@ -468,8 +482,12 @@ class Trainer(object):
                 start.record()
             else:
                 start = time.perf_counter()
-            model_input, gt = prepare_batch(model_input, gt, self.device)
-            total = self.train_step(model_input, gt)
+            if type(self).train_step is Trainer.train_step:
+                model_input, gt = prepare_batch(model_input, gt, self.device, sanitize=False)
+                total = self.train_step(model_input, gt, _raw=True)
+            else:       # a subclass with its own train_step(model_input, gt): the reference's call, sanitised batch
+                model_input, gt = prepare_batch(model_input, gt, self.device)
+                total = self.train_step(model_input, gt)
             self.total_steps += 1
             if self.verbose and step % 10 == 0:
                 logger.info(f"Train epoch {epoch} step {step} | train_loss={float(total.detach()):.2e}.")

@@ -147,9 +147,13 @@ def collate_batch_of_one(items):
     return lead(items[0])
 
 
-def prepare_batch(model_input, gt, device='cuda:0'):
-    model_input = sanitize_tensor_dict({k: v.to(device) for k, v in model_input.items()})
-    gt = sanitize_tensor_dict({k: v.to(device) for k, v in gt.items()})
+def prepare_batch(model_input, gt, device='cuda:0', sanitize=True):
+    """sanitize=False (ours): only the device move -- for a caller that folds nan_to_num into its first kernel
+    (GridTrainer's one-replay step) and sanitises itself whenever it takes another path."""
+    model_input = {k: v.to(device) for k, v in model_input.items()}
+    gt = {k: v.to(device) for k, v in gt.items()}
+    if sanitize:
+        model_input, gt = sanitize_tensor_dict(model_input), sanitize_tensor_dict(gt)
     return model_input, gt
 
 

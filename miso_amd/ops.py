@@ -720,10 +720,12 @@ class AdamDeviceStep:
                    "miso_adam_step_dev")
 
 
-def mapping_batch(R, t, table, frame_ids, coords_frame, target, valid, sign, weight, x_out, rows_out):
+def mapping_batch(R, t, table, frame_ids, coords_frame, target, valid, sign, weight, x_out, rows_out,
+                  sanitize: bool = False):
     """The input side of a mapping step in one launch (miso_mapping_batch): keyframe lookup, frame -> world map and
     the interleaved label rows, written into the step's static buffers ``x_out`` (N,3) / ``rows_out`` (N,4).  The
     label columns may be strided views ((N,1) slices of a row-major block); ``valid`` may be a bool mask.
+    sanitize: torch.nan_to_num on every float read (the trainer's prepare_batch folded in).
     Raises ValueError for layouts the launch does not take."""
     n = x_out.shape[0]
     strides = (C.c_int64 * 4)(1, 1, 1, 1)
@@ -752,7 +754,8 @@ def mapping_batch(R, t, table, frame_ids, coords_frame, target, valid, sign, wei
     _lib.check(_lib.load().miso_mapping_batch(_ptr(R), _ptr(t), R.shape[0], _ptr(table), table.numel(), _ptr(fid),
                                               _ptr(cf), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]), _ptr(cols[3]),
                                               strides, int(valid is not None and cols[1].dtype == torch.bool), n,
-                                              _ptr(x_out), _ptr(rows_out), _stream(x_out)), "miso_mapping_batch")
+                                              _ptr(x_out), _ptr(rows_out), int(bool(sanitize)), _stream(x_out)),
+               "miso_mapping_batch")
 
 
 # --------------------------------------------------------------------------- #

@@ -97,7 +97,7 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert lib.miso_adam_step_dev(None, None, None, None, None, None, 8, None, 1, None, 0, None, None) == E
     assert lib.miso_adam_touched(None, None, None, None, None, None, 8, 1e-3, 0.9, 0.999, 1e-8, 1, 0, None, None) == E
     assert lib.miso_adam_touched(None, None, None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0, 0, None, None) == E   # step 0
-    assert lib.miso_mapping_batch(None, None, 1, None, 1, None, None, None, None, None, None, None, 0, 0, None, None, None) == E
+    assert lib.miso_mapping_batch(None, None, 1, None, 1, None, None, None, None, None, None, None, 0, 0, None, None, 0, None) == E
     assert lib.miso_mapping_loss_rows(7, 1.0, 0.0, 0.0, None, None, 0, None, None, None) == E
     assert lib.miso_mapping_loss_rows(1, 1.0, 0.0, 0.0, None, None, 4, None, None, None) == E
     assert lib.miso_lm_track_step(None, None, None, None, None) == E
