@@ -1086,3 +1086,33 @@ def test_lattice_overlap_gate_counts_equal_the_point_list_gate(case):
         q = (w - t0[b_].cpu().reshape(1, 3)) @ R0[b_].cpu()
         ref = int(((q >= b[:, 0]) & (q <= b[:, 1])).all(dim=1).sum())
         assert abs(int(c[idx]) - ref) <= max(2, int(2e-4 * ref)), (idx, int(c[idx]), ref)     # matmul order differs
+
+
+@pytest.mark.gpu
+def test_mapping_batch_matches_the_op_sequence_and_sanitises():
+    """miso_mapping_batch = table lookup + rigid_by_index + the interleaved label rows, with strided / bool columns; with
+    sanitize it equals the same on torch.nan_to_num'ed inputs (what prepare_batch does, NaN -> 0, inf -> +-FLT_MAX)."""
+    from miso_amd import ops
+    g = torch.Generator().manual_seed(8)
+    n, K = 5000, 7
+    from miso_amd.so3 import so3_exp_map
+    R = so3_exp_map(torch.randn(K, 3, generator=g)).to(DEV).contiguous()
+    t = torch.randn(K, 3, generator=g).to(DEV)
+    table = torch.tensor([3, -1, 0, 6, 2, 5, 1, 4, -1], dtype=torch.int64, device=DEV)          # key -> pose index
+    fid = torch.randint(-2, 11, (n, 1), generator=g).to(DEV)                                    # some out of the table
+    x = torch.randn(n, 3, generator=g).to(DEV)
+    block = torch.randn(n, 4, generator=g).to(DEV)                                              # strided columns
+    valid = (torch.rand(n, 1, generator=g) > 0.2).to(DEV)
+    for sanitize in (False, True):
+        xs, bl = x.clone(), block.clone()
+        if sanitize:
+            xs[5, 1] = float("nan"); xs[9, 0] = float("inf"); bl[7, 0] = float("nan"); bl[11, 3] = float("-inf")
+        xo, ro = torch.empty(n, 3, device=DEV), torch.empty(n, 4, device=DEV)
+        ops.mapping_batch(R, t, table, fid, xs, bl[:, 0:1], valid, bl[:, 2:3], bl[:, 3:4], xo, ro, sanitize=sanitize)
+        xc, bc = (torch.nan_to_num(xs), torch.nan_to_num(bl)) if sanitize else (xs, bl)
+        idx = table[fid[:, 0].clamp(0, table.numel() - 1)].clamp(0, K - 1)
+        want_x = ops.rigid_by_index(R, t, idx, xc)
+        assert torch.equal(xo, want_x)
+        want_rows = torch.cat([bc[:, 0:1], valid.float(), bc[:, 2:3], bc[:, 3:4]], dim=1)
+        assert torch.equal(ro, want_rows)
+        assert torch.isfinite(xo).all() == sanitize or not sanitize
