@@ -50,6 +50,11 @@ class System:
 
     def _bind_submap(self):
         """A fresh tracker / mapper pair on the current submap, which is then initialised from its anchor keyframe."""
+        # the submap left behind is not trained by this loop again: let go of the captured training plans kept with it
+        # (gradient, Adam and binning buffers -- three quarters of a GB per ScanNet-sized submap)
+        old = getattr(getattr(self, 'mapper', None), 'grid', None)
+        if old is not None and old is not self.currrent_submap():
+            old.__dict__.pop('_fast_plans', None)
         self.tracker = Tracker(model=self.currrent_submap(), dataset=self.dataset_track, cfg=self.cfg)
         self.mapper = Mapper(model=self.currrent_submap(), dataset=self.dataset_map, cfg=self.cfg)
         self.mapper.mapping(mapping_kfs=[self.current_kf_id()], iterations=self.init_iterations,
