@@ -1116,3 +1116,55 @@ def test_mapping_batch_matches_the_op_sequence_and_sanitises():
         want_rows = torch.cat([bc[:, 0:1], valid.float(), bc[:, 2:3], bc[:, 3:4]], dim=1)
         assert torch.equal(ro, want_rows)
         assert torch.isfinite(xo).all() == sanitize or not sanitize
+
+
+@pytest.mark.gpu
+def test_round2_entry_points_on_empty_and_tiny_batches():
+    """Edges of the entry points added for the captured trainer step and the tracker: an empty batch launches nothing
+    that reads a row (loss slots cleared, step count untouched by a NaN-free empty loss), a 1-row and a 65-row batch
+    (one lane of the second wavefront) equal the op-by-op path."""
+    from miso_amd import ops
+    C_, H = 4, 64
+    feats = [(torch.randn(1, C_, 6, 5, 8) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d),
+             (torch.randn(1, C_, 12, 10, 16) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d)]
+    meta = ops.GridMeta.from_bound([[-1.0, 1.0], [-0.5, 0.5], [-0.8, 0.8]])
+    lin = [torch.nn.Linear(2 * C_, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.data.to(DEV) for l in lin], [l.bias.data.to(DEV) for l in lin])
+    g = torch.Generator().manual_seed(1)
+    for n in (0, 1, 65):
+        x = (torch.rand(n, 3, generator=g) * 2 - 1).to(DEV) * torch.tensor([1.0, 0.5, 0.8], device=DEV)
+        aux = torch.stack([torch.randn(n, generator=g) * 0.1, torch.ones(n), (torch.rand(n, generator=g) > 0.5).float(),
+                           torch.rand(n, generator=g) + 0.5], dim=1).to(DEV).contiguous()
+        mw = ops.sdf_mask_words(pack)
+        mask = torch.zeros(((n + 63) // 64) * 64 * mw + 1, device=DEV, dtype=torch.int32)
+        gsdf = torch.full((max(n, 1),), 7.0, device=DEV)[:n]
+        slots = torch.full((ops._lib.LOSS_SLOTS, 2), 5.0, device=DEV)
+        sdf = torch.empty(n, 1, device=DEV)
+        ops.sdf_fwd_loss_unsorted_raw(x.contiguous(), feats, meta, pack, aux, mask, gsdf, slots, "L1", 1.0, 0.3, 0.2,
+                                      sdf_out=sdf)
+        if n == 0:
+            assert float(slots.abs().sum()) == 0.0
+            continue
+        want_sdf, _ = ops.sdf_fwd_raw(x.contiguous(), feats, meta, pack, True)
+        assert torch.allclose(sdf, want_sdf, rtol=1e-6, atol=1e-7)
+        terms, gref = ops.mapping_loss_raw(want_sdf, aux[:, 0:1].contiguous(), aux[:, 1:2].contiguous(),
+                                           aux[:, 2:3].contiguous(), aux[:, 3:4].contiguous(), "L1", 1.0, 0.3, 0.2)
+        assert torch.allclose(slots.sum(0), terms, rtol=1e-5, atol=1e-8)
+        assert torch.allclose(gsdf, gref.reshape(-1), rtol=1e-6, atol=1e-9)
+    # mapping_batch with no rows: nothing written, no error
+    R = torch.eye(3, device=DEV).reshape(1, 3, 3).contiguous()
+    t = torch.zeros(1, 3, device=DEV)
+    table = torch.zeros(2, dtype=torch.int64, device=DEV)
+    e3, e4 = torch.empty(0, 3, device=DEV), torch.empty(0, 4, device=DEV)
+    ops.mapping_batch(R, t, table, torch.empty(0, 1, dtype=torch.int64, device=DEV), e3, torch.empty(0, 1, device=DEV),
+                      None, None, None, e3.clone(), e4, sanitize=True)
+    # loss total + step count: a NaN total leaves the count alone
+    dev = ops.AdamDeviceStep(1e-3, 0.9, 0.999, 1e-8, DEV, count=3)
+    tot = torch.zeros((), device=DEV)
+    dev.total_and_bump(torch.full((ops._lib.LOSS_SLOTS, 2), 0.25, device=DEV), tot)
+    assert float(tot) == 0.25 * 2 * ops._lib.LOSS_SLOTS and int(dev.step) == 4
+    bad = torch.full((ops._lib.LOSS_SLOTS, 2), 0.25, device=DEV)
+    bad[3, 1] = float("nan")
+    dev.total_and_bump(bad, tot)
+    assert bool(torch.isnan(tot)) and int(dev.step) == 4
+    assert dev.table.shape[1] == 6 and dev.rows > 20000
