@@ -409,7 +409,8 @@ def extras(step, dev):
     for key, fn in (("cfg4_align_8_submaps_28_pairs", cfg4),
                     ("sample_generation_scannet", lambda: sample_generation(dev)),
                     ("mesh_extraction_256", lambda: mesh_extraction(step, dev)),
-                    ("trainer_step_other_shapes", lambda: trainer_steps(dev))):
+                    ("trainer_step_other_shapes", lambda: trainer_steps(dev)),
+                    ("slam_components", lambda: slam_components(dev))):
         try:
             ex[key] = fn()
         except Exception as exc:  # noqa: BLE001
@@ -496,6 +497,95 @@ def trainer_steps(dev):
                      else "captured step + optimizer.step()"}
         del tr, net
         torch.cuda.empty_cache()
+    return out
+
+
+def slam_components(dev):
+    """The per-frame pieces of the SLAM loop as the reference's drivers call them (wall time, host included):
+    Mapper.mapping -- a NEW GridTrainer per call, coordinate+joint schedule, 10 iterations (slam/mapper.py:65-97) -- at
+    the ScanNet shape, and one tracker iteration with either solver (slam/tracker.py: lm_step / track_window) at 16 384
+    samples."""
+    import tempfile
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    from miso_amd.grid_opt.slam.mapper import Mapper
+    from miso_amd.grid_opt.slam.tracker import Tracker
+    out = {}
+    cfg_m = {"name": "grid_net", "spatial_dim": 3,
+             "decoder": {"type": "mlp", "hidden_dim": 64, "hidden_layers": 1, "out_dim": 1, "pos_invariant": True,
+                         "fix": True, "pretrained_model": None},
+             "grid": {"type": "regular", "feature_dim": 4, "init_stddev": 1e-2, "bound": [[-10., 10.], [-5., 5.], [-10., 10.]],
+                      "base_cell_size": 0.5, "per_level_scale": 5, "n_levels": 2},
+             "pose": {"optimize": True, "num_poses": 4}}
+
+    def dataset(n, frame):
+        g = torch.Generator().manual_seed(1)
+        pts = ((torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([6.0, 2.5, 6.0])).to(dev)
+        sdf = (torch.rand(n, 1, generator=g) * 0.2 - 0.1).to(dev)
+        ids = (torch.randint(0, 4, (n, 1), generator=g) if frame is None else torch.full((n, 1), frame)).to(dev)
+        one, zero = torch.ones(n, 1, device=dev), torch.zeros(n, 1, device=dev)
+
+        class DS(torch.utils.data.Dataset):
+            def select_keyframes(self, kfs):
+                pass
+
+            def __len__(self):
+                return 1
+
+            def __getitem__(self, i):
+                return ({"coords_frame": pts, "sample_frame_ids": ids, "weights": one},
+                        {"sdf": sdf, "sdf_valid": one, "sdf_signs": zero})
+        return DS()
+
+    def net():
+        torch.manual_seed(0)
+        m = GridNet(cfg_m, device=dev).to(dev)
+        for k in range(4):
+            m.set_initial_kf_pose(k, torch.eye(3), torch.tensor([[0.05 * k], [0.0], [0.02 * k]]), kf_key=f"KF{k}")
+        return m
+
+    log = tempfile.mkdtemp()
+    train = {"trainer": "base", "verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 50,
+             "ckpt_every": -1, "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": log,
+             "relchange_tol": 0, "max_epochs_in_level": 100, "grid_training_mode": "coordinate+joint"}
+    mapping = {"learning_rate": 1e-3, "loss_type": "L1", "weight_sdf": 1.0, "weight_eik": 0.0, "weight_fs": 0.1,
+               "trunc_dist": 0.15, "finite_diff_eps": 0.01, "grad_method": "finitediff", "eik_trunc_dist": 0.024,
+               "verbose": False}
+    mp = Mapper(net(), dataset(540000, None), {"device": dev, "train": train, "mapping": mapping})
+    for _ in range(2):
+        mp.mapping([0, 1, 2, 3], iterations=10, level_iterations=5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        mp.mapping([0, 1, 2, 3], iterations=10, level_iterations=5)
+    torch.cuda.synchronize()
+    out["mapper_mapping_540000pts_10_iterations"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3,
+                                                     "schedule": "coordinate+joint, 5 iterations per level, new GridTrainer per call"}
+    del mp
+    torch.cuda.empty_cache()
+    for solver, lt in (("lm", "GM"), ("adam", "L1")):
+        tracking = {"learning_rate": 1e-3, "verbose": False, "gm_scale_sdf": 0.1, "lm_lambda": 1e-4, "lm_max_iter": 10,
+                    "lm_tol_deg": 0.0, "lm_tol_m": 0.0, "loss_type": lt, "trunc_dist": None, "solver": solver}
+        trk = Tracker(net(), dataset(16384, 1), {"device": dev, "train": train, "tracking": tracking})
+        if solver == "lm":
+            for _ in range(3):
+                trk.lm_step(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                trk.lm_step(1)
+            torch.cuda.synchronize()
+            out["tracker_lm_step_16384pts"] = {"us_per_step": (time.perf_counter() - t0) / 30 * 1e6}
+        else:
+            trk.track_window([1], iterations=15)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                trk.track_window([1], iterations=15)
+            torch.cuda.synchronize()
+            out["tracker_adam_window_16384pts"] = {"us_per_iteration": (time.perf_counter() - t0) / 60 * 1e6,
+                                                   "iterations_per_window": 15}
+        del trk
+    torch.cuda.empty_cache()
     return out
 
 
