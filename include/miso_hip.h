@@ -405,6 +405,9 @@ typedef struct {
   float gm_scale, lm_lambda;
   float* pose; float* coords_world; float* sdf; float* grad; const float* ones; uint32_t* relu_mask; float* sums;
   float* info;
+  float* sanitized;                /* NULL, or scratch 5N floats: torch.nan_to_num (NaN -> 0, inf -> +-FLT_MAX) of
+                                      coords_frame, target and a float `valid` is taken first -- get_batch's
+                                      prepare_batch (grid_opt/utils/utils.py:487-493) folded into the call */
 } miso_lm_track_t;
 int miso_lm_track_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const miso_lm_track_t* args,
                        void* stream);

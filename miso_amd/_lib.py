@@ -49,7 +49,7 @@ class LmTrack(C.Structure):
                 ("trans_correction", C.c_void_p), ("loss_type", C.c_int32), ("gm_scale", C.c_float),
                 ("lm_lambda", C.c_float), ("pose", C.c_void_p), ("coords_world", C.c_void_p), ("sdf", C.c_void_p),
                 ("grad", C.c_void_p), ("ones", C.c_void_p), ("relu_mask", C.c_void_p), ("sums", C.c_void_p),
-                ("info", C.c_void_p)]
+                ("info", C.c_void_p), ("sanitized", C.c_void_p)]
 
 
 class TrackAdam(C.Structure):

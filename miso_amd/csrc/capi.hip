@@ -653,10 +653,18 @@ static int lm_track_args(const miso_grid_t* grid, const miso_lm_track_t* a, LmTr
   k.s_gt = a->stride_target; k.s_valid = a->stride_valid; k.s_fid = a->stride_frame_ids;
   k.valid_is_bool = a->valid_is_bool; k.n = a->n; k.kf = a->keyframe_id; k.trunc = a->trunc_dist;
   k.Rwk = a->R_base; k.twk = a->t_base; k.dr = a->rot_correction; k.dt = a->trans_correction;
-  k.pose = a->pose; k.xw = a->coords_world; k.sums = a->sums; k.info = a->info;
+  k.pose = a->pose; k.xw = a->coords_world; k.sums = a->sums; k.info = a->info; k.clean = a->sanitized;
   for (int i = 0; i < 3; ++i) { k.bmin[i] = grid->bound_min[i]; k.bmax[i] = grid->bound_max[i]; }
   k.lm_lambda = a->lm_lambda;
   return MISO_OK;
+}
+
+// after the head (pose + transform) has run: the later kernels read the sanitised copies
+static void lm_track_use_clean(LmTrackK* k) {
+  if (!k->clean) return;
+  k->x = k->clean; k->gt = k->clean + 3 * k->n; k->s_gt = 1;
+  k->valid = k->clean + 4 * k->n; k->s_valid = 1; k->valid_is_bool = 0;
+  k->clean = nullptr;
 }
 
 int miso_track_adam_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const miso_track_adam_t* t,
@@ -683,6 +691,7 @@ int miso_track_adam_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const f
   hipStream_t st = (hipStream_t)stream;
   int rc = (int)launch_lm_track_head(k.s, st);
   if (rc) return rc;
+  lm_track_use_clean(&k.s);
   if (a->n > 0) {
     rc = sdf_fwd_impl(grid, mlp, packed, a->coords_world, a->n, a->sdf, a->relu_mask, nullptr, stream);
     if (rc) return rc;
@@ -708,17 +717,11 @@ int miso_lm_track_step(const miso_grid_t* grid, const miso_mlp_t* mlp, const flo
   for (int l = 0; l < grid->n_levels && l < MISO_MAX_LEVELS; ++l)
     if (grid->level[l].grad) return MISO_E_BADARG;      // the step wants d sdf / d x only
   LmTrackK k;
-  memset(&k, 0, sizeof(k));
-  k.x = a->coords_frame; k.gt = a->target; k.valid = a->valid; k.frame_ids = a->frame_ids;
-  k.s_gt = a->stride_target; k.s_valid = a->stride_valid; k.s_fid = a->stride_frame_ids;
-  k.valid_is_bool = a->valid_is_bool; k.n = a->n; k.kf = a->keyframe_id; k.trunc = a->trunc_dist;
-  k.Rwk = a->R_base; k.twk = a->t_base; k.dr = a->rot_correction; k.dt = a->trans_correction;
-  k.pose = a->pose; k.xw = a->coords_world; k.sums = a->sums; k.info = a->info;
-  for (int i = 0; i < 3; ++i) { k.bmin[i] = grid->bound_min[i]; k.bmax[i] = grid->bound_max[i]; }
-  k.lm_lambda = a->lm_lambda;
+  lm_track_args(grid, a, &k);
   hipStream_t st = (hipStream_t)stream;
   int rc = (int)launch_lm_track_head(k, st);
   if (rc) return rc;
+  lm_track_use_clean(&k);
   if (a->n > 0) {
     rc = sdf_fwd_impl(grid, mlp, packed, a->coords_world, a->n, a->sdf, a->relu_mask, nullptr, stream);
     if (rc) return rc;

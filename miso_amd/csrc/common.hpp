@@ -139,6 +139,8 @@ struct LmTrackK {
   float* xw;                 // scratch (N,3): samples in the submap frame
   float* sums;               // scratch 36: 32 of lm_normal_eq + {rows kept, in bound, wrong frame id, invalid}
   float* info;               // out 8: |dR| (rad), |dt|, |g|, in bound, kept, wrong frame id, invalid, 0
+  float* clean;              // nullptr, or scratch 5N: torch.nan_to_num of x (3N), gt (N), valid (N, as floats) -- written
+                             // by the transform kernel, read by everything after it (the caller repoints x / gt / valid)
   float bmin[3], bmax[3];
   float lm_lambda;
 };

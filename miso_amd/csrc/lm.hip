@@ -117,8 +117,15 @@ __global__ __launch_bounds__(256) void lm_transform_kernel(LmTrackK k) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) t[i] = k.pose[9 + i];
   float c[4] = {0.f, 0.f, 0.f, 0.f};
+  // clean != nullptr: torch.nan_to_num of what is read (prepare_batch, utils.py:487-493, folded in), kept for the
+  // kernels after this one
+  auto clean = [&](float v) -> float {
+    if (!k.clean) return v;
+    if (v != v) return 0.0f;
+    return fminf(fmaxf(v, -3.4028234663852886e38f), 3.4028234663852886e38f);
+  };
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k.n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float a = k.x[3 * i], b = k.x[3 * i + 1], cc = k.x[3 * i + 2];
+    const float a = clean(k.x[3 * i]), b = clean(k.x[3 * i + 1]), cc = clean(k.x[3 * i + 2]);
     float y[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {      // transform_points_to: the row-times-matrix order of rigid.hip
@@ -128,18 +135,23 @@ __global__ __launch_bounds__(256) void lm_transform_kernel(LmTrackK k) {
       y[j] = __fadd_rn(s, t[j]);
       k.xw[3 * i + j] = y[j];
     }
-    const float g = k.gt[i * k.s_gt];
+    const float g = clean(k.gt[i * k.s_gt]);
+    bool ok = true;
+    if (k.valid)
+      ok = k.valid_is_bool ? reinterpret_cast<const unsigned char*>(k.valid)[i * k.s_valid] != 0
+                           : clean(reinterpret_cast<const float*>(k.valid)[i * k.s_valid]) == 1.0f;
+    if (k.clean) {
+      k.clean[3 * i] = a; k.clean[3 * i + 1] = b; k.clean[3 * i + 2] = cc;
+      k.clean[3 * k.n + i] = g;
+      k.clean[4 * k.n + i] = ok ? 1.0f : 0.0f;
+    }
     if (k.trunc >= 0.0f && !(fabsf(g) < k.trunc)) continue;
     c[0] += 1.0f;
     if (y[0] >= k.bmin[0] && y[0] <= k.bmax[0] && y[1] >= k.bmin[1] && y[1] <= k.bmax[1] && y[2] >= k.bmin[2] &&
         y[2] <= k.bmax[2])
       c[1] += 1.0f;
     if (k.frame_ids && k.frame_ids[i * k.s_fid] != k.kf) c[2] += 1.0f;
-    if (k.valid) {
-      const bool ok = k.valid_is_bool ? reinterpret_cast<const unsigned char*>(k.valid)[i * k.s_valid] != 0
-                                      : reinterpret_cast<const float*>(k.valid)[i * k.s_valid] == 1.0f;
-      if (!ok) c[3] += 1.0f;
-    }
+    if (!ok) c[3] += 1.0f;
   }
   __shared__ float red[4][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -107,7 +107,7 @@ class Tracker:
         grid.train()
         for epoch in range(iterations):
             for step_i, (model_input, gt) in enumerate(utils.iter_batches(loader)):
-                model_input, gt = utils.prepare_batch(model_input, gt, self.cfg['device'])
+                model_input, gt = utils.prepare_batch(model_input, gt, self.cfg['device'], sanitize=False)
                 coords_frame = model_input['coords_frame'][0]
                 n = coords_frame.shape[0]
                 if win is None:
@@ -121,7 +121,7 @@ class Tracker:
                     raise RuntimeError("tracking batches of one window differ in size")
                 win.step(feats, meta, pack, coords_frame.contiguous(), gt['sdf'][0], gt['sdf_valid'][0],
                          model_input['sample_frame_ids'][0], kf_key, lf.trunc_dist, grid.Rwk[kf], grid.twk[kf], dr, dt,
-                         lf.loss_type, lf.weight_sdf, lf.gm_scale_sdf)
+                         lf.loss_type, lf.weight_sdf, lf.gm_scale_sdf, sanitize=True)
                 batches.append((epoch, step_i))
         torch.autograd.graph.increment_version(grid.rotation_corrections)      # written through raw pointers:
         torch.autograd.graph.increment_version(grid.translation_corrections)   # pose caches key on the versions
@@ -177,7 +177,7 @@ class Tracker:
         try:
             out = step(feats, meta, pack, coords_frame.contiguous(), gt_sdf, gt_valid, frame_ids, optimize_kf,
                        self.trunc_dist, grid.Rwk[kf], grid.twk[kf], dr, dt, self.loss_type, self.gm_scale_sdf,
-                       self.lm_lambda)
+                       self.lm_lambda, sanitize=True)
         except ValueError:
             return None
         torch.autograd.graph.increment_version(grid.rotation_corrections)      # written through raw pointers:
@@ -199,13 +199,18 @@ class Tracker:
         """One damped Gauss-Newton step on the keyframe pose (reference :148-212):
         J_i = [ (hat(R x_i) grad_i)^T R , grad_i^T ], H = J^T W J + lambda I, g = J^T W r."""
         self.dataset.select_keyframes([optimize_kf])
-        model_input, gt = utils.get_batch(self.train_loader, self.cfg['device'])
+        # (the device-side step takes the batch before nan_to_num and does that itself; any other path sanitises here)
+        model_input, gt = utils.get_batch(self.train_loader, self.cfg['device'], sanitize=not self.fused)
+        info = None
+        if self.fused:
+            info = self._lm_step_on_device(optimize_kf, model_input['coords_frame'][0], model_input['sample_frame_ids'][0],
+                                           gt['sdf'][0], gt['sdf_valid'][0])
+            if info is not None:
+                return info
+            model_input, gt = utils.sanitize_tensor_dict(model_input), utils.sanitize_tensor_dict(gt)
         coords_frame = model_input['coords_frame'][0]
         frame_ids = model_input['sample_frame_ids'][0]
         gt_sdf, gt_valid = gt['sdf'][0], gt['sdf_valid'][0]
-        info = self._lm_step_on_device(optimize_kf, coords_frame, frame_ids, gt_sdf, gt_valid)
-        if info is not None:
-            return info
         if self.trunc_dist is not None:
             keep = torch.nonzero(torch.abs(gt_sdf[:, 0]) < self.trunc_dist, as_tuple=False).squeeze(1)
             coords_frame, frame_ids = coords_frame[keep], frame_ids[keep]

@@ -174,9 +174,9 @@ def iter_batches(loader):
         yield collate([dataset[i] for i in indices])
 
 
-def get_batch(data_loader, device='cuda:0'):
+def get_batch(data_loader, device='cuda:0', sanitize=True):
     for model_input, gt in iter_batches(data_loader):
-        return prepare_batch(model_input, gt, device)
+        return prepare_batch(model_input, gt, device, sanitize=sanitize)
 
 
 def relative_param_change(params_curr, params_prev=None):

@@ -1137,11 +1137,13 @@ class LmTrackStep:
         self.mask = torch.empty(((self.n + 63) // 64) * 64 * mw, device=device, dtype=torch.int32)
         self.sums = torch.empty(36, **f32)
         self.info = torch.empty(8, **f32)
+        self.clean = torch.empty(5 * max(self.n, 1), **f32)       # nan_to_num'ed coords / target / valid (sanitize=True)
         self.info_host = torch.empty(8, dtype=torch.float32, pin_memory=True)
 
     def _fill(self, a, coords_frame, target, valid, frame_ids, keyframe_id, trunc_dist, R_base, t_base, rot_correction,
-              trans_correction):
+              trans_correction, sanitize=False):
         n = self.n
+        a.sanitized = self.clean.data_ptr() if sanitize else 0
 
         def col(c, dtypes):
             if c is None:
@@ -1174,12 +1176,13 @@ class LmTrackStep:
 
     def __call__(self, features, meta: GridMeta, pack: DecoderPack, coords_frame, target, valid, frame_ids, keyframe_id,
                  trunc_dist, R_base, t_base, rot_correction, trans_correction, loss_type: str, gm_scale: float,
-                 lm_lambda: float):
+                 lm_lambda: float, sanitize: bool = False):
         """-> [|delta_R| rad, |delta_t|, |g|, rows in bound, rows kept, wrong frame ids, invalid rows, 0] (host floats).
-        rot_correction / trans_correction: 3-float views of the pose parameters, updated in place."""
+        rot_correction / trans_correction: 3-float views of the pose parameters, updated in place.
+        sanitize: torch.nan_to_num on the batch first (prepare_batch folded in)."""
         a = _lib.LmTrack()
         cf = self._fill(a, coords_frame, target, valid, frame_ids, keyframe_id, trunc_dist, R_base, t_base, rot_correction,
-                        trans_correction)
+                        trans_correction, sanitize)
         a.loss_type, a.gm_scale, a.lm_lambda = {"L2": 2, "GM": 3}[loss_type], float(gm_scale), float(lm_lambda)
         m, packed = pack.get()
         g = _fill_grid([f.detach() for f in features], meta)
@@ -1212,10 +1215,10 @@ class TrackAdamWindow(LmTrackStep):
 
     def step(self, features, meta: GridMeta, pack: DecoderPack, coords_frame, target, valid, frame_ids, keyframe_id,
              trunc_dist, R_base, t_base, rot_correction, trans_correction, loss_type: str, weight_sdf: float,
-             gm_scale: float):
+             gm_scale: float, sanitize: bool = False):
         t = _lib.TrackAdam()
         cf = self._fill(t.s, coords_frame, target, valid, frame_ids, keyframe_id, trunc_dist, R_base, t_base,
-                        rot_correction, trans_correction)
+                        rot_correction, trans_correction, sanitize)
         t.loss_type, t.weight_sdf, t.gm_scale = {"L1": 1, "L2": 2, "GM": 3}[loss_type], float(weight_sdf), float(gm_scale)
         t.grad_pred, t.adam_table, t.adam_table_len = self.gpred.data_ptr(), self.table.data_ptr(), self.table.shape[0]
         t.state, t.loss_ring, t.ring_len = self.state.data_ptr(), self.ring.data_ptr(), self.ring.shape[0]

@@ -109,5 +109,5 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     t = _lib.TrackAdam()
     assert lib.miso_track_adam_step(ctypes.byref(g), None, None, ctypes.byref(t), None) == E
     # struct sizes the header implies (LP64)
-    assert ctypes.sizeof(_lib.LmTrack) == 4 * 8 + 3 * 8 + 8 + 8 + 8 + 8 + 4 * 8 + 4 + 4 + 4 + 4 + 8 * 8
+    assert ctypes.sizeof(_lib.LmTrack) == 4 * 8 + 3 * 8 + 8 + 8 + 8 + 8 + 4 * 8 + 4 + 4 + 4 + 4 + 9 * 8
     assert ctypes.sizeof(_lib.TrackAdam) == ctypes.sizeof(_lib.LmTrack) + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8
