@@ -1005,8 +1005,11 @@ def test_lm_step_on_device_equals_the_op_by_op_step(lt, monkeypatch):
     n = pts.shape[0]
     gen = torch.Generator().manual_seed(3)
     pts = pts * 1.15                                            # some leave the bound
+    pts[3, 1] = float("nan")                                    # get_batch's nan_to_num: folded into the fused step
+    pts[9, 0] = float("inf")
     lab = torch.stack([T(g["sdf"])[:, 0] * (1.0 + 0.5 * torch.rand(n, generator=gen)), torch.ones(n), torch.zeros(n),
                        torch.ones(n)], dim=1).to(dev)            # (n,4) block: columns are strided views
+    lab[5, 0] = float("nan")
 
     def make(valid_dtype=torch.bool, frame=1, bad_valid=False):
         net = make_gridnet(case, dev, num_poses=2, optimize_pose=True)
