@@ -128,8 +128,6 @@ class _FastMappingPlan:
             if plan.n != n or plan.padded != padded:
                 continue
             old = plan.opt_ref()
-            if old is not None and old is not opt:
-                continue                              # still serving a live optimizer
             feats = plan.feats
             opt_params = {id(p) for group in opt.param_groups for p in group['params']}
             need = tuple(id(f) in opt_params and f.requires_grad for f in feats)
@@ -142,6 +140,13 @@ class _FastMappingPlan:
             fresh = all(not st for st in states)
             if not fresh and old is not opt:
                 continue                              # an optimizer with a history of its own: not ours to replace
+            if fresh and old is not None and old is not opt:
+                # the optimizer that used the plan last is still alive (a trainer kept around, or one whose collection
+                # is pending): it keeps its history in tensors of its own, the plan's buffers go to the new owner
+                for st in plan.states:
+                    for key in ('exp_avg', 'exp_avg_sq', 'active'):
+                        if key in st:
+                            st[key] = st[key].clone()
             if fresh:
                 for st, (m, v, act) in zip(states, [a for a in plan.step.adam_state if a is not None]):
                     m.zero_(); v.zero_(); act.zero_()
