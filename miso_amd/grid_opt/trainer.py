@@ -140,6 +140,10 @@ class _FastMappingPlan:
             fresh = all(not st for st in states)
             if not fresh and old is not opt:
                 continue                              # an optimizer with a history of its own: not ours to replace
+            bufs = [a for a in plan.step.adam_state if a is not None]
+            if not fresh and any(st.get('exp_avg') is not b[0] or st.get('exp_avg_sq') is not b[1] or st.get('active') is not b[2]
+                                 for st, b in zip(states, bufs)):
+                continue                              # its state no longer lives in the plan's buffers (a loaded state dict)
             if fresh and old is not None and old is not opt:
                 # the optimizer that used the plan last is still alive (a trainer kept around, or one whose collection
                 # is pending): it keeps its history in tensors of its own, the plan's buffers go to the new owner
@@ -148,7 +152,7 @@ class _FastMappingPlan:
                         if key in st:
                             st[key] = st[key].clone()
             if fresh:
-                for st, (m, v, act) in zip(states, [a for a in plan.step.adam_state if a is not None]):
+                for st, (m, v, act) in zip(states, bufs):
                     m.zero_(); v.zero_(); act.zero_()
                     st.update(step=0, exp_avg=m, exp_avg_sq=v, active=act)
                 plan.dev.set_count(0)
