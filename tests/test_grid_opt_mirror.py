@@ -1223,3 +1223,50 @@ def test_mapper_calls_adopt_the_fast_plan(mode, tmp_path):
     for a, b in zip(ref, got):
         d = (a - b).abs()
         assert d.mean().item() <= 5e-6 and (d > 1e-5).float().mean().item() <= 2e-3, (d.max().item(), d.mean().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["joint", "coordinate+joint"])
+def test_fast_plan_on_the_headline_grid(mode, tmp_path):
+    """The one-replay plan on the cfg-2 grid (3 levels {32,64,128}^3, 8 channels, all levels pulled by the block kernel)
+    with 262 144 samples, joint and on the coordinate schedule (2 epochs per level): same features as the checked path
+    after 8 steps (noise-aware bound, see test_fast_captured_step_equals_the_checked_one)."""
+    from miso_amd.grid_opt.loss import MisoLossMapping
+    from miso_amd.grid_opt.models.grid_net import GridNet
+    from miso_amd.grid_opt.trainer import GridTrainer
+    dev = "cuda:0"
+    cfg = gc.model_cfg([[-1.0, 1.0]] * 3, 2.0 / 32, 2, 3, 8, 64, num_poses=1, init_stddev=1e-2)
+    n = 262144
+    g = torch.Generator().manual_seed(12)
+    x = (torch.rand(n, 3, generator=g) * 2 - 1).to(dev)
+    mi = {"coords_frame": x[None], "sample_frame_ids": torch.zeros(1, n, 1, dtype=torch.int64, device=dev),
+          "weights": torch.ones(1, n, 1, device=dev)}
+    gt = {"sdf": (torch.rand(1, n, 1, generator=g) * 0.2 - 0.1).to(dev), "sdf_valid": torch.ones(1, n, 1, device=dev),
+          "sdf_signs": (torch.rand(1, n, 1, generator=g) > 0.7).float().to(dev)}
+
+    def run(fast):
+        torch.manual_seed(0)
+        net = GridNet(cfg, device=dev).to(dev)
+        net.set_initial_kf_pose(0, torch.eye(3), torch.zeros(3, 1), kf_key="KF0")
+        net.unlock_feature()
+        net.lock_pose()
+        tcfg = {"verbose": False, "optimizer": "adam", "learning_rate": 1e-3, "epochs": 1, "ckpt_every": -1,
+                "eval_every": -1, "eval_metric": None, "pretrained_model": None, "log_dir": str(tmp_path),
+                "relchange_tol": 0, "max_epochs_in_level": 2, "grid_training_mode": mode, "fast_captured_step": fast}
+        lf = MisoLossMapping(loss_type="L1", weight_sdf=1.0, weight_eik=0.0, weight_fs=0.1, trunc_dist=0.15)
+        tr = GridTrainer(tcfg, net, lf, None, None, dev, torch.float32)
+        used = 0
+        for epoch in range(8):
+            tr.pre_epoch(epoch)
+            tr.train_step(mi, gt)
+            used += tr.__dict__.get("_fast_plan") is not None
+        torch.cuda.synchronize()
+        return [f.feature.detach().clone() for f in net.features], used
+
+    ref, u0 = run(False)
+    got, u1 = run(True)
+    assert u0 == 0 and u1 >= (5 if mode == "joint" else 1)
+    for a, b in zip(ref, got):
+        d = (a - b).abs()
+        assert d.mean().item() <= 1e-6 and (d > 1e-5).float().mean().item() <= 2e-3, (d.max().item(), d.mean().item())
+    assert not torch.equal(ref[2], torch.zeros_like(ref[2]))
