@@ -569,12 +569,15 @@ def slam_components(dev):
         if solver == "lm":
             for _ in range(3):
                 trk.lm_step(1)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(30):
-                trk.lm_step(1)
-            torch.cuda.synchronize()
-            out["tracker_lm_step_16384pts"] = {"us_per_step": (time.perf_counter() - t0) / 30 * 1e6}
+            best = float("inf")
+            for _ in range(2):                      # best of two loops: a one-off host hiccup once cost 40 ms here
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    trk.lm_step(1)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / 30 * 1e6)
+            out["tracker_lm_step_16384pts"] = {"us_per_step": best}
         else:
             trk.track_window([1], iterations=15)
             torch.cuda.synchronize()
