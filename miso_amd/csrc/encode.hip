@@ -153,6 +153,59 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(GridK g, const float* _
   if (gx) { gx[po * 3 + 0] = gpx; gx[po * 3 + 1] = gpy; gx[po * 3 + 2] = gpz; }
 }
 
+// grad_x alone (channels-last levels, the grid gradient formed elsewhere or not wanted): the eight corner values
+// contract with gF first, d_k = <gF, G[:, corner k]>, and grad_x is the gradient of the trilinear interpolant of that
+// ONE scalar per corner -- a lerp tree instead of 24 derivative weights.
+__global__ __launch_bounds__(256) void encode_bwd_x_kernel(GridK g, const float* __restrict__ x, int64_t n,
+                                                          const float* __restrict__ gf, int64_t ld,
+                                                          float* __restrict__ gx, const int* __restrict__ perm) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float px, py, pz;
+  load_point(g, x, p, px, py, pz);
+  const int64_t po = perm ? (int64_t)perm[p] : p;
+  const float* go = gf + po * ld;
+  float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+  for (int l = 0; l < g.n_levels; ++l) {
+    const LevelK& lv = g.lv[l];
+    if ((g.ignore_mask >> l) & 1u) continue;
+    Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+    Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+    Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+    Cell c = make_cell(ax, ay, az, lv);
+    float d[8];
+    int off[8];
+    bool inb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      inb[k] = c.inx[dx] && c.iny[dy] && c.inz[dz];
+      off[k] = inb[k] ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+      d[k] = 0.0f;
+    }
+    for (int ch = 0; ch < lv.C; ch += 4) {
+      const float4 gv = *reinterpret_cast<const float4*>(go + lv.foff + ch);
+      float4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(lv.data + off[k] + ch);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] += gv.x * v[k].x + gv.y * v[k].y + gv.z * v[k].z + gv.w * v[k].w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = inb[k] ? d[k] : 0.0f;
+    const float tx = c.wx[1], ty = c.wy[1], tz = c.wz[1];
+    const float d00 = d[1] - d[0], d10 = d[3] - d[2], d01 = d[5] - d[4], d11 = d[7] - d[6];
+    const float a00 = d[0] + tx * d00, a10 = d[2] + tx * d10, a01 = d[4] + tx * d01, a11 = d[6] + tx * d11;
+    const float e0 = a10 - a00, e1 = a11 - a01;
+    const float b0 = a00 + ty * e0, b1 = a01 + ty * e1;
+    const float gx0 = d00 + ty * (d10 - d00), gx1 = d01 + ty * (d11 - d01);
+    gpx += (gx0 + tz * (gx1 - gx0)) * (g.gscale[0] * ax.mult);
+    gpy += (e0 + tz * (e1 - e0)) * (g.gscale[1] * ay.mult);
+    gpz += (b1 - b0) * (g.gscale[2] * az.mult);
+  }
+  gx[po * 3 + 0] = gpx; gx[po * 3 + 1] = gpy; gx[po * 3 + 2] = gpz;
+}
+
 // Second backward.  Inputs: ggG (= lv.gg, cotangent of grad_grid, may be null),
 // ggx (cotangent of grad_x, may be null), gF (= grad_feats of the first
 // backward).  Outputs: ggF (N,F); gG scatter (lv.grad, may be null); gx (may be null).
@@ -268,6 +321,117 @@ __global__ __launch_bounds__(256) void encode_bwd2_kernel(GridK g, const float* 
   if (gx) { gx[po * 3 + 0] = gpx; gx[po * 3 + 1] = gpy; gx[po * 3 + 2] = gpz; }
 }
 
+// The same second backward for the case the binned path produces (channels-last levels, no grid scatter from here: the
+// pull forms that gradient): value, first and mixed second derivatives of the trilinear interpolant by a lerp tree on
+// the zero-padded corner values instead of eight arrays of corner weights.  The weight form above keeps 64 weight
+// registers per level next to 64 gathered corner values (252 VGPRs: two wavefronts per SIMD on a kernel bound by the
+// latency of its gathers).
+//   ggF[c] = f(ggG_c) + d . grad f(G_c)
+//   gx_a   = mult_a * sum_c gF[c] * ( d_a f(ggG_c) + sum_{b != a} d_b d_ab f(G_c) )          (d_aa f = 0)
+struct Lerp3 {
+  float f, fx, fy, fz, fxy, fxz, fyz;
+};
+template <bool SECOND>
+__device__ __forceinline__ Lerp3 lerp_tree(const float v[8], float tx, float ty, float tz) {
+  Lerp3 r;
+  const float d00 = v[1] - v[0], d10 = v[3] - v[2], d01 = v[5] - v[4], d11 = v[7] - v[6];       // d/dx on the (y,z) edges
+  const float a00 = v[0] + tx * d00, a10 = v[2] + tx * d10, a01 = v[4] + tx * d01, a11 = v[6] + tx * d11;
+  const float e0 = a10 - a00, e1 = a11 - a01;                                                     // d/dy at z = 0, 1
+  const float b0 = a00 + ty * e0, b1 = a01 + ty * e1;
+  r.f = b0 + tz * (b1 - b0);
+  r.fz = b1 - b0;
+  r.fy = e0 + tz * (e1 - e0);
+  const float gx0 = d00 + ty * (d10 - d00), gx1 = d01 + ty * (d11 - d01);
+  r.fx = gx0 + tz * (gx1 - gx0);
+  if (SECOND) {
+    r.fyz = e1 - e0;
+    r.fxy = (d10 - d00) + tz * ((d11 - d01) - (d10 - d00));
+    r.fxz = (d01 - d00) + ty * ((d11 - d10) - (d01 - d00));
+  } else {
+    r.fyz = r.fxy = r.fxz = 0.0f;
+  }
+  return r;
+}
+
+template <bool HAS_GG>
+__global__ __launch_bounds__(256) void encode_bwd2_lean_kernel(GridK g, const float* __restrict__ x, int64_t n,
+                                                              const float* __restrict__ gf, int64_t ld,
+                                                              const float* __restrict__ ggx, float* __restrict__ ggo,
+                                                              int64_t ldgg, float* __restrict__ gx,
+                                                              const int* __restrict__ perm) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float px, py, pz;
+  load_point(g, x, p, px, py, pz);
+  const int64_t po = perm ? (int64_t)perm[p] : p;
+  const float* go = gf + po * ld;
+  float* ggout = ggo + po * ldgg;
+  float ex = 0.f, ey = 0.f, ez = 0.f;
+  if (ggx) { ex = ggx[po * 3 + 0]; ey = ggx[po * 3 + 1]; ez = ggx[po * 3 + 2]; }
+  float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+  for (int l = 0; l < g.n_levels; ++l) {
+    const LevelK& lv = g.lv[l];
+    if ((g.ignore_mask >> l) & 1u) {
+      for (int c = 0; c < lv.C; ++c) ggout[lv.foff + c] = 0.0f;
+      continue;
+    }
+    Axis ax = axis_coord(px, g.bmin[0], g.bmax[0], lv.X, g.flags);
+    Axis ay = axis_coord(py, g.bmin[1], g.bmax[1], lv.Y, g.flags);
+    Axis az = axis_coord(pz, g.bmin[2], g.bmax[2], lv.Z, g.flags);
+    Cell c = make_cell(ax, ay, az, lv);
+    const float mx = g.gscale[0] * ax.mult, my = g.gscale[1] * ay.mult, mz = g.gscale[2] * az.mult;
+    const float dxi = ex * mx, dyi = ey * my, dzi = ez * mz;
+    int off[8];
+    bool inb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      inb[k] = c.inx[dx] && c.iny[dy] && c.inz[dz];
+      off[k] = inb[k] ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+    }
+    const float tx = c.wx[1], ty = c.wy[1], tz = c.wz[1];
+    const bool gg_here = HAS_GG && lv.gg != nullptr;
+    float ax_ = 0.f, ay_ = 0.f, az_ = 0.f;
+    for (int ch = 0; ch < lv.C; ch += 4) {
+      const float4 gv4 = *reinterpret_cast<const float4*>(go + lv.foff + ch);
+      const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+      float4 vv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        vv[k] = inb[k] ? *reinterpret_cast<const float4*>(lv.data + off[k] + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float ggv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = e == 0 ? vv[k].x : (e == 1 ? vv[k].y : (e == 2 ? vv[k].z : vv[k].w));
+        const Lerp3 t = lerp_tree<true>(v, tx, ty, tz);
+        ggv[e] = dxi * t.fx + dyi * t.fy + dzi * t.fz;
+        ax_ += gv[e] * (dyi * t.fxy + dzi * t.fxz);
+        ay_ += gv[e] * (dxi * t.fxy + dzi * t.fyz);
+        az_ += gv[e] * (dxi * t.fxz + dyi * t.fyz);
+      }
+      if (gg_here) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          vv[k] = inb[k] ? *reinterpret_cast<const float4*>(lv.gg + off[k] + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = e == 0 ? vv[k].x : (e == 1 ? vv[k].y : (e == 2 ? vv[k].z : vv[k].w));
+          const Lerp3 t = lerp_tree<false>(v, tx, ty, tz);
+          ggv[e] += t.f;
+          ax_ += gv[e] * t.fx; ay_ += gv[e] * t.fy; az_ += gv[e] * t.fz;
+        }
+      }
+      *reinterpret_cast<float4*>(ggout + lv.foff + ch) = make_float4(ggv[0], ggv[1], ggv[2], ggv[3]);
+    }
+    gpx += ax_ * mx; gpy += ay_ * my; gpz += az_ * mz;
+  }
+  if (gx) { gx[po * 3 + 0] = gpx; gx[po * 3 + 1] = gpy; gx[po * 3 + 2] = gpz; }
+}
+
 // ---- host-side launch helpers (called from capi.hip) -----------------------
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
@@ -282,6 +446,12 @@ hipError_t launch_encode_fwd(const GridK& g, bool vec4, const float* x, int64_t 
 hipError_t launch_encode_bwd(const GridK& g, bool vec4, const float* x, int64_t n, const float* gf,
                              int64_t ld, float* gx, const int* perm, hipStream_t s) {
   if (n == 0) return hipSuccess;
+  bool scatter = false;
+  for (int l = 0; l < g.n_levels; ++l) scatter = scatter || g.lv[l].grad != nullptr;
+  if (vec4 && gx && !scatter && ld % 4 == 0 && ((uintptr_t)gf & 15u) == 0 && !getenv("MISO_BWD2_NO_LEAN")) {
+    encode_bwd_x_kernel<<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx, perm);
+    return hipGetLastError();
+  }
   if (vec4) encode_bwd_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx, perm);
   else encode_bwd_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx, perm);
   return hipGetLastError();
@@ -291,6 +461,20 @@ hipError_t launch_encode_bwd2(const GridK& g, bool vec4, const float* x, int64_t
                               const float* ggx, float* ggo, int64_t ldgg, float* gx, const int* perm,
                               hipStream_t s) {
   if (n == 0) return hipSuccess;
+  // no grid scatter from this launch (the binned path leaves it to the pull, or no cotangent of grad_x): lean kernel,
+  // given 16-B aligned rows
+  bool scatter = false, has_gg = false;
+  for (int l = 0; l < g.n_levels; ++l) {
+    scatter = scatter || (g.lv[l].grad != nullptr && ggx != nullptr);
+    has_gg = has_gg || g.lv[l].gg != nullptr;
+  }
+  static const bool no_lean = getenv("MISO_BWD2_NO_LEAN") != nullptr;      // dev
+  if (vec4 && !scatter && !no_lean && ld % 4 == 0 && ldgg % 4 == 0 && ((uintptr_t)gf & 15u) == 0 &&
+      ((uintptr_t)ggo & 15u) == 0) {
+    if (has_gg) encode_bwd2_lean_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx, perm);
+    else encode_bwd2_lean_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx, perm);
+    return hipGetLastError();
+  }
   if (vec4) encode_bwd2_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx, perm);
   else encode_bwd2_kernel<false><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx, perm);
   return hipGetLastError();

@@ -31,6 +31,9 @@ constexpr int PULL_ARRW = 192;    // words of byte counters: (8+1)^3 = 729 cells
 constexpr int PULL_LIST = 272;    // compacted candidate ids per level
 constexpr int PULL_CAP = 112;     // staged records per group (<= 2 per lane); < 256: counters are bytes.  112: the
                                   // block kernel fits two workgroups per CU (2 x 79 KB of LDS)
+// MODE 1 records are 8 words instead of 4: fewer of them per group so that a wavefront's staging area is the size of
+// MODE 0's and the block kernel still fits two workgroups per CU (at 112 records it fitted one, and ran at half speed)
+constexpr int pull_cap(int C, int mode) { return mode ? ((PULL_CAP * (4 + C)) / (8 + C)) & ~1 : PULL_CAP; }
 constexpr int PULL_RB = 4;        // rounds of 64 vertices pulled per pass over the staged records
 constexpr int PULL_MAXL = 4;      // levels swept together (the fused kernels cover <= 4 levels)
 // Heavy tiles.  One wavefront drains one tile serially (~50 ns per swept candidate), so a batch that piles its
@@ -145,7 +148,8 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
   // Loop nest.  Levels whose brick fits one block of rounds (the coarse ones): accumulate over all
   // groups, store once.  Otherwise (the finest level): groups outside, round blocks inside, every
   // (group, block) stored -- overflow groups add onto the first one's store, nothing is restaged.
-  const int ngroups = (pk.debug & 2) ? 1 : max(1, (n + PULL_CAP - 1) / PULL_CAP);
+  constexpr int CAP = pull_cap(C, MODE);
+  const int ngroups = (pk.debug & 2) ? 1 : max(1, (n + CAP - 1) / CAP);
   const int nrb = (nrounds + PULL_RB - 1) / PULL_RB;
   const bool single_rb = nrb == 1;
   const int npass = single_rb ? ngroups : ngroups * nrb;
@@ -161,8 +165,8 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
         for (int c = 0; c < C; ++c) acc[r][c] = 0.0f;
     }
     {
-      const int g0 = gi * PULL_CAP;
-      const int gn = (pk.debug & 2) ? 0 : max(0, min(PULL_CAP, n - g0));
+      const int g0 = gi * CAP;
+      const int gn = (pk.debug & 2) ? 0 : max(0, min(CAP, n - g0));
       if (single_rb || rb0 == 0) {
         // ---- stage group gi: count, scan, fill ---------------------------------------------------
         if (pass > 0) wave_sync_lds();     // the previous pass is done reading the staging area
@@ -170,7 +174,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
         wave_sync_lds();
         // (2a) exact cell of every listed candidate (the sweep's box test is conservative), count
         // per cell; the records stay in registers (<= 3 per lane)
-        constexpr int RPL = (PULL_CAP + 63) / 64;
+        constexpr int RPL = (CAP + 63) / 64;
         int rc[RPL], rp[RPL]; float rfx[RPL], rfy[RPL], rfz[RPL];
         constexpr int REC = MODE ? 8 : 4;
 #pragma unroll
@@ -544,9 +548,10 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   // loads.  readfirstlane pins it (and the list lengths below) to SGPRs.
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int REC = MODE ? 8 : 4;
-  constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARRW + PULL_CAP * REC + PULL_CAP * C;
+  constexpr int CAP = pull_cap(C, MODE);
+  constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARRW + CAP * REC + CAP * C;
   const int o_list = wave * PER_WAVE, o_arr = o_list + PULL_NLV * PULL_LIST, o_rec = o_arr + PULL_ARRW,
-            o_df = o_rec + PULL_CAP * REC;
+            o_df = o_rec + CAP * REC;
   const int T = pk.T, ntiles = T * T * T;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
@@ -614,12 +619,13 @@ __global__ __launch_bounds__(512, 4) void grad_pull_block_kernel(GridK g, PullK 
   constexpr int O_LISTS = BLK_CAND * 4;
   constexpr int O_CNT = O_LISTS + BLK_WAVES * BLK_POOL / 2;
   constexpr int O_STAGE = O_CNT + 32;
-  constexpr int STAGE = PULL_ARRW + PULL_CAP * REC + PULL_CAP * C;
+  constexpr int CAP = pull_cap(C, MODE);
+  constexpr int STAGE = PULL_ARRW + CAP * REC + CAP * C;
   static_assert(BLK_WAVES * NLV * PULL_LIST <= O_CNT, "fallback lists must fit the table + list area");
   float4* cand = reinterpret_cast<float4*>(smem);        // .w = the point's sorted index (bits)
   uint16_t* lists = reinterpret_cast<uint16_t*>(reinterpret_cast<int*>(smem) + O_LISTS);
   int* cnt = reinterpret_cast<int*>(smem) + O_CNT;       // [tile * NLV + level] list lengths, [24] survivors, [25] overflow
-  const int o_arr = O_STAGE + wave * STAGE, o_rec = o_arr + PULL_ARRW, o_df = o_rec + PULL_CAP * REC;
+  const int o_arr = O_STAGE + wave * STAGE, o_rec = o_arr + PULL_ARRW, o_df = o_rec + CAP * REC;
   const int T = pk.T, nb = T / 2;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
@@ -1024,7 +1030,8 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   pk.work0 = PULL_WORK0;
   if (const char* d = getenv("MISO_PULL_WORK0")) pk.work0 = atoi(d) > PULL_WORK0 ? atoi(d) : PULL_WORK0;   // dev
   if (const char* d = getenv("MISO_DEBUG_PULL")) pk.debug = atoi(d);
-  const int per_wave = pk.nl * PULL_LIST + PULL_ARRW + PULL_CAP * (ggx ? 8 : 4) + PULL_CAP * C;
+  const int cap = pull_cap(C, ggx ? 1 : 0);
+  const int per_wave = pk.nl * PULL_LIST + PULL_ARRW + cap * (ggx ? 8 : 4) + cap * C;
   size_t lds = (size_t)per_wave * 4 * sizeof(float);
   if (const char* d = getenv("MISO_PULL_LDS_PAD")) lds += (size_t)atoi(d);   // dev: force a lower occupancy
   const int ntiles = T * T * T;
@@ -1065,7 +1072,7 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
       off += pk.blk_cap[d];
     }
     const size_t words = (size_t)BLK_CAND * 4 + (size_t)BLK_WAVES * BLK_POOL / 2 + 32 +
-                         (size_t)BLK_WAVES * (PULL_ARRW + PULL_CAP * rec + PULL_CAP * C);
+                         (size_t)BLK_WAVES * (PULL_ARRW + cap * rec + cap * C);
     const size_t blds = words * sizeof(float);
     hipError_t e = hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
     if (e != hipSuccess) return e;

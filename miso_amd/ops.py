@@ -261,6 +261,9 @@ class _EncodeBackward(torch.autograd.Function):
         ctx.save_for_backward(gout, x, *features)
         ctx.meta = meta
         ctx.sorted = sb
+        # an eikonal loss differentiates grad_x only: without this autograd hands the second backward a zero tensor the
+        # size of every level as the cotangent of its (unused) grid gradient, filled and then gathered eight corners a point
+        ctx.set_materialize_grads(False)
         return (gx, *grads)
 
     @staticmethod
