@@ -448,7 +448,7 @@ hipError_t launch_encode_bwd(const GridK& g, bool vec4, const float* x, int64_t 
   if (n == 0) return hipSuccess;
   bool scatter = false;
   for (int l = 0; l < g.n_levels; ++l) scatter = scatter || g.lv[l].grad != nullptr;
-  if (vec4 && gx && !scatter && ld % 4 == 0 && ((uintptr_t)gf & 15u) == 0 && !getenv("MISO_BWD2_NO_LEAN")) {
+  if (vec4 && gx && !scatter && ld % 4 == 0 && ((uintptr_t)gf & 15u) == 0 && !getenv("MISO_ENCODE_NO_LEAN")) {   // dev / tests: the weight-form kernel
     encode_bwd_x_kernel<<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, gx, perm);
     return hipGetLastError();
   }
@@ -468,7 +468,7 @@ hipError_t launch_encode_bwd2(const GridK& g, bool vec4, const float* x, int64_t
     scatter = scatter || (g.lv[l].grad != nullptr && ggx != nullptr);
     has_gg = has_gg || g.lv[l].gg != nullptr;
   }
-  static const bool no_lean = getenv("MISO_BWD2_NO_LEAN") != nullptr;      // dev
+  const bool no_lean = getenv("MISO_ENCODE_NO_LEAN") != nullptr;      // dev / tests: the weight-form kernel
   if (vec4 && !scatter && !no_lean && ld % 4 == 0 && ldgg % 4 == 0 && ((uintptr_t)gf & 15u) == 0 &&
       ((uintptr_t)ggo & 15u) == 0) {
     if (has_gg) encode_bwd2_lean_kernel<true><<<blocks_for(n), 256, 0, s>>>(g, x, n, gf, ld, ggx, ggo, ldgg, gx, perm);

@@ -64,8 +64,20 @@ __device__ __forceinline__ void memory_phase(bool on, uint32_t tune) {
 #define MISO_FUSED_KERNEL_ATTR
 __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 // y = relu1(x): bit <- (x > 0)
-__device__ __forceinline__ void push_gt0(uint32_t& m, float y, int bit) { m |= min(__float_as_uint(y), 1u) << bit; }
-__device__ __forceinline__ bool mask_bit(uint32_t m, int t, int j) { return (m >> (t * 16 + j)) & 1u; }
+// The bits are SHIFTED IN (the k-th of 32 pushes ends at bit 31 - k): y's bits are a non-negative integer, so
+// bit 31 of y + 0x7fffffff is (y != 0) and v_alignbit(m, that, 31) = (m << 1) | bit -- two instructions.  (min(y, 1)
+// << k | m is canonicalised by the compiler into compare + select + or, with a wait state after every compare.)
+__device__ __forceinline__ void push_gt0(uint32_t& m, float y) {
+  m = __builtin_amdgcn_alignbit(m, __float_as_uint(y) + 0x7fffffffu, 31);
+}
+__device__ __forceinline__ bool mask_bit(uint32_t m, int t, int j) { return (m >> (31 - (t * 16 + j))) & 1u; }
+// mask_bit ? x : 0 as v_bfe_i32 (the bit, sign-extended: 0 or ~0) + v_and -- the select form costs and + compare +
+// select and a wait state per element
+__device__ __forceinline__ float gate(float x, uint32_t m, int t, int j) {
+  int e = __builtin_amdgcn_sbfe((int)m, 31 - (t * 16 + j), 1);
+  asm("" : "+v"(e));      // opaque: and(x, sext(bit)) would be folded back into compare + select
+  return __uint_as_float(__float_as_uint(x) & (uint32_t)e);
+}
 
 struct ChunkSched {
   int64_t cur, end, step;
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           buf[0][r][t][j] = relu1(buf[0][r][t][j]);
-          push_gt0(m, buf[0][r][t][j], t * 16 + j);
+          push_gt0(m, buf[0][r][t][j]);
         }
       mw[r] = m;
     }
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
             buf[ni][r][t][j] = relu1(buf[ni][r][t][j]);
-            push_gt0(m, buf[ni][r][t][j], t * 16 + j);
+            push_gt0(m, buf[ni][r][t][j]);
           }
         mw[(h + 1) * RT + r] = m;
       }
@@ -355,17 +367,17 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
             a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias : a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias : a1, 0, 0, 0);
           }
-        uint32_t m = 0;
+        uint32_t m = 0, m1 = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const float y0 = relu1(a0[j]), y1 = relu1(a1[j]);
-          push_gt0(m, y0, j);
-          push_gt0(m, y1, 16 + j);
+          push_gt0(m, y0);
+          push_gt0(m1, y1);
           float wv = wo[32 * r + row_of(j, hi)];
           p0 += wv * y0;
           p1 += wv * y1;
         }
-        mw[(h + 1) * RT + r] = m;
+        mw[(h + 1) * RT + r] = (m << 16) | m1;
       }
     }
     p0 += __shfl_xor(p0, 32);
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
         float wv = wo[32 * r + row_of(j, hi)];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          dbuf[0][r][t][j] = mask_bit(mw[NH * RT + r], t, j) ? wv * ds[t] : 0.0f;
+          dbuf[0][r][t][j] = gate(wv * ds[t], mw[NH * RT + r], t, j);
       }
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
@@ -500,7 +512,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int j = 0; j < 16; ++j)
-            dbuf[ni][r][t][j] = mask_bit(mw[h * RT + r], t, j) ? dbuf[ni][r][t][j] : 0.0f;
+            dbuf[ni][r][t][j] = gate(dbuf[ni][r][t][j], mw[h * RT + r], t, j);
     }
     f32x16 (&d)[RT][2] = dbuf[NH & 1];
     // d feats = W0^T d   (one 32-row tile; rows >= F are zero)

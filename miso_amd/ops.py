@@ -233,7 +233,7 @@ def encode_bwd2_raw(x, features, meta: GridMeta, gout, ggx, ggf, need_x: bool, n
         ggx = ggx.contiguous()
     gg_out = torch.empty((n, F), device=x.device, dtype=torch.float32)
     g_x = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
-    sb = sorted_batch if pulled else None      # the binned copy exists: gather in tile order as well
+    sb = sorted_batch      # a binned copy exists (the forward's, or the pull's above): gather in tile order as well
     if sb is not None:
         _lib.check(_lib.load().miso_encode_bwd2_sorted(
             C.byref(g), C.byref(gg) if gg is not None else None, C.byref(sb.struct), n, _ptr(gout),

@@ -656,6 +656,52 @@ def test_second_order_pull_path_vs_atomic_and_oracle(name, n, monkeypatch):
     assert relerr(ga[-1][:m].cpu() * (n / m), gxc) < 5e-4
 
 
+@pytest.mark.parametrize("name", ["small", "cfg2"])
+@pytest.mark.parametrize("binned", [False, True])
+def test_lerp_tree_encode_kernels_equal_weight_form(name, binned, monkeypatch):
+    """encode_bwd_x_kernel / encode_bwd2_lean_kernel (value, first and mixed second derivatives of the interpolant by
+    a lerp tree) against the weight-form kernels they replace when no grid gradient is scattered from the launch:
+    grad_x of the first backward; gg_out and grad_x of the second one, with and without a cotangent of the grid
+    gradient, points outside the bound and on its faces included (gridsample_cuda.cu:443-531)."""
+    from miso_amd import ops
+    case, feats, bound, ws, bs, x0, meta, fd, pack = setup_case(name)
+    fdd = [f.detach() for f in fd]
+    g = torch.Generator().manual_seed(5)
+    b = torch.tensor(case["bound"])
+    n = 20000
+    x = torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) * 1.2 + b[:, 0] - 0.1 * (b[:, 1] - b[:, 0])
+    x[:64] = b[:, 0]
+    x[64:128] = b[:, 1]
+    x = x.to(DEV)
+    F = sum(f.shape[1] for f in fdd)
+    gout = torch.randn(n, F, generator=g).to(DEV)
+    ggx = torch.randn(n, 3, generator=g).to(DEV)
+    ggf_all = [torch.randn(f.shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last_3d) * 1e-2
+               for f in fdd]
+    sb = ops.SortedBatch(n, x.device).sort(x, meta) if binned else None
+    none = [False] * len(fdd)
+
+    def run():
+        gx1, _ = ops.encode_bwd_raw(x, fdd, meta, gout, True, none, sorted_batch=sb)
+        outs = [gx1]
+        for ggf in (None, ggf_all, [ggf_all[0]] + [None] * (len(fdd) - 1)):
+            for e in (ggx, None):
+                if e is None and ggf is None:
+                    continue
+                ggo, gx2, _ = ops.encode_bwd2_raw(x, fdd, meta, gout, e, ggf, True, none, sorted_batch=sb)
+                outs += [ggo, gx2]
+        torch.cuda.synchronize()
+        return outs
+
+    lean = run()
+    monkeypatch.setenv("MISO_ENCODE_NO_LEAN", "1")
+    ref = run()
+    assert len(lean) == len(ref) == 11
+    for a, c in zip(lean, ref):
+        assert torch.isfinite(a).all()
+        assert relerr(a, c) < 2e-5
+
+
 def test_capi_rejects_bad_arguments_before_launching():
     """Return codes of the C ABI for malformed calls: nothing is launched,
     nothing crashes, the error string is meaningful."""
