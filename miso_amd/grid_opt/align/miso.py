@@ -83,8 +83,8 @@ def pairwise_loss_latent(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id
     if use_bound:
         mask = mask & utils_geometry.coords_in_bound(coords_to, sub_to.bound)
     if stability_thresh > 0:
-        mu_to = sub_to.query_stability(coords_to)[:, [0]]
-        mu_from = sub_from.query_stability(coords_from)[:, [0]]
+        mu_to = sub_to.query_stability(coords_to)[:, 0:1]
+        mu_from = sub_from.query_stability(coords_from)[:, 0:1]
         mask = mask & (mu_to > stability_thresh) & (mu_from > stability_thresh)
     if trunc_factor is not None:
         with torch.no_grad():
@@ -213,8 +213,8 @@ def pairwise_loss_sdf(grid_atlas: GridAtlas, data_loader, src_id: int, dst_id: i
     if use_bound:
         mask = mask & utils_geometry.coords_in_bound(coords_to, sub_to.bound)
     if stability_thresh > 0:
-        mask = mask & (sub_to.query_stability(coords_to)[:, [0]] > stability_thresh) \
-            & (sub_from.query_stability(coords_from)[:, [0]] > stability_thresh)
+        mask = mask & (sub_to.query_stability(coords_to)[:, 0:1] > stability_thresh) \
+            & (sub_from.query_stability(coords_from)[:, 0:1] > stability_thresh)
     keep = torch.nonzero(mask, as_tuple=False)[:, 0]
     resid = sub_from(coords_from[keep]) - sub_to(coords_to[keep])
     key = f'align_sdf_{src_id}_{dst_id}'

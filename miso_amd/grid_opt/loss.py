@@ -225,7 +225,9 @@ class MisoLossMappingBase(BaseLoss):
 
     def query_model(self, model, coords_world: torch.Tensor):
         out = model(coords_world)
-        d = {'sdf': out[:, [0]]}
+        # column 0 as a slice: the reference's out[:, [0]] (loss.py:745-752) is an advanced index whose autograd backward
+        # is a sort-based index_put -- 1.6 ms at 540 000 rows, three quarters of an op-by-op step
+        d = {'sdf': out[:, 0:1]}
         if self.weight_clip > 0:
             d['clip'] = out[:, 1:]
         return d
