@@ -73,6 +73,9 @@ extern "C" {
 #define MISO_F_ALIGN_CORNERS 1u    /* grid_sample align_corners=True (MISO uses False) */
 #define MISO_F_PAD_BORDER 2u       /* padding_mode='border' (MISO uses 'zeros') */
 #define MISO_F_COORDS_NORMALIZED 4u /* x is already in [-1,1]: skip normalize_coordinates */
+#define MISO_F_CROWDED 64u         /* hint: the batch crowds a few tiles (ray samples around surfaces and cameras), so
+                                     miso_sdf_bwd_sorted pushes every eligible coarse level through the matrix
+                                     cores whatever the average density per tile (default: from 100 samples per tile) */
 #define MISO_F_GRAD_SDF_SORTED 16u  /* miso_sdf_bwd_sorted: grad_sdf is in the binned order (what
                                        miso_sdf_fwd_sorted_loss writes), not the caller's */
 #define MISO_F_GRAD_ZEROED 32u      /* with MISO_F_GRAD_OVERWRITE: the levels miso_sdf_bwd_sorted ADDS to with atomics

@@ -760,6 +760,203 @@ __global__ __launch_bounds__(512, 4) void grad_pull_block_kernel(GridK g, PullK 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Levels whose tile bricks exceed PULL_BMAX vertices on an axis, up to 2 * PULL_BMAX (ScanNet's 200 x 100 x 200 fine
+// level over 16 tiles: bricks of 13 x 7 x 13) -- they used to fall back to the atomic scatter inside the backward
+// (177 of its 215 us at the ScanNet shape: 4.3 M row requests at the hardware's 21 G/s).  One workgroup per TILE: the
+// brick is halved along every axis and wavefront w owns octant w (<= 8 vertices per axis, what pull_level bins).
+//   (1) the eight wavefronts sweep the 3 x 3 x 3 tile neighbourhood together (nine tile rows, concatenated and strided
+//       over by all 512 lanes); a candidate outside the tile's catchment box is dropped after six compares, the
+//       survivors are compacted into an LDS table {xn, index};
+//   (2) the survivors are routed, densely re-read from the table: the exact cell, from it the one-to-eight octants
+//       whose vertices it touches, appended to that octant's list of 16-bit table slots;
+//   (3) wavefront w bins / pulls / stores its octant (pull_level, coordinates from the LDS table).
+// A tile under a crowd (more than SUB_CAND survivors, or SUB_LIST in one octant) is redone in epochs of SUB_EPOCH swept
+// candidates -- neither the table nor a list can overflow then -- the first epoch storing, the others adding.
+constexpr int SUB_CAND = 1536;
+constexpr int SUB_LIST = 1024;
+constexpr int SUB_EPOCH = 1024;
+static_assert(SUB_EPOCH <= SUB_LIST && SUB_EPOCH <= SUB_CAND, "an epoch must fit the table and every list");
+constexpr int SUB_UN = 8;             // 512-candidate steps in flight per workgroup
+
+// zero the gradient of a brick's vertices (an owned brick nobody contributes to, overwrite mode): plain stores,
+// nothing staged
+template <int C>
+__device__ __forceinline__ void zero_brick(const LevelK& lv, const Brick& b, int tid, int nthr) {
+  if (!lv.grad) return;
+  const int inv_bx = (65536 + b.B[0] - 1) / b.B[0], inv_by = (65536 + b.B[1] - 1) / b.B[1];    // nverts <= 4096
+  for (int v = tid; v < b.nverts; v += nthr) {
+    const int t_ = (v * inv_bx) >> 16, lx = v - t_ * b.B[0];
+    const int lz = (t_ * inv_by) >> 16, ly = t_ - lz * b.B[1];
+    float* dst = lv.grad + (b.v0[2] + lz) * lv.sZ + (b.v0[1] + ly) * lv.sY + (b.v0[0] + lx) * lv.sX;
+#pragma unroll
+    for (int c = 0; c < C; c += 4) *reinterpret_cast<float4*>(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int C, int MODE>
+__global__ __launch_bounds__(512, 4) void grad_pull_sub_kernel(GridK g, PullK pk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int REC = MODE ? 8 : 4;
+  constexpr int O_LISTS = SUB_CAND * 4;
+  constexpr int O_CNT = O_LISTS + BLK_WAVES * SUB_LIST / 2;      // [octant] list lengths, [8] survivors, [9] overflow
+  constexpr int O_ROWS = O_CNT + 16;                               // nine {start, length} pairs
+  constexpr int O_STAGE = O_ROWS + 32;
+  constexpr int CAP = pull_cap(C, MODE);
+  constexpr int STAGE = PULL_ARRW + CAP * REC + CAP * C;
+  float4* cand = reinterpret_cast<float4*>(smem);
+  uint16_t* lists = reinterpret_cast<uint16_t*>(reinterpret_cast<int*>(smem) + O_LISTS);
+  int* cnt = reinterpret_cast<int*>(smem) + O_CNT;
+  int* rows = reinterpret_cast<int*>(smem) + O_ROWS;
+  const int o_arr = O_STAGE + wave * STAGE, o_rec = o_arr + PULL_ARRW, o_df = o_rec + CAP * REC;
+  const int T = pk.T;
+  const LevelK& lv = g.lv[pk.lev[0]];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  for (int tile = blockIdx.x; tile < T * T * T; tile += gridDim.x) {
+    const int ta = tile % T, tb = (tile / T) % T, tc = tile / (T * T);
+    const Brick bt = make_brick(lv, ta, tb, tc, T, pk.bdiv[0]);
+    if (bt.nverts == 0) continue;
+    const int h[3] = {(bt.B[0] + 1) >> 1, (bt.B[1] + 1) >> 1, (bt.B[2] + 1) >> 1};
+    float ulo[3], uhi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      ulo[a] = (2.0f * bt.v0[a] - 1.0f) * pk.inv_size[0][a] - 1.0f - 8e-6f;
+      uhi[a] = (2.0f * (bt.v0[a] + bt.B[a]) + 1.0f) * pk.inv_size[0][a] - 1.0f + 8e-6f;
+    }
+    if (threadIdx.x < 9) {
+      const int ry = tb + (int)threadIdx.x % 3 - 1, rz = tc + (int)threadIdx.x / 3 - 1;
+      int st = 0, len = 0;
+      if (ry >= 0 && ry < T && rz >= 0 && rz < T) {
+        st = pk.tile_off[(rz * T + ry) * T + max(ta - 1, 0)];
+        len = pk.tile_off[(rz * T + ry) * T + min(ta + 1, T - 1) + 1] - st;
+      }
+      rows[2 * threadIdx.x] = st;
+      rows[2 * threadIdx.x + 1] = len;
+    }
+    __syncthreads();
+    int rst[9], rpre[10];
+    rpre[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      rst[r] = rows[2 * r];
+      rpre[r + 1] = rpre[r] + rows[2 * r + 1];
+    }
+    const int total = (pk.debug & 4) ? 0 : rpre[9];
+    if (total == 0) {          // nothing in the neighbourhood (most tiles of a ScanNet-shaped batch)
+      if (pk.overwrite) zero_brick<C>(lv, bt, threadIdx.x, 512);
+      __syncthreads();         // the next tile rewrites the row table
+      continue;
+    }
+    // the sub-brick of this wavefront
+    Brick b;
+    {
+      const int o3[3] = {wave & 1, (wave >> 1) & 1, wave >> 2};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        b.v0[a] = bt.v0[a] + (o3[a] ? h[a] : 0);
+        b.B[a] = o3[a] ? bt.B[a] - h[a] : h[a];
+      }
+      b.nverts = b.B[0] * b.B[1] * b.B[2];
+    }
+    int eraw = max(total, 1), ne = 1, ep = 0;      // optimistic: everything in one epoch
+    bool crowded = false;
+    while (true) {
+      __syncthreads();       // the previous epoch (or tile) is done with the counters, the table and the lists
+      if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+      __syncthreads();
+      const int lo = ep * eraw, hi = min(total, lo + eraw);
+      // ---- (1) sweep ---------------------------------------------------------------------------------------------
+#pragma unroll 1
+      for (int i0 = lo + (int)threadIdx.x; i0 - (int)threadIdx.x < hi; i0 += 512 * SUB_UN) {
+        if (!crowded && cnt[9]) break;
+        float4 c4[SUB_UN];
+        int pp[SUB_UN];
+#pragma unroll
+        for (int u = 0; u < SUB_UN; ++u) {
+          const int idx = i0 + u * 512;
+          int p = -1;
+#pragma unroll
+          for (int r = 0; r < 9; ++r)
+            if (idx >= rpre[r] && idx < rpre[r + 1]) p = rst[r] + (idx - rpre[r]);
+          if (idx >= hi) p = -1;
+          pp[u] = p;
+          c4[u] = make_float4(2e30f, 2e30f, 2e30f, 0.f);
+          if (p >= 0) c4[u] = pk.xn[p];
+        }
+#pragma unroll
+        for (int u = 0; u < SUB_UN; ++u) {
+          const bool in = c4[u].x >= ulo[0] && c4[u].x < uhi[0] && c4[u].y >= ulo[1] && c4[u].y < uhi[1] &&
+                          c4[u].z >= ulo[2] && c4[u].z < uhi[2];
+          const unsigned long long m = __ballot(in);
+          if (m == 0ull) continue;
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&cnt[8], (int)__popcll(m));
+          base = __builtin_amdgcn_readfirstlane(base);
+          const int slot = base + (int)__popcll(m & lt_mask);
+          if (in) {
+            if (slot < SUB_CAND) cand[slot] = make_float4(c4[u].x, c4[u].y, c4[u].z, __int_as_float(pp[u]));
+            else cnt[9] = 1;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- (2) route ---------------------------------------------------------------------------------------------
+      if (cnt[9] == 0) {
+        const int ncand = cnt[8];
+#pragma unroll 1
+        for (int s0 = wave * 64; s0 < ncand; s0 += 64 * BLK_WAVES) {
+          const int slot = s0 + lane;
+          const bool live = slot < ncand;
+          const float4 c4 = live ? cand[slot] : make_float4(2e30f, 2e30f, 2e30f, 0.f);
+          int i0[3]; float fr;
+          cell_of(c4.x, lv.X, i0[0], fr); cell_of(c4.y, lv.Y, i0[1], fr); cell_of(c4.z, lv.Z, i0[2], fr);
+          unsigned m3[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const int rel = i0[a] - bt.v0[a];      // vertex i0 relative to the tile's first; halves [0, h), [h, B)
+            unsigned mm = 0;
+            if (rel >= 0 && rel < bt.B[a]) mm |= (rel >= h[a]) ? 2u : 1u;
+            if (rel + 1 >= 0 && rel + 1 < bt.B[a]) mm |= (rel + 1 >= h[a]) ? 2u : 1u;
+            m3[a] = mm;
+          }
+          unsigned m8 = ((m3[2] & 1u ? 0x0Fu : 0u) | (m3[2] & 2u ? 0xF0u : 0u)) &
+                        ((m3[1] & 1u ? 0x33u : 0u) | (m3[1] & 2u ? 0xCCu : 0u)) &
+                        ((m3[0] & 1u ? 0x55u : 0u) | (m3[0] & 2u ? 0xAAu : 0u));
+          if (!live) m8 = 0;
+          while (m8) {
+            const int t = __ffs((int)m8) - 1;
+            m8 &= m8 - 1;
+            const int pos = atomicAdd(&cnt[t], 1);
+            if (pos < SUB_LIST) lists[t * SUB_LIST + pos] = (uint16_t)slot;
+            else cnt[9] = 1;
+          }
+        }
+      }
+      __syncthreads();
+      if (cnt[9] != 0) {       // a crowd (first pass only: an epoch cannot overflow): redo the tile in epochs
+        crowded = true;
+        eraw = SUB_EPOCH;
+        ne = (total + SUB_EPOCH - 1) / SUB_EPOCH;
+        ep = 0;
+        continue;
+      }
+      // ---- (3) wavefront w: octant w -----------------------------------------------------------------------------
+      if (b.nverts > 0 && !(pk.debug & 16)) {
+        const int n = __builtin_amdgcn_readfirstlane(cnt[wave]);
+        const int add = (pk.overwrite && ep == 0) ? 0 : 1;
+        if (n > 0)
+          pull_level<C, MODE, true>(g, pk, lv, b, smem, 0, n, o_arr, o_rec, o_df, lane, add, lists + wave * SUB_LIST, cand);
+        else if (!add)
+          zero_brick<C>(lv, b, lane, 64);
+      }
+      if (++ep >= ne) break;
+    }
+    __syncthreads();       // the next tile rewrites the row table
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Coarse levels under a crowd, pushed through the fp32 matrix cores.  A coarse level (ScanNet's 40 x 20 x 40 over 16
 // tiles) of a batch that piles hundreds of samples on every occupied tile: all samples of a tile touch the same
 // <= 5 x 5 x 5 vertices (its REGION), so the tile's contribution is a small dense product
@@ -939,20 +1136,33 @@ __global__ __launch_bounds__(64 * PUSH_WAVES) void grad_push_mfma_kernel(GridK g
   }
 }
 
-// Levels the pull kernel can own: default sampling convention, a brick of at most
-// PULL_BMAX^3 vertices per tile, a gradient requested; at most PULL_MAXL of them.
+// Levels the pull kernels can own: default sampling convention, a gradient requested, and a brick of at most
+// PULL_BMAX^3 vertices per tile (swept together, at most PULL_MAXL of them) or of at most (2 PULL_BMAX)^3 (one launch
+// of grad_pull_sub_kernel each).
+static inline bool pull_sub_level(const LevelK& lv, int T) {
+  auto bmax = [&](int size) { return (size + T - 1) / T; };
+  return bmax(lv.X) > PULL_BMAX || bmax(lv.Y) > PULL_BMAX || bmax(lv.Z) > PULL_BMAX;
+}
 uint32_t plan_grad_pull(const GridK& g, int T) {
   if (g.flags & (MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER)) return 0;
+  // grad_pull_sub_kernel is opt-in: at the ScanNet shape it costs what the atomic scatter it replaces costs (122 vs
+  // 112 us for 540 000 samples spread over 737 tiles), and tiles under a real crowd go through its epoch path
+  // (435 us per step on the ray samples of tools/demo_synthetic.py) -- see DESIGN.md section 4.4
+  const bool no_sub = getenv("MISO_PULL_SUB") == nullptr;
   uint32_t mask = 0;
   int cnt = 0;
-  for (int l = 0; l < g.n_levels && cnt < PULL_MAXL; ++l) {
+  for (int l = 0; l < g.n_levels; ++l) {
     const LevelK& lv = g.lv[l];
     if (!lv.grad) continue;
     auto bmax = [&](int size) { return (size + T - 1) / T; };
-    if (bmax(lv.X) > PULL_BMAX || bmax(lv.Y) > PULL_BMAX || bmax(lv.Z) > PULL_BMAX) continue;
+    if (bmax(lv.X) > 2 * PULL_BMAX || bmax(lv.Y) > 2 * PULL_BMAX || bmax(lv.Z) > 2 * PULL_BMAX) continue;
     if ((int64_t)lv.X * T >= (1 << 30) || (int64_t)lv.Y * T >= (1 << 30) || (int64_t)lv.Z * T >= (1 << 30)) continue;
+    if (pull_sub_level(lv, T)) {
+      if (no_sub || (lv.C != 4 && lv.C != 8)) continue;
+    } else if (cnt++ >= PULL_MAXL) {
+      continue;
+    }
     mask |= 1u << l;
-    ++cnt;
   }
   return mask;
 }
@@ -962,7 +1172,11 @@ uint32_t plan_grad_pull(const GridK& g, int T) {
 uint32_t plan_push(const GridK& g, int T, int64_t n, uint32_t pull) {
   static const int dense_min = [] { const char* e = getenv("MISO_DENSE_MIN"); return e ? atoi(e) : 100; }();
   static const bool off = getenv("MISO_PULL_NO_PUSH") != nullptr;      // dev
-  if (off || dense_min <= 0 || n < (int64_t)dense_min * T * T * T || n >= (1ll << 31)) return 0;
+  // MISO_F_CROWDED: the caller knows the batch piles up on a few tiles (ray samples: a 54 000-sample batch of the
+  // synthetic RGB-D demo put 112 us of pull + drain launches on the 40 x 20 x 40 level, the push 46 us), where the
+  // average density says nothing; a uniform batch below the threshold is better off pulled (cfg-2: 107 -> 180 us)
+  const bool crowded = (g.flags & MISO_F_CROWDED) != 0 && n >= 4096;
+  if (off || dense_min <= 0 || (!crowded && n < (int64_t)dense_min * T * T * T) || n >= (1ll << 31)) return 0;
   uint32_t push = 0;
   for (int l = 0; l < g.n_levels && l < 16; ++l) {
     const LevelK& lv = g.lv[l];
@@ -978,7 +1192,10 @@ uint32_t plan_push(const GridK& g, int T, int64_t n, uint32_t pull) {
 
 static hipError_t launch_push(const GridK& g, int C, int T, const int* tile_off, const float* xn, const float* dfeat,
                               int64_t ld, const int* perm, int level, int64_t n, hipStream_t s) {
-  static const int run = [] { const char* e = getenv("MISO_PUSH_RUN"); return e ? max(64, atoi(e)) : 512; }();   // dev
+  // samples per wavefront: 512 (fewest region flushes per sample) once that still makes >= 1024 wavefronts; a small
+  // batch is cut finer so that the chip is not left to a few dozen of them (54 000 samples: 105 wavefronts, 46 us)
+  static const int run_env = [] { const char* e = getenv("MISO_PUSH_RUN"); return e ? max(64, atoi(e)) : 0; }();   // dev
+  const int run = run_env ? run_env : (int)min((int64_t)512, max((int64_t)64, ((n / 1024 + 63) / 64) * 64));
   PullK pk;
   memset(&pk, 0, sizeof(pk));
   pk.T = T; pk.tile_off = tile_off; pk.xn = reinterpret_cast<const float4*>(xn); pk.dfeat = dfeat;
@@ -1007,6 +1224,34 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
         if (e != hipSuccess) return e;
       }
     level_mask &= ~push_mask;
+  }
+  for (int l = 0; l < g.n_levels; ++l) {
+    if (!((level_mask >> l) & 1u) || !pull_sub_level(g.lv[l], T)) continue;
+    level_mask &= ~(1u << l);
+    PullK ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.T = T; ps.tile_off = tile_off; ps.xn = reinterpret_cast<const float4*>(xn); ps.dfeat = dfeat;
+    ps.ld = ld; ps.perm = perm; ps.ggx = ggx; ps.overwrite = overwrite;
+    const int size[3] = {g.lv[l].X, g.lv[l].Y, g.lv[l].Z};
+    for (int a = 0; a < 3; ++a) {
+      ps.bdiv[0][a] = (size[a] % T == 0) ? size[a] / T : 0;
+      ps.inv_size[0][a] = 1.0f / (float)size[a];
+    }
+    ps.lev[0] = l; ps.nl = 1;
+    if (const char* d = getenv("MISO_DEBUG_PULL")) ps.debug = atoi(d);
+    void (*ks)(GridK, PullK) = nullptr;
+    if (C == 8) ks = ggx ? grad_pull_sub_kernel<8, 1> : grad_pull_sub_kernel<8, 0>;
+    if (C == 4) ks = ggx ? grad_pull_sub_kernel<4, 1> : grad_pull_sub_kernel<4, 0>;
+    if (!ks) return hipErrorInvalidValue;
+    const int cap = pull_cap(C, ggx ? 1 : 0);
+    const size_t words = (size_t)SUB_CAND * 4 + (size_t)BLK_WAVES * SUB_LIST / 2 + 16 + 32 +
+                         (size_t)BLK_WAVES * (PULL_ARRW + cap * (ggx ? 8 : 4) + cap * C);
+    hipError_t e = hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(words * sizeof(float)));
+    if (e != hipSuccess) return e;
+    ks<<<(unsigned)(T * T * T), 512, words * sizeof(float), s>>>(g, ps);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
   if (!level_mask) return hipSuccess;
   PullK pk;

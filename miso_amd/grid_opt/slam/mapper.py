@@ -38,6 +38,8 @@ class Mapper:
         cfg_train = deepcopy(self.cfg)['train']
         cfg_train.update(max_epochs_in_level=level_iterations, epochs=iterations, learning_rate=self.lr,
                          verbose=self.verbose)
+        # the keyframes' ray samples crowd the surfaces: see MappingStep(crowded=...)
+        cfg_train.setdefault('crowded_batches', True)
         trainer = GridTrainer(cfg_train, self.grid, self.loss_fn, self.train_loader, None, self.cfg['device'],
                               torch.float32)
         trainer.train()

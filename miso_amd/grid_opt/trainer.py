@@ -373,7 +373,7 @@ class Trainer(object):
                                float(lf.weight_fs) if lf.weight_fs > 0 else 0.0,
                                0.0 if lf.trunc_dist is None else float(lf.trunc_dist), need_levels=need,
                                keep_sdf=False, padded=live is not None, grads_cleared_by_optimizer=True,
-                               use_graph=False,
+                               use_graph=False, crowded=bool(self.cfg.get('crowded_batches', False)),
                                share_grads=None if prev is None or prev.need_levels != list(need) else prev.grads)
             cache[key] = step
         elif not step._use_graph and not step.__dict__.get('_seen_again'):

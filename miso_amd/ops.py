@@ -14,6 +14,7 @@ device and the library must be built, otherwise the call raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -403,7 +404,7 @@ class SortedBatch:
     # from 76 to 47 us, and the backward goes from 240 us (atomic scatter + 15 us zero-fill) to
     # 157 us (MFMA pass + owner-computes pull, no zero-fill).  Below ~64 K points the tiles hold
     # too few points for the sweep to pay.  None = never automatic.
-    AUTO_MIN_POINTS = 65536
+    AUTO_MIN_POINTS = int(os.environ.get("MISO_SORT_MIN_POINTS", 65536)) or None
 
     def __init__(self, n: int, device, tiles: int = TILES, keep_metric: bool = False):
         self.n, self.tiles = int(n), int(tiles)

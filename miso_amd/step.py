@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import dataclasses
+
 import torch
 
 from . import ops
@@ -19,6 +21,7 @@ from . import ops
 
 class MappingStep:
     TOUCHED_MIN_NUMEL = 32 << 20      # floats: levels from 128 MB up keep touched-chunk flags for Adam
+    CROWDED_MIN_POINTS = 16384      # crowded=True: batches are binned from this size (default SortedBatch.AUTO_MIN_POINTS)
 
     def __init__(self, features: Sequence[torch.Tensor], meta: ops.GridMeta, pack: ops.DecoderPack,
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
@@ -27,8 +30,12 @@ class MappingStep:
                  keep_sdf: bool = True, padded: bool = False, grads_cleared_by_optimizer: bool = False,
                  share_grads: Optional[Sequence[Optional[torch.Tensor]]] = None,
                  adam_device: Optional["ops.AdamDeviceStep"] = None,
-                 adam_state: Optional[Sequence[Optional[tuple]]] = None):
-        """padded: the batch buffers hold ``n_points`` rows of which only ``self.live_rows`` (one int32 on the
+                 adam_state: Optional[Sequence[Optional[tuple]]] = None, crowded: bool = False):
+        """crowded: the batches are ray samples (they pile up around surfaces and cameras instead of filling the
+        bound): bin from CROWDED_MIN_POINTS and push the coarse levels through the matrix cores whatever the average
+        density (MISO_F_CROWDED) -- on the 54 000-sample batches of tools/demo_synthetic.py the contended atomics of
+        the unbinned backward cost 200 us a step, the binned step with the push 96 us.
+        padded: the batch buffers hold ``n_points`` rows of which only ``self.live_rows`` (one int32 on the
         device, set through set_batch) are live, the rest neutral padding (valid = sign = weight = 0); the loss
         means divide by the live count.  Lets a sampler with a data-dependent row count (depth holes) feed ONE
         captured graph.
@@ -45,6 +52,8 @@ class MappingStep:
         self.keep_sdf = bool(keep_sdf)
         self.external_clear = bool(grads_cleared_by_optimizer)
         self.features = list(features)
+        if crowded and not meta.flags & ops._lib.F_CROWDED:
+            meta = dataclasses.replace(meta, flags=meta.flags | ops._lib.F_CROWDED)
         self.meta, self.pack = meta, pack
         self.n = int(n_points)
         self.loss_cfg = (loss_type, float(weight_sdf), float(weight_fs), float(trunc_dist))
@@ -93,7 +102,8 @@ class MappingStep:
         if padded:
             sort = True        # the live count is read by the binned forward
         if sort is None:   # default: bin when the batch is large enough for it to pay
-            sort = ops.SortedBatch.AUTO_MIN_POINTS is not None and self.n >= ops.SortedBatch.AUTO_MIN_POINTS
+            floor = self.CROWDED_MIN_POINTS if self.meta.flags & ops._lib.F_CROWDED else ops.SortedBatch.AUTO_MIN_POINTS
+            sort = ops.SortedBatch.AUTO_MIN_POINTS is not None and self.n >= floor
         self.sorted = ops.SortedBatch(self.n, dev) if sort else None
         if getattr(self, "_shared_grads", False) and self.sorted is None:
             # the small-batch path accumulates onto buffers it expects zeroed; the previous owner may have been a

@@ -68,7 +68,7 @@ def test_argument_validation_without_gpu():
     g.level[0].C = 4; g.level[0].X = 2; g.level[0].Y = 2; g.level[0].Z = 2
     g.level[0].sC = 1; g.level[0].sX = 4; g.level[0].sY = 8; g.level[0].sZ = 16
     assert lib.miso_encode_fwd(ctypes.byref(g), None, 0, None, 4, None) == 2001  # data NULL
-    g.flags = 64
+    g.flags = 128
     assert lib.miso_encode_fwd(ctypes.byref(g), None, 0, None, 4, None) == 2001  # bad flag
     m = _lib.Mlp()
     m.in_dim, m.hidden_dim, m.out_dim, m.n_linear = 24, 64, 1, 3

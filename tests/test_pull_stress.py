@@ -63,6 +63,62 @@ def test_binned_encode_matches_atomic(seed, monkeypatch):
         assert relerr(a, c) < 5e-5, (seed, l, dims, C, n)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_sub_brick_levels_match_atomic(seed, monkeypatch):
+    """Levels whose tile bricks hold 9..16 vertices on an axis (ScanNet's 200 x 100 x 200 over 16 tiles) are pulled by
+    grad_pull_sub_kernel -- one workgroup per tile, one wavefront per octant of its brick -- instead of the atomic
+    scatter: same gradient, with uniform points, with a tight cluster (tiles whose survivors overflow the table and
+    are redone in epochs), with points outside the bound, next to levels the ordinary pull owns."""
+    from miso_amd import ops
+    rs = np.random.RandomState(7000 + seed)
+    C = int(rs.choice([4, 8]))
+    big = [tuple(int(v) for v in rs.choice([100, 130, 144, 160, 200, 255, 256], size=3))]
+    if seed == 0:
+        big = [(200, 100, 200)]
+    dims = ([tuple(int(v) for v in rs.choice([8, 20, 40, 64], size=3))] if seed % 2 else []) + big
+    L = len(dims)
+    bmin = rs.uniform(-3, 0, size=3)
+    bmax = bmin + rs.uniform(0.5, 6, size=3)
+    bound = [[float(bmin[a]), float(bmax[a])] for a in range(3)]
+    n = int(rs.choice([16384, 50000, 131072]))
+    g = torch.Generator().manual_seed(seed)
+    feats = []
+    for (z, y, x) in dims:
+        f = (torch.randn(1, C, z, y, x, generator=g) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+        feats.append(f.requires_grad_(True))
+    b = torch.tensor(bound)
+    x = torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) * 1.1 + b[:, 0] - 0.05 * (b[:, 1] - b[:, 0])
+    k = [0, n // 2, n // 8, 0][seed % 4]
+    if k:
+        x[:k] = x[:k] * 0.03 + b.mean(dim=1)                     # thousands of points on a handful of tiles
+    x[-1] = float("nan")
+    meta = ops.GridMeta.from_bound(bound)
+    go = torch.randn(n, C * L, generator=g).to(DEV)
+    want = [torch.empty_like(f) for f in feats]
+    monkeypatch.setenv("MISO_PULL_SUB", "1")       # opt-in (see plan_grad_pull)
+    mask = int(ops._lib.load().miso_grad_pull_levels(ops.C.byref(ops._fill_grid(feats, meta, want, data=False)),
+                                                     ops.SortedBatch.TILES))
+    assert (mask >> (L - 1)) & 1, "the large level is not owned by the pull"
+
+    def run(second):
+        xd = x.to(DEV).requires_grad_(True)
+        out = ops.encode(xd, feats, meta)
+        if not second:
+            return torch.autograd.grad(out, feats, go)
+        (gx,) = torch.autograd.grad(out, xd, go, create_graph=True)
+        return torch.autograd.grad((torch.nan_to_num(gx) ** 2).sum(), feats)
+
+    monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", 16384)
+    for second in (False, True):
+        monkeypatch.setenv("MISO_PULL_SUB", "1")
+        gb = run(second)
+        monkeypatch.delenv("MISO_PULL_SUB")
+        ga = run(second)
+        for l, (a, c) in enumerate(zip(gb, ga)):
+            a, c = torch.nan_to_num(a), torch.nan_to_num(c)
+            assert relerr(a, c) < 5e-5, (seed, second, l, dims, C, n)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MISO_STRESS_SEEDS", "10"))))
 def test_binned_fused_matches_plain(seed):
     """Fused encode+decoder: binned forward / backward (incl. the loss-fused forward and grad_x) against
@@ -237,6 +293,45 @@ def test_captured_step_replayed_back_to_back_between_eager_launches():
         assert torch.isfinite(g).all()
         assert not (g != 0)[~s].any()                   # nothing outside the vertices the batch can touch
         assert float(a.float().mean()) < 0.5            # and Adam still skips the empty part of the bound
+
+
+@pytest.mark.gpu
+def test_crowded_hint_bins_small_batches_and_pushes_the_coarse_level():
+    """MappingStep(crowded=True) (what Mapper asks for: ray samples pile up on a few tiles) bins a 54 000-sample batch
+    and pushes the coarse ScanNet level through the matrix cores although the average density is 13 samples a tile;
+    same loss and gradients as the default step, which takes the unbinned atomic path at this size."""
+    from miso_amd import ops, _lib
+    from miso_amd.step import MappingStep
+    torch.manual_seed(0)
+    dev, C, H, n = "cuda:0", 4, 64, 54000
+    sizes = [(40, 20, 40), (200, 100, 200)]
+    meta = ops.GridMeta.from_bound([[-10., 10.], [-5., 5.], [-10., 10.]])
+    lin = [torch.nn.Linear(2 * C, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.data.to(dev) for l in lin], [l.bias.data.to(dev) for l in lin])
+    x = (torch.rand(n, 3, device=dev) * 2 - 1) * torch.tensor([6.0, 2.5, 6.0], device=dev)
+    x[: n // 2] = x[: n // 2] * 0.05 + torch.tensor([1.0, 0.5, -2.0], device=dev)        # half of it on a handful of tiles
+    tgt = torch.rand(n, 1, device=dev) * 0.2 - 0.1
+    one, zero = torch.ones(n, 1, device=dev), torch.zeros(n, 1, device=dev)
+    feats = [(torch.randn(1, C, z, y, xx, device=dev) * 1e-2).contiguous(memory_format=torch.channels_last_3d)
+             for (xx, y, z) in sizes]
+    res = []
+    for crowded in (False, True):
+        st = MappingStep(feats, meta, pack, n, "L1", 1.0, 0.1, 0.15, use_graph=False, keep_sdf=False, crowded=crowded)
+        assert (st.sorted is not None) == crowded
+        st.set_batch(x, tgt, one, zero, one)
+        st.run()
+        torch.cuda.synchronize()
+        res.append((st.loss.clone(), [g.clone() for g in st.grads]))
+        if crowded:
+            assert st.meta.flags & _lib.F_CROWDED
+            g = ops._fill_grid(feats, st.meta, st.grads, data=False)
+            assert int(_lib.load().miso_sdf_bwd_push_levels(ops.C.byref(g), ops.SortedBatch.TILES, n)) == 0b01
+            g = ops._fill_grid(feats, meta, st.grads, data=False)
+            assert int(_lib.load().miso_sdf_bwd_push_levels(ops.C.byref(g), ops.SortedBatch.TILES, n)) == 0
+    (la, ga), (lb, gb) = res
+    assert torch.allclose(la.sum(), lb.sum(), rtol=1e-5, atol=1e-7)
+    for a, c in zip(ga, gb):
+        assert relerr(c, a) < 5e-5
 
 
 @pytest.mark.gpu
