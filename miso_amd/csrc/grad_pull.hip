@@ -112,6 +112,113 @@ __device__ __forceinline__ Brick make_brick(const LevelK& lv, int ta, int tb, in
   return b;
 }
 
+// Bricks of at most 2 x 2 x 2 vertices (the coarsest level of a pyramid over 16 tiles: cfg-2's 32^3) under ~200
+// candidates: nothing is binned.  Lane = candidate computes its weight for each of the eight owned vertices (zero for a
+// vertex its cell does not touch -- the list is conservative) and fetches its d-feat row; both go to LDS transposed
+// ([vertex][candidate], [channel][candidate], rows padded to 68 words: conflict-free 16-B reads); then lane =
+// (vertex, channel) -- 64 outputs for C = 8; for C = 4 the two half-waves split the candidates -- sums its row pair
+// four candidates per step.  All d-feat rows of up to 256 candidates are requested before the first is used: one
+// global round trip per tile instead of one per staged group, no counting sort, no byte counters, no scans.
+constexpr int TINY_ROW = 68;
+template <int C, int MODE, bool BLK>
+__device__ __forceinline__ void pull_tiny(const GridK& g, const PullK& pk, const LevelK& lv, const Brick& b,
+                                          float* smem, int o_list, int n, int o_stage, int lane, int add,
+                                          const uint16_t* blk_list, const float4* cand) {
+  int* ismem = reinterpret_cast<int*>(smem);
+  float* wbuf = smem + o_stage;                 // [8][TINY_ROW]
+  float* dbuf = wbuf + 8 * TINY_ROW;            // [C][TINY_ROW]
+  constexpr int SUPER = (C == 8) ? 2 : 4;       // chunks of 64 candidates whose rows are in flight together
+  const int v = (C == 8) ? (lane >> 3) : ((lane >> 2) & 7), ch = (C == 8) ? (lane & 7) : (lane & 3);
+  const int half = (C == 8) ? 0 : (lane >> 5);  // C = 4: candidates [32 half, 32 half + 32) of every chunk
+  float acc = 0.0f;
+  for (int s0 = 0; s0 < max(n, 1); s0 += 64 * SUPER) {
+    float4 c4[SUPER];
+    float dv[SUPER][C];
+#pragma unroll
+    for (int u = 0; u < SUPER; ++u) {
+      const int i = s0 + u * 64 + lane;
+      c4[u] = make_float4(2e30f, 2e30f, 2e30f, 0.f);
+#pragma unroll
+      for (int c = 0; c < C; ++c) dv[u][c] = 0.0f;
+      if (i < n) {
+        int p;
+        if (BLK) {
+          c4[u] = cand[blk_list[i]];
+          p = __float_as_int(c4[u].w);
+        } else {
+          p = ismem[o_list + i];
+          c4[u] = pk.xn[p];
+        }
+        const int row = pk.perm ? pk.perm[p] : p;
+        c4[u].w = __int_as_float(row);
+        const float* src = pk.dfeat + (int64_t)row * pk.ld + lv.foff;
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(src + c);
+          dv[u][c] = t.x; dv[u][c + 1] = t.y; dv[u][c + 2] = t.z; dv[u][c + 3] = t.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SUPER; ++u) {
+      if (s0 + u * 64 >= n) break;              // wave-uniform
+      // per-axis weight of the two owned vertex planes (and, MODE 1, its derivative)
+      int i0[3]; float fr[3];
+      cell_of(c4[u].x, lv.X, i0[0], fr[0]); cell_of(c4[u].y, lv.Y, i0[1], fr[1]); cell_of(c4[u].z, lv.Z, i0[2], fr[2]);
+      float w[3][2], dw[3][2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+          const int V = b.v0[a] + l;
+          const bool own = l < b.B[a], lo = V == i0[a], hi = V == i0[a] + 1;
+          w[a][l] = own ? (lo ? 1.0f - fr[a] : (hi ? fr[a] : 0.0f)) : 0.0f;
+          dw[a][l] = own ? (lo ? -1.0f : (hi ? 1.0f : 0.0f)) : 0.0f;
+        }
+      float e[3] = {0.f, 0.f, 0.f};
+      if (MODE && s0 + u * 64 + lane < n) {
+        const float* eg = pk.ggx + (int64_t)__float_as_int(c4[u].w) * 3;
+        e[0] = eg[0] * (g.gscale[0] * (0.5f * (float)lv.X));
+        e[1] = eg[1] * (g.gscale[1] * (0.5f * (float)lv.Y));
+        e[2] = eg[2] * (g.gscale[2] * (0.5f * (float)lv.Z));
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int lx = k & 1, ly = (k >> 1) & 1, lz = k >> 2;
+        float wk = (w[0][lx] * w[1][ly]) * w[2][lz];
+        if (MODE)
+          wk = e[0] * (dw[0][lx] * w[1][ly] * w[2][lz]) + e[1] * (dw[1][ly] * w[0][lx] * w[2][lz]) +
+               e[2] * (dw[2][lz] * w[0][lx] * w[1][ly]);
+        wbuf[k * TINY_ROW + lane] = wk;
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) dbuf[c * TINY_ROW + lane] = dv[u][c];
+      wave_sync_lds();
+      if (!(pk.debug & 1)) {
+        constexpr int STEPS = (C == 8) ? 16 : 8;
+#pragma unroll
+        for (int q = 0; q < STEPS; ++q) {
+          const float4 ww = *reinterpret_cast<const float4*>(wbuf + v * TINY_ROW + 32 * half + 4 * q);
+          const float4 dd = *reinterpret_cast<const float4*>(dbuf + ch * TINY_ROW + 32 * half + 4 * q);
+          acc += ww.x * dd.x; acc += ww.y * dd.y; acc += ww.z * dd.z; acc += ww.w * dd.w;
+        }
+      }
+      wave_sync_lds();
+    }
+  }
+  if (C == 4) acc += __shfl_xor(acc, 32);
+  // ---- store: lane (v, ch); C = 4: the lower half-wave ------------------------------------------------------------
+  const int lx = v & 1, ly = (v >> 1) & 1, lz = v >> 2;
+  if (!lv.grad || lx >= b.B[0] || ly >= b.B[1] || lz >= b.B[2] || (C == 4 && lane >= 32)) return;
+  float* dst = lv.grad + (b.v0[2] + lz) * lv.sZ + (b.v0[1] + ly) * lv.sY + (b.v0[0] + lx) * lv.sX + ch;
+  if (lv.touched && acc != 0.0f) lv.touched[(dst - lv.grad) >> 8] = 1;
+  if (add == 2) {
+    if (acc != 0.0f) atomic_add_f32(dst, acc);
+  } else {
+    *dst = add ? *dst + acc : acc;
+  }
+}
+
 // Bin `n` listed candidates of one level by cell, pull them into the brick's vertices and store
 // the brick (steps 2-4 of the file comment).  `add`: accumulate onto what is already stored.
 //
@@ -133,6 +240,11 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
                                            float* smem, int o_list, int n, int o_arr, int o_rec, int o_df,
                                            int lane, int add,   // add: 0 store, 1 read-add-store, 2 atomic add
                                            const uint16_t* blk_list = nullptr, const float4* cand = nullptr) {
+  if (b.B[0] <= 2 && b.B[1] <= 2 && b.B[2] <= 2 && !(pk.debug & 256)) {
+    pull_tiny<C, MODE, BLK>(g, pk, lv, b, smem, o_list, n, o_arr, lane, add, blk_list, cand);
+    wave_sync_lds();   // the caller reuses the list and the staging area
+    return;
+  }
   int* ismem = reinterpret_cast<int*>(smem);
   unsigned* arrw = reinterpret_cast<unsigned*>(smem) + o_arr;
   const unsigned char* arrb = reinterpret_cast<const unsigned char*>(arrw);
