@@ -31,9 +31,12 @@ constexpr int PULL_ARRW = 192;    // words of byte counters: (8+1)^3 = 729 cells
 constexpr int PULL_LIST = 272;    // compacted candidate ids per level
 constexpr int PULL_CAP = 112;     // staged records per group (<= 2 per lane); < 256: counters are bytes.  112: the
                                   // block kernel fits two workgroups per CU (2 x 79 KB of LDS)
-// MODE 1 records are 8 words instead of 4: fewer of them per group so that a wavefront's staging area is the size of
-// MODE 0's and the block kernel still fits two workgroups per CU (at 112 records it fitted one, and ran at half speed)
-constexpr int pull_cap(int C, int mode) { return mode ? ((PULL_CAP * (4 + C)) / (8 + C)) & ~1 : PULL_CAP; }
+// MODE 1 records are 6 words ({fx, fy, fz, ex, ey, ez}, read as three 8-byte pairs) instead of 4: fewer of them per
+// group so that a wavefront's staging area is the size of MODE 0's and the block kernel still fits two workgroups per
+// CU (at 112 records of 8 words it fitted one, and ran at half speed).  96 records for C = 8: the finest level of a
+// uniform cfg-2 batch (~91 candidates per tile) still goes in one group.
+constexpr int pull_rec(int mode) { return mode ? 6 : 4; }
+constexpr int pull_cap(int C, int mode) { return mode ? ((PULL_CAP * (4 + C)) / (6 + C)) & ~1 : PULL_CAP; }
 constexpr int PULL_RB = 4;        // rounds of 64 vertices pulled per pass over the staged records
 constexpr int PULL_MAXL = 4;      // levels swept together (the fused kernels cover <= 4 levels)
 // Heavy tiles.  One wavefront drains one tile serially (~50 ns per swept candidate), so a batch that piles its
@@ -288,7 +291,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
         // per cell; the records stay in registers (<= 3 per lane)
         constexpr int RPL = (CAP + 63) / 64;
         int rc[RPL], rp[RPL]; float rfx[RPL], rfy[RPL], rfz[RPL];
-        constexpr int REC = MODE ? 8 : 4;
+        constexpr int REC = pull_rec(MODE);
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
           const int i = u * 64 + lane;
@@ -345,14 +348,15 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
           if (rc[u] >= 0) {
             const int sh = 8 * (rc[u] & 3);
             const int pos = (int)((atomicAdd(&arrw[rc[u] >> 2], 1u << sh) >> sh) & 255u);
-            *reinterpret_cast<float4*>(smem + o_rec + pos * REC) = make_float4(rfx[u], rfy[u], rfz[u], 0.0f);
+            if (!MODE) *reinterpret_cast<float4*>(smem + o_rec + pos * REC) = make_float4(rfx[u], rfy[u], rfz[u], 0.0f);
             const int row = pk.perm ? pk.perm[rp[u]] : rp[u];
             if (MODE) {
               // e_a = gg_x[a] * d ix_a / d x_a = gg_x[a] * (2 / len_a) * (size_a / 2)   (axis_coord's mult)
               const float* e = pk.ggx + (int64_t)row * 3;
-              *reinterpret_cast<float4*>(smem + o_rec + pos * REC + 4) =
-                  make_float4(e[0] * (g.gscale[0] * (0.5f * (float)lv.X)), e[1] * (g.gscale[1] * (0.5f * (float)lv.Y)),
-                              e[2] * (g.gscale[2] * (0.5f * (float)lv.Z)), 0.0f);
+              float2* rec2 = reinterpret_cast<float2*>(smem + o_rec + pos * REC);
+              const float ex = e[0] * (g.gscale[0] * (0.5f * (float)lv.X)), ey = e[1] * (g.gscale[1] * (0.5f * (float)lv.Y)),
+                          ez = e[2] * (g.gscale[2] * (0.5f * (float)lv.Z));
+              rec2[0] = make_float2(rfx[u], rfy[u]); rec2[1] = make_float2(rfz[u], ex); rec2[2] = make_float2(ey, ez);
             }
             const float* src = pk.dfeat + (int64_t)row * pk.ld + lv.foff;
 #pragma unroll
@@ -381,12 +385,19 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
             const int cc_ = c_hi - (dz * ncy + dy) * ncx - dx;
             const int q0 = (cc_ >= 1) ? (int)arrb[cc_ - 1] : 0, q1 = (int)arrb[cc_];
             for (int q = q0; q < q1; ++q) {
-              constexpr int REC = MODE ? 8 : 4;
-              const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * REC);
+              constexpr int REC = pull_rec(MODE);
+              float4 f, e;
+              if (MODE) {
+                const float2* rec2 = reinterpret_cast<const float2*>(smem + o_rec + q * REC);
+                const float2 r0 = rec2[0], r1 = rec2[1], r2 = rec2[2];
+                f = make_float4(r0.x, r0.y, r1.x, 0.0f);
+                e = make_float4(r1.y, r2.x, r2.y, 0.0f);
+              } else {
+                f = *reinterpret_cast<const float4*>(smem + o_rec + q * REC);
+              }
               const float ux = dx ? f.x : 1.0f - f.x, uy = dy ? f.y : 1.0f - f.y, uz = dz ? f.z : 1.0f - f.z;
               float w = (ux * uy) * uz;
               if (MODE) {
-                const float4 e = *reinterpret_cast<const float4*>(smem + o_rec + q * REC + 4);
                 w = e.x * ((dx ? 1.0f : -1.0f) * uy * uz) + e.y * ((dy ? 1.0f : -1.0f) * ux * uz) +
                     e.z * ((dz ? 1.0f : -1.0f) * ux * uy);
               }
@@ -413,13 +424,20 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
             const int dy = k & 1, dz = k >> 1;
             const int q0 = b0[k], q1 = b2[k];
             for (int q = q0; q < q1; ++q) {
-              constexpr int REC = MODE ? 8 : 4;
-              const float4 f = *reinterpret_cast<const float4*>(smem + o_rec + q * REC);
+              constexpr int REC = pull_rec(MODE);
+              float4 f, e;
+              if (MODE) {
+                const float2* rec2 = reinterpret_cast<const float2*>(smem + o_rec + q * REC);
+                const float2 r0 = rec2[0], r1 = rec2[1], r2 = rec2[2];
+                f = make_float4(r0.x, r0.y, r1.x, 0.0f);
+                e = make_float4(r1.y, r2.x, r2.y, 0.0f);
+              } else {
+                f = *reinterpret_cast<const float4*>(smem + o_rec + q * REC);
+              }
               const bool dx1 = q < b1[k];                         // record of cell c-1 => corner dx = 1
               const float ux = dx1 ? f.x : 1.0f - f.x, uy = dy ? f.y : 1.0f - f.y, uz = dz ? f.z : 1.0f - f.z;
               float w = (ux * uy) * uz;
               if (MODE) {
-                const float4 e = *reinterpret_cast<const float4*>(smem + o_rec + q * REC + 4);
                 w = e.x * ((dx1 ? 1.0f : -1.0f) * uy * uz) + e.y * ((dy ? 1.0f : -1.0f) * ux * uz) +
                     e.z * ((dz ? 1.0f : -1.0f) * ux * uy);
               }
@@ -659,7 +677,7 @@ __global__ __launch_bounds__(256) void grad_pull_kernel(GridK g, PullK pk) {
   // depends on it (tile, bricks, loop counters) as divergent: VGPRs, exec-mask juggling, no scalar
   // loads.  readfirstlane pins it (and the list lengths below) to SGPRs.
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int REC = MODE ? 8 : 4;
+  constexpr int REC = pull_rec(MODE);
   constexpr int CAP = pull_cap(C, MODE);
   constexpr int PER_WAVE = PULL_NLV * PULL_LIST + PULL_ARRW + CAP * REC + CAP * C;
   const int o_list = wave * PER_WAVE, o_arr = o_list + PULL_NLV * PULL_LIST, o_rec = o_arr + PULL_ARRW,
@@ -725,7 +743,7 @@ template <int C, int NLV, int MODE>
 __global__ __launch_bounds__(512, 4) void grad_pull_block_kernel(GridK g, PullK pk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int REC = MODE ? 8 : 4;
+  constexpr int REC = pull_rec(MODE);
   // LDS (words): survivor table {xn.x, xn.y, xn.z, index} | lists | counters | per-wave staging.  The per-tile
   // fallback reuses table + lists as its per-wave index lists (NLV * PULL_LIST ints per wave).
   constexpr int O_LISTS = BLK_CAND * 4;
@@ -909,7 +927,7 @@ template <int C, int MODE>
 __global__ __launch_bounds__(512, 4) void grad_pull_sub_kernel(GridK g, PullK pk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int REC = MODE ? 8 : 4;
+  constexpr int REC = pull_rec(MODE);
   constexpr int O_LISTS = SUB_CAND * 4;
   constexpr int O_CNT = O_LISTS + BLK_WAVES * SUB_LIST / 2;      // [octant] list lengths, [8] survivors, [9] overflow
   constexpr int O_ROWS = O_CNT + 16;                               // nine {start, length} pairs
@@ -1357,7 +1375,7 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
     if (!ks) return hipErrorInvalidValue;
     const int cap = pull_cap(C, ggx ? 1 : 0);
     const size_t words = (size_t)SUB_CAND * 4 + (size_t)BLK_WAVES * SUB_LIST / 2 + 16 + 32 +
-                         (size_t)BLK_WAVES * (PULL_ARRW + cap * (ggx ? 8 : 4) + cap * C);
+                         (size_t)BLK_WAVES * (PULL_ARRW + cap * pull_rec(ggx ? 1 : 0) + cap * C);
     hipError_t e = hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(words * sizeof(float)));
     if (e != hipSuccess) return e;
@@ -1388,7 +1406,7 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   if (const char* d = getenv("MISO_PULL_WORK0")) pk.work0 = atoi(d) > PULL_WORK0 ? atoi(d) : PULL_WORK0;   // dev
   if (const char* d = getenv("MISO_DEBUG_PULL")) pk.debug = atoi(d);
   const int cap = pull_cap(C, ggx ? 1 : 0);
-  const int per_wave = pk.nl * PULL_LIST + PULL_ARRW + cap * (ggx ? 8 : 4) + cap * C;
+  const int per_wave = pk.nl * PULL_LIST + PULL_ARRW + cap * pull_rec(ggx ? 1 : 0) + cap * C;
   size_t lds = (size_t)per_wave * 4 * sizeof(float);
   if (const char* d = getenv("MISO_PULL_LDS_PAD")) lds += (size_t)atoi(d);   // dev: force a lower occupancy
   const int ntiles = T * T * T;
@@ -1414,7 +1432,7 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   for (int d = 0; d < pk.nl; ++d)
     for (int a = 0; a < 3; ++a) block_ok = block_ok && pk.bdiv[d][a] > 0;
   if (block_ok) {
-    const int rec = ggx ? 8 : 4;
+    const int rec = pull_rec(ggx ? 1 : 0);
     // a tile's list pool, split in proportion to the catchment volume ((B+1)/B)^3 of each level's brick
     double w[PULL_MAXL], wsum = 0.0;
     for (int d = 0; d < pk.nl; ++d) {
