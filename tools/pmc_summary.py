@@ -51,14 +51,24 @@ for k, d in acc.items():
         b, a = sum(busy) / len(busy), sum(act) / len(act)
         out[k].update({"SQ_VALU_MFMA_BUSY_CYCLES_avg": b, "GRBM_GUI_ACTIVE_avg": a,
                        "mfma_busy_frac": b / (a / 8.0 * 1024.0) if a else None})
-sys.path.insert(0, os.getcwd())
-try:
-    from miso_amd.csrc_hash import source_hash
-    import subprocess
-    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    out["_meta"] = {"source_hash": source_hash(), "commit": commit or None,
-                    "note": "bench.py quotes these figures only while source_hash equals the hash in miso_version()"}
-except Exception as exc:  # noqa: BLE001
-    out["_meta"] = {"error": str(exc)}
+# Stamp the summary with the kernel-source hash of the library the counters were COLLECTED with: every pass's log holds
+# the bench line, whose "library" field is miso_version() ("... src=<hash>").  (Stamping the hash of the tree the
+# summary is made in would label stale counters as current after a failed or skipped collection run.)
+import re
+import subprocess
+hashes = set()
+for name in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_grbm"):
+    try:
+        m = re.findall(r"src=([0-9a-f]{8,})", open(f"gpurun_out/prof_{tag}/{name}.log").read())
+    except OSError:
+        m = []
+    hashes.update(m[-1:])
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+if len(hashes) == 1:
+    out["_meta"] = {"source_hash": hashes.pop(), "commit": commit or None,
+                    "note": "source_hash = the src= field of miso_version() in the collection runs' bench lines; bench.py "
+                            "quotes these figures only while it equals the hash of the library it runs"}
+else:
+    out["_meta"] = {"error": f"collection logs name {sorted(hashes) or 'no'} kernel-source hash(es)"}
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
