@@ -111,3 +111,45 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     # struct sizes the header implies (LP64)
     assert ctypes.sizeof(_lib.LmTrack) == 4 * 8 + 3 * 8 + 8 + 8 + 8 + 8 + 4 * 8 + 4 + 4 + 4 + 4 + 9 * 8
     assert ctypes.sizeof(_lib.TrackAdam) == ctypes.sizeof(_lib.LmTrack) + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8
+
+
+def test_gradient_plans_are_host_logic():
+    """Which levels the binned backward pulls, pushes or scatters is decided on the host from the grid shape, the batch
+    size and the flags (miso_grad_pull_levels / miso_sdf_bwd_push_levels): no device call, so it is checked here."""
+    from miso_amd import _lib
+    lib = _lib.load()
+
+    def grid(sizes, C, flags=0):
+        g = _lib.Grid()
+        g.n_levels = len(sizes)
+        g.flags = flags
+        for a in range(3):
+            g.bound_min[a], g.bound_max[a] = -1.0, 1.0
+        for l, (x, y, z) in enumerate(sizes):
+            lv = g.level[l]
+            lv.C, lv.X, lv.Y, lv.Z = C, x, y, z
+            lv.sC, lv.sX, lv.sY, lv.sZ = 1, C, C * x, C * x * y          # channels-last
+            lv.data = None
+            lv.grad = 0x100000 * (l + 1)                                 # never dereferenced by the planners
+        return g
+
+    T = 16
+    cfg2 = grid([(32, 32, 32), (64, 64, 64), (128, 128, 128)], 8)
+    assert lib.miso_grad_pull_levels(ctypes.byref(cfg2), T) == 0b111
+    assert lib.miso_sdf_bwd_push_levels(ctypes.byref(cfg2), T, 262144) == 0          # 64 samples a tile: pulled
+    scannet = grid([(40, 20, 40), (200, 100, 200)], 4)
+    assert lib.miso_grad_pull_levels(ctypes.byref(scannet), T) == 0b01                # 13 x 7 x 13 bricks: scattered
+    assert lib.miso_sdf_bwd_push_levels(ctypes.byref(scannet), T, 540000) == 0b01     # a crowd on the coarse level
+    assert lib.miso_sdf_bwd_push_levels(ctypes.byref(scannet), T, 54000) == 0
+    crowded = grid([(40, 20, 40), (200, 100, 200)], 4, flags=_lib.F_CROWDED)
+    assert lib.miso_sdf_bwd_push_levels(ctypes.byref(crowded), T, 54000) == 0b01      # the caller's hint
+    assert lib.miso_sdf_bwd_push_levels(ctypes.byref(crowded), T, 1000) == 0
+    os.environ["MISO_PULL_SUB"] = "1"                                                 # the opt-in sub-brick kernel
+    try:
+        assert lib.miso_grad_pull_levels(ctypes.byref(scannet), T) == 0b11
+        ncd = grid([(120, 120, 20), (600, 600, 100)], 4)
+        assert lib.miso_grad_pull_levels(ctypes.byref(ncd), T) == 0b01               # 38 vertices per tile and axis
+    finally:
+        del os.environ["MISO_PULL_SUB"]
+    border = grid([(32, 32, 32)], 8, flags=2)                                         # padding_mode='border'
+    assert lib.miso_grad_pull_levels(ctypes.byref(border), T) == 0
