@@ -1322,10 +1322,12 @@ uint32_t plan_push(const GridK& g, int T, int64_t n, uint32_t pull) {
 
 static hipError_t launch_push(const GridK& g, int C, int T, const int* tile_off, const float* xn, const float* dfeat,
                               int64_t ld, const int* perm, int level, int64_t n, hipStream_t s) {
-  // samples per wavefront: 512 (fewest region flushes per sample) once that still makes >= 1024 wavefronts; a small
-  // batch is cut finer so that the chip is not left to a few dozen of them (54 000 samples: 105 wavefronts, 46 us)
+  // samples per wavefront: 512 (fewest region flushes per sample) once that still makes >= 2048 wavefronts -- two per
+  // SIMD, one staging while the other multiplies (540 000 samples: 512 / 384 / 256 / 128 per wavefront give a trainer
+  // step of 360 / 356 / 353 / 366 us); a small batch is cut finer so that the chip is not left to a few dozen
+  // wavefronts (54 000 samples: 105 of them, 46 us; 844 of 64 samples, 26 us)
   static const int run_env = [] { const char* e = getenv("MISO_PUSH_RUN"); return e ? max(64, atoi(e)) : 0; }();   // dev
-  const int run = run_env ? run_env : (int)min((int64_t)512, max((int64_t)64, ((n / 1024 + 63) / 64) * 64));
+  const int run = run_env ? run_env : (int)min((int64_t)512, max((int64_t)64, ((n / 2048 + 63) / 64) * 64));
   PullK pk;
   memset(&pk, 0, sizeof(pk));
   pk.T = T; pk.tile_off = tile_off; pk.xn = reinterpret_cast<const float4*>(xn); pk.dfeat = dfeat;
