@@ -163,6 +163,15 @@ class _FastMappingPlan:
             if plan.sig[1:16] != saved[3][1:16]:
                 plan.states, plan.opt_ref, plan.other_params, plan.sig = saved
                 continue
+            # the plan's step ADDS to the levels in _adam_clears and relies on its own Adam launch having left them
+            # zero.  The buffers are shared with the checked-path steps of the trainers in between (share_grads), and a
+            # binned checked step (optimizer.step(clear_grads=False)) leaves them non-zero: clear them here, once per
+            # adoption (64 MB at the ScanNet shape, ~10 us), so the first replay does not add onto a stale gradient.
+            for l, g in enumerate(plan.step.grads):
+                if g is not None and (plan.step._adam_clears >> l) & 1:
+                    g.zero_()
+                    if plan.step.touched[l] is not None:
+                        plan.step.touched[l].zero_()
             return plan
         return None
 
@@ -223,7 +232,8 @@ class _FastMappingPlan:
         if hasattr(opt, '_step_count'):
             opt._step_count += 1
         total = step.total.clone()
-        opt.note_guarded_step(total, self.states)
+        # guards resolved while making room: those steps were skipped on the device, whose counter never moved
+        self.dev.count -= opt.note_guarded_step(total, self.states)
         return total
 
 

@@ -62,8 +62,10 @@ class DenseAdam(torch.optim.Optimizer):
     def state_dict(self):
         self.resolve_guard()
         sd = super().state_dict()
-        for st in sd['state'].values():
-            st.pop('active', None)            # derived (rebuilt on load): keeps the file a plain Adam state dict
+        # 'active' is derived (rebuilt on load) and left out so that the file is a plain Adam state dict.  The
+        # per-parameter dicts super() returns ARE the live ones (sd['state'][k] is self.state[p]): build new dicts,
+        # never pop from them -- a checkpoint in the middle of training must not take the flags away from the step.
+        sd['state'] = {k: {kk: vv for kk, vv in st.items() if kk != 'active'} for k, st in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):
@@ -151,11 +153,16 @@ class DenseAdam(torch.optim.Optimizer):
 
     def note_guarded_step(self, guard, stepped):
         """A step guarded by the device scalar ``guard`` has been launched for the states ``stepped`` (their 'step'
-        already counts it): remember to take the count back if the guard turns out NaN (resolve_guard)."""
+        already counts it): remember to take the count back if the guard turns out NaN (resolve_guard).
+        Returns the number of EARLIER steps found skipped while making room (a bounded number of guards is kept in
+        flight): a caller that mirrors a device-side step counter subtracts it from its mirror -- the device counter
+        never moved for those steps, and overwriting it with the host count while the step just launched is still
+        unresolved could leave it one ahead."""
         pending = self.__dict__.setdefault('_pending', [])        # (an unpickled optimizer has no such attributes)
         slots = self.__dict__.setdefault('_guard_slots', [])
+        skipped = 0
         if len(pending) >= 8:
-            self.resolve_guard(block=True)        # a bounded number of guards in flight
+            skipped = self.resolve_guard(block=True)        # a bounded number of guards in flight
         if slots:
             host, event = slots.pop()
         else:
@@ -166,3 +173,4 @@ class DenseAdam(torch.optim.Optimizer):
         # the device scalar stays referenced until the copy has been consumed: a caller that drops the loss
         # right away would hand its block back to the allocator while the asynchronous copy may still read it
         pending.append((host, event, stepped, src))
+        return skipped

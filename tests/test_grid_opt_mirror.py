@@ -834,6 +834,23 @@ def test_dense_adam_state_round_trips_with_torch_adam():
         torch.testing.assert_close(run(kinds), ref, rtol=0, atol=1e-7)
 
 
+def test_dense_adam_state_dict_leaves_the_live_state_alone():
+    """torch's Optimizer.state_dict() hands out the LIVE per-parameter dicts; DenseAdam leaves the
+    derived 'active' flags out of the file without taking them away from the optimizer (a checkpoint in the middle of
+    training used to delete them, and the captured trainer step reads them on the next call)."""
+    from miso_amd.optim import DenseAdam
+    p = torch.nn.Parameter(torch.zeros(5))
+    opt = DenseAdam([p], lr=1e-2)
+    p.grad = torch.ones(5)
+    opt.step()
+    flags = torch.ones(1, dtype=torch.uint8)
+    opt.state[p]["active"] = flags                 # what the kernel path keeps next to the moments
+    sd = opt.state_dict()
+    assert "active" not in sd["state"][0] and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert opt.state[p]["active"] is flags
+    assert sd["state"][0]["exp_avg"] is opt.state[p]["exp_avg"]        # still references, as torch's own state_dict
+
+
 @pytest.mark.parametrize("tag", ["eik", "grad", "all", "allL2"])
 def test_isdf_eikonal_gradient_smoothness_branches_match_reference(device_backend, tag, monkeypatch):
     """iSDFLoss.compute_default with the terms that differentiate a spatial gradient taken with create_graph=True
@@ -953,6 +970,12 @@ def test_fast_captured_step_equals_the_checked_one(n, tmp_path):
             mi, gt = bad if it == 6 else batches[it % 4]
             losses.append(tr.train_step(mi, gt))
             used_fast += tr.__dict__.get("_fast_plan") is not None
+            if it == 8:
+                # a checkpoint in the middle of training (Trainer.save_model from post_epoch): the file carries no
+                # 'active' flags, the optimizer keeps them, and the fast plan keeps replaying
+                mid = tr.optimizer.state_dict()
+                assert all("active" not in st for st in mid["state"].values())
+                assert all("active" in tr.optimizer.state[f.feature] for f in net.features)
         torch.cuda.synchronize()
         feats = [f.feature for f in net.features]
         snap = lambda: ([f.detach().clone() for f in feats]
