@@ -281,14 +281,17 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
  *   updated submap poses of grid_opt/models/grid_atlas.py:250-268.
  * coords_src (N,3): the source submap's cached voxel centres; feats_src (N, ld_feats >= F):
  *   its features there.  loss_type 1 = L1 (row-wise 2-norm), 2 = L2.
- * out (24 floats, device): [0] sum_i term_i over in-bound vertices, [1] their count,
+ * out (24 DOUBLES, device, 8-byte aligned): the lanes' fp32 terms are summed in fp64 (wave, workgroup and the atomics
+ *   across workgroups) -- the rotation cotangents are differences of large sums, and an fp32 fan-in over ~1e4
+ *   workgroups was less accurate than the reference's own fp32 tensor sum.
+ *   [0] sum_i term_i over in-bound vertices, [1] their count,
  *   [2..4] sum g_i (g_i = d term_i / d q_i, q_i the point in the dst frame),
  *   [5..13] sum (w_i - t_dst) g_i^T, [14..22] sum (R_dst g_i) p_i^T  (row-major 3x3).
  * The caller forms loss = weight * out[0] / (count * F) (L2) or / count (L1) and the pose
  * cotangents dL/dt_dst = -R_dst sum g, dL/dR_dst = sum (w - t_dst) g^T, dL/dt_src = sum R_dst g,
  * dL/dR_src = sum (R_dst g) p^T, scaled alike. */
 int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float* coords_src,
-                     const float* feats_src, int64_t ld_feats, int64_t n, int loss_type, float* out,
+                     const float* feats_src, int64_t ld_feats, int64_t n, int loss_type, double* out,
                      void* stream);
 
 /* --- submap overlap test ----------------------------------------------------
@@ -318,7 +321,7 @@ int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, co
  *                     miso_align_plan_bytes(n_pairs) bytes of HOST memory, which the caller copies to the device
  *                     and passes as cfg->plan; fills cfg->vec4 / max_n / max_gate_n.
  * state               miso_align_state_layout(...) floats on the device, ZEROED by the caller before the first
- *                     iteration; offsets[11] (in floats) = {params (S,6: dr, dt), pose (S,12: R, t), out (P,24),
+ *                     iteration; offsets[11] (in floats) = {params (S,6: dr, dt), pose (S,12: R, t), out (P,24) DOUBLES = 48 P floats,
  *                     overlap counts (P), pair losses (P, weighted, gated), flat (6S+2), adam exp_avg (S,6),
  *                     exp_avg_sq (S,6), ctrl (8 x int32: Adam steps taken, stopped flag, iterations run, NaN-skipped
  *                     iterations), ring, ring row length}.  Ring row k (ring_iters rows): {total loss, relative

@@ -32,7 +32,7 @@ AlignLayout align_layout(int S, int P, int ring_iters, int save_poses) {
   int64_t o = 0;
   L.params = o; o += up4(6 * S);
   L.pose = o; o += up4(12 * S);
-  L.out = o; o += up4(24 * (int64_t)P);
+  L.out = o; o += up4(48 * (int64_t)P);      // (P,24) DOUBLES (pair_latent.hip reduces in fp64)
   L.cnt = o; o += up4(P);
   L.pair_loss = o; o += up4(P);
   L.flat = o; o += up4(6 * S + 2);
@@ -97,7 +97,7 @@ constexpr int EPI_A_PAIRS = 512;      // pairs staged in LDS per pass (S <= 64 =
 __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK k) {
   const int32_t* ctrl = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl);
   if (ctrl[CTRL_STOPPED]) return;
-  const float* out = k.state + k.L.out;
+  const double* out = reinterpret_cast<const double*>(k.state + k.L.out);
   const float* cnt = k.state + k.L.cnt;
   const float* pose = k.state + k.L.pose;
   float* flat = k.state + k.L.flat;
@@ -117,9 +117,10 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
     for (int i = threadIdx.x; i < np; i += blockDim.x) {
       const int p = p0 + i;
       const AlignPairK& d = k.plan[p];
-      const float* o = out + 24 * p;
-      const float denom = fmaxf(o[1], 1.0f) * (k.loss_type == 2 ? d.n_ch : 1.0f);
-      const float val = o[0] / denom;
+      const double* o = out + 24 * p;
+      // (the count and n_ch are small integers: denom is exact in fp32, as the reference's clamp(min=1) * n_ch)
+      const float denom = fmaxf((float)o[1], 1.0f) * (k.loss_type == 2 ? d.n_ch : 1.0f);
+      const float val = (float)(o[0] / (double)denom);
       const bool finite = (val == val) && !isinf(val);          // nan_to_num passes no gradient otherwise
       const float gate = d.gate_p ? ((cnt[p] / (float)d.gate_n) > k.overlap_thresh ? 1.0f : 0.0f) : 1.0f;
       s_sc[i] = (finite && gate != 0.0f) ? k.align_weight / denom : 0.0f;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
         const float scf = s_sc[i];
         if (!(is_src || is_dst) || scf == 0.0f) continue;
         const double sc = (double)scf;
-        const float* o = out + 24 * (p0 + i);
+        const double* o = out + 24 * (p0 + i);
         const float* Rd = pose + 12 * s_dst[i];
         const double h[3] = {(double)Rd[0] * o[2] + (double)Rd[1] * o[3] + (double)Rd[2] * o[4],
                              (double)Rd[3] * o[2] + (double)Rd[4] * o[3] + (double)Rd[5] * o[4],
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
   }
 }
 
-hipError_t launch_pair_batch(const AlignPairK*, int, int64_t, int64_t, bool, const float*, int, float*, float*,
+hipError_t launch_pair_batch(const AlignPairK*, int, int64_t, int64_t, bool, const float*, int, double*, float*,
                              const int32_t*, int64_t, hipStream_t);
 
 hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, int64_t max_gate_rows, bool vec4,
@@ -247,7 +248,8 @@ hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, in
   align_prologue_kernel<<<1, 256, 0, s>>>(k);
   const int32_t* stopped = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl) + CTRL_STOPPED;
   hipError_t e = launch_pair_batch(k.plan, k.P, max_n, max_gate_n, vec4, k.state + k.L.pose, k.loss_type,
-                                   k.state + k.L.out, k.state + k.L.cnt, stopped, max_gate_rows, s);
+                                   reinterpret_cast<double*>(k.state + k.L.out), k.state + k.L.cnt, stopped,
+                                   max_gate_rows, s);
   if (e != hipSuccess) return e;
   align_epilogue_a_kernel<<<1, EPI_A_THREADS, 0, s>>>(k);
   return hipGetLastError();

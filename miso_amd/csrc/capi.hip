@@ -23,7 +23,7 @@ int64_t sort_workspace_bytes(int64_t n, int T);
 hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, float*, int*, int*,
                        hipStream_t);
 hipError_t launch_pair_latent(const GridK&, bool, const float*, const float*, const float*, int64_t, int64_t, int,
-                              float*, hipStream_t);
+                              double*, hipStream_t);
 hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
 hipError_t launch_adam_touched(float*, float*, float*, float*, unsigned char*, unsigned char*, int64_t, double, double,
                                double, double, int, int, const float*, hipStream_t, const float*, const int32_t*, int);
@@ -522,9 +522,10 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
 }
 
 int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float* coords_src,
-                     const float* feats_src, int64_t ld_feats, int64_t n, int loss_type, float* out,
+                     const float* feats_src, int64_t ld_feats, int64_t n, int loss_type, double* out,
                      void* stream) {
   if (n < 0 || !pose || !out || (loss_type != 1 && loss_type != 2)) return MISO_E_BADARG;
+  if (reinterpret_cast<uintptr_t>(out) & 7u) return MISO_E_BADARG;      // fp64 atomics
   if (n > 0 && (!coords_src || !feats_src)) return MISO_E_BADARG;
   GridK g; bool v4;
   int rc = convert_grid(dst_grid, &g, true, &v4);

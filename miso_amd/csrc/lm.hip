@@ -62,17 +62,19 @@ __global__ __launch_bounds__(256) void lm_normal_eq_kernel(LmK k) {
     acc[27] += w * r * r;
     acc[28] += 1.0f;
   }
-  __shared__ float red[4][32];
+  // the fan-in of a workgroup (64 lanes, 4 waves) in double; what crosses workgroups is at most 128 fp32 partials per
+  // sum (the outputs stay the 32 floats the 6x6 fp32 solve reads, as torch.linalg.solve does upstream)
+  __shared__ double red[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 29; ++i) {
-    float v = acc[i];
+    double v = (double)acc[i];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
   if (threadIdx.x < 29) {
-    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const float v = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
     if (v != 0.0f) atomic_add_f32(k.out + threadIdx.x, v);
   }
 }
@@ -235,12 +237,13 @@ __global__ __launch_bounds__(256) void track_loss_kernel(TrackAdamK k) {
     else { const float q = k.gm_scale + r * r, w = k.gm_scale / (q * q); acc += w * r * r; d = w * 2.0f * r; }
     k.gpred[i] = ok ? k.weight_sdf * d * inv_n : 0.0f;
   }
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-  __shared__ float red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  double accd = (double)acc;
+  for (int o = 32; o > 0; o >>= 1) accd += __shfl_down(accd, o);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = accd;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float v = (red[0] + red[1]) + (red[2] + red[3]);
+    const float v = (float)((red[0] + red[1]) + (red[2] + red[3]));
     if (v != 0.0f || v != v) atomic_add_f32(s.sums + 12, k.weight_sdf * v * inv_n);
   }
 }
@@ -258,17 +261,17 @@ __global__ __launch_bounds__(256) void track_reduce_kernel(TrackAdamK k) {
     acc[6] += g2 * x0; acc[7] += g2 * x1; acc[8] += g2 * x2;
     acc[9] += g0; acc[10] += g1; acc[11] += g2;
   }
-  __shared__ float red[4][12];
+  __shared__ double red[4][12];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
-    float v = acc[i];
+    double v = (double)acc[i];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
   if (threadIdx.x < 12) {
-    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const float v = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
     if (v != 0.0f || v != v) atomic_add_f32(s.sums + threadIdx.x, v);
   }
 }

@@ -25,8 +25,13 @@ struct PairK {
   int64_t ld;
   int64_t n;
   int loss_type;       // 1 = L1 (vector norm), 2 = L2
-  float* out;          // 24 floats, zeroed by the launcher
+  double* out;         // 24 doubles, zeroed by the launcher
 };
+
+// hardware fp64 add at L2 (global_atomic_add_f64, no return value)
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+  (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)(p), v);
+}
 
 // One workgroup's share (grid-stride from block bx of nbx) of one pair.  pose_s / pose_d: R[9] t[3] of the source
 // and the destination submap.  Shared by the single-pair kernel and the batched one (one launch for all pairs of an
@@ -98,8 +103,8 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
         Axis ax = axis_coord(q[0], g.bmin[0], g.bmax[0], lv.X, g.flags);
         Axis ay = axis_coord(q[1], g.bmin[1], g.bmax[1], lv.Y, g.flags);
         Axis az = axis_coord(q[2], g.bmin[2], g.bmax[2], lv.Z, g.flags);
-        const bool ign = (g.ignore_mask >> l) & 1u;
         Cell c = make_cell(ax, ay, az, lv);
+        const bool ign = (g.ignore_mask >> l) & 1u;
         // Corner values with zeros outside the grid (padding_mode = zeros), then the trilinear value and its three
         // derivatives by a lerp tree along x, y, z -- the same polynomial as sum_k v_k w_k with w = (wx wy) wz and its
         // derivative weights, without 32 weight registers per level live next to the 32 corner values: the kernel is
@@ -171,19 +176,24 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
     }
     __builtin_amdgcn_wave_barrier();      // the list is rewritten by the next chunk's pass 1
   }
-  // block reduction: wave shuffles, then one atomic per value per block
-  __shared__ float red[4][24];
+  // Reduction: a wavefront's 64 lanes by an fp32 shuffle tree (pairwise: a few ulps), then IN DOUBLE -- the four wave
+  // sums of the workgroup and one fp64 atomic per value per workgroup.  Round 2 finished with fp32 atomics: up to 2048
+  // workgroups per pair adding one after the other into an fp32 word (error grows with the length of that chain, and
+  // the order of the atomics changes from run to run); in double the fan-in adds nothing measurable and the result is
+  // reproducible to ~1e-16.  (Shuffling doubles -- two ds_bpermute per step instead of one DPP move -- made the tail of
+  // every workgroup three times as long and the level-1 pair stage 1.24 -> 1.9 ms: the tree stays fp32.)
+  __shared__ double red[4][24];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 23; ++i) {
     float v = acc[i];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if (lane == 0) red[wave][i] = v;
+    if (lane == 0) red[wave][i] = (double)v;
   }
   __syncthreads();
   if (threadIdx.x < 23) {
-    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (v != 0.0f) atomic_add_f32(k.out + threadIdx.x, v);
+    const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (v != 0.0) atomic_add_f64(k.out + threadIdx.x, v);
   }
 }
 
@@ -194,11 +204,11 @@ __global__ __launch_bounds__(256, 4) void pair_latent_kernel(GridK g, PairK k) {
 
 // All pairs of one alignment iteration in one launch: blockIdx.y = pair, the pair's descriptor (destination
 // levels, source vertices and features) is read from the device-resident plan, the two poses from the (S,12)
-// table the prologue kernel of align.hip wrote.  out_all: (P,24), zeroed by that prologue.
+// table the prologue kernel of align.hip wrote.  out_all: (P,24) doubles, zeroed by that prologue.
 template <bool VEC4>
 __global__ __launch_bounds__(256, 4) void pair_latent_batch_kernel(const AlignPairK* __restrict__ plan,
                                                                const float* __restrict__ pose_all, int loss_type,
-                                                               float* __restrict__ out_all,
+                                                               double* __restrict__ out_all,
                                                                const int32_t* __restrict__ stopped) {
   if (stopped && *stopped) return;
   const AlignPairK& d = plan[blockIdx.y];
@@ -401,8 +411,8 @@ hipError_t launch_overlap_count(const float* pose, const float* p, int64_t n, co
 }
 
 hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, const float* p, const float* fsrc,
-                              int64_t ld, int64_t n, int loss_type, float* out, hipStream_t s) {
-  hipError_t e = launch_zero_words(out, 24, s);
+                              int64_t ld, int64_t n, int loss_type, double* out, hipStream_t s) {
+  hipError_t e = launch_zero_words(out, 48, s);
   if (e != hipSuccess || n == 0) return e;
   PairK k{pose, p, fsrc, ld, n, loss_type, out};
   unsigned blocks = (unsigned)((n + 2047) / 2048);      // a workgroup takes 256 x PAIR_K vertices per trip
@@ -414,7 +424,7 @@ hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, cons
 
 // The pair stage of one fused alignment iteration (align.hip): overlap counts, then the pair residuals.
 hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t max_n, int64_t max_gate_n, bool vec4,
-                             const float* pose_all, int loss_type, float* out_all, float* cnt_all,
+                             const float* pose_all, int loss_type, double* out_all, float* cnt_all,
                              const int32_t* stopped, int64_t max_gate_rows, hipStream_t s) {
   if (n_pairs <= 0) return hipSuccess;
   if (max_gate_n > 0) {
@@ -427,9 +437,16 @@ hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t ma
   }
   if (max_n > 0) {
     unsigned blocks = (unsigned)((max_n + 2047) / 2048);
-    if (blocks > 2048u) blocks = 2048u;
-    if (vec4) pair_latent_batch_kernel<true><<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
-    else pair_latent_batch_kernel<false><<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
+    // ~7000 workgroups in all (seven rounds of the 1024 that are resident at four waves per SIMD), at least 128 and at
+    // most 2048 per pair: a workgroup's fixed part -- poses, the 23-value reduction, 23 atomics -- is paid per
+    // workgroup, and with 2048 of them for each of cfg-4's 28 pairs it was a fifth of the level-1 pair stage
+    // (1.15 -> 0.89 ms per iteration at 256 per pair)
+    unsigned cap = (unsigned)(7168 / n_pairs);
+    cap = cap < 128u ? 128u : (cap > 2048u ? 2048u : cap);
+    if (blocks > cap) blocks = cap;
+    const dim3 grid(blocks, (unsigned)n_pairs);
+    if (vec4) pair_latent_batch_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
+    else pair_latent_batch_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
   }
   return hipGetLastError();
 }

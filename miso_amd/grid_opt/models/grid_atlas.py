@@ -70,7 +70,7 @@ class GridAtlas(BaseNet):
 
     def print_submap_pose_info(self):
         for i in range(self.num_submaps):
-            deg = math.degrees(torch.linalg.norm(self.rotation_corrections[i]))
+            deg = math.degrees(torch.linalg.norm(self.rotation_corrections[i].detach()))
             print(f"Base submap {i} pose corrections: rot={deg:.2f}deg, "
                   f"tran={torch.linalg.norm(self.translation_corrections[i]):.2f}m")
 

@@ -844,25 +844,26 @@ class _PairLatent(torch.autograd.Function):
         n_ch = _feature_dim(feats_dst)
         assert feats_src.shape[1] >= n_ch
         pose = torch.cat((R_s.reshape(9), t_s.reshape(3), R_d.reshape(9), t_d.reshape(3))).contiguous()
-        out = torch.empty(24, device=coords_src.device, dtype=torch.float32)
+        out = torch.empty(24, device=coords_src.device, dtype=torch.float64)      # the sums arrive in fp64
         g = _fill_grid(feats_dst, meta_dst)
         _lib.check(_lib.load().miso_pair_latent(C.byref(g), _ptr(pose), _ptr(coords_src), _ptr(feats_src),
                                                 feats_src.stride(0) if n else n_ch, n, _LOSS_TYPES[loss_type],
                                                 _ptr(out), _stream(coords_src)), "miso_pair_latent")
         denom = out[1].clamp(min=1.0) * (n_ch if loss_type == "L2" else 1)
         ctx.save_for_backward(out, denom, R_d)
-        return out[0] / denom
+        return (out[0] / denom).to(R_s.dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gl):
         out, denom, R_d = ctx.saved_tensors
-        s = gl / denom
-        h = R_d @ out[2:5]                      # sum_i R_dst g_i
-        g_Rs = out[14:23].view(3, 3) * s
-        g_ts = h.view(3, 1) * s
-        g_Rd = out[5:14].view(3, 3) * s
-        g_td = -h.view(3, 1) * s
+        s = gl.double() / denom
+        h = R_d.double() @ out[2:5]             # sum_i R_dst g_i
+        f = lambda t: t.to(R_d.dtype)
+        g_Rs = f(out[14:23].view(3, 3) * s)
+        g_ts = f(h.view(3, 1) * s)
+        g_Rd = f(out[5:14].view(3, 3) * s)
+        g_td = f(-h.view(3, 1) * s)
         return (g_Rs, g_ts, g_Rd, g_td) + (None,) * (4 + (len(ctx.needs_input_grad) - 8))
 
 
@@ -897,7 +898,7 @@ class _PairLatentMulti(torch.autograd.Function):
         src, dst = const["src"], const["dst"]
         pose_all = torch.cat((R_all.reshape(S, 9), t_all.reshape(S, 3)), dim=1)            # (S,12)
         pose_pairs = torch.cat((pose_all[src], pose_all[dst]), dim=1).contiguous()           # (P,24)
-        out = torch.empty((P, 24), device=dev, dtype=torch.float32)
+        out = torch.empty((P, 24), device=dev, dtype=torch.float64)
         cnt = torch.empty(P, device=dev, dtype=torch.float32) if plan["gate_pts"] is not None else None
         stream = _stream(pose_pairs)
         lt = _LOSS_TYPES[plan["loss_type"]]
@@ -906,18 +907,18 @@ class _PairLatentMulti(torch.autograd.Function):
             n = coords.shape[0]
             _lib.check(lib.miso_pair_latent(C.byref(grid), C.c_void_p(pose_pairs.data_ptr() + 96 * p), _ptr(coords),
                                             _ptr(fsrc), fsrc.stride(0) if n else nch, n, lt,
-                                            C.c_void_p(out.data_ptr() + 96 * p), stream), "miso_pair_latent")
+                                            C.c_void_p(out.data_ptr() + 192 * p), stream), "miso_pair_latent")
             if cnt is not None:
                 pts, bmin, bmax = plan["gate_pts"][p]
                 _lib.check(lib.miso_overlap_count(C.c_void_p(pose_pairs.data_ptr() + 96 * p), _ptr(pts), pts.shape[0],
                                                   bmin, bmax, C.c_void_p(cnt.data_ptr() + 4 * p), stream),
                            "miso_overlap_count")
-        denom = out[:, 1].clamp(min=1.0) * (const["nch"] if plan["loss_type"] == "L2" else 1.0)
+        denom = out[:, 1].clamp(min=1.0) * (const["nch"].double() if plan["loss_type"] == "L2" else 1.0)
         gate = torch.ones(P, device=dev)
         if cnt is not None:
             gate = ((cnt / const["npts"]) > plan["overlap_thresh"]).to(torch.float32)
         ctx.save_for_backward(out, denom, gate, R_all, src, dst)
-        return torch.nan_to_num(out[:, 0] / denom) * gate
+        return torch.nan_to_num((out[:, 0] / denom).to(R_all.dtype)) * gate
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -925,17 +926,17 @@ class _PairLatentMulti(torch.autograd.Function):
         out, denom, gate, R_all, src, dst = ctx.saved_tensors
         # nan_to_num in the forward passes no gradient for a non-finite pair loss (its derivative is
         # grad * isfinite(input)); the raw sums of such a pair may be NaN as well and must not reach the poses
-        finite = torch.isfinite(out[:, 0] / denom)
+        finite = torch.isfinite((out[:, 0] / denom).to(R_all.dtype))
         out = torch.where(finite.view(-1, 1), out, torch.zeros_like(out))
-        s = torch.where(finite, torch.nan_to_num(gl) * gate / denom, torch.zeros_like(denom)).view(-1, 1, 1)
-        h = R_all[dst] @ out[:, 2:5].unsqueeze(-1)                  # sum_i R_dst g_i, (P,3,1)
-        gR = torch.zeros_like(R_all)
-        gt = torch.zeros((R_all.shape[0], 3, 1), device=R_all.device, dtype=R_all.dtype)
+        s = torch.where(finite, (torch.nan_to_num(gl) * gate).double() / denom, torch.zeros_like(denom)).view(-1, 1, 1)
+        h = R_all[dst].double() @ out[:, 2:5].unsqueeze(-1)         # sum_i R_dst g_i, (P,3,1)
+        gR = torch.zeros(R_all.shape, device=R_all.device, dtype=torch.float64)
+        gt = torch.zeros((R_all.shape[0], 3, 1), device=R_all.device, dtype=torch.float64)
         gR.index_add_(0, src, out[:, 14:23].reshape(-1, 3, 3) * s)
         gR.index_add_(0, dst, out[:, 5:14].reshape(-1, 3, 3) * s)
         gt.index_add_(0, src, h * s)
         gt.index_add_(0, dst, -h * s)
-        return gR, gt, None
+        return gR.to(R_all.dtype), gt.to(R_all.dtype), None
 
 
 def pair_latent_multi(R_all, t_all, plan) -> torch.Tensor:
@@ -1045,7 +1046,8 @@ class AlignPlan:
 
     @property
     def pair_out(self) -> torch.Tensor:
-        return self._view(2, 24 * self.P).view(self.P, 24)
+        """(P,24) fp64 sums of the last iteration_a (miso_pair_latent's `out` per pair)."""
+        return self._view(2, 48 * self.P).view(torch.float64).view(self.P, 24)
 
     @property
     def overlap_counts(self) -> torch.Tensor:

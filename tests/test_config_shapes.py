@@ -223,10 +223,19 @@ def test_cfg4_eight_submaps_alignment_vs_oracle_loop():
     gated = int((plan.pair_losses.cpu() == 0).sum())
     assert 0 < gated < len(pairs)               # the lattice has pairs that do not overlap: the gate is exercised
     # ---- level 1, two pairs, one iteration, against the oracle in fp32 AND fp64 ----------------------------------------
-    # The rotation gradient is a difference of large sums (the antisymmetric part of sum_i (R g_i) p_i^T over ~1e6
-    # in-bound vertices with |p| up to 10 m): in fp32 it is conditioned to ~2e-3 of its largest component whoever
-    # computes it.  Measured (tools/align_precision_check.py): reference arithmetic (torch fp32) vs fp64 2.2e-3, HIP vs
-    # fp64 3.5e-3, HIP vs torch fp32 1.8e-3.  So the bar is: as close to the exact value as the reference's own fp32.
+    # What limits this comparison (round 3, tools/align_precision_check.py + a CPU experiment on pair (0,1), DESIGN
+    # section 2): these submaps carry random features, so the residual is noise and its pose gradient a sum that
+    # cancels down to ~sqrt(N) of its 1.9e6 terms.  The trilinear interpolant is continuous but its GRADIENT jumps at
+    # cell faces, and an fp32 position (ulp 1e-6 m at 10 m = 1e-5 cells) puts ~24 of the in-bound lattice vertices into
+    # the neighbouring cell (counted: 3 at level 0, 21 at level 1): each is an error of a whole term, sqrt(24) terms
+    # against sqrt(1.9e6) ~ 3e-3.  ANY fp32 evaluation sits there: torch's own ops 2.2e-3 on these two pairs and
+    # 3.9e-3 on pair (0,1) alone; torch with fp64 points and fp64 sums but fp32 interpolation 3.5e-3; the kernel 3.4e-3
+    # with fp32 atomics (round 2), 3.8e-3 with the fan-in in fp64 (now: the reduction was never the cause), 2.4e-3
+    # with the cells of vertices near a face redone in double (tried: +22 % kernel time for a figure still inside the
+    # spread, not kept).  Two fp32 implementations misplace DIFFERENT vertices, so they differ from each other by as
+    # much (1.5e-3 ... 2.2e-3).  The bar is therefore "the same order as the reference's own fp32 arithmetic"; on a
+    # field that is actually alignable the gradient is coherent and the kernel is within 1e-4 of fp64
+    # (tests/test_align_convergence.py).
     some = [(0, 1), (2, 3)]
     inp = AM.latent_pair_inputs(atlas, some, level=1, fdim=4, check_intersection=True)
     assert all(p["coords"].shape[0] == 4000000 for p in inp)
@@ -253,8 +262,9 @@ def test_cfg4_eight_submaps_alignment_vs_oracle_loop():
     scale = f64[:-1].abs().max().item()
     err_hip = (f_gpu - f64)[:-1].abs().max().item() / scale
     err_ref = (f32 - f64)[:-1].abs().max().item() / scale
-    assert err_hip <= max(2.5 * err_ref, 1e-4), (err_hip, err_ref)
-    assert err_hip <= 1e-2
+    print(f"level-1 pose gradient vs fp64: HIP {err_hip:.3e}, torch fp32 {err_ref:.3e}")
+    assert err_hip <= max(2.0 * err_ref, 1e-4), (err_hip, err_ref)
+    assert err_hip <= 6e-3
 
 
 def test_full_size_cfg2_gradient_outliers_are_relu_ties():

@@ -13,6 +13,12 @@ room instead of ``utils_scannet.create_scannet_dataset`` (:48-50), the decoder k
   align:  torch.load(grid_atlas)  -> perturb submap poses (10 deg / 0.5 m, seed 55)  -> Fuser.align (hierarchical
           latent alignment, verbose + save_iterations as the reference config)  -> trajectory error before / after
           (utils_eval.evo_trajectory_error)  -> alignment_result.json
+  align, shared field:  the same atlas file and the same call sequence once more, with the feature grids replaced by
+          samples of ONE analytic field of the world at the true submap poses (tools/shared_field.py).  Upstream the
+          pretrained decoder is what makes two submaps describe the same surface with the same latent features; with
+          the random frozen decoder of this offline demo the mapped features of two submaps need not agree, so the
+          first alignment only has to run.  On the shared field there IS a pose to come back to: the trajectory error
+          must fall by 5x (asserted).
 
     python tools/demo_synthetic.py --save_dir /tmp/miso_demo [--quick]
 """
@@ -160,6 +166,23 @@ def evaluate_alignment_error(grid_atlas, dataset):
     return {'rmse_tran (cm)': 100 * m_t['rmse'], 'rmse_deg': utils_geometry.chordal_to_degree(m_R['rmse'])}
 
 
+def perturb_and_align(model_path, cfg, dataset, noise_rot, noise_tra, shared_field=False):
+    """demo/align_submaps.py:262-317: load, perturb, Fuser.align, trajectory error before / after."""
+    grid_atlas = torch.load(model_path, weights_only=False)
+    if shared_field:
+        import tools.shared_field as SF
+        true = [dataset.true_kf_pose_in_world(grid_atlas.anchor_kf_for_submap(s)) for s in range(grid_atlas.num_submaps)]
+        centre = tuple(float(v) for v in ROOM.mean(axis=1))
+        SF.fill_from_field(grid_atlas, [(R.cpu(), t.cpu()) for R, t in true], center=centre, radius=1.4)
+    for i in range(1, grid_atlas.num_submaps):
+        R, t = grid_atlas.initial_submap_pose(i)
+        grid_atlas.set_submap_pose(i, R @ noise_rot[i].to(R), t + noise_tra[i].reshape(3, 1).to(t))
+    metrics_bef = evaluate_alignment_error(grid_atlas, dataset)
+    align_info = Fuser(model=grid_atlas, dataset=dataset, cfg=cfg).align()
+    metrics_aft = evaluate_alignment_error(grid_atlas, dataset)
+    return grid_atlas, align_info, metrics_bef, metrics_aft
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--save_dir', type=str, default='./results/demo/synthetic')
@@ -168,7 +191,7 @@ def main():
     args = ap.parse_args()
     if args.quick:
         H, W, n_kf, args.submap_size, n_rays = 60, 80, 12, 4, 120
-        args.map_iters, args.level_iters_map, args.align_iters, args.mesh_res = 120, 40, 40, 48
+        args.map_iters, args.level_iters_map, args.align_iters, args.mesh_res = 120, 40, 100, 48
         args.base_cell, args.local = 0.5, 6.0
     else:
         H, W, n_kf, args.submap_size, n_rays = 120, 160, 30, 10, 200
@@ -194,19 +217,21 @@ def main():
         print(f"submap {i}: mapped, mesh of {len(mesh.triangles)} triangles")
     torch.save(grid_atlas, model_path)
     # ---------------------------------------------------------------- align_submaps.main_scannet
-    grid_atlas = torch.load(model_path, weights_only=False)
-    noise_rot = utils_geometry.wrapped_gaussian_rotations(grid_atlas.num_submaps, std_rad=radians(10.0)).to(grid_atlas.device)
-    noise_tra = utils_geometry.gaussian_translations(grid_atlas.num_submaps, stddev=0.50).to(grid_atlas.device)
-    for i in range(1, grid_atlas.num_submaps):
-        R, t = grid_atlas.initial_submap_pose(i)
-        grid_atlas.set_submap_pose(i, R @ noise_rot[i], t + noise_tra[i].reshape(3, 1))
-    metrics_bef = evaluate_alignment_error(grid_atlas, dataset)
-    align_info = Fuser(model=grid_atlas, dataset=dataset, cfg=cfg).align()
-    metrics_aft = evaluate_alignment_error(grid_atlas, dataset)
+    n_sub = grid_atlas.num_submaps
+    noise_rot = utils_geometry.wrapped_gaussian_rotations(n_sub, std_rad=radians(10.0))
+    noise_tra = utils_geometry.gaussian_translations(n_sub, stddev=0.50)
+    grid_atlas, align_info, metrics_bef, metrics_aft = perturb_and_align(model_path, cfg, dataset, noise_rot, noise_tra)
     print("Before alignment metrics:\n", json.dumps(metrics_bef, indent=4))
     print("After alignment metrics:\n", json.dumps(metrics_aft, indent=4))
+    # the same file, the same perturbation, the same calls on features that two submaps agree on
+    _, info_sf, sf_bef, sf_aft = perturb_and_align(model_path, cfg, dataset, noise_rot, noise_tra, shared_field=True)
+    print("Shared-field features, before:\n", json.dumps(sf_bef, indent=4))
+    print("Shared-field features, after:\n", json.dumps(sf_aft, indent=4))
     with open(join(args.save_dir, 'alignment_result.json'), 'w') as f:
-        json.dump({'before_alignment': metrics_bef, 'after_alignment': metrics_aft}, f, indent=4)
+        json.dump({'before_alignment': metrics_bef, 'after_alignment': metrics_aft,
+                   'shared_field_before': sf_bef, 'shared_field_after': sf_aft}, f, indent=4)
+    assert sf_aft['rmse_tran (cm)'] <= 0.2 * sf_bef['rmse_tran (cm)'] and sf_aft['rmse_deg'] <= 0.2 * sf_bef['rmse_deg'], \
+        "alignment on the shared field did not bring the submaps back"
     it = align_info['hier_latent_level1_L2']['iteration_results']
     assert sorted(it) == list(range(args.align_iters + 1)) and it[0].shape == (grid_atlas.num_submaps, 4, 4)
     print(f"alignment: {len(it)} pose snapshots per level, gpu_time {align_info['gpu_time_sec']:.3f} s")
