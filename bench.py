@@ -123,10 +123,15 @@ def cpu_baseline(data, budget_s=20.0):
         dt1 = (time.perf_counter() - t1) / 2
     finally:
         torch.set_num_threads(cores)
-    return {"value": N_POINTS / dt, "unit": "point-samples/s", "cores": cores, "kind": "port", **host_cpu(),
-            "sample": f"{k} full fwd+bwd iterations of 262144 points (stock torch CPU ops arranged as "
-                      f"the reference: F.grid_sample per level, cat, nn.Sequential, L1), {dt:.2f} s each",
-            "one_thread_value": N_POINTS / dt1}, pred
+    # the baseline is the FASTER of the two (on a 128-thread host the one-thread run wins: thread launch and
+    # reduction overheads around a serial grid_sample); both are reported
+    v_all, v_one = N_POINTS / dt, N_POINTS / dt1
+    return {"value": max(v_all, v_one), "unit": "point-samples/s", "cores": cores if v_all >= v_one else 1,
+            "kind": "port", **host_cpu(),
+            "sample": f"{k} full fwd+bwd iterations of 262144 points on {cores} threads (stock torch CPU ops arranged "
+                      f"as the reference: F.grid_sample per level, cat, nn.Sequential, L1), {dt:.2f} s each, and 2 on "
+                      f"one thread, {dt1:.2f} s each; value = the faster",
+            "all_threads_value": v_all, "all_threads": cores, "one_thread_value": v_one}, pred
 
 
 SCANNET_CFG = {"name": "grid_net", "spatial_dim": 3,
@@ -187,7 +192,7 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
     for level in levels:
         loss = AM.latent_loss_for_level(atlas, level, device=dev)
 
-        def run(n_it):
+        def run(n_it, lr=1e-2):
             for s in range(S):
                 atlas.set_submap_pose_correction(s, *start[s])
             torch.cuda.synchronize()
@@ -196,22 +201,26 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
             t0 = time.perf_counter()
             if dist is not None:
                 mdist.align_multiple_submaps_distributed(atlas, _DS(), (f"latent{level}", loss), num_iters=n_it - 1,
-                                                         lr=1e-2, verbose=True, save_iterations=True)
+                                                         lr=lr, verbose=True, save_iterations=True)
             else:
-                AB.generic_align_multiple_submaps(atlas, _DS(), (f"latent{level}", loss), num_iters=n_it - 1, lr=1e-2,
+                AB.generic_align_multiple_submaps(atlas, _DS(), (f"latent{level}", loss), num_iters=n_it - 1, lr=lr,
                                                   verbose=True, save_iterations=True)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
-            return time.perf_counter() - t0
+            lp = atlas.__dict__["_last_align_loop"]      # the iterations proper (set-up, warm-up, capture excluded)
+            return time.perf_counter() - t0, lp["seconds"] / max(lp["iterations"], 1)
 
         run(4)                                      # warm-up (plan build, source features cached)
-        # wall time of a run = plan set-up (host) + iterations: the difference of a long and a short run is iterations only
-        t_a, t_b = min(run(iters), run(iters), run(iters)), min(run(6 * iters), run(6 * iters))
-        per_it = (t_b - t_a) / (5 * iters)
+        t_a = min(run(iters)[0] for _ in range(3))
+        per_it = min(run(6 * iters)[1] for _ in range(2))
+        # the same with lr = 0: Adam moves nothing, every iteration sees the START poses -- the state the pair stage
+        # below is timed at (while the poses move the overlap changes, and so does the work per iteration)
+        per_it_fixed = min(run(6 * iters, 0.0)[1] for _ in range(2))
         nv = sum(atlas.coordinates_for_alignment(a, level).shape[0] for a in range(S) for b in range(a + 1, S))
         C_ = SCANNET_CFG["grid"]["feature_dim"]
         rec = {"source_vertices_per_iteration": nv, "ms_per_iteration": per_it * 1e3,
+               "ms_per_iteration_fixed_start_poses": per_it_fixed * 1e3,
                f"ms_{iters}_iterations": t_a * 1e3, "vertices_per_s": nv / per_it,
                "ms_per_pair_iteration": per_it * 1e3 / out["pairs"]}
         if dist is None:
@@ -229,6 +238,9 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
             inb = float(plan.pair_out[:, 1].sum().item())
             b_alg = 12 * nv + inb * (4 + 32) * C_ * (level + 1)
             rec["pair_stage_us"] = t_k
+            rec["pair_stage_note"] = ("iteration_a (prologue, gates, pair kernel, epilogue A) at the start poses, launch by "
+                                      "launch with HIP events: compare with ms_per_iteration_fixed_start_poses (the "
+                                      "captured loop at the same poses)")
             rec["in_bound_vertices"] = inb
             rec["roofline"] = {"bound": "hbm", "kernel": "pair_latent_batch_kernel (+ overlap_count_batch_kernel, "
                                "prologue, epilogue A)", "achieved": b_alg / (t_k * 1e-6) / 1e9, "peak": 8000.0,
@@ -254,10 +266,11 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
     return out
 
 
-def map_cfg3(dev, atlas, dist, steps=20, n=540000):
+def map_cfg3(dev, atlas, dist, steps=300, n=540000):
     """cfg-3: the S submaps mapped submap-parallel (rank r owns {s : s % world == r}, no per-step collective:
-    decoder frozen, grids disjoint), `steps` GridTrainer.train_step iterations of 540 000 samples each per submap,
-    then sync_submaps (every owner broadcasts its grids).  Wall time over all ranks, broadcast included."""
+    decoder frozen, grids disjoint), `steps` GridTrainer.train_step iterations of 540 000 samples each per submap
+    (300: what demo/build_submaps.py:76-91 trains a submap for), then sync_submaps (every owner broadcasts what it
+    owns as one buffer).  Wall time over all ranks, broadcast included, and the two parts separately."""
     import tempfile
     import miso_amd.grid_opt.loss as L
     from miso_amd import dist as mdist
@@ -283,6 +296,7 @@ def map_cfg3(dev, atlas, dist, steps=20, n=540000):
     for tr, inp in trainers:
         for _ in range(3):
             tr.train_step(inp, gt)
+    _maybe_fail("map_cfg3")
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -308,10 +322,77 @@ def map_cfg3(dev, atlas, dist, steps=20, n=540000):
             "broadcast_bytes": bytes_b, "point_samples_per_s": S * steps * n / t_all}
 
 
-def extras_multi(dev, dist):
+def _maybe_fail(where):
+    """dev / test: MISO_BENCH_FAIL=<rank>:<where> makes that rank throw there (tests the watchdog below)."""
+    spec = os.environ.get("MISO_BENCH_FAIL")
+    if spec and spec == f"{os.environ.get('RANK', '0')}:{where}":
+        raise RuntimeError(f"injected failure in {where}")
+
+
+class Watchdog:
+    """Keeps the headline line safe from the collective-bearing extras.  One thread per rank: when the wall-clock
+    budget runs out, or ANY rank has raised the abort flag (a file next to the rendezvous port: one node, so every
+    rank sees it), rank 0 prints the finished headline record with extras_multi_gpu = {"error": ...} and every rank
+    leaves with os._exit -- a rank blocked in an all-reduce whose peer threw would otherwise sit there until the
+    process-group timeout.  (Exiting is all it does: no re-exec of a GPU process.)"""
+
+    def __init__(self, rank, budget_s):
+        import threading
+        self.rank, self.deadline = rank, time.time() + budget_s
+        self.flag = os.path.join("/tmp", f"miso_bench_abort_{os.environ.get('MASTER_PORT', '0')}")
+        self.headline = None          # rank 0: the finished record
+        self.partial = {}             # extras that did finish
+        self._off = threading.Event()
+        if rank == 0 and os.path.exists(self.flag):
+            os.remove(self.flag)      # a stale flag of an earlier run on this port
+        self._th = threading.Thread(target=self._watch, daemon=True)
+
+    def start(self):
+        self._th.start()
+
+    def raise_flag(self, reason):
+        try:
+            with open(self.flag, "x") as f:         # the FIRST reason stays (a peer that dies makes the others fail too)
+                f.write(reason)
+        except OSError:
+            pass
+
+    def _watch(self):
+        while not self._off.wait(0.25):
+            reason = None
+            if os.path.exists(self.flag):
+                try:
+                    reason = open(self.flag).read() or "a rank failed"
+                except OSError:
+                    reason = "a rank failed"
+            elif time.time() > self.deadline:
+                reason = "wall-clock budget of the multi-GPU extras exceeded"
+            if reason is not None:
+                self.expire(reason)
+
+    def expire(self, reason):
+        if self.rank == 0 and self.headline is not None:
+            out = dict(self.headline)
+            out["extras_multi_gpu"] = dict(self.partial, error=reason)
+            sys.stdout.write(json.dumps(out) + "\n")
+            sys.stdout.flush()
+        os._exit(0 if self.rank == 0 else 3)
+
+    def stop(self):
+        self._off.set()
+        if self.rank == 0 and os.path.exists(self.flag):
+            try:
+                os.remove(self.flag)
+            except OSError:
+                pass
+
+
+def extras_multi(dev, dist, dog):
     """Collective-bearing workloads at N > 1 ranks: cfg-3 (submap-parallel mapping + the grid broadcast) and cfg-4
-    (alignment with the pair list sharded and one all-reduce per iteration)."""
-    ex = {}
+    (alignment with the pair list sharded and one all-reduce per iteration).  A rank that throws inside one of them
+    cannot rejoin the collectives the others are in: it raises the watchdog's flag and every rank abandons the extras
+    together (the headline line is printed with the error)."""
+    ex = dog.partial
     atlas = scannet_atlas(dev, 8)
     for key, fn in (("cfg3_map_8_submaps_parallel", lambda: map_cfg3(dev, atlas, dist)),
                     ("cfg4_align_8_submaps_sharded", lambda: (atlas.precompute_coordinates_for_alignment(),
@@ -319,7 +400,8 @@ def extras_multi(dev, dist):
         try:
             ex[key] = fn()
         except Exception as exc:  # noqa: BLE001
-            ex[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            dog.raise_flag(f"{key} on rank {dog.rank}: {type(exc).__name__}: {exc}")
+            time.sleep(3600)          # the watchdog thread ends this process within a fraction of a second
     return ex
 
 
@@ -706,10 +788,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=300)      # a collective nobody answers ends the job in minutes, not half an hour
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
         # sanity value of the collective layer: every rank contributes rank + 1 -> world (world + 1) / 2
         from miso_amd import dist as mdist
         chk = torch.full((1,), float(rank + 1), device=dev)
@@ -738,18 +822,47 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # rank 0 finishes the headline record FIRST (per-kernel timings, roofline: single-rank work); the collective-bearing
+    # extras run after it, under a watchdog that prints the record if they hang or a rank fails
+    out = headline_record(args, step, dev, world, elapsed) if rank == 0 else None
+    if rank == 0 and collective is not None:
+        out.update(collective)
     multi = None
     if dist is not None and not args.no_extras:
-        # collective-bearing workloads (every rank takes part; rank 0 reports)
-        try:
-            multi = extras_multi(dev, dist)
-        except Exception as exc:  # noqa: BLE001
-            multi = {"error": f"{type(exc).__name__}: {exc}"}
+        dog = Watchdog(rank, float(os.environ.get("MISO_BENCH_EXTRAS_BUDGET_S", "150")))
+        dog.headline = out
+        dog.start()
+        multi = extras_multi(dev, dist, dog)
+        dog.stop()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
+    if multi is not None:
+        out["extras_multi_gpu"] = multi
+    if world == 1 and not args.no_extras:
+        try:                      # secondary figures must never cost the headline line
+            out["extras"] = extras(step, dev)
+        except Exception as exc:  # noqa: BLE001
+            out["extras"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cb, pred_cpu = cpu_baseline(data)
+            out["cpu_baseline"] = cb
+            sdf_gpu, _ = ops.sdf_fwd_raw(step.x, step.features, step.meta, step.pack, False)
+            err = (sdf_gpu.detach().cpu() - pred_cpu.detach()).abs()
+            out["sdf_L1_vs_cpu"] = {"mean": err.mean().item(), "max": err.max().item()}
+            out["speedup_vs_cpu"] = out["value"] / cb["value"]
+        except Exception as exc:  # noqa: BLE001  (the headline line is printed regardless)
+            out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
 
+
+def headline_record(args, step, dev, world, elapsed):
+    """The headline JSON record (rank 0): value, per-kernel durations measured live with HIP events, roofline."""
+    from miso_amd import ops
     ms_per_step = elapsed / args.steps * 1e3
     value = world * N_POINTS * args.steps / elapsed
 
@@ -855,28 +968,7 @@ def main():
                      "(keep_sdf=False): the 4 B/point SDF write of SURVEY 8(d)'s B_alg is not moved by this step "
                      "(1 MB of 408 MB); step_fraction_of_hbm_roofline uses the full B_alg = 20 + 64 L C",
     }
-    if collective is not None:
-        out.update(collective)
-    if multi is not None:
-        out["extras_multi_gpu"] = multi
-    if world == 1 and not args.no_extras:
-        try:                      # secondary figures must never cost the headline line
-            out["extras"] = extras(step, dev)
-        except Exception as exc:  # noqa: BLE001
-            out["extras"] = {"error": f"{type(exc).__name__}: {exc}"}
-    if world == 1 and not args.no_cpu_baseline:
-        try:
-            cb, pred_cpu = cpu_baseline(data)
-            out["cpu_baseline"] = cb
-            sdf_gpu, _ = ops.sdf_fwd_raw(step.x, step.features, step.meta, step.pack, False)
-            err = (sdf_gpu.detach().cpu() - pred_cpu.detach()).abs()
-            out["sdf_L1_vs_cpu"] = {"mean": err.mean().item(), "max": err.max().item()}
-            out["speedup_vs_cpu"] = value / cb["value"]
-        except Exception as exc:  # noqa: BLE001  (the headline line is printed regardless)
-            out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
-    print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

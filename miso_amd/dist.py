@@ -6,12 +6,16 @@ unit follows from its data model: every submap is an independent GridNet with it
 grids, keyframe poses and optimiser state (grid_opt/models/grid_atlas.py:146-150).
 
 * mapping   rank r owns submaps {s : s % world == r}; NO per-step collective (decoder
-            frozen, grids disjoint).  ``sync_submaps`` broadcasts each owner's grids
-            once afterwards (61 MiB per ScanNet submap ~ 0.4 ms per xGMI hop).
-* alignment grids are read-only and replicated; the pair list is dealt round-robin;
-            each iteration ends with ONE all-reduce(SUM) of a flat fp32 buffer holding
-            the pose gradients of submaps 1..S-1 and the loss (6(S-1)+1 floats: latency
-            bound, xGMI bandwidth irrelevant), then the identical Adam step everywhere.
+            frozen, grids disjoint).  ``sync_submaps`` afterwards: every owner packs ALL it
+            owns into one flat buffer and broadcasts it -- `world` collectives of ~80 MB
+            (61 MiB of grids per ScanNet submap) instead of one per parameter and buffer
+            (~10 per submap, most of them a few bytes: latency, not bytes).
+* alignment grids are read-only and replicated; the pair list is dealt by estimated cost
+            (source vertices + in-bound vertices at the start poses, longest first onto the
+            least loaded rank: a gated pair costs a fraction of an overlapping one); each
+            iteration ends with ONE all-reduce(SUM) of a flat fp32 buffer holding the pose
+            gradients and the loss (6S+1 floats: latency bound, xGMI bandwidth irrelevant)
+            between two captured halves, then the identical Adam step everywhere.
 """
 from __future__ import annotations
 
@@ -67,9 +71,10 @@ def _needs_host_staging(t: torch.Tensor) -> bool:
     return t.is_cuda and dist.get_backend() == "gloo"
 
 
-def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
-    """In-place SUM over ranks of a small flat tensor (the 6S + 1 floats of an alignment iteration)."""
-    if rank_world()[1] == 1:
+def all_reduce_sum(t: torch.Tensor, always: bool = False) -> torch.Tensor:
+    """In-place SUM over ranks of a small flat tensor (the 6S + 1 floats of an alignment iteration).
+    always: issue the collective even in a group of one rank (the single-GPU RCCL smoke test)."""
+    if rank_world()[1] == 1 and not (always and dist.is_available() and dist.is_initialized()):
         return t
     if _needs_host_staging(t):
         h = t.cpu()
@@ -105,34 +110,111 @@ def map_submaps_parallel(atlas, map_one: Callable[[int], None], sync: bool = Tru
         sync_submaps(atlas)
 
 
+def _pack_list(atlas, submaps):
+    """The tensors (parameters, then buffers, in module order) of `submaps`, and their byte sizes padded to 16."""
+    ts = [t.data for s in submaps for t in list(atlas.get_submap(s).parameters()) + list(atlas.get_submap(s).buffers())]
+    return ts, [(t.numel() * t.element_size() + 15) // 16 * 16 for t in ts]
+
+
 @torch.no_grad()
-def sync_submaps(atlas):
-    """Every rank ends up with every submap's parameters and buffers (owner broadcasts)."""
+def sync_submaps(atlas, always: bool = False):
+    """Every rank ends up with every submap's parameters and buffers.  One collective per OWNER: rank r packs all the
+    tensors of the submaps it owns (physical order: channels-last grids stay channels-last) into one byte buffer,
+    broadcasts it, and everybody else unpacks.  The broadcasts of all owners are issued back to back and waited for
+    together.  (Round 2 sent one blocking broadcast per parameter and buffer -- ~80 collectives for 8 submaps, most of
+    them a handful of bytes.)  always: also in a group of one rank (RCCL smoke test)."""
     _, world = rank_world()
-    if world == 1:
+    if world == 1 and not (always and dist.is_available() and dist.is_initialized()):
         return
-    for s in range(atlas.num_submaps):
-        src = owner_of(s, world)
-        sub = atlas.get_submap(s)
-        for t in list(sub.parameters()) + list(sub.buffers()):
-            flat = _flat_view(t.data)
-            _broadcast(flat, src)
-            if flat.data_ptr() != t.data.data_ptr():   # a copy was needed: write it back
-                t.data.copy_(flat.view_as(t.data))
+    rank = rank_world()[0]
+    S = atlas.num_submaps
+    dev = next(atlas.get_submap(0).parameters()).device
+    bufs, works = [], []
+    for owner in range(world):
+        subs = owned_submaps(S, owner, world)
+        ts, sizes = _pack_list(atlas, subs)
+        if not ts:
+            bufs.append(None)
+            continue
+        buf = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+        if owner == rank:
+            off = 0
+            for t, nb in zip(ts, sizes):
+                src = _flat_view(t)
+                buf[off:off + src.numel() * src.element_size()].copy_(src.view(torch.uint8))
+                off += nb
+        bufs.append((buf, ts, sizes))
+        if _needs_host_staging(buf):
+            h = buf.cpu()
+            dist.broadcast(h, src=owner)
+            buf.copy_(h)
+        else:
+            works.append(dist.broadcast(buf, src=owner, async_op=True))
+    for w in works:
+        w.wait()
+    for owner, item in enumerate(bufs):
+        if item is None or owner == rank:
+            continue
+        buf, ts, sizes = item
+        off = 0
+        for t, nb in zip(ts, sizes):
+            n = t.numel() * t.element_size()
+            dst = _flat_view(t)
+            src = buf[off:off + n].view(t.dtype)
+            if dst.data_ptr() == t.data_ptr():
+                dst.copy_(src)
+            else:                                   # a strided parameter: _flat_view made a copy, write it back
+                t.copy_(src.view_as(t))
+            off += nb
+
+
+def pair_costs(grid_atlas, pairs) -> List[float]:
+    """Relative cost of every pair for the fused pair kernel at the CURRENT poses: every source vertex is transformed
+    and tested (12 B), an in-bound one gathers 8 corners per level and ~300 flops on top.  Estimated on the coarsest
+    level's vertex lattice with plain tensor ops (identical on every rank: same inputs, same ops), one read-back."""
+    if not pairs:
+        return []
+    fracs = []
+    with torch.no_grad():
+        world_pts, inv = {}, {}
+        for a, b in pairs:
+            if a not in world_pts:                      # once per source submap, not per pair
+                v = grid_atlas.get_submap(a).features[0].vertex_positions()
+                Ra, ta = grid_atlas.updated_submap_pose(a)
+                world_pts[a] = v.to(Ra.device) @ Ra.T + ta.reshape(1, 3)
+            if b not in inv:
+                Rb, tb = grid_atlas.updated_submap_pose(b)
+                inv[b] = (Rb, tb.reshape(1, 3), grid_atlas.get_submap(b).bound.to(Rb))
+            Rb, tb, bd = inv[b]
+            q = (world_pts[a] - tb) @ Rb
+            fracs.append(((q >= bd[:, 0]) & (q <= bd[:, 1])).all(dim=1).float().mean())
+        fracs = torch.stack(fracs).cpu().tolist()
+    return [1.0 + 30.0 * f for f in fracs]
 
 
 def partition_pairs(pairs: Sequence[Tuple[int, int]], rank: Optional[int] = None,
-                    world: Optional[int] = None) -> List[Tuple[int, int]]:
+                    world: Optional[int] = None, costs: Optional[Sequence[float]] = None) -> List[Tuple[int, int]]:
+    """This rank's share of the pair list.  Without costs: round-robin.  With costs (pair_costs): longest first onto
+    the least loaded rank (ties: lower rank), the share returned in list order -- every rank computes the same deal."""
     r, w = rank_world()
     rank = r if rank is None else rank
     world = w if world is None else world
-    return [p for i, p in enumerate(pairs) if i % world == rank]
+    if costs is None:
+        return [p for i, p in enumerate(pairs) if i % world == rank]
+    assert len(costs) == len(pairs)
+    load = [0.0] * world
+    owner = [0] * len(pairs)
+    for i in sorted(range(len(pairs)), key=lambda i: (-costs[i], i)):
+        k = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = k
+        load[k] += costs[i]
+    return [p for i, p in enumerate(pairs) if owner[i] == rank]
 
 
 def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple, num_iters=10, lr=1e-2,
                                        rel_change_thresh=0, submap_pairs=None, check_intersection=True,
                                        pose_reg_weight=0, pose_thresh_rad=1.0, pose_thresh_m=1.0,
-                                       verbose=False, save_iterations=False):
+                                       verbose=False, save_iterations=False, always_reduce=False):
     """generic_align_multiple_submaps (grid_opt/align/base.py:89-163) with the pair list sharded over ranks.
     Every rank must hold all submaps (sync_submaps) and identical pose parameters.
 
@@ -140,7 +222,8 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
     iteration (no per-pair Python, no host sync on the overlap test or the NaN guard), the 6S + 1 floats of pose
     gradients + loss are all-reduced, and the identical regulariser / NaN guard / Adam step runs on every rank, so
     the replicas stay bit-identical.  Results equal the single-process run up to fp32 summation order of the pair
-    sums.  The pair loss must carry ``fused`` (align.miso.latent_loss_for_level)."""
+    sums.  The pair loss must carry ``fused`` (align.miso.latent_loss_for_level).  always_reduce: keep the
+    all-reduce hook live in a group of one rank (exercises RCCL on a single GPU)."""
     from miso_amd.grid_opt.align.base import fused_alignment_loop
     rank, world = rank_world()
     loss_name, loss_func = pairwise_loss_tuple
@@ -151,9 +234,13 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
     if submap_pairs is None:
         n = grid_atlas.num_submaps
         submap_pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
-    my_pairs = partition_pairs(submap_pairs, rank, world)
+    my_pairs = partition_pairs(submap_pairs, rank, world, costs=pair_costs(grid_atlas, submap_pairs) if world > 1 else None)
     timer = utils.PerfTimer(activate=True)
-    reduce = all_reduce_sum if world > 1 else None
+    reduce = None
+    if world > 1:
+        reduce = all_reduce_sum
+    elif always_reduce and dist.is_available() and dist.is_initialized():      # the single-GPU RCCL smoke test
+        reduce = lambda t: all_reduce_sum(t, always=True)                       # noqa: E731
     iteration_results = fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr, num_iters,
                                              rel_change_thresh, pose_reg_weight, pose_thresh_rad, pose_thresh_m,
                                              verbose and rank == 0, save_iterations, f"{loss_name}[rank {rank}/{world}]",

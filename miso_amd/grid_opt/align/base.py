@@ -117,8 +117,13 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
 
     done = 0
     graph = None
-    if use_graph and reduce is None and dev.type == 'cuda' and total_iters >= 8:
-        try:        # level 0 iterations are ~30 us of GPU work: replay them instead of issuing five launches each
+    if use_graph and dev.type == 'cuda' and total_iters >= 8:
+        # level 0 iterations are ~30 us of GPU work: replay them instead of issuing five launches each.  With the
+        # multi-rank hook the iteration is TWO graphs around the collective -- half A (poses, gates, pair stage, pull-back),
+        # all-reduce of `flat` issued on the same stream, half B (regulariser, guard, Adam) -- and still no host sync
+        # (round 2 dropped the capture altogether under `reduce`: five eager launches + an all-reduce for ~10 us of
+        # work per rank at 8 ranks).
+        try:
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()
             side.wait_stream(cur)
@@ -126,22 +131,44 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
                 iteration()                                           # iteration 0, eagerly (capture wants a warm-up)
             cur.wait_stream(side)
             done = 1
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                iteration()
+            def capture(fn):
+                # capture_begin / capture_end on the side stream, NOT the torch.cuda.graph context manager: that one
+                # runs gc.collect() and torch.cuda.empty_cache() on entry, and a loop is captured per level per call
+                # (emptying the allocator's cache makes every allocation of the next set-up a hipMalloc)
+                g = torch.cuda.CUDAGraph()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    g.capture_begin(capture_error_mode="thread_local")
+                    try:
+                        fn()
+                    finally:
+                        g.capture_end()
+                torch.cuda.current_stream().wait_stream(side)
+                return g
+            graph = capture(iteration) if reduce is None else (capture(plan.iteration_a), capture(plan.iteration_b))
         except Exception as exc:                                    # pragma: no cover - depends on the runtime
             logger.warning(f"alignment iteration not captured ({type(exc).__name__}: {exc}); issuing it launch by launch")
             graph = None
     check_every = 16 if rel_change_thresh > 0 else 0
+    import time
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
+    t_loop, n_loop = time.perf_counter(), done
     while done < total_iters:
-        if graph is not None:
+        if isinstance(graph, tuple):
+            graph[0].replay()
+            reduce(plan.flat)
+            graph[1].replay()
+        elif graph is not None:
             graph.replay()
         else:
             iteration()
         done += 1
         if check_every and done % check_every == 0 and plan.ctrl()['stopped']:
             break                                                    # further iterations would change nothing
-    ctrl = plan.ctrl()
+    ctrl = plan.ctrl()                                                # (one host read: the loop is over)
+    # wall time of the iterations proper (plan set-up, warm-up and capture excluded), for whoever times the loop
+    grid_atlas.__dict__['_last_align_loop'] = dict(seconds=time.perf_counter() - t_loop, iterations=done - n_loop)
     with torch.no_grad():
         prm = plan.params.clone()
         for s in range(1, S):                                        # submap 0 is fixed

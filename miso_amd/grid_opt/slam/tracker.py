@@ -105,6 +105,13 @@ class Tracker:
                 utils.cond_mkdir(d)
             dirs.add(cfg_train['log_dir'])
         grid.train()
+        # one Adam step per BATCH per epoch: the step-scalar table and the loss ring of the window are sized for all of
+        # them (a loader with several batches per epoch would otherwise run past the table -- its last row would be
+        # reused, i.e. wrong bias corrections -- and finish() would cut the losses short)
+        try:
+            n_steps = int(iterations) * max(len(loader), 1)
+        except TypeError:
+            return False                                        # a loader without a length: let the Trainer run
         for epoch in range(iterations):
             for step_i, (model_input, gt) in enumerate(utils.iter_batches(loader)):
                 model_input, gt = utils.prepare_batch(model_input, gt, self.cfg['device'], sanitize=False)
@@ -112,10 +119,10 @@ class Tracker:
                 n = coords_frame.shape[0]
                 if win is None:
                     win = self.__dict__.get('_adam_dev')
-                    if (win is None or win.n != n or win.hyper != (float(self.lr), (0.9, 0.999), 1e-8, int(iterations))
+                    if (win is None or win.n != n or win.hyper != (float(self.lr), (0.9, 0.999), 1e-8, n_steps)
                             or win.pose.device != coords_frame.device):
                         win = self.__dict__['_adam_dev'] = ops.TrackAdamWindow(n, coords_frame.device, pack, self.lr,
-                                                                               iterations)
+                                                                               n_steps)
                     win.reset()
                 elif n != win.n:
                     raise RuntimeError("tracking batches of one window differ in size")

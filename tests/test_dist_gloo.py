@@ -135,3 +135,13 @@ def test_shard_helpers():
     pairs = [(a, b) for a in range(8) for b in range(a + 1, 8)]
     parts = [mdist.partition_pairs(pairs, r, 8) for r in range(8)]
     assert sorted(sum(parts, [])) == pairs and max(map(len, parts)) - min(map(len, parts)) <= 1
+    # dealt by cost: a gated pair (cost 1) is nearly free next to an overlapping one (cost ~ 1 + 30 x in-bound
+    # fraction); longest first onto the least loaded rank -- every pair exactly once, loads within one heavy pair
+    costs = [1.0 + 30.0 * (0.5 if (b - a) in (1, 2) else 0.0) for a, b in pairs]
+    parts = [mdist.partition_pairs(pairs, r, 4, costs=costs) for r in range(4)]
+    assert sorted(sum(parts, [])) == pairs
+    load = [sum(costs[pairs.index(p)] for p in part) for part in parts]
+    assert max(load) - min(load) <= 16.0 + 1e-9
+    rr = [sum(costs[i] for i in range(len(pairs)) if i % 4 == r) for r in range(4)]
+    assert max(load) <= max(rr)                      # never worse than the round-robin deal
+    assert all(part == sorted(part, key=pairs.index) for part in parts)      # a share keeps the list order
