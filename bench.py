@@ -869,17 +869,24 @@ def headline_record(args, step, dev, world, elapsed):
     # ---- per-kernel durations (HIP events on the launch stream) and roofline --------------------
     L = len(LEVELS)
     feats, meta, pack = step.features, step.meta, step.pack
-    mask, sb = step._mask, step.sorted
+    sb = step.sorted
+    mask = torch.empty(((N_POINTS + 63) // 64) * 64 * ops.sdf_mask_words(pack), device=dev, dtype=torch.int32)
     t_sort = time_kernel(lambda: sb.sort(step.x, meta)) if sb is not None else 0.0
+    fused = sb is not None and step._fused_train()
+    t_train = None
     if sb is not None:
-        # binned step: the mapping loss is folded into the forward launch, the backward reads
-        # d loss / d sdf in binned order
+        # the two-launch form of forward and backward, each timed alone (the generic entry points; what runs when a
+        # level is still scattered from the backward) ...
         t_fwd = time_kernel(lambda: ops.sdf_fwd_loss_raw(feats, meta, pack, sb, step.aux, mask, step.gpred,
                                                          step.loss_slots, "L1", 1.0, 0.0, 0.0, sdf_out=None))
         t_loss = 0.0
         t_bwd = time_kernel(lambda: ops.sdf_bwd_raw(step.x, feats, meta, pack, step.gpred, mask, False,
                                                     [True] * L, step.grads, sorted_batch=sb, overwrite=True,
                                                     gsdf_sorted=True))
+        if fused:
+            # ... and what the step actually launches: forward + loss + decoder backward as ONE kernel, then the pull
+            t_train = time_kernel(lambda: ops.sdf_train_raw(feats, meta, pack, sb, step.aux, step.loss_slots, step.grads,
+                                                            "L1", 1.0, 0.0, 0.0))
     else:
         t_fwd = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, True, out=step.sdf, mask=mask))
         cols = [c.contiguous() for c in (step.target, step.valid, step.sign, step.weight)]
@@ -902,12 +909,17 @@ def headline_record(args, step, dev, world, elapsed):
         t_pull = time_kernel(lambda: ops.grad_pull_raw(feats, meta, sb, ws, step.grads, overwrite=True))
         kernels_us["grad_pull_kernel"] = t_pull
         kernels_us["sdf_bwd_kernel(MFMA pass)"] = t_bwd - t_pull
+        if t_train is not None:
+            kernels_us["sdf_train_kernel(forward + loss + decoder backward, one launch: what the step runs)"] = t_train - t_pull
         # algorithmic bytes of the pull: the gradient of 8 corners x C channels per level, counted
         # once as a write (SURVEY 8d backward figure without the 4 B of dL/dsdf the MFMA pass reads)
         # (at cfg-2 the pull is grad_pull_block_kernel -- one workgroup per 2x2x2 tiles -- followed by the drain launch
         # of grad_pull_kernel for sliced tiles, which finds an empty queue on this uniform batch)
         dom = ("grad_pull_block_kernel", t_pull, 32 * L * C)
-    if t_fwd > dom[1]:
+    if t_train is not None and t_train - t_pull > dom[1]:
+        # the fused kernel moves the bytes of both passes except the gradient write (the pull's): corners read once
+        dom = ("sdf_train_kernel", t_train - t_pull, b_fwd)
+    elif t_train is None and t_fwd > dom[1]:
         dom = ("sdf_fwd_kernel", t_fwd, b_fwd)
     achieved = N_POINTS * dom[2] / (dom[1] * 1e-6) / 1e9
     # HBM traffic and MFMA busy fraction are PMC figures (rocprofv3 --pmc, separate passes: tools/profile_bench.sh ->
@@ -939,6 +951,7 @@ def headline_record(args, step, dev, world, elapsed):
     t_bwd_mfma = kernels_us.get("sdf_bwd_kernel(MFMA pass)", t_bwd)
     mfma = {"peak_TFLOPs": 157.3, "sdf_fwd_kernel": mlp_flop / (t_fwd * 1e-6) / 157.3e12,
             "sdf_bwd_kernel": mlp_flop / (t_bwd_mfma * 1e-6) / 157.3e12,
+            **({"sdf_train_kernel": 2 * mlp_flop / ((t_train - t_pull) * 1e-6) / 157.3e12} if t_train is not None else {}),
             "definition": "decoder matrix FLOPs / kernel time / fp32 MFMA peak (live, HIP events)"}
     if mfma_pmc:
         mfma["pmc_busy_frac"] = mfma_pmc

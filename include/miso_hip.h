@@ -218,6 +218,18 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
                              float weight_fs, float trunc_dist, const float* loss_inputs, float* sdf,
                              uint32_t* relu_mask, float* grad_sdf_sorted, float* loss_slots,
                              const int32_t* n_live, void* stream);
+/* The whole binned training step behind one call: forward + mapping loss + decoder backward in ONE launch
+ * (sdf_train_kernel: the ReLU sign bits and d loss / d sdf never leave the registers), then the owner-computes pull /
+ * matrix-core push of every level's gradient from the d-feat rows left in `workspace`
+ * (miso_sdf_bwd_workspace_floats floats, 16-byte aligned).  Same results as miso_sdf_fwd_sorted_loss followed by
+ * miso_sdf_bwd_sorted with MISO_F_GRAD_SDF_SORTED (same arithmetic, same order of operations per point).  Requires a
+ * frozen decoder and that every level with a gradient is formed from the d-feat rows (miso_grad_pull_levels covers them
+ * all): MISO_E_UNSUPPORTED otherwise -- use the two calls then.  grid->flags: MISO_F_GRAD_OVERWRITE / _ZEROED /
+ * MISO_F_CROWDED as for miso_sdf_bwd_sorted.  sdf (caller order) may be NULL. */
+int miso_sdf_train_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                          const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf, float weight_fs,
+                          float trunc_dist, const float* loss_inputs, float* sdf, float* loss_slots,
+                          const int32_t* n_live, float* workspace, void* stream);
 /* The same for an unbinned (small) batch: x (N,3) and loss_inputs in the caller's order, grad_sdf (N) in that order too
  * (feed it to miso_sdf_bwd).  Replaces miso_sdf_fwd + miso_mapping_loss_rows and the clear of their two sums. */
 int miso_sdf_fwd_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n,

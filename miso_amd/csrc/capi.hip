@@ -19,6 +19,8 @@ hipError_t launch_sdf_fwd(int, int, int, int, const GridK&, const float*, const 
 hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const float*, int64_t,
                           const float*, const uint32_t*, float*, bool, const int*, float*, uint32_t, bool,
                           hipStream_t);
+hipError_t launch_sdf_train(int, int, int, int, const GridK&, const float*, const float*, int64_t, float*, const int*,
+                            const LossInK&, float*, hipStream_t);
 int64_t sort_workspace_bytes(int64_t n, int T);
 hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, float*, int*, int*,
                        hipStream_t);
@@ -519,6 +521,62 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   if (rc) return rc;
   return sdf_bwd_impl(grid, mlp, packed, nullptr, n, grad_sdf, relu_mask, grad_x, sorted, workspace,
                       stream);
+}
+
+int miso_sdf_train_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                          const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf, float weight_fs,
+                          float trunc_dist, const float* loss_inputs, float* sdf, float* loss_slots,
+                          const int32_t* n_live, float* workspace, void* stream) {
+  int rc = check_sorted(sorted, n);
+  if (rc) return rc;
+  if ((loss_type != 1 && loss_type != 2) || !loss_slots || !packed || (n > 0 && (!loss_inputs || !workspace)))
+    return MISO_E_BADARG;
+  if ((((uintptr_t)loss_inputs | (uintptr_t)packed | (uintptr_t)workspace) & 15u) != 0) return MISO_E_BADARG;
+  if (!sorted->xn_sorted && n > 0) return MISO_E_BADARG;
+  GridK g; bool v4;
+  rc = convert_grid(grid, &g, true, &v4);
+  if (rc) return rc;
+  int C, L, H, NH;
+  rc = fused_shape(g, v4, mlp, &C, &L, &H, &NH);
+  if (rc) return rc;
+  // every level with a gradient must be formed from the d-feat rows (pull or push): nothing is scattered from here
+  const uint32_t pull = plan_grad_pull(g, sorted->tiles_per_axis);
+  uint32_t want = 0;
+  for (int l = 0; l < g.n_levels; ++l)
+    if (g.lv[l].grad && !((g.ignore_mask >> l) & 1u)) want |= 1u << l;
+  if (!want || (want & ~pull)) return MISO_E_UNSUPPORTED;
+  const uint32_t push = plan_push(g, sorted->tiles_per_axis, n, pull);
+  hipStream_t st = (hipStream_t)stream;
+  const bool overwrite = (grid->flags & MISO_F_GRAD_OVERWRITE) != 0;
+  if (overwrite && !(grid->flags & MISO_F_GRAD_ZEROED)) {
+    for (int l = 0; l < g.n_levels; ++l) {      // pushed levels are added to with atomics: they start from zero
+      const LevelK& lv = g.lv[l];
+      if (!lv.grad || !((push >> l) & 1u)) continue;
+      size_t span = (size_t)(lv.C - 1) * lv.sC + (size_t)(lv.X - 1) * lv.sX + (size_t)(lv.Y - 1) * lv.sY +
+                    (size_t)(lv.Z - 1) * lv.sZ + 1;
+      hipError_t e = launch_zero_fill(lv.grad, (int64_t)span, st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  if (n == 0) {
+    hipError_t e = launch_zero_words(loss_slots, MISO_LOSS_SLOTS * 2, st);
+    if (e != hipSuccess) return (int)e;
+  } else {
+    LossInK lin;
+    memset(&lin, 0, sizeof(lin));
+    lin.p.loss_type = loss_type; lin.p.w_sdf = weight_sdf; lin.p.w_fs = weight_fs; lin.p.trunc = trunc_dist;
+    lin.aux = reinterpret_cast<const float4*>(loss_inputs);
+    lin.loss_out = loss_slots;
+    lin.inv_n = 1.0f / (float)n;
+    lin.n_live = n_live;
+    GridK gp = g;
+    const float* x = sorted_points(&gp, sorted);
+    rc = (int)launch_sdf_train(C, L, H, NH, gp, packed, x, n, sdf, sorted->perm, lin, workspace, st);
+    if (rc) return rc;
+  }
+  return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace, g.F,
+                               nullptr, pull, overwrite ? 1 : 0, nullptr, sorted->pull_queue, sorted->pull_queue_ints,
+                               st, push, n);
 }
 
 int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float* coords_src,

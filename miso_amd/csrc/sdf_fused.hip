@@ -677,6 +677,293 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Training step in ONE kernel (binned batches, frozen decoder, every level's grid gradient left to the pull / push):
+// gather -> decoder forward -> mapping loss -> decoder backward -> d-feat rows, per 64-point chunk, per wavefront.
+// What sdf_fwd_kernel + sdf_bwd_kernel<.., true, false> do as two launches, minus everything that only carried state
+// from one to the other: the ReLU sign bits (16 B per point written and read back), d loss / d sdf (4 + 4 B), the second
+// kernel's launch, ramp and tail, its own staging of the weights -- and, what matters most on gfx950, the two phases
+// now share a SIMD: fp32 MFMA and VALU use one datapath (tools/ubench/mfma_valu.hip), so a kernel's floor is the SUM
+// of its matrix and vector clocks, but a wavefront waiting for its corner gathers costs the neighbour's matrix chain
+// nothing.  The backward pass is ~all matrix work (it reads 20 B per point), the forward has the long memory phase:
+// with both in one kernel a wavefront's gathers hide behind TWICE the matrix work of its neighbour.
+// The bodies are those of the two kernels above (kept separate: they also serve inference, the unsorted path, the
+// coordinate backward and levels scattered from the backward); the sign bits stay in the registers they were formed
+// in, d loss / d sdf moves between the point-per-lane layout of the loss and the two 32-point tiles of the backward
+// with two lane reads.
+template <int C, int L, int H, int NH>
+__global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kernel(GridK g, const float* __restrict__ packed,
+                                                          const float* __restrict__ x, int64_t n,
+                                                          float* __restrict__ sdf, const int* __restrict__ perm,
+                                                          LossInK lin, float* __restrict__ dfeat_out) {
+  constexpr int F = C * L, RT = H / 32, KS0 = (F + 1) / 2, KS1 = H / 2;
+  constexpr int MW = (NH + 1) * RT;
+  constexpr int FP = ((F + 3) / 4) * 4 + 4;      // d-feat row pitch in LDS: 16-B aligned, conflict-free b128 writes
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const PackLayout pl(F, H, NH);
+  // the whole pack: forward part [0, fwd_end), transposed weights [o_whT, total) right behind it
+  for (int i = threadIdx.x * 4; i < pl.total; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hi = lane >> 5;
+  const int64_t nchunks = (n + 63) / 64;
+  const float* w0p = smem + pl.o_w0;
+  const float* whp = smem + pl.o_wh;
+  const float* b0 = smem + pl.o_b0;
+  const float* bh = smem + pl.o_bh;
+  const float* wo = smem + pl.o_wo;
+  const float bo = smem[pl.o_bo];
+  const float* whT = smem + pl.o_whT;
+  const float* w0T = smem + pl.o_w0T;
+  float* dF = smem + ((pl.total + 3) / 4) * 4 + wave * (64 * FP);      // this wavefront's d-feat tile [64][FP]
+
+  float loss_sdf = 0.0f, loss_fs = 0.0f;
+  float inv_n = lin.inv_n;
+  if (lin.n_live) { const int live = *lin.n_live; inv_n = 1.0f / (float)(live > 1 ? live : 1); }
+  ChunkSched sched(nchunks, wave, 4, true);
+  for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
+    asm volatile("" ::: "memory");      // see sdf_fwd_kernel: keeps the LDS reads of weights / biases inside the loop
+    const int64_t p = chunk * 64 + lane;
+    const bool valid = p < n;
+    const int64_t po = (valid && perm) ? (int64_t)perm[p] : p;
+    float4 l_in = make_float4(0.f, 1.f, 0.f, 1.f);
+    if (valid) l_in = lin.aux[po];
+    float f[2 * KS0];
+#pragma unroll
+    for (int i = 0; i < 2 * KS0; ++i) f[i] = 0.0f;
+    memory_phase(true, g.tune);
+    if (valid) {
+      float px, py, pz;
+      load_point(g, x, p, px, py, pz);
+      float bmn[3] = {g.bmin[0], g.bmin[1], g.bmin[2]}, bmx[3] = {g.bmax[0], g.bmax[1], g.bmax[2]};
+      asm volatile("" : "+s"(bmn[0]), "+s"(bmn[1]), "+s"(bmn[2]), "+s"(bmx[0]), "+s"(bmx[1]), "+s"(bmx[2]));
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        LevelK lv = g.lv[l];
+        if ((g.ignore_mask >> l) & 1u) continue;
+        asm volatile("" : "+s"(lv.X), "+s"(lv.Y), "+s"(lv.Z));
+        Axis ax = axis_coord(px, bmn[0], bmx[0], lv.X, g.flags);
+        Axis ay = axis_coord(py, bmn[1], bmx[1], lv.Y, g.flags);
+        Axis az = axis_coord(pz, bmn[2], bmx[2], lv.Z, g.flags);
+        Cell c = make_cell(ax, ay, az, lv);
+        gather_level<C>(lv, c, &f[l * C]);
+      }
+    }
+    memory_phase(false, g.tune);
+    // ================================ forward =====================================================================
+    uint32_t mw[MW];
+    float p0 = 0.0f, p1 = 0.0f;
+    {
+      f32x16 buf[2][RT][2];
+      {
+        f32x16 bias[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) bias[r][j] = b0[32 * r + row_of(j, hi)];
+#pragma unroll
+        for (int s = 0; s < KS0; ++s) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[2 * s]), __float_as_uint(f[2 * s + 1]), false, false);
+          float bt0 = __uint_as_float(sw[0]), bt1 = __uint_as_float(sw[1]);
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            float a = w0p[(s * 64 + lane) * RT + r];
+            buf[0][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt0, s == 0 ? bias[r] : buf[0][r][0], 0, 0, 0);
+            buf[0][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt1, s == 0 ? bias[r] : buf[0][r][1], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            buf[0][r][t][j] = relu1(buf[0][r][t][j]);
+            push_gt0(m, buf[0][r][t][j]);
+          }
+        mw[r] = m;
+      }
+#pragma unroll
+      for (int h = 0; h + 1 < NH; ++h) {
+        const int ci = h & 1, ni = ci ^ 1;
+        f32x16 bias[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) bias[r][j] = bh[h * H + 32 * r + row_of(j, hi)];
+#pragma unroll
+        for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int ks = rp * 16 + j;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+              float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
+              buf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias[r] : buf[ni][r][0], 0, 0, 0);
+              buf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias[r] : buf[ni][r][1], 0, 0, 0);
+            }
+          }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          uint32_t m = 0;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              buf[ni][r][t][j] = relu1(buf[ni][r][t][j]);
+              push_gt0(m, buf[ni][r][t][j]);
+            }
+          mw[(h + 1) * RT + r] = m;
+        }
+      }
+      if (NH == 0) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            float wv = wo[32 * r + row_of(j, hi)];
+            p0 += wv * buf[0][r][0][j];
+            p1 += wv * buf[0][r][1][j];
+          }
+      } else {
+        constexpr int h = NH > 0 ? NH - 1 : 0, ci = h & 1;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          f32x16 a0, a1, bias;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) bias[j] = bh[h * H + 32 * r + row_of(j, hi)];
+#pragma unroll
+          for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int ks = rp * 16 + j;
+              float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
+              a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias : a0, 0, 0, 0);
+              a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias : a1, 0, 0, 0);
+            }
+          uint32_t m = 0, m1 = 0;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float y0 = relu1(a0[j]), y1 = relu1(a1[j]);
+            push_gt0(m, y0);
+            push_gt0(m1, y1);
+            float wv = wo[32 * r + row_of(j, hi)];
+            p0 += wv * y0;
+            p1 += wv * y1;
+          }
+          mw[(h + 1) * RT + r] = (m << 16) | m1;
+        }
+      }
+    }
+    p0 += __shfl_xor(p0, 32);
+    p1 += __shfl_xor(p1, 32);
+    const float sdf_v = (hi ? p1 : p0) + bo;
+    if (valid && sdf) sdf[po] = sdf_v;
+    // ================================ loss: lane = point ============================================================
+    float gl = 0.0f;
+    if (valid) {
+      float gsd, gfs;
+      map_loss_one(lin.p, sdf_v, l_in.x, l_in.w, l_in.y == 1.0f, lin.p.w_fs > 0.f && l_in.z == 1.0f, gsd, gfs,
+                   loss_sdf, loss_fs);
+      gl = (gsd + gfs) * inv_n;
+    }
+    // the backward works on two tiles of 32 points, lane (hi, c) on point 32 t + c of tile t
+    float ds[2];
+    ds[0] = __shfl(gl, lane & 31);
+    ds[1] = __shfl(gl, 32 + (lane & 31));
+    // ================================ backward ======================================================================
+    f32x16 df[2];
+    {
+      f32x16 dbuf[2][RT][2];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float wv = wo[32 * r + row_of(j, hi)];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) dbuf[0][r][t][j] = gate(wv * ds[t], mw[NH * RT + r], t, j);
+        }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        const int h = NH - 1 - hh;
+        const int ci = hh & 1, ni = ci ^ 1;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { dbuf[ni][r][0][j] = 0.0f; dbuf[ni][r][1][j] = 0.0f; }
+#pragma unroll
+        for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int ks = rp * 16 + j;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+              float a = whT[((h * KS1 + ks) * 64 + lane) * RT + r];
+              dbuf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dbuf[ci][rp][0][j], dbuf[ni][r][0], 0, 0, 0);
+              dbuf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dbuf[ci][rp][1][j], dbuf[ni][r][1], 0, 0, 0);
+            }
+          }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dbuf[ni][r][t][j] = gate(dbuf[ni][r][t][j], mw[h * RT + r], t, j);
+      }
+      f32x16 (&d)[RT][2] = dbuf[NH & 1];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { df[0][j] = 0.0f; df[1][j] = 0.0f; }
+#pragma unroll
+      for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float a = w0T[(rp * 16 + j) * 64 + lane];
+          df[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][0][j], df[0], 0, 0, 0);
+          df[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][1][j], df[1], 0, 0, 0);
+        }
+    }
+    // ---- d-feat rows: accumulator layout -> LDS tile -> 64 contiguous rows of the (N, F) buffer, 16-B stores --------
+    memory_phase(true, g.tune);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int gq = 0; gq < (F + 7) / 8; ++gq) {
+        const int f0 = 8 * gq + 4 * hi;
+        if (f0 < F)
+          *reinterpret_cast<float4*>(dF + (32 * t + (lane & 31)) * FP + f0) =
+              make_float4(df[t][4 * gq], df[t][4 * gq + 1], df[t][4 * gq + 2], df[t][4 * gq + 3]);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      float* dst = dfeat_out + chunk * 64 * F;
+      const int64_t rows_left = n - chunk * 64;
+      for (int i = lane; i < 64 * F / 4; i += 64) {
+        const int row = (i * 4) / F, col = (i * 4) % F;
+        if (row < rows_left)
+          *reinterpret_cast<float4*>(dst + row * F + col) = *reinterpret_cast<const float4*>(dF + row * FP + col);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();      // the next chunk overwrites the tile
+    memory_phase(false, g.tune);
+  }
+  // loss sums: as sdf_fwd_kernel (every block stores its pair into its own slot, the slots nobody owns are cleared)
+  for (int o = 32; o > 0; o >>= 1) { loss_sdf += __shfl_down(loss_sdf, o); loss_fs += __shfl_down(loss_fs, o); }
+  __syncthreads();
+  if (lane == 0) { smem[2 * wave] = loss_sdf; smem[2 * wave + 1] = loss_fs; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = (smem[0] + smem[2]) + (smem[4] + smem[6]), b = (smem[1] + smem[3]) + (smem[5] + smem[7]);
+    float2* slots = reinterpret_cast<float2*>(lin.loss_out);
+    slots[blockIdx.x] = make_float2(lin.p.w_sdf * a * inv_n, lin.p.w_fs * b * inv_n);
+    for (int sl = blockIdx.x + gridDim.x; sl < MISO_LOSS_SLOTS; sl += gridDim.x) slots[sl] = make_float2(0.f, 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
 static hipError_t allow_lds(const void* k, size_t lds) {
@@ -735,6 +1022,25 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   return hipGetLastError();
 }
 
+
+template <int C, int L, int H, int NH>
+static hipError_t launch_train_t(const GridK& g, const float* packed, const float* x, int64_t n, float* sdf,
+                                 const int* perm, const LossInK& lin, float* dfeat_out, hipStream_t s) {
+  PackLayout pl(C * L, H, NH);
+  constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4;
+  size_t lds = (size_t)(((pl.total + 3) / 4) * 4 + 4 * 64 * FP) * sizeof(float);
+  int64_t nchunks = (n + 63) / 64;
+  unsigned blocks = (unsigned)((nchunks + 3) / 4);
+  static const unsigned cap = [] { const char* e = getenv("MISO_TRAIN_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();      // dev
+  if (blocks > cap) blocks = cap;
+  if (blocks > MISO_LOSS_SLOTS) blocks = MISO_LOSS_SLOTS;   // one loss slot per block
+  auto k = sdf_train_kernel<C, L, H, NH>;
+  hipError_t e = allow_lds((const void*)k, lds);
+  if (e != hipSuccess) return e;
+  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out);
+  return hipGetLastError();
+}
+
 #define MISO_FUSED_SHAPES(X) \
   X(4, 1, 32, 1) X(4, 1, 64, 1) X(4, 2, 32, 1) X(4, 2, 64, 1) X(4, 3, 64, 1) X(4, 4, 64, 1) \
   X(8, 1, 64, 1) X(8, 2, 64, 1) X(8, 3, 64, 1) X(8, 4, 64, 1) X(8, 3, 32, 1)
@@ -766,6 +1072,21 @@ hipError_t launch_sdf_bwd(int C, int L, int H, int NH, const GridK& g, const flo
 #define X(c, l, h, nh) \
   if (C == c && L == l && H == h && NH == nh) \
     return launch_bwd_t<c, l, h, nh>(g, packed, x, n, gsdf, mask, gx, want_grid, perm, dfeat_out, defer_mask, gsdf_sorted, s);
+  MISO_FUSED_SHAPES(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
+
+// forward + mapping loss + decoder backward of a binned batch in one launch (sdf_train_kernel): d-feat rows for the
+// pull, loss slots; sdf (caller order) optional
+hipError_t launch_sdf_train(int C, int L, int H, int NH, const GridK& g, const float* packed, const float* x,
+                            int64_t n, float* sdf, const int* perm, const LossInK& lin, float* dfeat_out,
+                            hipStream_t s) {
+  if (n == 0) return hipSuccess;
+#define X(c, l, h, nh) \
+  if (C == c && L == l && H == h && NH == nh) \
+    return launch_train_t<c, l, h, nh>(g, packed, x, n, sdf, perm, lin, dfeat_out, s);
   MISO_FUSED_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;

@@ -153,9 +153,16 @@ class MappingStep:
                 if g is not None:
                     g.zero_()
         L = len(self.features)
-        if self.sorted is not None:
-            # binned path
+        if self.sorted is not None and self._fused_train():
+            # binned path, every level's gradient formed from the d-feat rows: forward + loss + decoder backward are ONE
+            # launch (sdf_train_kernel), then the pull / push
             self.sorted.sort(self.x, self.meta)   # part of the step: a new batch arrives every iteration
+            ops.sdf_train_raw(self.features, self.meta, self.pack, self.sorted, self.aux, self.loss_slots, self.grads,
+                              lt, ws, wf, td, sdf_out=self.sdf if self.keep_sdf else None, n_live=self.live_rows,
+                              touched=self.touched, zeroed=self.adam_device is not None)
+        elif self.sorted is not None:
+            # binned path, a level still scattered from the backward kernel (bricks beyond what the pull owns)
+            self.sorted.sort(self.x, self.meta)
             if getattr(self, "_mask", None) is None:
                 mw = ops.sdf_mask_words(self.pack)
                 self._mask = torch.empty(((self.n + 63) // 64) * 64 * mw, device=self.x.device, dtype=torch.int32)
@@ -192,6 +199,15 @@ class MappingStep:
                 # zero_grad=True: the gradient is cleared in the same pass, so the next
                 # iteration needs no memset
                 ops.adam_active_(p.data, g, m, v, act, self.t, zero_grad=self.sorted is None, touched=tch, **self.adam)
+
+    def _fused_train(self) -> bool:
+        """Whether the binned step runs as sort -> sdf_train_kernel -> pull (decided once: the grids do not change)."""
+        ok = self.__dict__.get("_fused_train_ok")
+        if ok is None:
+            import os
+            ok = self._fused_train_ok = (os.environ.get("MISO_NO_FUSED_TRAIN") is None      # dev: the two-launch form
+                                         and ops.sdf_train_supported(self.features, self.meta, self.grads))
+        return ok
 
     @property
     def loss(self) -> torch.Tensor:

@@ -1,0 +1,140 @@
+"""sdf_train_kernel (miso_sdf_train_sorted: forward + mapping loss + decoder backward in ONE launch, then the pull) against
+the two-launch form it replaces (miso_sdf_fwd_sorted_loss + miso_sdf_bwd_sorted): same SDF and loss bit for bit (the
+forward is the same instruction sequence), the same d-feat rows -- hence gradients equal up to the pull's summation
+order -- over the fused shape table, both losses, free-space term, invalid / NaN-labelled rows, padded batches (n_live),
+a crowded batch whose coarse level goes through the matrix-core push, and an ignored level.  Plus: a grid with a level
+the pull cannot own is refused (MISO_E_UNSUPPORTED) and MappingStep keeps the two launches for it.
+The two-launch form itself is pinned to the reference goldens and the CPU oracle elsewhere (test_hip_parity.py,
+test_config_shapes.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [  # (C, level sizes (cubic), hidden)
+    (8, (32, 64, 128), 64),      # cfg-2
+    (4, (16, 80), 64),           # ScanNet-like ratio 5, both levels pullable
+    (4, (48,), 32),
+    (8, (16, 32, 64, 128), 64),
+    (8, (32, 48, 64), 32),
+    (4, (16, 32, 48, 64), 64),
+]
+
+
+def _setup(C, sizes, H, n, seed, crowded=False, ignore=None, bound=None):
+    from miso_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    feats = [(torch.randn(1, C, s, s, s, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+             for s in sizes]
+    F = C * len(sizes)
+    lin = [torch.nn.Linear(F, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    torch.manual_seed(seed)
+    for m in lin:
+        torch.nn.init.normal_(m.weight, std=0.3)
+    pack = ops.DecoderPack([m.weight.detach().to(DEV) for m in lin], [m.bias.detach().to(DEV) for m in lin])
+    bound = bound or [[-1.0, 1.0], [-0.5, 1.5], [0.0, 2.0]]
+    meta = ops.GridMeta.from_bound(bound, ignore_level=ignore)
+    if crowded:
+        import dataclasses
+        meta = dataclasses.replace(meta, flags=meta.flags | ops._lib.F_CROWDED)
+    b = torch.tensor(bound)
+    x = torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) * 1.1 + b[:, 0] - 0.05 * (b[:, 1] - b[:, 0])
+    if crowded:
+        x[: n // 2] = x[: n // 2] * 0.05 + b.mean(dim=1)
+    aux = torch.stack((torch.randn(n, generator=g) * 0.1, (torch.rand(n, generator=g) > 0.15).float(),
+                       (torch.rand(n, generator=g) > 0.6).float(), torch.rand(n, generator=g) + 0.5), dim=1)
+    aux[7, 0] = float("nan")
+    return feats, meta, pack, x.to(DEV).contiguous(), aux.to(DEV).contiguous()
+
+
+def _both(feats, meta, pack, x, aux, lt, ws, wf, td, n_live=None, need=None):
+    from miso_amd import ops
+    n, L = x.shape[0], len(feats)
+    need = need or [True] * L
+    sb = ops.SortedBatch(n, DEV).sort(x, meta)
+    mask = torch.empty(((n + 63) // 64) * 64 * ops.sdf_mask_words(pack), device=DEV, dtype=torch.int32)
+    gpred = torch.empty(n, 1, device=DEV)
+    s2, sdf2 = torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), torch.empty(n, 1, device=DEV)
+    g2 = [torch.full_like(f, 7.0) if nd else None for f, nd in zip(feats, need)]
+    ops.sdf_fwd_loss_raw(feats, meta, pack, sb, aux, mask, gpred, s2, lt, ws, wf, td, sdf_out=sdf2, n_live=n_live)
+    ops.sdf_bwd_raw(x, feats, meta, pack, gpred, mask, False, need, g2, sorted_batch=sb, overwrite=True, gsdf_sorted=True)
+    s1, sdf1 = torch.zeros_like(s2), torch.empty_like(sdf2)
+    g1 = [torch.full_like(f, -3.0) if nd else None for f, nd in zip(feats, need)]
+    assert ops.sdf_train_supported(feats, meta, g1)
+    ops.sdf_train_raw(feats, meta, pack, sb, aux, s1, g1, lt, ws, wf, td, sdf_out=sdf1, n_live=n_live)
+    torch.cuda.synchronize()
+    return (s1, sdf1, g1), (s2, sdf2, g2)
+
+
+def _check(a, b):
+    (s1, sdf1, g1), (s2, sdf2, g2) = a, b
+    assert torch.equal(torch.nan_to_num(s1, nan=123.0), torch.nan_to_num(s2, nan=123.0))
+    assert torch.equal(sdf1, sdf2)
+    for x1, x2 in zip(g1, g2):
+        if x1 is None:
+            assert x2 is None
+            continue
+        fin = torch.isfinite(x2)
+        assert torch.equal(fin, torch.isfinite(x1))
+        scale = x2[fin].abs().max().item()
+        assert (x1[fin] - x2[fin]).abs().max().item() <= 2e-6 * scale      # the pull's summation order only
+
+
+@pytest.mark.parametrize("shape", range(len(SHAPES)))
+@pytest.mark.parametrize("lt", ["L1", "L2"])
+def test_train_kernel_equals_forward_plus_backward(shape, lt):
+    C, sizes, H = SHAPES[shape]
+    feats, meta, pack, x, aux = _setup(C, sizes, H, 70001, seed=shape)
+    aux[7, 0] = 0.0                                   # (NaN labels: below)
+    a, b = _both(feats, meta, pack, x, aux, lt, 1.0, 0.1, 0.15)
+    _check(a, b)
+    assert all(float(g.abs().max()) > 0 for g in a[2])
+
+
+def test_train_kernel_nan_label_padded_batch_and_subset_of_levels():
+    from miso_amd import ops
+    feats, meta, pack, x, aux = _setup(8, (32, 64, 128), 64, 66000, seed=11)
+    a, b = _both(feats, meta, pack, x, aux, "L1", 1.0, 0.0, 0.0)
+    assert torch.isnan(a[0].sum()) and torch.isnan(b[0].sum())        # the NaN label poisons the loss of both alike
+    aux[7, 0] = 0.5
+    aux[60000:] = 0.0                                                  # neutral padding rows
+    live = torch.tensor([60000], device=DEV, dtype=torch.int32)
+    _check(*_both(feats, meta, pack, x, aux, "L2", 0.7, 0.2, 0.1, n_live=live))
+    _check(*_both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.1, need=[False, True, True]))
+    # an ignored level: its features do not enter, its gradient is written as zeros by both forms
+    feats, meta, pack, x, aux = _setup(8, (32, 64, 128), 64, 66000, seed=12, ignore=[False, True, False])
+    aux[7, 0] = 0.0
+    a, b = _both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.1)
+    _check(a, b)
+    assert float(a[2][1].abs().max()) == 0.0
+
+
+def test_train_kernel_with_the_matrix_core_push_on_a_crowded_batch():
+    from miso_amd import ops
+    feats, meta, pack, x, aux = _setup(4, (40, 80), 64, 120000, seed=21, crowded=True,
+                                       bound=[[-10.0, 10.0], [-10.0, 10.0], [-10.0, 10.0]])
+    aux[7, 0] = 0.0
+    grads = [torch.empty_like(f) for f in feats]
+    assert ops.sdf_bwd_scattered_levels(feats, meta, grads, x.shape[0]) & 1        # level 0 is pushed
+    _check(*_both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.15))
+
+
+def test_levels_the_pull_cannot_own_keep_the_two_launches():
+    from miso_amd import ops
+    from miso_amd.step import MappingStep
+    # 200 vertices over 16 tiles: 12.5 per tile and axis, beyond the pull's 8 -> scattered from the backward kernel
+    feats, meta, pack, x, aux = _setup(4, (40, 200), 64, 70000, seed=31)
+    aux[7, 0] = 0.0
+    grads = [torch.empty_like(f) for f in feats]
+    assert not ops.sdf_train_supported(feats, meta, grads)
+    sb = ops.SortedBatch(x.shape[0], DEV).sort(x, meta)
+    with pytest.raises(RuntimeError):
+        ops.sdf_train_raw(feats, meta, pack, sb, aux, torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), grads)
+    step = MappingStep(feats, meta, pack, x.shape[0], "L1", 1.0, 0.1, 0.15, keep_sdf=False)
+    assert step.sorted is not None and not step._fused_train()
+    step.set_batch(x, aux[:, 0:1], aux[:, 1:2], aux[:, 2:3], aux[:, 3:4])
+    step.run()
+    torch.cuda.synchronize()
+    assert torch.isfinite(step.loss).all()
