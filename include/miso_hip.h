@@ -321,9 +321,11 @@ int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, co
  * 1..S-1, submap 0 fixed.  One iteration = miso_align_iteration_a (poses from the corrections, overlap gate and
  * latent residual of EVERY pair in one launch each, pose cotangents pulled back through R0 Exp(dr)) followed by
  * miso_align_iteration_b (trust-region regulariser, NaN guard, Adam, relative-change early stop, bookkeeping).
- * Between the two the caller may all-reduce `flat` (6S + 1 floats: d loss / d (dr_s, dt_s) for every submap, then
- * the summed pair loss) over ranks that each hold a share of the pair list (miso_amd/dist.py); nothing is read
- * back by the host inside the loop.
+ * Between the two the caller may all-reduce `flat` (7S + 1 floats: d loss / d (dr_s, dt_s) for every submap, the
+ * summed pair loss, then per submap the number of its pairs that passed the overlap gate) over ranks that each hold a
+ * share of the pair list (miso_amd/dist.py); nothing is read back by the host inside the loop.  A submap none of
+ * whose pairs passed the gate has no gradient in the reference (its pair losses are not in the loss dict, base.py:134)
+ * and torch.optim.Adam leaves such a parameter alone: so does _b -- value, moments and the submap's own step count.
  *
  * miso_align_pair_t   one (src, dst) pair: the destination's levels 0..level (data only) with its bound, the
  *                     source's cached voxel centres and its features there (as miso_pair_latent), and the
@@ -333,10 +335,10 @@ int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, co
  *                     miso_align_plan_bytes(n_pairs) bytes of HOST memory, which the caller copies to the device
  *                     and passes as cfg->plan; fills cfg->vec4 / max_n / max_gate_n.
  * state               miso_align_state_layout(...) floats on the device, ZEROED by the caller before the first
- *                     iteration; offsets[11] (in floats) = {params (S,6: dr, dt), pose (S,12: R, t), out (P,24) DOUBLES = 48 P floats,
- *                     overlap counts (P), pair losses (P, weighted, gated), flat (6S+2), adam exp_avg (S,6),
- *                     exp_avg_sq (S,6), ctrl (8 x int32: Adam steps taken, stopped flag, iterations run, NaN-skipped
- *                     iterations), ring, ring row length}.  Ring row k (ring_iters rows): {total loss, relative
+ *                     iteration; offsets[12] (in floats) = {params (S,6: dr, dt), pose (S,12: R, t), out (P,24) DOUBLES = 48 P floats,
+ *                     overlap counts (P), pair losses (P, weighted, gated), flat (7S+2), adam exp_avg (S,6),
+ *                     exp_avg_sq (S,6), ctrl (8 x int32: iterations that stepped, stopped flag, iterations run,
+ *                     NaN-skipped iterations), ring, ring row length, per-submap Adam step counts (S x int32)}.  Ring row k (ring_iters rows): {total loss, relative
  *                     pose change (inf at k = 0)} of iteration k [+ (S,4,4) poses BEFORE its step when save_poses:
  *                     iteration_results_helper, base.py:29-39].  The caller writes the initial corrections into
  *                     `params` and reads the final ones from there.

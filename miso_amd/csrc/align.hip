@@ -13,10 +13,13 @@
 //   pairs       the masked latent residual + 23 pose-cotangent sums of every pair, pair_latent.hip, grid.y = pair
 //   epilogue A  per pair: normalise, nan_to_num (base.py:138-141), overlap gate; per submap: sum the cotangents of
 //               its pairs, pull them back through R0 Exp(.) -> d loss / d (dr_s, dt_s); writes `flat` = 6S pose
-//               gradients + the summed pair loss.  With the pair list sharded over ranks (miso_amd/dist.py) `flat`
-//               is what the ONE all-reduce of the iteration sums.
+//               gradients + the summed pair loss + S flags "a pair of this submap passed the overlap gate".  With the
+//               pair list sharded over ranks (miso_amd/dist.py) `flat` is what the ONE all-reduce of the iteration sums.
 //   epilogue B  trust-region regulariser (base.py:20-27), NaN guard (:147-151), Adam on the poses of submaps 1..S-1
-//               (:104-111), relative pose change + early stop (:152-158), loss / change into the ring.
+//               (:104-111), relative pose change + early stop (:152-158), loss / change into the ring.  As
+//               torch.optim.Adam does with a parameter whose .grad is None, a submap NONE of whose pairs passed the
+//               gate (and no regulariser) is left alone -- value, moments and its own step count (bias corrections
+//               are per submap): it neither drifts on old momentum nor ages.
 //
 // Everything the host reads (losses, changes, snapshots, iteration count) stays on the device until the loop ends.
 #include <math.h>
@@ -35,9 +38,10 @@ AlignLayout align_layout(int S, int P, int ring_iters, int save_poses) {
   L.out = o; o += up4(48 * (int64_t)P);      // (P,24) DOUBLES (pair_latent.hip reduces in fp64)
   L.cnt = o; o += up4(P);
   L.pair_loss = o; o += up4(P);
-  L.flat = o; o += up4(6 * S + 2);
+  L.flat = o; o += up4(7 * S + 2);      // 6S pose gradients, the loss sum, S "this submap has a gradient" flags
   L.adam_m = o; o += up4(6 * S);
   L.adam_v = o; o += up4(6 * S);
+  L.adam_t = o; o += up4(S);            // int32 per submap: Adam steps THIS submap has taken
   L.ctrl = o; o += 8;
   L.ring_row = 2 + (save_poses ? 16 * S : 0);
   L.ring = o; o += (int64_t)ring_iters * L.ring_row;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void align_prologue_kernel(AlignK k) {
   }
   // accumulators of the pair stage and the reduction buffer (out, cnt, pair_loss are adjacent; flat follows)
   float* z = k.state + k.L.out;
-  const int64_t nz = (k.L.flat + up4(6 * k.S + 2)) - k.L.out;
+  const int64_t nz = (k.L.flat + up4(7 * k.S + 2)) - k.L.out;
   for (int64_t i = threadIdx.x; i < nz; i += blockDim.x) z[i] = 0.0f;
 }
 
@@ -108,6 +112,8 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
   // them back through R0 Exp(dr).
   __shared__ float s_sc[EPI_A_PAIRS], s_loss[EPI_A_PAIRS];
   __shared__ int s_src[EPI_A_PAIRS], s_dst[EPI_A_PAIRS];
+  __shared__ unsigned char s_gate[EPI_A_PAIRS];
+  bool had = false;      // a pair of this thread's submap is in the loss (passed the gate): its poses get a gradient
   __shared__ float s_total;
   double gR[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, gt[3] = {0., 0., 0.};
   float total = 0.0f;
@@ -128,13 +134,16 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
       s_loss[i] = v;
       pl[p] = v;
       s_src[i] = d.src; s_dst[i] = d.dst;
+      s_gate[i] = gate != 0.0f;
     }
     __syncthreads();
     if (s < k.S) {
       for (int i = 0; i < np; ++i) {
         const bool is_src = s_src[i] == s, is_dst = s_dst[i] == s;
         const float scf = s_sc[i];
-        if (!(is_src || is_dst) || scf == 0.0f) continue;
+        if (!(is_src || is_dst)) continue;
+        had = had || s_gate[i];      // (a non-finite pair loss is nan_to_num'ed: in the loss, with a zero gradient)
+        if (scf == 0.0f) continue;
         const double sc = (double)scf;
         const double* o = out + 24 * (p0 + i);
         const float* Rd = pose + 12 * s_dst[i];
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
     double gw[3];
     so3_exp_backward(w, G, gw);
     for (int i = 0; i < 3; ++i) { flat[6 * s + i] = (float)gw[i]; flat[6 * s + 3 + i] = (float)gt[i]; }
+    flat[6 * k.S + 1 + s] = had ? 1.0f : 0.0f;
   }
   if (threadIdx.x == 0) flat[6 * k.S] = total;
   (void)s_total;
@@ -197,10 +207,7 @@ __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
   const float total = s_total;
   const bool skip = total != total;      // "Loss at iter .. is nan! Skip backward step." (base.py:147-151)
   const int t = ctrl[CTRL_STEP] + 1;
-  const double bc1 = 1.0 - pow(k.b1, (double)t), bc2 = 1.0 - pow(k.b2, (double)t);
-  AdamScalars a;
-  a.one_minus_b1 = (float)(1.0 - k.b1); a.b2 = (float)k.b2; a.one_minus_b2 = (float)(1.0 - k.b2);
-  a.neg_step_size = (float)(-(k.lr / bc1)); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)k.eps;
+  int32_t* adam_t = reinterpret_cast<int32_t*>(k.state + k.L.adam_t);
   double num = 0., den = 0.;
   for (int i = threadIdx.x; i < 6 * (k.S - 1); i += blockDim.x) {
     const int s = 1 + i / 6, c = i % 6;      // submap 0 stays fixed (base.py:104-107)
@@ -211,8 +218,16 @@ __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
       const float nrm = c < 3 ? s_nr[s] : s_nt[s];
       if (nrm - (c < 3 ? k.reg_rad : k.reg_m) > 0.0f) g += k.reg_weight * (old / nrm);
     }
+    // torch.optim.Adam skips a parameter whose .grad is None: a submap none of whose pairs is in the loss this
+    // iteration (all gated off) and no regulariser.  Its value, moments and step count stay.
+    const bool has = k.reg_weight > 0.0f || flat[6 * k.S + 1 + s] > 0.0f;
     float pv = old;
-    if (!skip) {
+    if (!skip && has) {
+      const int ts = adam_t[s] + 1;          // this submap's own step count (read by its six threads, written below)
+      const double bc1 = 1.0 - pow(k.b1, (double)ts), bc2 = 1.0 - pow(k.b2, (double)ts);
+      AdamScalars a;
+      a.one_minus_b1 = (float)(1.0 - k.b1); a.b2 = (float)k.b2; a.one_minus_b2 = (float)(1.0 - k.b2);
+      a.neg_step_size = (float)(-(k.lr / bc1)); a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)k.eps;
       float m = k.state[k.L.adam_m + j], v = k.state[k.L.adam_v + j];
       adam_one(pv, g, m, v, a);
       k.state[k.L.adam_m + j] = m; k.state[k.L.adam_v + j] = v;
@@ -221,6 +236,10 @@ __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
     num += ((double)pv - old) * ((double)pv - old);
     den += (double)old * old;
   }
+  __syncthreads();                           // every thread has read adam_t
+  if (!skip)
+    for (int s = 1 + threadIdx.x; s < k.S; s += blockDim.x)
+      if (k.reg_weight > 0.0f || flat[6 * k.S + 1 + s] > 0.0f) adam_t[s] += 1;
   __syncthreads();
   s_num[threadIdx.x] = num; s_den[threadIdx.x] = den;
   __syncthreads();

@@ -657,9 +657,9 @@ int64_t miso_align_state_layout(int32_t n_submaps, int32_t n_pairs, int32_t ring
   if (n_submaps < 1 || n_submaps > 64 || n_pairs < 0 || ring_iters < 0) return 0;
   const AlignLayout L = align_layout(n_submaps, n_pairs, ring_iters, save_poses);
   if (offsets) {
-    const int64_t o[11] = {L.params, L.pose, L.out, L.cnt, L.pair_loss, L.flat, L.adam_m, L.adam_v, L.ctrl, L.ring,
-                           L.ring_row};
-    for (int i = 0; i < 11; ++i) offsets[i] = o[i];
+    const int64_t o[12] = {L.params, L.pose, L.out, L.cnt, L.pair_loss, L.flat, L.adam_m, L.adam_v, L.ctrl, L.ring,
+                           L.ring_row, L.adam_t};
+    for (int i = 0; i < 12; ++i) offsets[i] = o[i];
   }
   return L.total;
 }

@@ -112,7 +112,7 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
     def iteration():
         plan.iteration_a()
         if reduce is not None:
-            reduce(plan.flat)
+            reduce(plan.flat_reduce)
         plan.iteration_b()
 
     done = 0
@@ -157,7 +157,7 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
     while done < total_iters:
         if isinstance(graph, tuple):
             graph[0].replay()
-            reduce(plan.flat)
+            reduce(plan.flat_reduce)
             graph[1].replay()
         elif graph is not None:
             graph.replay()

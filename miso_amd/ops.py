@@ -1057,7 +1057,7 @@ class AlignPlan:
         blob = (C.c_uint8 * nbytes)()
         _lib.check(lib.miso_align_plan_build(descs, C.byref(cfg), blob), "miso_align_plan_build")
         self._plan = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-        off = (C.c_int64 * 11)()
+        off = (C.c_int64 * 12)()
         total = int(lib.miso_align_state_layout(S, P, cfg.ring_iters, cfg.save_poses, off))
         self._off = [int(v) for v in off]
         self.state = torch.zeros(max(total, 4), device=dev, dtype=torch.float32)
@@ -1098,6 +1098,18 @@ class AlignPlan:
     def flat(self) -> torch.Tensor:
         """6S + 1 floats: d loss / d (dr_s, dt_s) of every submap from THIS plan's pairs, then their loss sum."""
         return self._view(5, 6 * self.S + 1)
+
+    @property
+    def flat_reduce(self) -> torch.Tensor:
+        """What a multi-rank caller sums between iteration_a and iteration_b: ``flat`` followed by S counts "pairs of
+        submap s (in this plan) that passed the overlap gate" -- iteration_b leaves a submap with none alone, as
+        torch.optim.Adam leaves a parameter without a gradient."""
+        return self._view(5, 7 * self.S + 1)
+
+    @property
+    def adam_steps(self) -> torch.Tensor:
+        """(S,) int32: Adam steps each submap's pose has taken."""
+        return self._view(11, self.S).view(torch.int32)
 
     def iteration_a(self):
         _lib.check(_lib.load().miso_align_iteration_a(C.byref(self.cfg), _stream(self.state)), "miso_align_iteration_a")

@@ -170,6 +170,17 @@ def atlas_inputs():
     return subs
 
 
+def atlas_stability(s):
+    """Per-level stability grids (1,1,Z,Y,X) of submap s, values in [0,1): what GridNet.feature_stability holds once a
+    stability estimate has been written (pairwise_loss_latent's stability_thresh branch, align/miso.py:160-171)."""
+    c = ATLAS
+    rs = np.random.RandomState(c["seed"] + 300 + s)
+    return [rs.uniform(0.0, 1.0, grid_shape(c["bound"], cell, 1)).astype(np.float32) for cell in level_cells(c)]
+
+
+ATLAS_BRANCHES = dict(pair=(0, 1), stability_thresh=0.4, trunc_factor=1.5, subsample_points=300, subsample_seed=4242)
+
+
 def atlas_world_points():
     c = ATLAS
     rs = np.random.RandomState(c["seed"] + 5)

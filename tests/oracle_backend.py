@@ -53,7 +53,9 @@ class AlignPlan:
                       b2=betas[1], eps=eps, reg=float(reg_weight), rad=float(reg_thresh_rad), m=float(reg_thresh_m),
                       rel=float(rel_change_thresh))
         self.params = torch.zeros(self.S, 6)
-        self.flat = torch.zeros(6 * self.S + 1)
+        self.flat_reduce = torch.zeros(7 * self.S + 1)      # flat + per-submap counts of pairs that passed the gate
+        self.flat = self.flat_reduce[:6 * self.S + 1]
+        self.steps = [0] * self.S
         self.pair_losses = torch.zeros(self.P)
         self.m, self.v = torch.zeros(self.S, 6), torch.zeros(self.S, 6)
         self.ring_iters, self.save_poses = int(ring_iters), bool(save_poses)
@@ -74,6 +76,7 @@ class AlignPlan:
             T[:, :3, :3], T[:, :3, 3:], T[:, 3, 3] = Rm.detach(), tm.detach(), 1.0
             self._ring[it, 2:] = T.reshape(-1)
         total = torch.zeros(())
+        had = torch.zeros(self.S)
         for i, pr in enumerate(self.pairs):
             a, b = pr["src"], pr["dst"]
             bound = _bound(pr["meta_dst"])
@@ -92,9 +95,12 @@ class AlignPlan:
             val = diff.pow(2).sum() / (n_valid * F) if k['loss_type'] == "L2" \
                 else torch.linalg.vector_norm(diff, dim=1).sum() / n_valid
             val = torch.nan_to_num(val) * k['w'] * gate
+            had[a] += gate
+            had[b] += gate
             self.pair_losses[i] = val.detach()
             total = total + val
-        self.flat.zero_()
+        self.flat_reduce.zero_()
+        self.flat_reduce[6 * self.S + 1:] = had
         if total.requires_grad:
             gr, gt = torch.autograd.grad(total, (dr, dt), allow_unused=True)
             g = torch.cat((torch.zeros_like(dr) if gr is None else gr, torch.zeros_like(dt) if gt is None else gt), 1)
@@ -117,12 +123,18 @@ class AlignPlan:
         old = self.params[1:].clone()
         if not bool(torch.isnan(total)):
             c['steps'] += 1
-            t = c['steps']
-            m, v, gg = self.m[1:], self.v[1:], g[1:]
-            m.lerp_(gg, 1 - k['b1'])
-            v.mul_(k['b2']).addcmul_(gg, gg, value=1 - k['b2'])
-            denom = (v.sqrt() / (1 - k['b2'] ** t) ** 0.5).add_(k['eps'])
-            self.params[1:] = old.addcdiv(m, denom, value=-(k['lr'] / (1 - k['b1'] ** t)))
+            # torch.optim.Adam per pose tensor: a submap without a gradient (none of its pairs passed the overlap gate,
+            # no regulariser) is skipped -- value, moments, its own step count
+            for s in range(1, self.S):
+                if not (k['reg'] > 0 or float(self.flat_reduce[6 * self.S + 1 + s]) > 0):
+                    continue
+                self.steps[s] += 1
+                t = self.steps[s]
+                m, v, gg = self.m[s], self.v[s], g[s]
+                m.lerp_(gg, 1 - k['b1'])
+                v.mul_(k['b2']).addcmul_(gg, gg, value=1 - k['b2'])
+                denom = (v.sqrt() / (1 - k['b2'] ** t) ** 0.5).add_(k['eps'])
+                self.params[s] = self.params[s].addcdiv(m, denom, value=-(k['lr'] / (1 - k['b1'] ** t)))
         else:
             c['skipped'] += 1
         it = c['iterations']

@@ -263,6 +263,52 @@ def test_atlas_queries_and_pairwise_alignment(device_backend):
         close(dt, T(g[f"align_l{l}_dt"]), 0, 2e-4)
 
 
+def test_pairwise_loss_latent_optional_branches(device_backend):
+    """The branches of pairwise_loss_latent the default alignment never takes (reference align/miso.py:147-180,
+    :204-209): stability pruning, truncation pruning, np.random.choice subsampling (the reference's own draw, recorded),
+    the cos and InfoNCE losses -- value and the pose gradients of both submaps against the reference run
+    (tests/golden/atlas_branches.npz, tools/make_goldens.py::gen_atlas_branches)."""
+    import miso_amd.grid_opt.align.miso as AM
+    dev = device_backend
+    c, b = gc.ATLAS, gc.ATLAS_BRANCHES
+    g = G("atlas_branches")
+    atlas = make_atlas(dev)
+    for s in range(c["n_submaps"]):
+        net = atlas.get_submap(s)
+        with torch.no_grad():
+            for l, f in enumerate(gc.atlas_stability(s)):
+                net.feature_stability[l].feature.copy_(T(f))
+    atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+    src, dst = b["pair"]
+    variants = [("stab_l0", dict(level=0, align_loss="L2", stability_thresh=b["stability_thresh"])),
+                ("stab_l1", dict(level=1, align_loss="L1", stability_thresh=b["stability_thresh"])),
+                ("trunc_l1", dict(level=1, align_loss="L2", trunc_factor=b["trunc_factor"])),
+                ("trunc_stab_l0", dict(level=0, align_loss="L1", trunc_factor=4.0, stability_thresh=0.2)),
+                ("cos_l0", dict(level=0, align_loss="cos")),
+                ("cos_l1", dict(level=1, align_loss="cos")),
+                ("nce_l0", dict(level=0, align_loss="InfoNCE")),
+                ("sub_l1", dict(level=1, align_loss="L2", subsample_points=b["subsample_points"])),
+                ("sub_cos_l1", dict(level=1, align_loss="cos", subsample_points=b["subsample_points"]))]
+    for name, kw in variants:
+        atlas.zero_grad(set_to_none=True)
+        if "subsample_points" in kw:
+            np.random.seed(b["subsample_seed"])
+            n_all = atlas.coordinates_for_alignment(src, kw["level"]).shape[0]
+            draw = np.random.choice(n_all, min(kw["subsample_points"], n_all), replace=False)
+            assert np.array_equal(draw, g[name + "_draw"])              # the reference drew exactly these vertices
+            np.random.seed(b["subsample_seed"])
+        d = AM.pairwise_loss_latent(atlas, None, src, dst, fdim=c["fdim"], device=dev, **kw)
+        (val,) = d.values()
+        assert list(d) == [f"align_latent_level{kw['level']}_{src}_{dst}"]
+        assert abs(val.item() - float(g[name])) <= 5e-5 * abs(float(g[name])), (name, val.item(), float(g[name]))
+        val.backward()
+        for which, s in (("src", src), ("dst", dst)):
+            gR, gt = T(g[f"{name}_gR_{which}"]), T(g[f"{name}_gt_{which}"])
+            tol = 2e-3 * max(float(gR.abs().max()), float(gt.abs().max()))
+            close(atlas.rotation_corrections[s].grad, gR, 0, tol)
+            close(atlas.translation_corrections[s].grad, gt, 0, tol)
+
+
 class _OneItem(torch.utils.data.Dataset):
     def __len__(self):
         return 1
@@ -355,6 +401,63 @@ def test_fused_alignment_regulariser_nan_guard_and_early_stop(device_backend):
                                       pose_reg_weight=1.0)
     for p, q in zip(atlas.params_for_all_submap_poses(), before):
         assert torch.equal(torch.nan_to_num(p.detach(), nan=7.0), torch.nan_to_num(q, nan=7.0))
+
+
+def test_fused_alignment_leaves_submaps_without_a_gradient_alone(device_backend):
+    """torch.optim.Adam skips a parameter whose .grad is None -- in generic_align_multiple_submaps a submap
+    none of whose pairs is in the loss (skipped by check_submap_intersection, or not in submap_pairs) with no
+    regulariser.  Neither its value nor its moments nor its step count move; the other submaps' bias corrections run
+    on their OWN step counts.  (The fused loop used to step all 6(S-1) numbers with one global count: such a submap
+    kept drifting on decaying momentum.)"""
+    from miso_amd import ops
+    import miso_amd.grid_opt.align.base as AB
+    import miso_amd.grid_opt.align.miso as AM
+    dev = device_backend
+
+    def run(fused):
+        atlas = make_atlas(dev)
+        atlas.no_fused_alignment = not fused
+        atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+        loss = AM.latent_loss_for_level(atlas, 0, align_loss="L2", device=dev)
+        AB.generic_align_multiple_submaps(atlas, _OneItem(), ("latent0", loss), num_iters=4, lr=1e-2, verbose=False,
+                                          submap_pairs=[(0, 1)])
+        return (torch.stack([p.detach().cpu() for p in atlas.rotation_corrections]),
+                torch.stack([p.detach().cpu() for p in atlas.translation_corrections]))
+
+    start = make_atlas(dev)
+    dr_f, dt_f = run(True)
+    dr_e, dt_e = run(False)
+    close(dr_f, dr_e, 0, 2e-4)
+    close(dt_f, dt_e, 0, 2e-4)
+    assert torch.equal(dr_f[2], start.rotation_corrections[2].detach().cpu())       # submap 2: in no pair
+    assert torch.equal(dt_f[2], start.translation_corrections[2].detach().cpu())
+    assert not torch.equal(dr_f[1], start.rotation_corrections[1].detach().cpu())
+    # ... also when it carries momentum from an earlier iteration in which it did have a gradient (a gate that closed)
+    atlas = make_atlas(dev)
+    atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+    S = atlas.num_submaps
+    R0 = torch.stack([R.to(dev) for R in atlas.R_world_submap_list])
+    t0 = torch.stack([t.to(dev) for t in atlas.t_world_submap_list])
+    plan = ops.AlignPlan(R0, t0, AM.latent_pair_inputs(atlas, [(0, 1)], level=0, fdim=gc.ATLAS["fdim"]), lr=1e-2,
+                         ring_iters=4)
+    prm0 = torch.cat((torch.cat([p.detach().reshape(1, 3) for p in atlas.rotation_corrections]),
+                      torch.cat([p.detach().reshape(1, 3) for p in atlas.translation_corrections])), 1)
+    plan.params.copy_(prm0)
+    mom = torch.full((6,), 0.3)
+    if hasattr(plan, "state"):                                   # HIP: exp_avg lives in the device state
+        plan._view(6, 6 * S).view(S, 6)[2].copy_(mom)
+    else:
+        plan.m[2] = mom.clone()
+    for _ in range(3):
+        plan.iteration_a()
+        plan.iteration_b()
+    prm = plan.params.detach().cpu()
+    assert torch.equal(prm[2], prm0[2].cpu()) and not torch.equal(prm[1], prm0[1].cpu())
+    if hasattr(plan, "state"):
+        assert torch.equal(plan._view(6, 6 * S).view(S, 6)[2].cpu(), mom)
+        assert plan.adam_steps.cpu().tolist() == [0, 3, 0]
+    else:
+        assert torch.equal(plan.m[2], mom) and plan.steps == [0, 3, 0]
 
 
 @pytest.mark.parametrize("lt", ["GM", "L2"])

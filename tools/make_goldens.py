@@ -217,6 +217,47 @@ def gen_atlas(GridAtlas, miso, rbase, gc):
                       if k.startswith("latent") and k.endswith(("L2", "L1"))})
 
 
+def gen_atlas_branches(GridAtlas, miso, gc):
+    """The optional branches of pairwise_loss_latent (grid_opt/align/miso.py:147-180, :204-209): stability pruning,
+    truncation pruning, seeded subsampling, the cos and InfoNCE losses -- value and pose gradients of one pair."""
+    atlas = build_atlas(GridAtlas, gc)
+    c, b = gc.ATLAS, gc.ATLAS_BRANCHES
+    for s in range(c["n_submaps"]):
+        net = atlas.get_submap(s)
+        with torch.no_grad():
+            for l, f in enumerate(gc.atlas_stability(s)):
+                net.feature_stability[l].feature.copy_(T(f))
+    atlas.precompute_coordinates_for_alignment(norm_thresh=1e-5)
+    src, dst = b["pair"]
+    out = {}
+    variants = [("stab_l0", dict(level=0, align_loss="L2", stability_thresh=b["stability_thresh"])),
+                ("stab_l1", dict(level=1, align_loss="L1", stability_thresh=b["stability_thresh"])),
+                ("trunc_l1", dict(level=1, align_loss="L2", trunc_factor=b["trunc_factor"])),
+                ("trunc_stab_l0", dict(level=0, align_loss="L1", trunc_factor=4.0, stability_thresh=0.2)),
+                ("cos_l0", dict(level=0, align_loss="cos")),
+                ("cos_l1", dict(level=1, align_loss="cos")),
+                ("nce_l0", dict(level=0, align_loss="InfoNCE")),
+                ("sub_l1", dict(level=1, align_loss="L2", subsample_points=b["subsample_points"])),
+                ("sub_cos_l1", dict(level=1, align_loss="cos", subsample_points=b["subsample_points"]))]
+    for name, kw in variants:
+        for p in atlas.parameters():
+            p.grad = None
+        if "subsample_points" in kw:
+            np.random.seed(b["subsample_seed"])
+            n_all = atlas.coordinates_for_alignment(src, kw["level"]).shape[0]
+            out[name + "_draw"] = np.random.choice(n_all, min(kw["subsample_points"], n_all), replace=False)
+            np.random.seed(b["subsample_seed"])          # the call below makes the same draw
+        d = miso.pairwise_loss_latent(atlas, None, src, dst, fdim=c["fdim"], device="cpu", **kw)
+        (val,) = d.values()
+        out[name] = np.float64(val.item())
+        val.backward()
+        for which, s in (("src", src), ("dst", dst)):
+            out[f"{name}_gR_{which}"] = atlas.rotation_corrections[s].grad.numpy().copy()
+            out[f"{name}_gt_{which}"] = atlas.translation_corrections[s].grad.numpy().copy()
+    np.savez_compressed(gc.golden_path("atlas_branches"), **out)
+    print("[atlas_branches]", {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
+
+
 def gen_losses(GridNet, rloss, risdf, gc):
     """MisoLossMapping / MisoLossTracking on a 3-keyframe GridNet + iSDF helpers."""
     case = dict(gc.CASES["small"])
@@ -895,7 +936,7 @@ def main():
     os.makedirs(gc.GOLDEN_DIR, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
-    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra", "geometry", "formats", "encoder", "second_order"]
+    which = sys.argv[1:] or ["small", "cfg1", "cfg2", "atlas", "losses", "trainer", "tracker", "so3", "samples", "extra", "geometry", "formats", "encoder", "second_order", "atlas_branches"]
     for name in which:
         if name in gc.CASES:
             gen_encode_decode(name, GridNet, rloss, gc)
@@ -921,6 +962,8 @@ def main():
             gen_extra(GridNet, GridAtlas, miso, rtrainer, gc)
         elif name == "second_order":
             gen_second_order(GridNet, rloss, risdf, gc)
+        elif name == "atlas_branches":
+            gen_atlas_branches(GridAtlas, miso, gc)
 
 
 if __name__ == "__main__":
