@@ -978,8 +978,7 @@ static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float*
   size_t lds = (size_t)((pl.fwd_end + 3) / 4 * 4) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
-  static const unsigned cap = [] { const char* e = getenv("MISO_FWD_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();
-  if (blocks > cap) blocks = cap;
+  if (blocks > 512u) blocks = 512u;      // persistent: two workgroups per CU
   if (lin.p.loss_type && blocks > MISO_LOSS_SLOTS) blocks = MISO_LOSS_SLOTS;   // one loss slot per block
   auto k = sdf_fwd_kernel<C, L, H, NH>;
   hipError_t e = allow_lds((const void*)k, lds);
@@ -998,14 +997,11 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   bool lean = want_grid && !gx && dfeat_out != nullptr;      // every gradient level deferred to the pull?
   for (int l = 0; l < L && lean; ++l)
     if (g.lv[l].grad && !((g.ignore_mask >> l) & 1u) && !((defer_mask >> l) & 1u)) lean = false;
-  static const bool no_lean = getenv("MISO_BWD_NO_LEAN") != nullptr;      // dev
-  if (no_lean) lean = false;
   size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * (lean ? 64 * FP : WAVE_LDS) : 0)) *
                sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
-  static const unsigned cap = [] { const char* e = getenv("MISO_BWD_BLOCKS"); return e ? (unsigned)atoi(e) : 0u; }();
-  const unsigned use_cap = cap ? cap : (lean ? 768u : 512u);
+  const unsigned use_cap = lean ? 768u : 512u;
   if (blocks > use_cap) blocks = use_cap;
   int debug = 0;
   if (const char* d = getenv("MISO_DEBUG_BWD")) debug = atoi(d) & ~(16 | 32);
@@ -1031,8 +1027,7 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
   size_t lds = (size_t)(((pl.total + 3) / 4) * 4 + 4 * 64 * FP) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
-  static const unsigned cap = [] { const char* e = getenv("MISO_TRAIN_BLOCKS"); return e ? (unsigned)atoi(e) : 512u; }();      // dev
-  if (blocks > cap) blocks = cap;
+  if (blocks > 512u) blocks = 512u;      // persistent: two workgroups per CU (256 .. 1024 measured: 512 and up equal)
   if (blocks > MISO_LOSS_SLOTS) blocks = MISO_LOSS_SLOTS;   // one loss slot per block
   auto k = sdf_train_kernel<C, L, H, NH>;
   hipError_t e = allow_lds((const void*)k, lds);

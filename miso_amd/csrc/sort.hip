@@ -185,7 +185,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, con
 }
 
 static inline int sort_blocks(int64_t n) {
-  static const int per = [] { const char* e = getenv("MISO_SORT_PER_BLOCK"); return e ? atoi(e) : 2048; }();
+  constexpr int per = 2048;      // points per block (512 / 1024 / 2048 / 4096 measured: 21.4 / 21.1 / 20.1 / 22.9 us)
   int64_t b = (n + per - 1) / per;
   if (b > SORT_MAX_BLOCKS) b = SORT_MAX_BLOCKS;
   if (b < 1) b = 1;

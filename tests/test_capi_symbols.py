@@ -144,12 +144,7 @@ def test_gradient_plans_are_host_logic():
     crowded = grid([(40, 20, 40), (200, 100, 200)], 4, flags=_lib.F_CROWDED)
     assert lib.miso_sdf_bwd_push_levels(ctypes.byref(crowded), T, 54000) == 0b01      # the caller's hint
     assert lib.miso_sdf_bwd_push_levels(ctypes.byref(crowded), T, 1000) == 0
-    os.environ["MISO_PULL_SUB"] = "1"                                                 # the opt-in sub-brick kernel
-    try:
-        assert lib.miso_grad_pull_levels(ctypes.byref(scannet), T) == 0b11
-        ncd = grid([(120, 120, 20), (600, 600, 100)], 4)
-        assert lib.miso_grad_pull_levels(ctypes.byref(ncd), T) == 0b01               # 38 vertices per tile and axis
-    finally:
-        del os.environ["MISO_PULL_SUB"]
+    ncd = grid([(120, 120, 20), (600, 600, 100)], 4)
+    assert lib.miso_grad_pull_levels(ctypes.byref(ncd), T) == 0b01                   # 38 vertices per tile and axis
     border = grid([(32, 32, 32)], 8, flags=2)                                         # padding_mode='border'
     assert lib.miso_grad_pull_levels(ctypes.byref(border), T) == 0

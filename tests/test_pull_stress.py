@@ -63,19 +63,19 @@ def test_binned_encode_matches_atomic(seed, monkeypatch):
         assert relerr(a, c) < 5e-5, (seed, l, dims, C, n)
 
 
-@pytest.mark.parametrize("seed", range(8))
-def test_sub_brick_levels_match_atomic(seed, monkeypatch):
-    """Levels whose tile bricks hold 9..16 vertices on an axis (ScanNet's 200 x 100 x 200 over 16 tiles) are pulled by
-    grad_pull_sub_kernel -- one workgroup per tile, one wavefront per octant of its brick -- instead of the atomic
-    scatter: same gradient, with uniform points, with a tight cluster (tiles whose survivors overflow the table and
-    are redone in epochs), with points outside the bound, next to levels the ordinary pull owns."""
+@pytest.mark.parametrize("seed", range(4))
+def test_levels_with_large_bricks_next_to_pulled_ones(seed, monkeypatch):
+    """Levels whose tile bricks hold more than 8 vertices on an axis (ScanNet's 200 x 100 x 200 over 16 tiles) are not
+    owned by the pull: in a binned batch they are scattered with float atomics while the levels next to them are pulled
+    (the split of miso_grad_pull_levels).  Same gradients as the unbinned path, first and second order, with a tight
+    cluster and points outside the bound."""
     from miso_amd import ops
     rs = np.random.RandomState(7000 + seed)
     C = int(rs.choice([4, 8]))
     big = [tuple(int(v) for v in rs.choice([100, 130, 144, 160, 200, 255, 256], size=3))]
     if seed == 0:
         big = [(200, 100, 200)]
-    dims = ([tuple(int(v) for v in rs.choice([8, 20, 40, 64], size=3))] if seed % 2 else []) + big
+    dims = [tuple(int(v) for v in rs.choice([8, 20, 40, 64], size=3))] + big
     L = len(dims)
     bmin = rs.uniform(-3, 0, size=3)
     bmax = bmin + rs.uniform(0.5, 6, size=3)
@@ -95,10 +95,9 @@ def test_sub_brick_levels_match_atomic(seed, monkeypatch):
     meta = ops.GridMeta.from_bound(bound)
     go = torch.randn(n, C * L, generator=g).to(DEV)
     want = [torch.empty_like(f) for f in feats]
-    monkeypatch.setenv("MISO_PULL_SUB", "1")       # opt-in (see plan_grad_pull)
     mask = int(ops._lib.load().miso_grad_pull_levels(ops.C.byref(ops._fill_grid(feats, meta, want, data=False)),
                                                      ops.SortedBatch.TILES))
-    assert (mask >> (L - 1)) & 1, "the large level is not owned by the pull"
+    assert mask == 0b01, "the small level is pulled, the large one is not"
 
     def run(second):
         xd = x.to(DEV).requires_grad_(True)
@@ -108,11 +107,10 @@ def test_sub_brick_levels_match_atomic(seed, monkeypatch):
         (gx,) = torch.autograd.grad(out, xd, go, create_graph=True)
         return torch.autograd.grad((torch.nan_to_num(gx) ** 2).sum(), feats)
 
-    monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", 16384)
     for second in (False, True):
-        monkeypatch.setenv("MISO_PULL_SUB", "1")
+        monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", 16384)
         gb = run(second)
-        monkeypatch.delenv("MISO_PULL_SUB")
+        monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", None)      # unbinned: everything with float atomics
         ga = run(second)
         for l, (a, c) in enumerate(zip(gb, ga)):
             a, c = torch.nan_to_num(a), torch.nan_to_num(c)
