@@ -50,16 +50,37 @@ def build_workload(dev, rank):
     targ = torch.randn(N_POINTS, 1, generator=gp) * 0.1
     # keep_sdf=False: a training step needs the loss and the gradients, not the per-point SDF in the
     # caller's order (the accuracy check below evaluates the forward separately)
-    step = MappingStep(feats, meta, pack, N_POINTS, loss_type="L1", weight_sdf=1.0, weight_fs=0.0, keep_sdf=False)
+    # MISO_BENCH_LAUNCH=graph|stream (dev: A/B of the two launch modes; default: MappingStep's own choice by batch size)
+    mode = {"graph": True, "stream": False}.get(os.environ.get("MISO_BENCH_LAUNCH", ""), None)
+    step = MappingStep(feats, meta, pack, N_POINTS, loss_type="L1", weight_sdf=1.0, weight_fs=0.0, keep_sdf=False,
+                       use_graph=mode)
     step.set_batch(x.to(dev), targ.to(dev))
     return step, (feats, ws, bs, x, targ)
 
 
-def time_kernel(fn, iters=30, warm=5):
-    """Average duration (us) of `fn` (one launch) with HIP events on the launch stream."""
-    for _ in range(warm):
+SETTLE_STEPS = 256
+
+
+def settle_device(step):
+    """Untimed steps in front of the W warmup steps, so that the timed region measures the sustained rate: an MI355X
+    that has been without work for more than ~2 ms lowers its clocks and needs ~70 steps (11 ms) of this workload to
+    bring them back (tools/ramp_probe.py, us per step in blocks of 5 from a cold device: 166 166 166 164 164 164 163 161
+    162 160 162 160 159 158 158 -> 156-157 sustained).  The driver's default run times 20 steps = 3.3 ms after 5 warmup
+    steps, i.e. entirely inside that ramp (172 us per step, either launch mode).  Reported as `settle_steps`."""
+    for _ in range(SETTLE_STEPS):
+        step.run()
+
+
+def time_kernel(fn, iters=30, warm=5, warm_ms=12.0):
+    """Average duration (us) of `fn` (one launch) with HIP events on the launch stream, after `warm_ms` of the same
+    launches (clock ramp, see settle_device) with no idle gap in front of the timed ones."""
+    t0 = time.perf_counter()
+    n = 0
+    while n < warm or (time.perf_counter() - t0) * 1e3 < warm_ms:
         fn()
-    torch.cuda.synchronize()
+        n += 1
+        if n % 32 == 0:
+            torch.cuda.synchronize()        # the host must not run a thousand launches ahead of a 100 us kernel
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -245,7 +266,11 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
             rec["roofline"] = {"bound": "hbm", "kernel": "pair_latent_batch_kernel (+ overlap_count_batch_kernel, "
                                "prologue, epilogue A)", "achieved": b_alg / (t_k * 1e-6) / 1e9, "peak": 8000.0,
                                "unit": "GB/s", "frac": b_alg / (t_k * 1e-6) / 8e12,
-                               "algorithmic_bytes": b_alg}
+                               "algorithmic_bytes": b_alg,
+                               "note": "algorithmic bytes count each of the 8 corner fetches of an in-bound vertex (SURVEY "
+                                       "8d's convention, as in the headline's 784 B per point); lattice vertices of one row "
+                                       "share most corners, which then come from L2 -- a fraction near 1 says the gathers "
+                                       "are cache hits, not that HBM runs at its peak"}
             del plan
         else:
             flat = torch.zeros(6 * S + 1, device=dev)
@@ -804,6 +829,12 @@ def main():
     from miso_amd import ops
     step, data = build_workload(dev, rank)
 
+    # the step runs as plain stream launches (MappingStep.STREAM_MIN_POINTS): the host has to stay in front of the
+    # device, and a full collection of Python's collector over what `import torch` left behind is a 45 ms pause
+    import gc
+    gc.collect()
+    gc.freeze()
+    settle_device(step)
     for _ in range(args.warmup):
         step.run()
     torch.cuda.synchronize()
@@ -965,13 +996,15 @@ def headline_record(args, step, dev, world, elapsed):
     out = {
         "metric": "3D point-samples/sec (encode+decode fwd+bwd), 262144-pt batch",
         "value": value, "unit": "point-samples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "warmup": args.warmup, "settle_steps": SETTLE_STEPS, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "cfg-2: one submap per GPU, 3-level {32,64,128}^3 grid C=8 + MLP 24-64-64-1 "
                                "(frozen, seeded random weights), 262144 uniform-in-bbox points per GPU per "
                                "step, L1 loss, grads to all levels",
                    "points_per_gpu": N_POINTS, "levels": list(LEVELS), "feature_dim": C,
-                   "decoder": [C * L, HIDDEN, HIDDEN, 1], "parallelism": f"submap-parallel x{world}"},
+                   "decoder": [C * L, HIDDEN, HIDDEN, 1], "parallelism": f"submap-parallel x{world}",
+                   "launch": "one graph replay per step" if step._use_graph else
+                             "six stream launches per step (a graph replay leaves the device idle ~6 us between replays)"},
         "roofline": roofline,
         "step_fraction_of_hbm_roofline": value / world * (20 + 64 * L * C) / 8e12,
         "kernels_us": kernels_us,

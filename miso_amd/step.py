@@ -22,10 +22,11 @@ from . import ops
 class MappingStep:
     TOUCHED_MIN_NUMEL = 32 << 20      # floats: levels from 128 MB up keep touched-chunk flags for Adam
     CROWDED_MIN_POINTS = 16384      # crowded=True: batches are binned from this size (default SortedBatch.AUTO_MIN_POINTS)
+    STREAM_MIN_POINTS = 131072      # use_graph=None: batches from this size run as plain stream launches
 
     def __init__(self, features: Sequence[torch.Tensor], meta: ops.GridMeta, pack: ops.DecoderPack,
                  n_points: int, loss_type: str = "L1", weight_sdf: float = 1.0, weight_fs: float = 0.0,
-                 trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: bool = True,
+                 trunc_dist: float = 0.0, adam: Optional[dict] = None, use_graph: Optional[bool] = None,
                  sort: Optional[bool] = None, need_levels: Optional[Sequence[bool]] = None,
                  keep_sdf: bool = True, padded: bool = False, grads_cleared_by_optimizer: bool = False,
                  share_grads: Optional[Sequence[Optional[torch.Tensor]]] = None,
@@ -35,6 +36,7 @@ class MappingStep:
         bound): bin from CROWDED_MIN_POINTS and push the coarse levels through the matrix cores whatever the average
         density (MISO_F_CROWDED) -- on the 54 000-sample batches of tools/demo_synthetic.py the contended atomics of
         the unbinned backward cost 200 us a step, the binned step with the push 96 us.
+        use_graph: True = one graph replay per step, False = plain stream launches, None = by batch size (see below).
         padded: the batch buffers hold ``n_points`` rows of which only ``self.live_rows`` (one int32 on the
         device, set through set_batch) are live, the rest neutral padding (valid = sign = weight = 0); the loss
         means divide by the live count.  Lets a sampler with a data-dependent row count (depth holes) feed ONE
@@ -125,6 +127,15 @@ class MappingStep:
                 if g is not None and (self._adam_clears >> l) & 1:
                     g.zero_()
         self._graph = None
+        if use_graph is None:
+            # a graph replay saves the host's launch work (decisive for small batches: the step is launch-bound) and
+            # costs ~6 us of device idle time between two replays (measured on the cfg-2 step: 163.3 us per replay,
+            # 157.0 us as plain stream launches with the host 35 us per step, tools/graph_vs_eager.py) -- from
+            # STREAM_MIN_POINTS the device time per step is several times the host's and plain launches win.  (The
+            # host may run ahead as far as the runtime's queue lets it, ~47 steps; what does starve the device is a
+            # full collection of Python's garbage collector, ~45 ms over the objects `import torch` leaves behind:
+            # a long-running loop calls gc.freeze() after its setup, as bench.py does.)
+            use_graph = self.n < self.STREAM_MIN_POINTS
         self._use_graph = use_graph and adam is None  # the Adam step count changes per call (adam_device: on the device)
 
     def set_batch(self, x, target, valid=None, sign=None, weight=None, live_rows=None):

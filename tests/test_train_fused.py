@@ -138,3 +138,26 @@ def test_levels_the_pull_cannot_own_keep_the_two_launches():
     step.run()
     torch.cuda.synchronize()
     assert torch.isfinite(step.loss).all()
+
+
+def test_stream_launches_and_graph_replays_give_the_same_step():
+    """use_graph=None picks by batch size (MappingStep.STREAM_MIN_POINTS); both launch modes run the same kernels."""
+    from miso_amd.step import MappingStep
+    n = MappingStep.STREAM_MIN_POINTS
+    feats, meta, pack, x, aux = _setup(8, (32, 64, 128), 64, n, seed=41)
+    aux[7, 0] = 0.0
+    out = {}
+    for mode in (None, True, False):
+        st = MappingStep(feats, meta, pack, n, "L1", 1.0, 0.1, 0.15, keep_sdf=False, use_graph=mode)
+        assert st._use_graph == (mode is True)                       # None at this size: stream launches
+        st.set_batch(x, aux[:, 0:1], aux[:, 1:2], aux[:, 2:3], aux[:, 3:4])
+        for _ in range(3):
+            st.run()
+        torch.cuda.synchronize()
+        out[mode] = (st.loss.clone(), [g.clone() for g in st.grads])
+    small = MappingStep(feats, meta, pack, n // 4, "L1", 1.0, 0.1, 0.15, keep_sdf=False)
+    assert small._use_graph
+    for mode in (None, False):
+        assert torch.equal(out[mode][0], out[True][0])
+        for a, b in zip(out[mode][1], out[True][1]):
+            assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
