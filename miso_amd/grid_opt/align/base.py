@@ -116,7 +116,8 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
         plan.iteration_b()
 
     done = 0
-    graph = None
+    graph = graph_many = None
+    UNROLL = 8
     if use_graph and dev.type == 'cuda' and total_iters >= 8:
         # level 0 iterations are ~30 us of GPU work: replay them instead of issuing five launches each.  With the
         # multi-rank hook the iteration is TWO graphs around the collective -- half A (poses, gates, pair stage, pull-back),
@@ -146,9 +147,17 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
                 torch.cuda.current_stream().wait_stream(side)
                 return g
             graph = capture(iteration) if reduce is None else (capture(plan.iteration_a), capture(plan.iteration_b))
+            if reduce is None and total_iters - done >= 2 * UNROLL:
+                # a replay follows the previous one after ~6 us of device idle time, 5-8 % of a level-0
+                # iteration: UNROLL iterations per replay while that many are left (they are identical launches -- the
+                # iteration counter, the ring slot and the early-stop flag live on the device)
+                def several():
+                    for _ in range(UNROLL):
+                        iteration()
+                graph_many = capture(several)
         except Exception as exc:                                    # pragma: no cover - depends on the runtime
             logger.warning(f"alignment iteration not captured ({type(exc).__name__}: {exc}); issuing it launch by launch")
-            graph = None
+            graph = graph_many = None
     check_every = 16 if rel_change_thresh > 0 else 0
     import time
     if dev.type == 'cuda':
@@ -159,6 +168,9 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
             graph[0].replay()
             reduce(plan.flat_reduce)
             graph[1].replay()
+        elif graph_many is not None and total_iters - done >= UNROLL and (not check_every or done % UNROLL == 0):
+            graph_many.replay()
+            done += UNROLL - 1
         elif graph is not None:
             graph.replay()
         else:
