@@ -9,5 +9,5 @@ out=gpurun_out/prof_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/align -o align -- python tools/align8_bench.py > $out/align.log 2>&1
 GRID=scannet N=540000 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trainer_scannet -o t -- python tools/trainer_bench.py > $out/trainer_scannet.log 2>&1
 GRID=ncd N=6144 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trainer_ncd -o t -- python tools/trainer_bench.py > $out/trainer_ncd.log 2>&1
-python bench.py --steps 100 --warmup 10 > $out/bench.json 2> $out/bench.err
+python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 find $out -name "*_kernel_stats.csv" | head; tail -c 400 $out/bench.json
