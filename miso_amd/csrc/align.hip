@@ -96,7 +96,7 @@ __device__ __forceinline__ float nan_to_num_f(float v) {
 }
 
 constexpr int EPI_A_THREADS = 256;
-constexpr int EPI_A_PAIRS = 512;      // pairs staged in LDS per pass (S <= 64 => at most 2016 pairs: 4 passes)
+constexpr int EPI_A_PAIRS = 128;      // pairs staged in LDS per pass (S <= 64 => at most 2016 pairs: 16 passes)
 
 __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK k) {
   const int32_t* ctrl = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl);
@@ -109,7 +109,9 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
   // Pass structure: (1) one thread per pair normalises it -- loss value, overlap gate, the scale of its cotangents --
   // into LDS (the descriptors live in global memory: read in parallel, not P times in a row by every submap's
   // thread); (2) one thread per submap sums the cotangents of its pairs IN LIST ORDER (deterministic) and pulls
-  // them back through R0 Exp(dr).
+  // them back through R0 Exp(dr).  The pairs' 24 sums are staged in LDS too: read from global memory inside the
+  // per-submap loop they were seven dependent round trips per thread (16 us for the whole kernel, 5 with the copy).
+  __shared__ double s_out[EPI_A_PAIRS * 24];
   __shared__ float s_sc[EPI_A_PAIRS], s_loss[EPI_A_PAIRS];
   __shared__ int s_src[EPI_A_PAIRS], s_dst[EPI_A_PAIRS];
   __shared__ unsigned char s_gate[EPI_A_PAIRS];
@@ -120,10 +122,12 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
   const int s = threadIdx.x;      // submap of this thread in pass (2) (S <= 64 < EPI_A_THREADS)
   for (int p0 = 0; p0 < k.P; p0 += EPI_A_PAIRS) {
     const int np = min(EPI_A_PAIRS, k.P - p0);
+    for (int i = threadIdx.x; i < np * 24; i += blockDim.x) s_out[i] = out[(int64_t)24 * p0 + i];
+    __syncthreads();
     for (int i = threadIdx.x; i < np; i += blockDim.x) {
       const int p = p0 + i;
       const AlignPairK& d = k.plan[p];
-      const double* o = out + 24 * p;
+      const double* o = s_out + 24 * i;
       // (the count and n_ch are small integers: denom is exact in fp32, as the reference's clamp(min=1) * n_ch)
       const float denom = fmaxf((float)o[1], 1.0f) * (k.loss_type == 2 ? d.n_ch : 1.0f);
       const float val = (float)(o[0] / (double)denom);
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
         had = had || s_gate[i];      // (a non-finite pair loss is nan_to_num'ed: in the loss, with a zero gradient)
         if (scf == 0.0f) continue;
         const double sc = (double)scf;
-        const double* o = out + 24 * (p0 + i);
+        const double* o = s_out + 24 * i;
         const float* Rd = pose + 12 * s_dst[i];
         const double h[3] = {(double)Rd[0] * o[2] + (double)Rd[1] * o[3] + (double)Rd[2] * o[4],
                              (double)Rd[3] * o[2] + (double)Rd[4] * o[3] + (double)Rd[5] * o[4],
