@@ -61,7 +61,9 @@ for captured in (True, False):
             torch.cuda.synchronize()
             print("   step", _, [(float((p_.grad != 0).float().mean()), int(torch.isnan(p_.grad).sum()), float(p_.grad.abs().max()))
                                  for p_ in tr.optimizer.state if p_.grad is not None and p_.dim() == 5])
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
+    print(f"   host side of the loop: {t_host / iters * 1e6:.0f} us per step")
     if os.environ.get("SHOW_ACTIVE"):
         for prm, st in tr.optimizer.state.items():
             if "active" in st:
