@@ -600,8 +600,9 @@ def trainer_steps(dev):
         us = (time.perf_counter() - t0) / 30 * 1e6
         out[name] = {"us_per_step": us, "grid_floats": sum(f.feature.numel() for f in net.features),
                      "point_samples_per_s": n / (us * 1e-6),
-                     "path": "one graph replay incl. Adam (_FastMappingPlan)" if tr.__dict__.get("_fast_plan") is not None
-                     else "captured step + optimizer.step()"}
+                     "path": ("captured step + optimizer.step()" if tr.__dict__.get("_fast_plan") is None else
+                              "one graph replay incl. Adam (_FastMappingPlan)" if tr._fast_plan.step._use_graph else
+                              "stream launches incl. Adam (_FastMappingPlan)")}
         del tr, net
         torch.cuda.empty_cache()
     return out

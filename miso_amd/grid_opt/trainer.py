@@ -42,7 +42,9 @@ class _FastMappingPlan:
     batch shape has come back; every call re-checks a fingerprint of everything the capture baked in (which tensors,
     which flags, which hyper-parameters) and hands the step back to the checked path if any of it moved.
     Why: at the Newer College shape (6 144 samples, 145 M grid floats) the GPU needs ~0.1 ms per step and the host
-    side of the checked path 0.22 ms."""
+    side of the checked path 0.22 ms.  From MappingStep.STREAM_MIN_POINTS samples the same launches go to the stream
+    one by one instead (host 105 instead of 85 us per step, the device 284 instead of 293 us at cfg-2 and 342 instead
+    of 357 us at the ScanNet shape: no idle time between replays)."""
 
     @staticmethod
     def eligible_loss(lf, model):
@@ -84,7 +86,9 @@ class _FastMappingPlan:
                           for nd in need]
             lt, ws, wf, td = prev_step.loss_cfg
             step = MappingStep([f.data for f in feats], prev_step.meta, pack, n, lt, ws, wf, td, need_levels=need,
-                               keep_sdf=False, padded=padded, grads_cleared_by_optimizer=True, use_graph=True,
+                               keep_sdf=False, padded=padded, grads_cleared_by_optimizer=True,
+                               use_graph=None,      # a replay below MappingStep.STREAM_MIN_POINTS, stream launches from there
+
                                sort=prev_step.sorted is not None, share_grads=prev_step.grads,
                                adam_device=dev, adam_state=adam_state)
         except (ValueError, RuntimeError, AssertionError) as exc:

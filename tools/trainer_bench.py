@@ -13,6 +13,9 @@ from miso_amd.grid_opt.models.grid_net import GridNet  # noqa: E402
 from miso_amd.grid_opt.trainer import GridTrainer  # noqa: E402
 
 dev = "cuda:0"
+if os.environ.get("STREAM_MIN") is not None:      # dev: force stream launches (0) / graph replays (huge) whatever n
+    from miso_amd.step import MappingStep
+    MappingStep.STREAM_MIN_POINTS = int(os.environ["STREAM_MIN"])
 n = int(os.environ.get("N", 262144))
 cfg = {"name": "grid_net", "spatial_dim": 3,
        "decoder": {"type": "mlp", "hidden_dim": 64, "hidden_layers": 1, "out_dim": 1, "pos_invariant": True,
