@@ -392,7 +392,9 @@ class Trainer(object):
             cache[key] = step
         elif not step._use_graph and not step.__dict__.get('_seen_again'):
             step._seen_again = True
-            step._use_graph = True   # same batch shape twice in a row: from now on one graph replay per step
+            # same batch shape twice in a row: from now on one graph replay per step (small batches; large ones stay
+            # on the stream, MappingStep.STREAM_MIN_POINTS)
+            step._use_graph = step.n < step.STREAM_MIN_POINTS
             if self.cfg.get('fast_captured_step', True):
                 # ... and from the step after this one, with the optimizer inside the replay (_FastMappingPlan)
                 self._fast_plan_due = key
