@@ -835,6 +835,16 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    # for the record, the protocol WITHOUT the settle phase first (rank-local, no barrier): W warm-up steps and K timed
+    # steps on a device that has been idle -- the figure the clock ramp produces (settle_device), reported next to `value`
+    for _ in range(args.warmup):
+        step.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    torch.cuda.synchronize()
+    cold_elapsed = time.perf_counter() - t0
     settle_device(step)
     for _ in range(args.warmup):
         step.run()
@@ -857,6 +867,11 @@ def main():
     # rank 0 finishes the headline record FIRST (per-kernel timings, roofline: single-rank work); the collective-bearing
     # extras run after it, under a watchdog that prints the record if they hang or a rank fails
     out = headline_record(args, step, dev, world, elapsed) if rank == 0 else None
+    if rank == 0:
+        out["without_settle_phase"] = {
+            "ms_per_step": cold_elapsed / args.steps * 1e3, "point_samples_per_s_this_rank": N_POINTS * args.steps / cold_elapsed,
+            "note": "the same W warm-up + K timed steps on rank 0 right after set-up, device clocks still ramping "
+                    "(DESIGN section 5); `value` is measured after settle_steps more untimed steps"}
     if rank == 0 and collective is not None:
         out.update(collective)
     multi = None
