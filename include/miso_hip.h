@@ -92,9 +92,9 @@ typedef struct {
   float* grad;       /* scatter-add target with the SAME strides, or NULL        */
   int32_t C, Z, Y, X;
   int64_t sC, sZ, sY, sX;
-  /* NULL, or one byte per MISO_ADAM_CHUNK (256) consecutive floats of the DENSE storage that starts at `grad`:
-   * every kernel of this library that adds or stores a non-zero into grad[off] also sets grad_touched[off / 256]
-   * = 1 (nothing here ever clears a byte).  miso_adam_touched then steps a 0.6 G-byte level from its 0.5 M flag
+  /* NULL, or one byte per MISO_ADAM_CHUNK (64) consecutive floats of the DENSE storage that starts at `grad`:
+   * every kernel of this library that adds or stores a non-zero into grad[off] also sets grad_touched[off / 64]
+   * = 1 (nothing here ever clears a byte).  miso_adam_touched then steps a 0.6 G-byte level from its 2.3 M flag
    * bytes instead of reading the whole gradient to find the few chunks a small batch wrote. */
   uint8_t* grad_touched;
 } miso_level_t;
@@ -536,7 +536,7 @@ int miso_sample_rays(const miso_ray_frames_t* frames, const miso_ray_sampling_t*
  * guard (device float, or NULL): the loss of the step.  If it is NaN the launch changes no parameter, moment or
  * flag (the reference's NaN guard, grid_opt/trainer.py:213-219: "Loss is nan! Skip backward step") and only
  * clears the gradients it was asked to clear -- the host can launch without reading the loss back first. */
-#define MISO_ADAM_CHUNK 256
+#define MISO_ADAM_CHUNK 64
 int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
                      int64_t numel, double lr, double beta1, double beta2, double eps,
                      int32_t step /* 1-based */, int zero_grad, const float* guard, void* stream);
@@ -544,7 +544,8 @@ int miso_adam_active(float* param, float* grad, float* exp_avg, float* exp_avg_s
 /* miso_adam_active driven by the flags the scatter kernels leave (miso_level_t.grad_touched) instead of by reading
  * the gradient: a chunk is stepped if active[c] or touched[c]; touched[c] is cleared.  Same arithmetic, same results
  * PROVIDED every writer of `grad` since the last call maintained the flags (the kernels of this library do; a caller
- * that adds to the gradient by other means must use miso_adam_active).  Traffic: 2 B per chunk + 28 B per stepped
+ * that adds to the gradient by other means must use miso_adam_active).  `active` and `touched` must be 4-byte aligned
+ * (four flag bytes are read as one word) and hold the values 0 / 1 only.  Traffic: 2 B per chunk + 28 B per stepped
  * element.  zero_grad and guard as above (a NaN guard leaves parameters, moments and `active` alone, still clears
  * the flags and, if asked, the touched gradients). */
 int miso_adam_touched(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,

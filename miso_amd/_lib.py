@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libmiso_hip.so")
 MAX_LEVELS = 8
 MAX_LINEAR = 4
 RAY_MAX_BINS = 64
-ADAM_CHUNK = 256
+ADAM_CHUNK = 64
 
 F_ALIGN_CORNERS = 1
 F_PAD_BORDER = 2

@@ -73,13 +73,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 // m = v = 0 and its update is lr * 0 / (0 + eps) = 0: the dense kernel reads 16 B and writes 12 B per element to
 // change nothing.  For a submap whose bound is mostly empty space (Newer College: a 120 x 120 x 20 m bound,
 // 144 M floats in the fine level, of which a 6144-point batch touches a few thousand) that is the whole cost of
-// a training step.  Here one wavefront looks at one 256-float chunk of the gradient (1 KB, one float4 per
-// lane); a chunk is updated if any of its gradients is non-zero or if it has ever been updated (`active`, one
-// byte per chunk: once touched, moments decay and the parameters keep moving, exactly as in the dense step).
-// Results are bit-identical to the dense kernel; traffic is 4 B per element plus 28 B per active element, and
-// because every non-zero gradient belongs to an active chunk, ZERO clears exactly what needs clearing.
+// a training step.  A chunk is 64 floats (256 B: sixteen cells of an x-row at C = 4 -- a sample's corners touch two of
+// them; with the 256-float chunks of rounds 1-2 the step of such a level moved 4x the bytes, 27 us of the 92 us
+// Newer College trainer step); a chunk is updated if any of its gradients is non-zero or if it has ever been updated
+// (`active`, one byte per chunk: once touched, moments decay and the parameters keep moving, exactly as in the dense
+// step).  One wavefront takes a SLAB of four chunks at a time (one float4 per lane, a quarter wavefront per chunk) and
+// the lanes of chunks that cannot move sit the loads and stores out.  Results are bit-identical to the dense kernel;
+// traffic is 4 B per element plus 28 B per active element, and because every non-zero gradient belongs to an active
+// chunk, ZERO clears exactly what needs clearing.
 constexpr int ADAM_CHUNK = MISO_ADAM_CHUNK;   // floats
-constexpr int ADAM_UN = 4;                    // chunks in flight per wavefront
+constexpr int ADAM_SLAB = 4 * ADAM_CHUNK;     // floats a wavefront takes per slot: one float4 per lane
+constexpr int ADAM_UN = 4;                    // slabs in flight per wavefront
+static_assert(ADAM_CHUNK == 64, "a chunk is the sixteen float4s of a quarter wavefront");
 
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -88,27 +93,26 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
                                                          AdamScalars a, const float* __restrict__ guard,
                                                          AdamDevK dev) {
   if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];     // a captured step: see AdamDevK
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, q = lane >> 4;      // q: this lane's chunk within the slab
   // guard (optional, device): the step's loss.  NaN => the reference skips backward and optimizer step
   // (grid_opt/trainer.py:213-219); here the launch leaves parameters, moments and flags alone (and still clears
   // the consumed gradients when asked), so the host need not read the loss back before launching.
   const bool skip = guard != nullptr && !(guard[0] == guard[0]);
-  // wave-uniform chunk indices (readfirstlane): the flag bytes become scalar loads
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const int64_t nfull = n / ADAM_CHUNK;            // whole chunks: float4 path
-  for (int64_t c0 = wave * ADAM_UN; c0 < nfull; c0 += nwaves * ADAM_UN) {
+  const int64_t nslab = n / ADAM_SLAB;             // whole slabs: float4 path
+  for (int64_t s0 = wave * ADAM_UN; s0 < nslab; s0 += nwaves * ADAM_UN) {
     float4 gg[ADAM_UN], pp[ADAM_UN], mm[ADAM_UN], vv[ADAM_UN];
     bool act[ADAM_UN];
     // chunks already moving: everything is loaded at once, as in the dense kernel; the others show their
     // gradient first
 #pragma unroll
     for (int u = 0; u < ADAM_UN; ++u) {
-      const int64_t c = c0 + u, i = c * ADAM_CHUNK + lane * 4;
+      const int64_t sl = s0 + u, i = sl * ADAM_SLAB + lane * 4;
       act[u] = false;
       gg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < nfull) {
-        act[u] = active[c] != 0;
+      if (sl < nslab) {
+        act[u] = active[sl * 4 + q] != 0;
         gg[u] = *reinterpret_cast<const float4*>(g + i);
         if (act[u]) {
           pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
@@ -118,10 +122,12 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
     }
 #pragma unroll
     for (int u = 0; u < ADAM_UN; ++u) {
-      const int64_t c = c0 + u, i = c * ADAM_CHUNK + lane * 4;
+      const int64_t sl = s0 + u, i = sl * ADAM_SLAB + lane * 4;
       const bool nz = gg[u].x != 0.f || gg[u].y != 0.f || gg[u].z != 0.f || gg[u].w != 0.f;   // NaN counts
-      const bool any = __ballot(nz) != 0ull;
-      if (c >= nfull || !(any || act[u])) continue;      // wave-uniform
+      const bool any = ((__ballot(nz) >> (16 * q)) & 0xffffull) != 0ull;      // a non-zero in this lane's chunk
+      const bool go = sl < nslab && (any || act[u]);
+      if (__ballot(go) == 0ull) continue;                // wave-uniform: the whole slab stays where it is
+      if (!go) continue;
       if (skip) {
         if (ZERO && any) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
         continue;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
       if (!act[u]) {
         pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
         vv[u] = *reinterpret_cast<float4*>(v + i);
-        if (lane == 0) active[c] = 1;
+        if ((lane & 15) == 0) active[sl * 4 + q] = 1;
       }
       adam_one(pp[u].x, gg[u].x, mm[u].x, vv[u].x, a); adam_one(pp[u].y, gg[u].y, mm[u].y, vv[u].y, a);
       adam_one(pp[u].z, gg[u].z, mm[u].z, vv[u].z, a); adam_one(pp[u].w, gg[u].w, mm[u].w, vv[u].w, a);
@@ -139,30 +145,41 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
       if (ZERO && any) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  // the ragged last chunk (numel % 256 elements), element-wise by the first wavefront
-  if (wave == 0 && nfull * ADAM_CHUNK < n) {
-    const int64_t c = nfull;
-    bool nz = false;
-    for (int64_t i = c * ADAM_CHUNK + lane; i < n; i += 64) nz = nz || g[i] != 0.f;
-    const bool was = active[c] != 0;
-    if (__ballot(nz) != 0ull || was) {
-      for (int64_t i = c * ADAM_CHUNK + lane; i < n; i += 64) {
-        if (!skip) adam_one(p[i], g[i], m[i], v[i], a);
-        if (ZERO) g[i] = 0.0f;
+  // the ragged end (numel % 256 elements: up to four chunks, the last one partial), element-wise by the first wavefront
+  if (wave == 0) {
+    for (int64_t c = nslab * 4; c * ADAM_CHUNK < n; ++c) {
+      const int64_t i = c * ADAM_CHUNK + lane;
+      const bool in = i < n;
+      const bool nz = in && g[i] != 0.f;
+      const bool was = active[c] != 0;
+      if (__ballot(nz) != 0ull || was) {
+        if (in) {
+          if (!skip) adam_one(p[i], g[i], m[i], v[i], a);
+          if (ZERO) g[i] = 0.0f;
+        }
+        if (!skip && !was && lane == 0) active[c] = 1;
       }
-      if (!skip && !was && lane == 0) active[c] = 1;
     }
   }
 }
 
 // The same step driven by flags instead of by reading the gradient (miso_adam_touched): the scatter kernels set
 // touched[c] when they put a non-zero into chunk c (common.hpp:touch_chunk), so a chunk is stepped iff
-// active[c] | touched[c].  One wavefront looks at ADAM_FPW chunks' flag bytes at a time (lane = chunk), then walks
-// the set bits of the ballot, all lanes on one chunk and ADAM_UN chunks in flight as above.  A 144 M-float level (Newer College, fine)
-// whose batch wrote a few thousand chunks costs its 1.1 MB of flags instead of a 576 MB gradient scan (150 us).
-// flag bytes a wavefront looks at per round: few enough that a level whose chunks are all moving (the coarse ones) still
-// spreads over the chip -- with 64, the 4 500 chunks of a 1.1 M-float level were 18 workgroups walking 64 chunks each
-constexpr int ADAM_FPW = 16;
+// active[c] | touched[c].  A sparse level is latency, not bytes -- the Newer College fine level has 2.3 M flag bytes of
+// which a batch sets a few per cent, all in the rows around the sensor:
+//  * a lane reads the four flag bytes of one slab as ONE 32-bit word (the arrays are 4-byte aligned);
+//  * a wavefront looks at ADAM_SLOTS groups of 16 consecutive slabs per round, the groups far apart in the level
+//    (slot t of wavefront w: group t * nwaves + w), all flag words loaded before any is used -- one round trip decides
+//    about 128 slabs, and the busy rows are dealt over all wavefronts instead of landing on the few that own them
+//    (256 consecutive slabs per wavefront: 64 us, the owners of the busy rows walking 54 slabs each; a lane per flag
+//    byte and 16 consecutive chunks per wavefront, rounds 1-2: 27 us, ~9 dependent rounds per resident wavefront);
+//  * then it steps the slabs that have a set byte, up to ADAM_UN of them in flight whatever their number (the lanes of
+//    a slab's idle chunks sit out).
+// Such a level costs its flags instead of a 576 MB gradient scan.
+constexpr int ADAM_GROUP = 16;                // consecutive slabs (flag words) per group: a quarter wavefront
+constexpr int ADAM_LOADS = 2;                 // flag words per lane and round
+constexpr int ADAM_SLOTS = 4 * ADAM_LOADS;    // groups per wavefront and round
+constexpr int ADAM_TUN = 4;                   // slabs in flight per wavefront (8: 202 VGPRs and slower, 31 vs 25 us)
 
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adam_touched_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -171,69 +188,96 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(float* __restrict__ p
                                                           unsigned char* __restrict__ touched, int64_t n,
                                                           AdamScalars a, const float* __restrict__ guard,
                                                           AdamDevK dev) {
-  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];
-  const int lane = threadIdx.x & 63;
-  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
+  const int lane = threadIdx.x & 63, q = lane >> 4;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK, nfull = n / ADAM_CHUNK;
-  for (int64_t c0 = wave * ADAM_FPW; c0 < nchunks; c0 += nwaves * ADAM_FPW) {
-    const int64_t mine = c0 + lane;
-    unsigned char act = 0, tch = 0;
-    if (lane < ADAM_FPW && mine < nchunks) { act = active[mine]; tch = touched[mine]; }
-    if (tch) {
-      touched[mine] = 0;
-      if (!act && !skip) active[mine] = 1;
-    }
-    unsigned long long todo = __ballot((act | tch) != 0);
-    const unsigned long long was_touched = __ballot(tch != 0);
-    // the common case first, branch-free: ADAM_UN whole chunks in flight (all loads issued before the first use)
-    while (!skip && __popcll(todo) >= ADAM_UN && c0 + 63 - __builtin_clzll(todo) < nfull) {
-      int64_t ii[ADAM_UN];
-      bool tt[ADAM_UN];
-      float4 gg[ADAM_UN], pp[ADAM_UN], mm[ADAM_UN], vv[ADAM_UN];
+  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK, nslab = n / ADAM_SLAB;
+  const int64_t nwords = (nchunks + 3) / 4;                // slabs, a ragged last one included
+  const int64_t ngroups = (nwords + ADAM_GROUP - 1) / ADAM_GROUP;
+  uint32_t* active32 = reinterpret_cast<uint32_t*>(active);
+  uint32_t* touched32 = reinterpret_cast<uint32_t*>(touched);
+  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];
+  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
+  for (int64_t base = 0; base < ngroups; base += nwaves * ADAM_SLOTS) {
+    uint32_t w[ADAM_LOADS], tw[ADAM_LOADS];                 // byte c of word k = chunk c of this lane's slab of load k
 #pragma unroll
-      for (int u = 0; u < ADAM_UN; ++u) {
-        const int b = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        tt[u] = (was_touched >> b) & 1ull;
-        ii[u] = (c0 + b) * ADAM_CHUNK + lane * 4;
-        gg[u] = *reinterpret_cast<const float4*>(g + ii[u]);
-        pp[u] = *reinterpret_cast<float4*>(p + ii[u]); mm[u] = *reinterpret_cast<float4*>(m + ii[u]);
-        vv[u] = *reinterpret_cast<float4*>(v + ii[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < ADAM_UN; ++u) {
-        adam_one(pp[u].x, gg[u].x, mm[u].x, vv[u].x, a); adam_one(pp[u].y, gg[u].y, mm[u].y, vv[u].y, a);
-        adam_one(pp[u].z, gg[u].z, mm[u].z, vv[u].z, a); adam_one(pp[u].w, gg[u].w, mm[u].w, vv[u].w, a);
-        *reinterpret_cast<float4*>(p + ii[u]) = pp[u];
-        *reinterpret_cast<float4*>(m + ii[u]) = mm[u];
-        *reinterpret_cast<float4*>(v + ii[u]) = vv[u];
-        if (ZERO && tt[u]) *reinterpret_cast<float4*>(g + ii[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    while (todo) {      // what is left (fewer than ADAM_UN chunks, the ragged last one, a skipped step): one at a time
-      const int b = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      const int64_t c = c0 + b;
-      const bool tt = (was_touched >> b) & 1ull;
-      if (c < nfull) {
-        const int64_t i = c * ADAM_CHUNK + lane * 4;
-        if (!skip) {
-          float4 gg = *reinterpret_cast<const float4*>(g + i);
-          float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i);
-          float4 vv = *reinterpret_cast<float4*>(v + i);
-          adam_one(pp.x, gg.x, mm.x, vv.x, a); adam_one(pp.y, gg.y, mm.y, vv.y, a);
-          adam_one(pp.z, gg.z, mm.z, vv.z, a); adam_one(pp.w, gg.w, mm.w, vv.w, a);
-          *reinterpret_cast<float4*>(p + i) = pp;
-          *reinterpret_cast<float4*>(m + i) = mm;
-          *reinterpret_cast<float4*>(v + i) = vv;
+    for (int k = 0; k < ADAM_LOADS; ++k) {
+      const int64_t grp = base + (int64_t)(k * 4 + q) * nwaves + wave;
+      const int64_t mine = grp * ADAM_GROUP + (lane & 15);
+      uint32_t aw = 0;
+      tw[k] = 0;
+      const bool whole = grp < ngroups && mine * 4 + 4 <= nchunks;      // all four flag bytes exist
+      if (whole) {
+        aw = active32[mine]; tw[k] = touched32[mine];
+      } else if (grp < ngroups && mine < nwords) {
+        for (int c = 0; mine * 4 + c < nchunks; ++c) {
+          aw |= (uint32_t)active[mine * 4 + c] << (8 * c);
+          tw[k] |= (uint32_t)touched[mine * 4 + c] << (8 * c);
         }
-        if (ZERO && tt) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {   // the ragged last chunk, element-wise
-        for (int64_t i = c * ADAM_CHUNK + lane; i < n; i += 64) {
-          if (!skip) adam_one(p[i], g[i], m[i], v[i], a);
-          if (ZERO) g[i] = 0.0f;
+      }
+      if (tw[k]) {
+        // flag bytes are 0 / 1: the chunks that wake up are the touched ones
+        if (whole) {
+          touched32[mine] = 0;
+          if (!skip && (tw[k] & ~aw)) active32[mine] = aw | tw[k];
+        } else {
+          for (int c = 0; mine * 4 + c < nchunks; ++c)
+            if ((tw[k] >> (8 * c)) & 0xffu) {
+              touched[mine * 4 + c] = 0;
+              if (!skip) active[mine * 4 + c] = 1;
+            }
+        }
+      }
+      w[k] = aw | tw[k];
+    }
+#pragma unroll
+    for (int k = 0; k < ADAM_LOADS; ++k) {
+      unsigned long long slabs = __ballot(w[k] != 0u);      // bit b: the slab of lane b (load k) has a chunk to step
+      while (slabs) {
+        // up to ADAM_TUN slabs in flight whatever their number (all loads issued before the first use)
+        int64_t ii[ADAM_TUN];
+        bool on[ADAM_TUN], tt[ADAM_TUN];
+        float4 gg[ADAM_TUN], pp[ADAM_TUN], mm[ADAM_TUN], vv[ADAM_TUN];
+#pragma unroll
+        for (int u = 0; u < ADAM_TUN; ++u) {
+          on[u] = tt[u] = false;
+          ii[u] = 0;
+          if (!slabs) continue;                             // wave-uniform
+          const int b = __builtin_ctzll(slabs);
+          slabs &= slabs - 1;
+          const int64_t sl = (base + (int64_t)(k * 4 + (b >> 4)) * nwaves + wave) * ADAM_GROUP + (b & 15);
+          const uint32_t wb = __shfl(w[k], b), tb = __shfl(tw[k], b);
+          if (sl >= nslab) {
+            // the ragged end (numel % 256 elements: the one slab that is not whole), element-wise, chunk by chunk
+            for (int c = 0; c < 4; ++c) {
+              if (!((wb >> (8 * c)) & 0xffu)) continue;
+              const int64_t i = (sl * 4 + c) * ADAM_CHUNK + lane;
+              if (i < n) {
+                if (!skip) adam_one(p[i], g[i], m[i], v[i], a);
+                if (ZERO) g[i] = 0.0f;
+              }
+            }
+            continue;
+          }
+          on[u] = ((wb >> (8 * q)) & 0xffu) != 0u;
+          tt[u] = ((tb >> (8 * q)) & 0xffu) != 0u;
+          ii[u] = sl * ADAM_SLAB + lane * 4;
+          if (on[u] && !skip) {
+            gg[u] = *reinterpret_cast<const float4*>(g + ii[u]);
+            pp[u] = *reinterpret_cast<float4*>(p + ii[u]); mm[u] = *reinterpret_cast<float4*>(m + ii[u]);
+            vv[u] = *reinterpret_cast<float4*>(v + ii[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < ADAM_TUN; ++u) {
+          if (on[u] && !skip) {
+            adam_one(pp[u].x, gg[u].x, mm[u].x, vv[u].x, a); adam_one(pp[u].y, gg[u].y, mm[u].y, vv[u].y, a);
+            adam_one(pp[u].z, gg[u].z, mm[u].z, vv[u].z, a); adam_one(pp[u].w, gg[u].w, mm[u].w, vv[u].w, a);
+            *reinterpret_cast<float4*>(p + ii[u]) = pp[u];
+            *reinterpret_cast<float4*>(m + ii[u]) = mm[u];
+            *reinterpret_cast<float4*>(v + ii[u]) = vv[u];
+          }
+          if (ZERO && tt[u]) *reinterpret_cast<float4*>(g + ii[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     }
@@ -276,8 +320,8 @@ hipError_t launch_adam_active(float* p, float* g, float* m, float* v, unsigned c
   if (n == 0) return hipSuccess;
   const AdamScalars a = adam_scalars(lr, b1, b2, eps, step);
   const AdamDevK dev{reinterpret_cast<const AdamScalars*>(table), step_dev, table_len};
-  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
-  int64_t blocks = (nchunks + 4 * ADAM_UN - 1) / (4 * ADAM_UN);
+  const int64_t nslabs = (n + ADAM_SLAB - 1) / ADAM_SLAB;
+  int64_t blocks = (nslabs + 4 * ADAM_UN - 1) / (4 * ADAM_UN);
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (zero_grad) adam_active_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard, dev);
   else adam_active_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard, dev);
@@ -291,8 +335,9 @@ hipError_t launch_adam_touched(float* p, float* g, float* m, float* v, unsigned 
   if (n == 0) return hipSuccess;
   const AdamScalars a = adam_scalars(lr, b1, b2, eps, step);
   const AdamDevK dev{reinterpret_cast<const AdamScalars*>(table), step_dev, table_len};
-  const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK;
-  int64_t blocks = (nchunks + 4 * ADAM_FPW - 1) / (4 * ADAM_FPW);
+  const int64_t nwords = ((n + ADAM_CHUNK - 1) / ADAM_CHUNK + 3) / 4;
+  const int64_t per_block = 4 * (int64_t)ADAM_SLOTS * ADAM_GROUP;      // slabs four wavefronts look at per round
+  int64_t blocks = (nwords + per_block - 1) / per_block;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (zero_grad) adam_touched_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, touched, n, a, guard, dev);
   else adam_touched_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, touched, n, a, guard, dev);

@@ -862,6 +862,7 @@ int miso_adam_touched(float* param, float* grad, float* exp_avg, float* exp_avg_
     return MISO_E_BADARG;
   if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15u)
     return MISO_E_BADARG;
+  if ((((uintptr_t)active) | ((uintptr_t)touched)) & 3u) return MISO_E_BADARG;      // read four flag bytes at a time
   return (int)launch_adam_touched(param, grad, exp_avg, exp_avg_sq, active, touched, numel, lr, beta1, beta2, eps,
                                   step, zero_grad, guard, (hipStream_t)stream, nullptr, nullptr, 0);
 }
@@ -891,6 +892,7 @@ int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg
     return MISO_E_BADARG;
   if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15u)
     return MISO_E_BADARG;
+  if (touched && ((((uintptr_t)active) | ((uintptr_t)touched)) & 3u)) return MISO_E_BADARG;
   if (touched)
     return (int)launch_adam_touched(param, grad, exp_avg, exp_avg_sq, active, touched, numel, 1e-3, 0.9, 0.999, 1e-8, 1,
                                     zero_grad, guard, (hipStream_t)stream, table, step, table_len);

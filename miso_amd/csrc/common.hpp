@@ -12,7 +12,7 @@ struct LevelK {
   const float* data;
   float* grad;
   const float* gg;  // cotangent-of-grad grid (second order), or nullptr
-  unsigned char* touched;  // miso_level_t.grad_touched: one byte per 256 floats of `grad`, or nullptr
+  unsigned char* touched;  // miso_level_t.grad_touched: one byte per MISO_ADAM_CHUNK floats of `grad`, or nullptr
   int32_t C, Z, Y, X;
   int32_t sC, sZ, sY, sX;  // element strides, validated < 2^31 on the host
   int32_t foff;            // first output column of this level
@@ -146,9 +146,10 @@ struct LmTrackK {
 };
 
 // miso_level_t.grad_touched: a non-zero went into grad[off] (element offset from lv.grad)
-static_assert(MISO_ADAM_CHUNK == 256, "touch_chunk shifts by 8");
+constexpr int ADAM_CHUNK_SHIFT = 6;
+static_assert(MISO_ADAM_CHUNK == (1 << ADAM_CHUNK_SHIFT), "touch_chunk shifts by log2 of the chunk");
 __device__ __forceinline__ void touch_chunk(const LevelK& lv, int64_t off) {
-  if (lv.touched) lv.touched[off >> 8] = 1;
+  if (lv.touched) lv.touched[off >> ADAM_CHUNK_SHIFT] = 1;
 }
 
 // One (src, dst) pair of a fused alignment iteration, as the batched kernels of pair_latent.hip read it from the

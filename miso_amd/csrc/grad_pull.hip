@@ -214,7 +214,7 @@ __device__ __forceinline__ void pull_tiny(const GridK& g, const PullK& pk, const
   const int lx = v & 1, ly = (v >> 1) & 1, lz = v >> 2;
   if (!lv.grad || lx >= b.B[0] || ly >= b.B[1] || lz >= b.B[2] || (C == 4 && lane >= 32)) return;
   float* dst = lv.grad + (b.v0[2] + lz) * lv.sZ + (b.v0[1] + ly) * lv.sY + (b.v0[0] + lx) * lv.sX + ch;
-  if (lv.touched && acc != 0.0f) lv.touched[(dst - lv.grad) >> 8] = 1;
+  if (lv.touched && acc != 0.0f) lv.touched[(dst - lv.grad) >> ADAM_CHUNK_SHIFT] = 1;
   if (add == 2) {
     if (acc != 0.0f) atomic_add_f32(dst, acc);
   } else {
@@ -475,7 +475,7 @@ __device__ __forceinline__ void pull_level(const GridK& g, const PullK& pk, cons
       for (int c = 0; c < C; c += 4) {
         float4 v = make_float4(acc[r][c], acc[r][c + 1], acc[r][c + 2], acc[r][c + 3]);
         if (lv.touched && (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f))
-          lv.touched[(dst + c - lv.grad) >> 8] = 1;
+          lv.touched[(dst + c - lv.grad) >> ADAM_CHUNK_SHIFT] = 1;
         if (add_eff == 2) {   // a queued slice: other wavefronts add to the same brick
           if (v.x != 0.0f) atomic_add_f32(dst + c, v.x);
           if (v.y != 0.0f) atomic_add_f32(dst + c + 1, v.y);

@@ -420,7 +420,7 @@ class Trainer(object):
         clear = step.sorted is None
         # NaN guard (reference :213-219) on the device: the optimizer's kernels leave everything alone if the
         # loss is NaN and the host hears about it one step later -- no read-back between backward and step
-        # the step's scatter kernels flagged the 256-float chunks they wrote: Adam reads the flags, not the gradient
+        # the step's scatter kernels flagged the 64-float chunks they wrote: Adam reads the flags, not the gradient
         self.optimizer.step(clear_grads=clear, guard=total,
                             touched={id(f): t for f, t, nd in zip(feats, step.touched, need) if nd})
         if self.__dict__.pop('_fast_plan_due', None) == key:

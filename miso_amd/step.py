@@ -87,7 +87,7 @@ class MappingStep:
             self._shared_grads = True
         else:
             self.grads = [torch.zeros_like(f) if nd else None for f, nd in zip(self.features, need)]
-        # one flag byte per 256 gradient floats, set by the scatter kernels where they put a non-zero: Adam finds the
+        # one flag byte per ADAM_CHUNK (64) gradient floats, set by the scatter kernels where they put a non-zero: Adam finds the
         # chunks a batch wrote from these instead of reading the whole gradient (a 144 M-float Newer College level:
         # 0.6 MB of flags instead of 576 MB: 124 -> 28 us with 2 % of the chunks moving).  Valid because nothing but
         # this step's kernels writes self.grads.  Only for big levels: where every chunk moves anyway the flag-driven

@@ -1046,7 +1046,7 @@ def test_adam_touched_flags_equal_gradient_scan(path):
                             overwrite=True, touched=tch)
         for g, tc in zip(grads, tch):            # every non-zero gradient lies in a flagged chunk
             nz = (torch.as_strided(g, (g.numel(),), (1,)) != 0).nonzero().reshape(-1)      # storage order
-            assert bool(tc[nz // 256].all()) and int(tc.sum()) > 0
+            assert bool(tc[nz // ops._lib.ADAM_CHUNK].all()) and int(tc.sum()) > 0
         gA = [g.clone() for g in grads]
         for i in range(2):
             ops.adam_active_(featsA[i], gA[i], mA[i], vA[i], actA[i], t + 1, 1e-3, zero_grad=zero, guard=guard)
