@@ -344,6 +344,46 @@ def test_adam_active_is_bit_identical_to_dense(numel):
         torch.testing.assert_close(res["active"][0].cpu(), pc.detach(), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("numel", [256 * 40, 256 * 37 + 130, 1027, 5, 64 * 3, 64 * 4 + 1, 256 * 3 + 64 * 2 + 7,
+                                   256 * 8 * 16 * 5 + 64 * 3 + 9])
+def test_adam_touched_ragged_sizes_equal_the_gradient_scan(numel):
+    """miso_adam_touched on sizes that end inside a slab / inside a chunk / inside a flag word, flags written by hand
+    (touched = the chunks of this step's non-zero gradients): parameters, moments, `active`, cleared gradients and
+    cleared flags equal miso_adam_active's bit for bit over a run with chunks waking up at different steps and a NaN
+    guard."""
+    from miso_amd import ops, _lib
+    CH = _lib.ADAM_CHUNK
+    g = torch.Generator().manual_seed(numel + 1)
+    p0 = torch.randn(numel, generator=g)
+    nchunks = (numel + CH - 1) // CH
+    wake = torch.randint(0, 7, (nchunks,), generator=g)
+    res = {}
+    for kind in ("scan", "flags"):
+        gg = torch.Generator().manual_seed(numel + 2)
+        p, m, v = p0.to(DEV).clone(), torch.zeros(numel, device=DEV), torch.zeros(numel, device=DEV)
+        act = ops.adam_active_flags(p)
+        tch = ops.adam_active_flags(p)
+        for t in range(5):
+            gr = torch.randn(numel, generator=gg) * 1e-2
+            on = ((wake <= t) & (torch.rand(nchunks, generator=gg) < 0.6)).repeat_interleave(CH)[:numel]
+            gr = gr * on * (torch.rand(numel, generator=gg) < 0.4)
+            gd = gr.to(DEV).clone()
+            guard = torch.tensor([float("nan") if t == 3 else 0.5], device=DEV)
+            zero = t % 2 == 0
+            if kind == "scan":
+                ops.adam_active_(p, gd, m, v, act, t + 1, 1e-2, zero_grad=zero, guard=guard)
+            else:
+                nz = torch.nn.functional.pad(gr != 0, (0, nchunks * CH - numel)).reshape(nchunks, CH).any(1)
+                tch.copy_(nz.to(torch.uint8))
+                ops.adam_active_(p, gd, m, v, act, t + 1, 1e-2, zero_grad=zero, guard=guard, touched=tch)
+                assert int(tch.sum()) == 0
+            res.setdefault(kind, []).append((p.clone(), m.clone(), v.clone(), act.clone(), gd.clone()))
+    for a, b in zip(res["scan"], res["flags"]):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x,
+                               y.view(torch.int32) if y.dtype == torch.float32 else y)
+
+
 def test_native_library_is_loaded():
     """The ops above ran through libmiso_hip.so (no eager fallback exists)."""
     from miso_amd import _lib
