@@ -595,11 +595,14 @@ def trainer_steps(dev):
             tr.train_step(*batch)
             k += 1
         torch.cuda.synchronize()
+        import gc
+        gc.disable()
         t0 = time.perf_counter()
         for _ in range(60):
             tr.train_step(*batch)
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / 60 * 1e6
+        gc.enable()
         out[name] = {"us_per_step": us, "grid_floats": sum(f.feature.numel() for f in net.features),
                      "point_samples_per_s": n / (us * 1e-6),
                      "path": ("captured step + optimizer.step()" if tr.__dict__.get("_fast_plan") is None else
@@ -842,11 +845,13 @@ def main():
     for _ in range(args.warmup):
         step.run()
     torch.cuda.synchronize()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step.run()
     torch.cuda.synchronize()
     cold_elapsed = time.perf_counter() - t0
+    gc.enable()
     settle_device(step)
     for _ in range(args.warmup):
         step.run()
@@ -854,6 +859,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.disable()                      # as timeit does: no collector pause inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step.run()
@@ -861,6 +867,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../../include/miso_hip.h"
 
 namespace miso {
@@ -150,6 +153,30 @@ constexpr int ADAM_CHUNK_SHIFT = 6;
 static_assert(MISO_ADAM_CHUNK == (1 << ADAM_CHUNK_SHIFT), "touch_chunk shifts by log2 of the chunk");
 __device__ __forceinline__ void touch_chunk(const LevelK& lv, int64_t off) {
   if (lv.touched) lv.touched[off >> ADAM_CHUNK_SHIFT] = 1;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size): the call is ~5 us of host time, and a
+// training step that issues its six launches on the stream makes it three times (the host's lead over the device is
+// what protects such a step against a busy host).  The attribute only ever grows.
+inline hipError_t allow_dynamic_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return hipSuccess;
+  static std::mutex mu;
+  static std::unordered_map<uint64_t, size_t> granted;      // (kernel address ^ device) -> bytes
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t key = (uint64_t)(uintptr_t)kernel ^ ((uint64_t)(dev + 1) << 56);
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find(key);
+    if (it != granted.end() && it->second >= bytes) return hipSuccess;
+  }
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& g = granted[key];
+  if (g < bytes) g = bytes;
+  return hipSuccess;
 }
 
 // One (src, dst) pair of a fused alignment iteration, as the batched kernels of pair_latent.hip read it from the

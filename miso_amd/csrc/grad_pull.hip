@@ -1212,13 +1212,13 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
     const size_t words = (size_t)BLK_CAND * 4 + (size_t)BLK_WAVES * BLK_POOL / 2 + 32 +
                          (size_t)BLK_WAVES * (PULL_ARRW + cap * rec + cap * C);
     const size_t blds = words * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+    hipError_t e = allow_dynamic_lds((const void*)kb, blds);
     if (e != hipSuccess) return e;
     const int nb = T / 2;
     kb<<<(unsigned)(nb * nb * nb), 512, blds, s>>>(g, pk);
   } else {
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+      hipError_t e = allow_dynamic_lds((const void*)k, lds);
       if (e != hipSuccess) return e;
     }
     k<<<blocks, 256, lds, s>>>(g, pk);
@@ -1226,8 +1226,8 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   if (pk.queue) {
     pk.drain = 1;
     const unsigned dblocks = 1024;
-    if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+      hipError_t e = allow_dynamic_lds((const void*)kd, lds);
       if (e != hipSuccess) return e;
     }
     kd<<<dblocks, 256, lds, s>>>(g, pk);

@@ -966,10 +966,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kerne
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
-static hipError_t allow_lds(const void* k, size_t lds) {
-  if (lds <= 48 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
+static hipError_t allow_lds(const void* k, size_t lds) { return allow_dynamic_lds(k, lds); }
 
 template <int C, int L, int H, int NH>
 static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
