@@ -158,6 +158,8 @@ def test_stream_launches_and_graph_replays_give_the_same_step():
     small = MappingStep(feats, meta, pack, n // 4, "L1", 1.0, 0.1, 0.15, keep_sdf=False)
     assert small._use_graph
     for mode in (None, False):
-        assert torch.equal(out[mode][0], out[True][0])
+        # (not bit for bit: the order of the points inside a tile run depends on the sort's LDS atomics, and with it the
+        # fp32 order of the loss and gradient sums)
+        assert (out[mode][0] - out[True][0]).abs().max().item() <= 2e-6 * out[True][0].abs().max().item()
         for a, b in zip(out[mode][1], out[True][1]):
             assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
