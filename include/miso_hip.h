@@ -223,14 +223,21 @@ int miso_sdf_fwd_sorted_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, con
  * matrix-core push of every level's gradient from the d-feat rows left in `workspace`
  * (miso_sdf_bwd_workspace_floats floats, 16-byte aligned).  Same results as miso_sdf_fwd_sorted_loss followed by
  * miso_sdf_bwd_sorted with MISO_F_GRAD_SDF_SORTED (same arithmetic, same order of operations per point).  Requires a
- * frozen decoder and that every level with a gradient is formed from the d-feat rows (miso_grad_pull_levels covers them
- * all): MISO_E_UNSUPPORTED otherwise -- use the two calls then.  grid->flags: MISO_F_GRAD_OVERWRITE / _ZEROED /
- * MISO_F_CROWDED as for miso_sdf_bwd_sorted.  sdf (caller order) may be NULL. */
+ * frozen decoder and at least one level with a gradient (MISO_E_UNSUPPORTED otherwise).  A level the pull cannot form
+ * (bricks of more than 8 vertices per tile and axis: not in miso_grad_pull_levels) is scattered with float atomics from
+ * the same launch, as miso_sdf_bwd_sorted scatters it.  grid->flags: MISO_F_GRAD_OVERWRITE / _ZEROED / MISO_F_CROWDED as
+ * for miso_sdf_bwd_sorted.  sdf (caller order) may be NULL. */
 int miso_sdf_train_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                           const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf, float weight_fs,
                           float trunc_dist, const float* loss_inputs, float* sdf, float* loss_slots,
                           const int32_t* n_live, float* workspace, void* stream);
-/* The same for an unbinned (small) batch: x (N,3) and loss_inputs in the caller's order, grad_sdf (N) in that order too
+/* The same step for an unbinned (small) batch, x (N,3) and loss_inputs (N,4) in the caller's order: forward + mapping
+ * loss + decoder backward + the atomic scatter of every level's gradient in ONE launch (what miso_sdf_fwd_loss +
+ * miso_sdf_bwd do in two).  The gradients are ADDED to `grad` (clear them first, or let miso_adam_active(zero_grad)). */
+int miso_sdf_train(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n,
+                   int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* loss_inputs,
+                   float* sdf /* may be NULL */, float* loss_slots, void* stream);
+/* The forward half for an unbinned (small) batch: x (N,3) and loss_inputs in the caller's order, grad_sdf (N) in that order too
  * (feed it to miso_sdf_bwd).  Replaces miso_sdf_fwd + miso_mapping_loss_rows and the clear of their two sums. */
 int miso_sdf_fwd_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n,
                       int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* loss_inputs,

@@ -147,6 +147,8 @@ SIGNATURES = {
     "miso_sdf_train_sorted": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.POINTER(Sorted), C.c_int64,
                                         C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_sdf_train": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
+                                 C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_overlap_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      C.c_void_p, C.c_void_p]),
     "miso_grad_pull_dx": (C.c_int, [C.POINTER(Grid), C.POINTER(Sorted), C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,

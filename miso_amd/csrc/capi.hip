@@ -20,7 +20,7 @@ hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const 
                           const float*, const uint32_t*, float*, bool, const int*, float*, uint32_t, bool,
                           hipStream_t);
 hipError_t launch_sdf_train(int, int, int, int, const GridK&, const float*, const float*, int64_t, float*, const int*,
-                            const LossInK&, float*, hipStream_t);
+                            const LossInK&, float*, uint32_t, bool, hipStream_t);
 int64_t sort_workspace_bytes(int64_t n, int T);
 hipError_t launch_sort(const GridK&, const float*, int64_t, int, void*, float*, float*, int*, int*,
                        hipStream_t);
@@ -523,35 +523,40 @@ int miso_sdf_bwd_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
                       stream);
 }
 
-int miso_sdf_train_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+// One training iteration of a frozen-decoder submap: forward + mapping loss + decoder backward in ONE launch
+// (sdf_train_kernel).  sorted != nullptr: a binned batch -- the levels the pull / push can form get their gradient from
+// the d-feat rows left in `workspace`, the others (bricks beyond the pull's reach) are scattered with float atomics from
+// the kernel itself.  sorted == nullptr: an unbinned batch (x in the caller's order), every level scattered.
+static int sdf_train_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
                           const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf, float weight_fs,
                           float trunc_dist, const float* loss_inputs, float* sdf, float* loss_slots,
                           const int32_t* n_live, float* workspace, void* stream) {
-  int rc = check_sorted(sorted, n);
-  if (rc) return rc;
-  if ((loss_type != 1 && loss_type != 2) || !loss_slots || !packed || (n > 0 && (!loss_inputs || !workspace)))
+  if ((loss_type != 1 && loss_type != 2) || !loss_slots || !packed || n < 0 || (n > 0 && !loss_inputs))
     return MISO_E_BADARG;
   if ((((uintptr_t)loss_inputs | (uintptr_t)packed | (uintptr_t)workspace) & 15u) != 0) return MISO_E_BADARG;
-  if (!sorted->xn_sorted && n > 0) return MISO_E_BADARG;
+  if (sorted && !sorted->xn_sorted && n > 0) return MISO_E_BADARG;
+  if (!sorted && n > 0 && !x) return MISO_E_BADARG;
   GridK g; bool v4;
-  rc = convert_grid(grid, &g, true, &v4);
+  int rc = convert_grid(grid, &g, true, &v4);
   if (rc) return rc;
   int C, L, H, NH;
   rc = fused_shape(g, v4, mlp, &C, &L, &H, &NH);
   if (rc) return rc;
-  // every level with a gradient must be formed from the d-feat rows (pull or push): nothing is scattered from here
-  const uint32_t pull = plan_grad_pull(g, sorted->tiles_per_axis);
   uint32_t want = 0;
   for (int l = 0; l < g.n_levels; ++l)
     if (g.lv[l].grad && !((g.ignore_mask >> l) & 1u)) want |= 1u << l;
-  if (!want || (want & ~pull)) return MISO_E_UNSUPPORTED;
-  const uint32_t push = plan_push(g, sorted->tiles_per_axis, n, pull);
+  if (!want) return MISO_E_UNSUPPORTED;
+  // levels formed from the d-feat rows (pull or push); the rest is scattered from the kernel
+  // (an ignored level with a gradient buffer stays in `pull`: the pull writes its zeros, as miso_sdf_bwd_sorted does)
+  const uint32_t pull = (sorted && workspace) ? plan_grad_pull(g, sorted->tiles_per_axis) : 0u;
+  const uint32_t push = pull ? plan_push(g, sorted->tiles_per_axis, n, pull) : 0u;
+  const uint32_t scat = want & ~pull;
   hipStream_t st = (hipStream_t)stream;
-  const bool overwrite = (grid->flags & MISO_F_GRAD_OVERWRITE) != 0;
+  const bool overwrite = sorted && (grid->flags & MISO_F_GRAD_OVERWRITE) != 0;
   if (overwrite && !(grid->flags & MISO_F_GRAD_ZEROED)) {
-    for (int l = 0; l < g.n_levels; ++l) {      // pushed levels are added to with atomics: they start from zero
+    for (int l = 0; l < g.n_levels; ++l) {      // pushed and scattered levels are added to with atomics: they start from zero
       const LevelK& lv = g.lv[l];
-      if (!lv.grad || !((push >> l) & 1u)) continue;
+      if (!lv.grad || !(((push | scat) >> l) & 1u)) continue;
       size_t span = (size_t)(lv.C - 1) * lv.sC + (size_t)(lv.X - 1) * lv.sX + (size_t)(lv.Y - 1) * lv.sY +
                     (size_t)(lv.Z - 1) * lv.sZ + 1;
       hipError_t e = launch_zero_fill(lv.grad, (int64_t)span, st);
@@ -570,13 +575,33 @@ int miso_sdf_train_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const 
     lin.inv_n = 1.0f / (float)n;
     lin.n_live = n_live;
     GridK gp = g;
-    const float* x = sorted_points(&gp, sorted);
-    rc = (int)launch_sdf_train(C, L, H, NH, gp, packed, x, n, sdf, sorted->perm, lin, workspace, st);
+    if (sorted) x = sorted_points(&gp, sorted);
+    rc = (int)launch_sdf_train(C, L, H, NH, gp, packed, x, n, sdf, sorted ? sorted->perm : nullptr, lin,
+                               pull ? workspace : nullptr, pull, scat != 0, st);
     if (rc) return rc;
   }
+  if (!pull) return MISO_OK;
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace, g.F,
                                nullptr, pull, overwrite ? 1 : 0, nullptr, sorted->pull_queue, sorted->pull_queue_ints,
                                st, push, n);
+}
+
+int miso_sdf_train_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
+                          const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf, float weight_fs,
+                          float trunc_dist, const float* loss_inputs, float* sdf, float* loss_slots,
+                          const int32_t* n_live, float* workspace, void* stream) {
+  int rc = check_sorted(sorted, n);
+  if (rc) return rc;
+  if (n > 0 && !workspace) return MISO_E_BADARG;
+  return sdf_train_impl(grid, mlp, packed, nullptr, sorted, n, loss_type, weight_sdf, weight_fs, trunc_dist,
+                        loss_inputs, sdf, loss_slots, n_live, workspace, stream);
+}
+
+int miso_sdf_train(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n,
+                   int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* loss_inputs,
+                   float* sdf, float* loss_slots, void* stream) {
+  return sdf_train_impl(grid, mlp, packed, x, nullptr, n, loss_type, weight_sdf, weight_fs, trunc_dist, loss_inputs,
+                        sdf, loss_slots, nullptr, nullptr, stream);
 }
 
 int miso_pair_latent(const miso_grid_t* dst_grid, const float* pose, const float* coords_src,

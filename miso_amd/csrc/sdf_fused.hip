@@ -690,14 +690,21 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
 // coordinate backward and levels scattered from the backward); the sign bits stay in the registers they were formed
 // in, d loss / d sdf moves between the point-per-lane layout of the loss and the two 32-point tiles of the backward
 // with two lane reads.
-template <int C, int L, int H, int NH>
+// SCAT: levels with a gradient that are NOT in defer_mask (bricks beyond what the pull owns: cfg-3's fine level; or
+// every level of an unbinned batch, perm == nullptr) are scattered from here with float atomics exactly as
+// sdf_bwd_kernel<.., true, false> does it -- per-point cell records kept in LDS from the forward's gather, lanes
+// (point slot, dx, channel) walking the chunk's d-feat tile.  dfeat_out may then be null (nothing deferred).
+template <int C, int L, int H, int NH, bool SCAT>
 __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kernel(GridK g, const float* __restrict__ packed,
                                                           const float* __restrict__ x, int64_t n,
                                                           float* __restrict__ sdf, const int* __restrict__ perm,
-                                                          LossInK lin, float* __restrict__ dfeat_out) {
+                                                          LossInK lin, float* __restrict__ dfeat_out,
+                                                          uint32_t defer_mask) {
   constexpr int F = C * L, RT = H / 32, KS0 = (F + 1) / 2, KS1 = H / 2;
   constexpr int MW = (NH + 1) * RT;
   constexpr int FP = ((F + 3) / 4) * 4 + 4;      // d-feat row pitch in LDS: 16-B aligned, conflict-free b128 writes
+  constexpr int REC = 8;                         // ints per (point, level) cell record (SCAT)
+  constexpr int WAVE_LDS = 64 * FP + (SCAT ? 64 * L * REC : 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PackLayout pl(F, H, NH);
   // the whole pack: forward part [0, fwd_end), transposed weights [o_whT, total) right behind it
@@ -714,7 +721,12 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kerne
   const float bo = smem[pl.o_bo];
   const float* whT = smem + pl.o_whT;
   const float* w0T = smem + pl.o_w0T;
-  float* dF = smem + ((pl.total + 3) / 4) * 4 + wave * (64 * FP);      // this wavefront's d-feat tile [64][FP]
+  float* dF = smem + ((pl.total + 3) / 4) * 4 + wave * WAVE_LDS;       // this wavefront's d-feat tile [64][FP]
+  int* rec = reinterpret_cast<int*>(dF + 64 * FP);                      // SCAT: its cell records [64][L][REC]
+  uint32_t scatter_mask = 0;
+  if (SCAT)
+    for (int l = 0; l < L; ++l)
+      if (g.lv[l].grad && !((g.ignore_mask >> l) & 1u) && !((defer_mask >> l) & 1u)) scatter_mask |= 1u << l;
 
   float loss_sdf = 0.0f, loss_fs = 0.0f;
   float inv_n = lin.inv_n;
@@ -746,7 +758,20 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kerne
         Axis az = axis_coord(pz, bmn[2], bmx[2], lv.Z, g.flags);
         Cell c = make_cell(ax, ay, az, lv);
         gather_level<C>(lv, c, &f[l * C]);
+        if (SCAT && ((scatter_mask >> l) & 1u)) {
+          // the record sdf_bwd_kernel forms from the point again: base offset, in-bound bits, the six weights
+          const int flags = (c.inx[0] ? 1 : 0) | (c.inx[1] ? 2 : 0) | (c.iny[0] ? 4 : 0) | (c.iny[1] ? 8 : 0) |
+                            (c.inz[0] ? 16 : 0) | (c.inz[1] ? 32 : 0);
+          int* r = rec + (lane * L + l) * REC;
+          *reinterpret_cast<int4*>(r) = make_int4(c.k0 * lv.sZ + c.j0 * lv.sY + c.i0 * lv.sX, flags,
+                                                  __float_as_int(c.wx[1]), __float_as_int(c.wy[1]));
+          *reinterpret_cast<int4*>(r + 4) = make_int4(__float_as_int(c.wz[1]), __float_as_int(c.wx[0]),
+                                                      __float_as_int(c.wy[0]), __float_as_int(c.wz[0]));
+        }
       }
+    } else if (SCAT) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) rec[(lane * L + l) * REC + 1] = 0;      // a row past the batch: no corner in bound
     }
     memory_phase(false, g.tune);
     // ================================ forward =====================================================================
@@ -937,7 +962,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kerne
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
+    if (!SCAT || dfeat_out) {
       float* dst = dfeat_out + chunk * 64 * F;
       const int64_t rows_left = n - chunk * 64;
       for (int i = lane; i < 64 * F / 4; i += 64) {
@@ -946,8 +971,40 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kerne
           *reinterpret_cast<float4*>(dst + row * F + col) = *reinterpret_cast<const float4*>(dF + row * FP + col);
       }
     }
+    if (SCAT) {
+      // the scatter of sdf_bwd_kernel: 64 / SLOTS trips, lane = (point slot, dx, channel), four (dy, dz) atomics each
+      constexpr int LPR = 2 * C, SLOTS = 64 / LPR;
+      const int slot = lane / LPR, dx = (lane / C) & 1, ch = lane % C;
+#pragma unroll 1
+      for (int pg = 0; pg < (scatter_mask ? 64 / SLOTS : 0); ++pg) {
+        const int pt = pg * SLOTS + slot;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          const LevelK& lv = g.lv[l];
+          if (!((scatter_mask >> l) & 1u)) continue;
+          const int* r = rec + (pt * L + l) * REC;
+          const int4 r0 = *reinterpret_cast<const int4*>(r);
+          const int4 r1 = *reinterpret_cast<const int4*>(r + 4);
+          const int fl = r0.y;
+          if (!((fl >> dx) & 1)) continue;
+          const float v = dF[pt * FP + l * C + ch];
+          const float wx = dx ? __int_as_float(r0.z) : __int_as_float(r1.y);
+          const float wy[2] = {__int_as_float(r1.z), __int_as_float(r0.w)};
+          const float wz[2] = {__int_as_float(r1.w), __int_as_float(r1.x)};
+          float* base = lv.grad + r0.x + dx * lv.sX + ch;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int dy = q & 1, dz = q >> 1;
+            if (((fl >> (2 + dy)) & 1) && ((fl >> (4 + dz)) & 1)) {
+              atomic_add_f32(base + dy * lv.sY + dz * lv.sZ, v * ((wx * wy[dy]) * wz[dz]));
+              if (ch == 0) touch_chunk(lv, r0.x + dx * lv.sX + dy * lv.sY + dz * lv.sZ);   // C floats: one chunk
+            }
+          }
+        }
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();      // the next chunk overwrites the tile
+    __builtin_amdgcn_wave_barrier();      // the next chunk overwrites the tile (and the records)
     memory_phase(false, g.tune);
   }
   // loss sums: as sdf_fwd_kernel (every block stores its pair into its own slot, the slots nobody owns are cleared)
@@ -1018,18 +1075,19 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
 
 template <int C, int L, int H, int NH>
 static hipError_t launch_train_t(const GridK& g, const float* packed, const float* x, int64_t n, float* sdf,
-                                 const int* perm, const LossInK& lin, float* dfeat_out, hipStream_t s) {
+                                 const int* perm, const LossInK& lin, float* dfeat_out, uint32_t defer_mask, bool scat,
+                                 hipStream_t s) {
   PackLayout pl(C * L, H, NH);
   constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4;
-  size_t lds = (size_t)(((pl.total + 3) / 4) * 4 + 4 * 64 * FP) * sizeof(float);
+  size_t lds = (size_t)(((pl.total + 3) / 4) * 4 + 4 * (64 * FP + (scat ? 64 * L * 8 : 0))) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   if (blocks > 512u) blocks = 512u;      // persistent: two workgroups per CU (256 .. 1024 measured: 512 and up equal)
   if (blocks > MISO_LOSS_SLOTS) blocks = MISO_LOSS_SLOTS;   // one loss slot per block
-  auto k = sdf_train_kernel<C, L, H, NH>;
+  auto k = scat ? sdf_train_kernel<C, L, H, NH, true> : sdf_train_kernel<C, L, H, NH, false>;
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
-  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out);
+  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
   return hipGetLastError();
 }
 
@@ -1070,15 +1128,16 @@ hipError_t launch_sdf_bwd(int C, int L, int H, int NH, const GridK& g, const flo
 }
 
 
-// forward + mapping loss + decoder backward of a binned batch in one launch (sdf_train_kernel): d-feat rows for the
-// pull, loss slots; sdf (caller order) optional
+// forward + mapping loss + decoder backward of a batch in one launch (sdf_train_kernel): d-feat rows for the levels in
+// defer_mask (formed by the pull / push afterwards), float atomics for the other levels with a gradient (scat: there
+// are such levels), loss slots; sdf (caller order) optional; perm == nullptr: an unbinned batch
 hipError_t launch_sdf_train(int C, int L, int H, int NH, const GridK& g, const float* packed, const float* x,
                             int64_t n, float* sdf, const int* perm, const LossInK& lin, float* dfeat_out,
-                            hipStream_t s) {
+                            uint32_t defer_mask, bool scat, hipStream_t s) {
   if (n == 0) return hipSuccess;
 #define X(c, l, h, nh) \
   if (C == c && L == l && H == h && NH == nh) \
-    return launch_train_t<c, l, h, nh>(g, packed, x, n, sdf, perm, lin, dfeat_out, s);
+    return launch_train_t<c, l, h, nh>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask, scat, s);
   MISO_FUSED_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;

@@ -558,22 +558,26 @@ def sdf_fwd_loss_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatc
 
 
 def sdf_train_supported(features, meta, grads) -> bool:
-    """True when sdf_train_raw covers this (grid, gradient request): every level with a gradient is formed from the
-    d-feat rows by the pull / push (miso_grad_pull_levels), nothing is scattered from the backward itself."""
+    """True when sdf_train_raw / sdf_train_unsorted_raw cover this gradient request: a level with a gradient exists
+    (the fused decoder shape itself is sdf_fused_supported's business).  Levels the pull / push cannot form from the
+    d-feat rows are scattered with float atomics from the same launch (sdf_train_scattered_levels)."""
+    return any(gr is not None and not (meta.ignore_mask >> l) & 1 for l, gr in enumerate(grads))
+
+
+def sdf_train_scattered_levels(features, meta, grads) -> int:
+    """Bit mask of the levels sdf_train_raw scatters with atomics from its kernel (bricks beyond the pull's reach)."""
     want = sum(1 << l for l, gr in enumerate(grads) if gr is not None and not (meta.ignore_mask >> l) & 1)
-    if not want:
-        return False
     pulled = int(_lib.load().miso_grad_pull_levels(C.byref(_fill_grid(features, meta, grads, data=False)), SortedBatch.TILES))
-    return (want & ~pulled) == 0
+    return want & ~pulled
 
 
 def sdf_train_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatch, loss_inputs, loss_slots, grads,
                   loss_type="L1", weight_sdf=1.0, weight_fs=0.0, trunc_dist=0.0, sdf_out=None, n_live=None,
                   touched=None, zeroed: bool = False):
     """One binned training step of a frozen-decoder submap in one library call (miso_sdf_train_sorted): forward +
-    mapping loss + decoder backward as ONE launch, then the pull / push of every level's gradient (overwrite
-    semantics: ``grads`` need no zero-fill).  Same results as sdf_fwd_loss_raw + sdf_bwd_raw(gsdf_sorted=True,
-    overwrite=True); requires sdf_train_supported(...)."""
+    mapping loss + decoder backward as ONE launch -- which also scatters the levels the pull cannot form, with float
+    atomics -- then the pull / push of the other levels' gradient (overwrite semantics: ``grads`` need no zero-fill).
+    Same results as sdf_fwd_loss_raw + sdf_bwd_raw(gsdf_sorted=True, overwrite=True)."""
     _require_hip(loss_inputs, loss_slots, *features)
     if n_live is not None:
         assert n_live.is_cuda and n_live.dtype == torch.int32 and n_live.numel() == 1
@@ -590,6 +594,22 @@ def sdf_train_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatch, 
         C.byref(g), C.byref(m), _ptr(packed), C.byref(sorted_batch.struct), n, _LOSS_TYPES[loss_type], float(weight_sdf),
         float(weight_fs), float(trunc_dist), _ptr(loss_inputs), _ptr(sdf_out), _ptr(loss_slots), _ptr(n_live), _ptr(ws),
         _stream(loss_inputs)), "miso_sdf_train_sorted")
+
+
+def sdf_train_unsorted_raw(x, features, meta, pack: DecoderPack, loss_inputs, loss_slots, grads, loss_type="L1",
+                           weight_sdf=1.0, weight_fs=0.0, trunc_dist=0.0, sdf_out=None, touched=None):
+    """One training step of a frozen-decoder submap on an UNBINNED (small) batch in one launch (miso_sdf_train):
+    forward + mapping loss + decoder backward + the atomic scatter of every level's gradient, ADDED to ``grads``.
+    Same results as sdf_fwd_loss_unsorted_raw + sdf_bwd_raw up to the order of the float atomics."""
+    _require_hip(x, loss_inputs, loss_slots, *features)
+    m, packed = pack.get()
+    n = x.shape[0]
+    assert x.is_contiguous() and loss_inputs.shape == (n, 4) and loss_inputs.is_contiguous()
+    assert loss_slots.is_contiguous() and loss_slots.numel() == _lib.LOSS_SLOTS * 2
+    g = _fill_grid(features, meta, grads, touched=touched)
+    _lib.check(_lib.load().miso_sdf_train(
+        C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _LOSS_TYPES[loss_type], float(weight_sdf), float(weight_fs),
+        float(trunc_dist), _ptr(loss_inputs), _ptr(sdf_out), _ptr(loss_slots), _stream(x)), "miso_sdf_train")
 
 
 def sdf_fwd_loss_unsorted_raw(x, features, meta, pack: DecoderPack, loss_inputs, mask, gsdf, loss_slots, loss_type="L1",

@@ -165,8 +165,8 @@ class MappingStep:
                     g.zero_()
         L = len(self.features)
         if self.sorted is not None and self._fused_train():
-            # binned path, every level's gradient formed from the d-feat rows: forward + loss + decoder backward are ONE
-            # launch (sdf_train_kernel), then the pull / push
+            # binned path: forward + loss + decoder backward are ONE launch (sdf_train_kernel, which also scatters the
+            # levels whose bricks are beyond the pull's reach), then the pull / push of the other levels
             self.sorted.sort(self.x, self.meta)   # part of the step: a new batch arrives every iteration
             ops.sdf_train_raw(self.features, self.meta, self.pack, self.sorted, self.aux, self.loss_slots, self.grads,
                               lt, ws, wf, td, sdf_out=self.sdf if self.keep_sdf else None, n_live=self.live_rows,
@@ -184,6 +184,10 @@ class MappingStep:
             ops.sdf_bwd_raw(self.x, self.features, self.meta, self.pack, self.gpred, self._mask, False,
                             self.need_levels, self.grads, sorted_batch=self.sorted, overwrite=True, gsdf_sorted=True,
                             touched=self.touched, zeroed=self.adam_device is not None)
+        elif self._fused_train() and self.live_rows is None:
+            # unbinned (small) batch: forward + loss + decoder backward + the atomic scatter of every level, one launch
+            ops.sdf_train_unsorted_raw(self.x, self.features, self.meta, self.pack, self.aux, self.loss_slots, self.grads,
+                                       lt, ws, wf, td, sdf_out=self.sdf if self.keep_sdf else None, touched=self.touched)
         else:
             # forward + mapping loss in one launch here too (the label rows are read by the forward itself)
             if getattr(self, "_mask", None) is None:

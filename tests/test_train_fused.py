@@ -2,8 +2,8 @@
 the two-launch form it replaces (miso_sdf_fwd_sorted_loss + miso_sdf_bwd_sorted): same SDF and loss bit for bit (the
 forward is the same instruction sequence), the same d-feat rows -- hence gradients equal up to the pull's summation
 order -- over the fused shape table, both losses, free-space term, invalid / NaN-labelled rows, padded batches (n_live),
-a crowded batch whose coarse level goes through the matrix-core push, and an ignored level.  Plus: a grid with a level
-the pull cannot own is refused (MISO_E_UNSUPPORTED) and MappingStep keeps the two launches for it.
+a crowded batch whose coarse level goes through the matrix-core push, and an ignored level.  Plus: a level the pull
+cannot own is scattered from the train kernel itself, and unbinned batches (miso_sdf_train) against their two launches.
 The two-launch form itself is pinned to the reference goldens and the CPU oracle elsewhere (test_hip_parity.py,
 test_config_shapes.py)."""
 import numpy as np
@@ -45,7 +45,8 @@ def _setup(C, sizes, H, n, seed, crowded=False, ignore=None, bound=None):
         x[: n // 2] = x[: n // 2] * 0.05 + b.mean(dim=1)
     aux = torch.stack((torch.randn(n, generator=g) * 0.1, (torch.rand(n, generator=g) > 0.15).float(),
                        (torch.rand(n, generator=g) > 0.6).float(), torch.rand(n, generator=g) + 0.5), dim=1)
-    aux[7, 0] = float("nan")
+    if n > 7:
+        aux[7, 0] = float("nan")
     return feats, meta, pack, x.to(DEV).contiguous(), aux.to(DEV).contiguous()
 
 
@@ -121,23 +122,66 @@ def test_train_kernel_with_the_matrix_core_push_on_a_crowded_batch():
     _check(*_both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.15))
 
 
-def test_levels_the_pull_cannot_own_keep_the_two_launches():
+def test_levels_the_pull_cannot_own_are_scattered_from_the_train_kernel():
+    """A level with bricks beyond the pull's reach (200 vertices over 16 tiles: 12.5 per tile and axis; cfg-3's fine
+    level) no longer forces the two launches: sdf_train_kernel<.., SCAT> scatters it with float atomics itself, the
+    other level still goes through the d-feat rows.  Against the two-launch form: SDF and loss bit for bit, the pulled
+    level to the pull's summation order, the scattered one to the order of the atomics."""
     from miso_amd import ops
     from miso_amd.step import MappingStep
-    # 200 vertices over 16 tiles: 12.5 per tile and axis, beyond the pull's 8 -> scattered from the backward kernel
     feats, meta, pack, x, aux = _setup(4, (40, 200), 64, 70000, seed=31)
     aux[7, 0] = 0.0
     grads = [torch.empty_like(f) for f in feats]
-    assert not ops.sdf_train_supported(feats, meta, grads)
-    sb = ops.SortedBatch(x.shape[0], DEV).sort(x, meta)
-    with pytest.raises(RuntimeError):
-        ops.sdf_train_raw(feats, meta, pack, sb, aux, torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), grads)
+    assert ops.sdf_train_supported(feats, meta, grads) and ops.sdf_train_scattered_levels(feats, meta, grads) == 2
+    (s1, sdf1, g1), (s2, sdf2, g2) = _both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.15)
+    assert torch.equal(s1, s2) and torch.equal(sdf1, sdf2)
+    assert (g1[0] - g2[0]).abs().max().item() <= 2e-6 * g2[0].abs().max().item()
+    assert (g1[1] - g2[1]).abs().max().item() <= 2e-5 * g2[1].abs().max().item() and float(g2[1].abs().max()) > 0
+    # only the scattered level wanted: nothing goes through the workspace at all
+    a, b = _both(feats, meta, pack, x, aux, "L2", 1.0, 0.0, 0.0, need=[False, True])
+    assert a[2][0] is None and (a[2][1] - b[2][1]).abs().max().item() <= 2e-5 * b[2][1].abs().max().item()
     step = MappingStep(feats, meta, pack, x.shape[0], "L1", 1.0, 0.1, 0.15, keep_sdf=False)
-    assert step.sorted is not None and not step._fused_train()
+    assert step.sorted is not None and step._fused_train()
     step.set_batch(x, aux[:, 0:1], aux[:, 1:2], aux[:, 2:3], aux[:, 3:4])
     step.run()
     torch.cuda.synchronize()
     assert torch.isfinite(step.loss).all()
+    for a_, b_ in zip(step.grads, g2):
+        assert (a_ - b_).abs().max().item() <= 2e-5 * b_.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(4, (16, 80), 64), (8, (32, 64, 128), 64), (4, (48,), 32), (4, (16, 32, 48, 64), 64)])
+@pytest.mark.parametrize("n", [1, 65, 3000])
+def test_unbinned_train_kernel_equals_forward_plus_backward(shape, n):
+    """miso_sdf_train (an unbinned batch: forward + loss + decoder backward + the atomic scatter of every level in one
+    launch) against miso_sdf_fwd_loss + miso_sdf_bwd: SDF bit for bit, loss to the order of the per-workgroup sums,
+    gradients (added to what the buffers held) to the order of the float atomics; touched flags alike."""
+    from miso_amd import ops
+    C, sizes, H = shape
+    feats, meta, pack, x, aux = _setup(C, sizes, H, n, seed=n + len(sizes))
+    if n > 7:
+        aux[7, 0] = 0.0
+    else:
+        aux[:, 0] = 0.1
+    L = len(feats)
+    mask = torch.empty(((n + 63) // 64) * 64 * ops.sdf_mask_words(pack), device=DEV, dtype=torch.int32)
+    gpred = torch.empty(n, 1, device=DEV)
+    s2, sdf2 = torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), torch.empty(n, 1, device=DEV)
+    g2 = [torch.full_like(f, 0.25) for f in feats]
+    t2 = [ops.adam_active_flags(f) for f in feats]
+    ops.sdf_fwd_loss_unsorted_raw(x, feats, meta, pack, aux, mask, gpred, s2, "L1", 1.0, 0.1, 0.15, sdf_out=sdf2)
+    ops.sdf_bwd_raw(x, feats, meta, pack, gpred, mask, False, [True] * L, g2, touched=t2)
+    s1, sdf1 = torch.ones_like(s2), torch.empty_like(sdf2)
+    g1 = [torch.full_like(f, 0.25) for f in feats]
+    t1 = [ops.adam_active_flags(f) for f in feats]
+    ops.sdf_train_unsorted_raw(x, feats, meta, pack, aux, s1, g1, "L1", 1.0, 0.1, 0.15, sdf_out=sdf1, touched=t1)
+    torch.cuda.synchronize()
+    assert torch.equal(sdf1, sdf2)
+    assert (s1.sum(0) - s2.sum(0)).abs().max().item() <= 2e-6 * max(s2.sum(0).abs().max().item(), 1e-12)
+    for a, b, ta, tb in zip(g1, g2, t1, t2):
+        scale = (b - 0.25).abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-7         # (0.25 + tiny: one ulp of 0.25 is 3e-8)
+        assert torch.equal(ta, tb)
 
 
 def test_stream_launches_and_graph_replays_give_the_same_step():
