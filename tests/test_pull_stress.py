@@ -14,9 +14,15 @@ def relerr(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
 
 
+@pytest.mark.parametrize("mc", [True, False], ids=["matrix_core", "vector"])
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MISO_STRESS_SEEDS", "14"))))
-def test_binned_encode_matches_atomic(seed, monkeypatch):
+def test_binned_encode_matches_atomic(seed, mc, monkeypatch):
+    """mc: the matrix-core pull (grad_pull_mc.hip: taken for levels at least as fine as the binning) or, with
+    MISO_PULL_MC=0, the vector kernels of grad_pull.hip for every level (they stay the path of coarser grids and of the
+    second-order gradient)."""
     from miso_amd import ops
+    if not mc:
+        monkeypatch.setenv("MISO_PULL_MC", "0")
     rs = np.random.RandomState(1000 + seed)
     L = int(rs.randint(1, 5))
     C = int(rs.choice([4, 8]))
@@ -165,8 +171,9 @@ def test_binned_fused_matches_plain(seed):
 
 @pytest.mark.parametrize("shape", ["coarse_only", "cfg2"])
 def test_heavy_tiles_are_cut_and_summed_exactly(shape, monkeypatch):
-    """A batch that crowds 60 % of its points into two spots: the pull cuts the over-full tiles into slices and a
-    second launch adds them.  Same gradients as with the cut disabled (one wavefront per tile) up to fp32
+    """A batch that crowds 60 % of its points into two spots.  The matrix-core pull (grad_pull_mc.hip) works such blocks
+    off in epochs (table and pool overflow); the vector kernels (MISO_PULL_MC=0) cut the over-full tiles into slices
+    that a second launch adds.  Same gradients from both, as with the cut disabled (one wavefront per tile) up to fp32
     summation order, same as the atomic scatter, and the slice queue is left rewound."""
     from miso_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -199,15 +206,20 @@ def test_heavy_tiles_are_cut_and_summed_exactly(shape, monkeypatch):
         return torch.autograd.grad(out, feats, go)
 
     monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", 16384)
+    g_mc = run()
+    assert all(int(q.abs().sum()) == 0 for q in queues)                  # the matrix-core pull queues nothing
+    monkeypatch.setenv("MISO_PULL_MC", "0")
     g_split = run()
     assert queues and all(int(q[:4].abs().sum()) == 0 for q in queues)   # header rewound after use
     assert any(int(q[4:].abs().sum()) > 0 for q in queues)               # and slices were indeed queued
     monkeypatch.setenv("MISO_PULL_NO_SPLIT", "1")
     g_whole = run()
     monkeypatch.delenv("MISO_PULL_NO_SPLIT")
+    monkeypatch.delenv("MISO_PULL_MC")
     monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", None)
     g_atomic = run()
-    for a, w, c in zip(g_split, g_whole, g_atomic):
+    for m, a, w, c in zip(g_mc, g_split, g_whole, g_atomic):
+        assert relerr(m, c) < 2e-5
         assert relerr(a, w) < 2e-5
         assert relerr(a, c) < 2e-5
 
