@@ -38,12 +38,23 @@ namespace miso {
 
 constexpr int MC_WAVES = 8;
 constexpr int MC_CAND = 1024;          // table entries (a uniform cfg-2 batch: ~1000 per block)
-constexpr int MC_POOL = 5120;          // (sample, sub-brick) pairs incl. padding (uniform cfg-2: ~3800)
+constexpr int MC_POOL = 4608;          // (sample, sub-brick) pairs incl. padding (uniform cfg-2: 3830 +- 130, max 4200; more: halved ranges)
 constexpr int MC_ITEMS = 512;          // sub-brick code space: level (2 bits) | sz (3) | sy (2) | sx (2)
 constexpr int MC_UN = 8;               // 64-sample steps in flight per wavefront in the sweep
 constexpr int MC_NULL = 0xFFFF;        // pool padding
 constexpr int MC_LVL = 20;             // words per level record in LDS
 constexpr int MC_MAXL = 4;
+
+// one pulled level, as the kernel reads it (everything by value: no dependent kernel-argument loads)
+struct McLv {
+  float* grad;
+  unsigned char* touched;    // miso_level_t.grad_touched or nullptr
+  int X, Y, Z, foff;
+  int sX, sY, sZ;            // element strides of grad (channels are contiguous)
+  int live;                  // 0: an ignored level -- zero-filled, nothing routed
+  int bdiv[3];               // size / T where T divides the size, else 0
+  float inv_size[3];
+};
 
 struct McK {
   int T[3];                  // sort tiles per axis
@@ -54,35 +65,37 @@ struct McK {
   const int* perm;
   int64_t ld;
   int nl;                    // pulled levels
-  int lev[MC_MAXL];
-  int bdiv[MC_MAXL][3];      // size / T where T divides the size, else 0
-  float inv_size[MC_MAXL][3];
   int overwrite;             // 1: grad = sum, 0: grad += sum
-  int prof_wave;             // dev: the wavefront that stamps (MISO_MC_PROF=1+wave)
-  unsigned long long* prof;  // dev (MISO_MC_PROF): clocks per phase summed over the workgroups' wavefront 0, or nullptr
   unsigned int drow_bytes;   // bytes of the d-feat rows: n * ld * 4 (< 2^31: row offsets are 32-bit buffer offsets)
   int debug;                 // dev ablation (MISO_DEBUG_PULL): 1 no MFMAs, 2 no staging loads, 4 no stores, 8 no multiply
                              // phase, 16 nothing after the sweep
+  int prof_wave;             // dev: the wavefront that stamps (MISO_MC_PROF=1+wave)
+  unsigned long long* prof;  // dev (MISO_MC_PROF): clocks per phase, or nullptr
+  McLv lv[MC_MAXL];
 };
 
 // LDS layout (32-bit words)
 constexpr int MC_CS = 68;              // words per staged component: 64 pairs, padded so that 16-byte reads of different
                                        // components fall into different banks
 template <int C, int NLV> struct McLds {
+  static constexpr int ZS = 16 / C;
   static constexpr int O_CAND = 0;                                   // float4[MC_CAND + 1]: the last is the null entry
-  static constexpr int O_POOL = O_CAND + (MC_CAND + 1) * 4;                // uint16[MC_POOL]: table slot of every pair
-  static constexpr int O_GCODE = O_POOL + MC_POOL / 2;               // uint16[MC_POOL / 4]: sub-brick code of every 4 pairs
-  static constexpr int O_CNT = O_GCODE + MC_POOL / 8;                // int[MC_ITEMS]: pairs per sub-brick
-  static constexpr int O_CUR = O_CNT + MC_ITEMS;                     // int[MC_ITEMS]: fill cursors
+  static constexpr int O_POOL = O_CAND + (MC_CAND + 1) * 4;          // uint32[MC_POOL]: table slot | sub-brick code << 16
+  static constexpr int O_CNT = O_POOL + MC_POOL;                     // int[MC_ITEMS]: pairs per sub-brick
+  static constexpr int O_CUR = O_CNT + MC_ITEMS;                     // int[MC_ITEMS]: fill cursors (absolute)
   static constexpr int O_OFF = O_CUR + MC_ITEMS;                     // int[MC_ITEMS]: first pair of every sub-brick
-  static constexpr int O_COST = O_OFF + MC_ITEMS;                    // int[MC_ITEMS]: cost of the sub-bricks before (share bounds)
-  static constexpr int O_MISC = O_COST + MC_ITEMS;                   // 96 ints
-  static constexpr int O_LVL = O_MISC + 96;                          // MC_MAXL records of MC_LVL ints
-  static constexpr int O_STAGE = O_LVL + MC_MAXL * MC_LVL;           // per wavefront: (12 weights + C d-feats) x MC_CS
-  static constexpr int STAGE = (12 + C) * MC_CS;
+  static constexpr int O_MISC = O_OFF + MC_ITEMS;                    // 96 ints
+  static constexpr int O_LVL = O_MISC + 96;                          // MC_MAXL block-geometry records of MC_LVL words
+  static constexpr int O_LVG = O_LVL + MC_MAXL * MC_LVL;             // MC_MAXL records of 8 words: grad, strides, touched
+  static constexpr int O_STAGE = O_LVG + MC_MAXL * 8;                // per wavefront: (8 + ZS weights + C d-feats) x MC_CS
+  static constexpr int NCOMP = 8 + ZS + C;
+  static constexpr int STAGE = NCOMP * MC_CS;
   static constexpr int WORDS = O_STAGE + MC_WAVES * STAGE;
-  // the routing codes (uint16 per table entry and level) live in the staging area, which is idle while routing runs
-  static_assert(NLV * MC_CAND / 2 <= MC_WAVES * STAGE, "codes must fit the staging area");
+  // while routing runs the staging area is idle: it holds the routing codes (uint16 per table entry and level) and,
+  // behind them, the sub-bricks' cost prefix
+  static constexpr int O_COST = O_STAGE + MC_MAXL * MC_CAND / 2;
+  static_assert(O_COST + MC_ITEMS <= WORDS, "codes + cost prefix must fit the staging area");
+  static_assert(WORDS * 4 <= 80 * 1024, "two workgroups per CU");
 };
 // O_MISC slots
 constexpr int M_NSURV = 0, M_FULL = 1, M_MORE = 2, M_PTOT = 3, M_A = 8, M_B = 16, M_CONT = 24, M_EMPTY = 32, M_BOUND = 40,
@@ -115,7 +128,7 @@ __device__ __forceinline__ McLevel mc_level(const int* lvl, int d) {
   }
 
 template <int C, int NLV>
-__global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g, McK pk) {
+__global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) {
   using L = McLds<C, NLV>;
   constexpr int ZS = 16 / C;                    // sub-brick vertices along z
   constexpr int ZSH = (C == 8) ? 1 : 2;         // log2(ZS)
@@ -123,14 +136,14 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* ismem = reinterpret_cast<int*>(smem);
   float4* cand = reinterpret_cast<float4*>(smem + L::O_CAND);
-  uint16_t* pool = reinterpret_cast<uint16_t*>(ismem + L::O_POOL);
-  uint16_t* gcode = reinterpret_cast<uint16_t*>(ismem + L::O_GCODE);
+  unsigned* pool = reinterpret_cast<unsigned*>(ismem + L::O_POOL);
   int* cnt = ismem + L::O_CNT;
   int* cur = ismem + L::O_CUR;
   int* off = ismem + L::O_OFF;
   int* misc = ismem + L::O_MISC;
-  int* coff = ismem + L::O_COST;
+  int* coff = ismem + L::O_COST;                 // (in the staging area: idle while routing runs)
   int* lvl = ismem + L::O_LVL;
+  int* lvg = ismem + L::O_LVG;
   uint16_t* codes = reinterpret_cast<uint16_t*>(ismem + L::O_STAGE);      // [NLV][MC_CAND]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* stg = smem + L::O_STAGE + wave * L::STAGE;       // [12 + C][MC_CS]: wx[4], wy[4], wz[4], d[C]; pair (g, k) at k 16 + g
@@ -143,10 +156,20 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
   const int o_vz = (C == 8) ? (o_i >> 3) : (o_i >> 2), o_c = (C == 8) ? (o_i & 7) : (o_i & 3);
   // this lane's four operand components in the staging area (word offsets; + 4 Q for quad Q of the chunk)
   const int rd_x = (o_i & 3) * MC_CS + o_k * 16, rd_y = (4 + (o_i >> 2)) * MC_CS + o_k * 16;
-  const int rd_z = (8 + o_vz) * MC_CS + o_k * 16, rd_d = (12 + o_c) * MC_CS + o_k * 16;
+  const int rd_z = (8 + o_vz) * MC_CS + o_k * 16, rd_d = (8 + ZS + o_c) * MC_CS + o_k * 16;
   // and where it writes the pair it stages: pair = lane, group g = lane >> 2, k = lane & 3
   const int wr_p = (lane & 3) * 16 + (lane >> 2);
 
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int d = 0; d < NLV; ++d) {
+      if (d >= pk.nl) continue;
+      const McLv& lv = pk.lv[d];
+      *reinterpret_cast<float**>(lvg + d * 8) = lv.grad;
+      lvg[d * 8 + 2] = lv.sX; lvg[d * 8 + 3] = lv.sY; lvg[d * 8 + 4] = lv.sZ;
+      *reinterpret_cast<unsigned char**>(lvg + d * 8 + 6) = lv.touched;
+    }
+  }
   if (pk.prof && threadIdx.x < 16) misc[M_PROF + threadIdx.x] = 0;
   unsigned long long t_prev = pk.prof ? __builtin_readcyclecounter() : 0ull;
   {
@@ -159,37 +182,47 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
       const int b3[3] = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};      // one workgroup per block of tiles
 #pragma unroll
       for (int a = 0; a < 3; ++a) { tlo[a] = 1 << 20; thi[a] = -1; ulo[a] = 3e30f; uhi[a] = -3e30f; }
+      // (all kernel-argument fields first: one batch of scalar loads instead of a dependent load per level and axis)
+      int size_[NLV][3], bdiv_[NLV][3], foff_[NLV], live_[NLV];
+      float inv_[NLV][3];
+#pragma unroll
+      for (int d = 0; d < NLV; ++d) {
+        const McLv& lv = pk.lv[d];
+        size_[d][0] = lv.X; size_[d][1] = lv.Y; size_[d][2] = lv.Z; foff_[d] = lv.foff; live_[d] = lv.live;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { bdiv_[d][a] = lv.bdiv[a]; inv_[d][a] = lv.inv_size[a]; }
+      }
+      const int T3[3] = {pk.T[0], pk.T[1], pk.T[2]};
 #pragma unroll
       for (int d = 0; d < NLV; ++d) {
         if (d >= pk.nl) continue;
-        const LevelK& lv = g.lv[pk.lev[d]];
-        const bool live = !((g.ignore_mask >> pk.lev[d]) & 1u);
-        const int size[3] = {lv.X, lv.Y, lv.Z};
+        const bool live = live_[d] != 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const int t0 = 2 * b3[a], t1 = min(2 * b3[a] + 2, pk.T[a]);
-          const int B = pk.bdiv[d][a];
+          const int sz = size_[d][a];
+          const int t0 = 2 * b3[a], t1 = min(2 * b3[a] + 2, T3[a]);
+          const int B = bdiv_[d][a];
           int lo, hi, v0, E;
           if (B) {
             v0 = t0 * B; E = (t1 - t0) * B;
             lo = t0 - 1; hi = t1;                      // exact for size = B T
           } else {
-            v0 = t0 * size[a] / pk.T[a];
-            E = t1 * size[a] / pk.T[a] - v0;
-            lo = floor_div((2 * v0 - 1) * pk.T[a] - 1, 2 * size[a]);
-            hi = floor_div((2 * (v0 + E) + 1) * pk.T[a] + 1, 2 * size[a]);
+            v0 = t0 * sz / T3[a];
+            E = t1 * sz / T3[a] - v0;
+            lo = floor_div((2 * v0 - 1) * T3[a] - 1, 2 * sz);
+            hi = floor_div((2 * (v0 + E) + 1) * T3[a] + 1, 2 * sz);
           }
           if (threadIdx.x == 0) {
-            lvl[d * MC_LVL + a] = size[a]; lvl[d * MC_LVL + 4 + a] = v0; lvl[d * MC_LVL + 8 + a] = E;
-            if (a == 0) lvl[d * MC_LVL + 3] = lv.foff;
+            lvl[d * MC_LVL + a] = sz; lvl[d * MC_LVL + 4 + a] = v0; lvl[d * MC_LVL + 8 + a] = E;
+            if (a == 0) lvl[d * MC_LVL + 3] = foff_[d];
             // the routing's position relative to the block, one fma: xn size/2 + ((size - 1)/2 - v0)
-            reinterpret_cast<float*>(lvl)[d * MC_LVL + 12 + a] = 0.5f * (float)size[a];
-            reinterpret_cast<float*>(lvl)[d * MC_LVL + 16 + a] = 0.5f * (float)(size[a] - 1) - (float)v0;
+            reinterpret_cast<float*>(lvl)[d * MC_LVL + 12 + a] = 0.5f * (float)sz;
+            reinterpret_cast<float*>(lvl)[d * MC_LVL + 16 + a] = 0.5f * (float)(sz - 1) - (float)v0;
           }
           if (live) {        // (an ignored level is still zero-filled, its points are just not routed)
-            tlo[a] = min(tlo[a], max(lo, 0)); thi[a] = max(thi[a], min(hi, pk.T[a] - 1));
-            ulo[a] = fminf(ulo[a], (2.0f * v0 - 1.0f) * pk.inv_size[d][a] - 1.0f - 8e-6f);
-            uhi[a] = fmaxf(uhi[a], (2.0f * (v0 + E) + 1.0f) * pk.inv_size[d][a] - 1.0f + 8e-6f);
+            tlo[a] = min(tlo[a], max(lo, 0)); thi[a] = max(thi[a], min(hi, T3[a] - 1));
+            ulo[a] = fminf(ulo[a], (2.0f * v0 - 1.0f) * inv_[d][a] - 1.0f - 8e-6f);
+            uhi[a] = fmaxf(uhi[a], (2.0f * (v0 + E) + 1.0f) * inv_[d][a] - 1.0f + 8e-6f);
           }
         }
       }
@@ -213,7 +246,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
         cand[MC_CAND] = make_float4(2e30f, 2e30f, 2e30f, __int_as_float(-1));      // what pool padding points at
       }
       for (int i = threadIdx.x; i < MC_ITEMS; i += NT) cnt[i] = 0;
-      for (int i = threadIdx.x; i < MC_POOL / 2; i += NT) ismem[L::O_POOL + i] = (int)0xFFFFFFFFu;
+      for (int i = threadIdx.x; i < MC_POOL; i += NT) pool[i] = 0xFFFFFFFFu;
       __syncthreads();
       if (p_cur < 0) p_cur = (r_cur < nrows) ? __builtin_amdgcn_readlane(rs_v, min(r_cur, 63)) : 0;
       MC_STAMP(0)
@@ -292,7 +325,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
           const float xs[3] = {c4.x, c4.y, c4.z};
 #pragma unroll
           for (int d = 0; d < NLV; ++d) {
-            if (d >= pk.nl || ((g.ignore_mask >> pk.lev[d]) & 1u)) continue;
+            if (d >= pk.nl || !pk.lv[d].live) continue;
             // (cell relative to the block by ONE fma: a sample within an ulp of a cell face may be routed by the neighbouring
             // cell -- the sub-brick it then misses would have got a weight of that ulp)
             const int4 re = *reinterpret_cast<const int4*>(lvl + d * MC_LVL + 8);
@@ -392,7 +425,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
           const bool act = t < hi;
 #pragma unroll
           for (int d = 0; d < NLV; ++d) {
-            if (d >= pk.nl || ((g.ignore_mask >> pk.lev[d]) & 1u)) continue;
+            if (d >= pk.nl || !pk.lv[d].live) continue;
             const int code = act ? (int)codes[d * MC_CAND + t] : 0;
             const bool ok = (code & 0x8000) != 0;
             const int s0x = code & 3, s0y = (code >> 2) & 3, s0z = (code >> 4) & 7;
@@ -421,11 +454,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
               for (int j = 0; j < 4; ++j) {
                 if (j < n && mm[j]) {
                   const int b = __builtin_amdgcn_readlane(base, j), cj = __builtin_amdgcn_readlane(mycode, j);
-                  if ((mm[j] >> lane) & 1ull) {
-                    const int p = b + (int)__popcll(mm[j] & lt_mask);
-                    pool[p] = (uint16_t)t;
-                    if ((p & 3) == 0) gcode[p >> 2] = (uint16_t)cj;
-                  }
+                  if ((mm[j] >> lane) & 1ull) pool[b + (int)__popcll(mm[j] & lt_mask)] = (unsigned)t | ((unsigned)cj << 16);
                 }
               }
             } else {
@@ -443,10 +472,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
 #pragma unroll
               for (int k = 0; k < 8; ++k) {
                 const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-                if (pos[k] >= 0) {
-                  pool[pos[k]] = (uint16_t)t;
-                  if ((pos[k] & 3) == 0) gcode[pos[k] >> 2] = (uint16_t)(item0 + (dz << 4) + (dy << 2) + dx);
-                }
+                if (pos[k] >= 0) pool[pos[k]] = (unsigned)t | ((unsigned)(item0 + (dz << 4) + (dy << 2) + dx) << 16);
               }
             }
           }
@@ -458,9 +484,8 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
 #pragma unroll
           for (int d = 0; d < NLV; ++d) {
             if (d >= pk.nl) continue;
-            const LevelK& lv = g.lv[pk.lev[d]];
             const McLevel m = mc_level(lvl, d);
-            const bool live = !((g.ignore_mask >> pk.lev[d]) & 1u);
+            const bool live = pk.lv[d].live != 0;
             const int j = 16 * wave + (lane & 15);
             const int sx = j & 3, sy = (j >> 2) & 3, sz = j >> 4;
             const bool valid = lane < 16 && 4 * sx < m.E[0] && 4 * sy < m.E[1] && ZS * sz < m.E[2];
@@ -469,9 +494,12 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
               const int jj = 16 * wave + (int)__builtin_ctzll(em);
               em &= em - 1;
               const int lx = 4 * (jj & 3) + a_vx, ly = 4 * ((jj >> 2) & 3) + a_vy, lz = ZS * (jj >> 4) + a_vz;
-              if (lx < m.E[0] && ly < m.E[1] && lz < m.E[2])
-                *reinterpret_cast<float4*>(lv.grad + (m.v0[2] + lz) * lv.sZ + (m.v0[1] + ly) * lv.sY + (m.v0[0] + lx) * lv.sX +
-                                           a_c0) = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (lx < m.E[0] && ly < m.E[1] && lz < m.E[2]) {
+                const int4 gq = *reinterpret_cast<const int4*>(lvg + d * 8);                 // grad, sX, sY
+                float* gp = *reinterpret_cast<float* const*>(lvg + d * 8);
+                *reinterpret_cast<float4*>(gp + (m.v0[2] + lz) * lvg[d * 8 + 4] + (m.v0[1] + ly) * gq.w + (m.v0[0] + lx) * gq.z + a_c0) =
+                    make_float4(0.f, 0.f, 0.f, 0.f);
+              }
             }
           }
         }
@@ -486,10 +514,10 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
         int first_code = -1, last_code = -1;
         bool sh_before = false, sh_after = false;
         if (g_begin < g_end) {
-          first_code = __builtin_amdgcn_readfirstlane((int)gcode[g_begin]);
-          last_code = __builtin_amdgcn_readfirstlane((int)gcode[g_end - 1]);
-          sh_before = g_begin > 0 && __builtin_amdgcn_readfirstlane((int)gcode[g_begin - 1]) == first_code;
-          sh_after = g_end < G && __builtin_amdgcn_readfirstlane((int)gcode[g_end]) == last_code;
+          first_code = __builtin_amdgcn_readfirstlane((int)(pool[4 * g_begin] >> 16));
+          last_code = __builtin_amdgcn_readfirstlane((int)(pool[4 * g_end - 4] >> 16));
+          sh_before = g_begin > 0 && __builtin_amdgcn_readfirstlane((int)(pool[4 * g_begin - 4] >> 16)) == first_code;
+          sh_after = g_end < G && __builtin_amdgcn_readfirstlane((int)(pool[4 * g_end] >> 16)) == last_code;
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, part_a = {0.f, 0.f, 0.f, 0.f};
         int cur_code = -1;
@@ -507,9 +535,14 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
           const int d = code >> 7;
           if (d != fl_d) {
             fl_d = d;
-            const LevelK& lv = g.lv[pk.lev[d]];
             const McLevel m = mc_level(lvl, d);
-            fl_sX = lv.sX; fl_sY = lv.sY; fl_sZ = lv.sZ; fl_grad = lv.grad; fl_touched = lv.touched;
+            const int4 g0_ = *reinterpret_cast<const int4*>(lvg + d * 8), g1_ = *reinterpret_cast<const int4*>(lvg + d * 8 + 4);
+            fl_sX = __builtin_amdgcn_readfirstlane(g0_.z); fl_sY = __builtin_amdgcn_readfirstlane(g0_.w);
+            fl_sZ = __builtin_amdgcn_readfirstlane(g1_.x);
+            fl_grad = reinterpret_cast<float*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(g0_.y) << 32) |
+                                               (unsigned)__builtin_amdgcn_readfirstlane(g0_.x));
+            fl_touched = reinterpret_cast<unsigned char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane(g1_.w) << 32) |
+                                                          (unsigned)__builtin_amdgcn_readfirstlane(g1_.z));
             fl_e0 = __builtin_amdgcn_readfirstlane(m.E[0]); fl_e1 = __builtin_amdgcn_readfirstlane(m.E[1]);
             fl_e2 = __builtin_amdgcn_readfirstlane(m.E[2]);
             fl_full = !(fl_e0 & 3) && !(fl_e1 & 3) && !(fl_e2 & (ZS - 1));
@@ -540,8 +573,10 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
         auto stage_a = [&](int g0, int ng) {
           const int q = 4 * g0 + lane;
           const bool live = lane < 4 * ng;
-          nslot = live ? min((int)pool[q], MC_CAND) : MC_CAND;     // padding (0xFFFF) and idle lanes: the null entry
-          rcode = live ? (int)gcode[q >> 2] : last_code;           // (idle groups of the last chunk continue its last item)
+          const unsigned e = live ? pool[q] : 0xFFFFFFFFu;
+          nslot = min((int)(e & 0xffffu), MC_CAND);                // padding (0xFFFF) and idle lanes: the null entry
+          // the group's code is its first pair's (always a real entry); idle groups of the last chunk continue its last item
+          rcode = __builtin_amdgcn_mov_dpp(live ? (int)(e >> 16) : last_code, 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, true);
         };
         auto stage_l = [&]() {      // the d-feat row through a buffer load: the null entry's row -1 is out of range, reads as zeros
           int row = __float_as_int(smem[L::O_CAND + 4 * nslot + 3]);
@@ -616,7 +651,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
 #pragma unroll
           for (int o = 0; o < 8 + ZS; ++o) stg[o * MC_CS + wr_p] = rw[o];
 #pragma unroll
-          for (int c = 0; c < C; ++c) stg[(12 + c) * MC_CS + wr_p] = rd[c];
+          for (int c = 0; c < C; ++c) stg[(8 + ZS + c) * MC_CS + wr_p] = rd[c];
           const int codev = rcode;
           wave_sync_lds();
           MC_STAMP(12)
@@ -692,7 +727,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(GridK g,
         if (lo < ncand) {      // (rare: the pool overflowed) the next range recounts
           __syncthreads();
           for (int i = threadIdx.x; i < MC_ITEMS; i += NT) cnt[i] = 0;
-          for (int i = threadIdx.x; i < MC_POOL / 2; i += NT) ismem[L::O_POOL + i] = (int)0xFFFFFFFFu;
+          for (int i = threadIdx.x; i < MC_POOL; i += NT) pool[i] = 0xFFFFFFFFu;
         }
         __syncthreads();
         MC_STAMP(11)
@@ -736,12 +771,17 @@ hipError_t launch_grad_pull_mc(const GridK& g, int C, const int T[3], const int*
   pk.tile_off = tile_off; pk.xn = reinterpret_cast<const float4*>(xn); pk.dfeat = dfeat; pk.perm = perm; pk.ld = ld;
   for (int l = 0; l < g.n_levels; ++l)
     if ((level_mask >> l) & 1u) {
-      const int size[3] = {g.lv[l].X, g.lv[l].Y, g.lv[l].Z};
+      const LevelK& lv = g.lv[l];
+      McLv& o = pk.lv[pk.nl++];
+      const int size[3] = {lv.X, lv.Y, lv.Z};
+      o.grad = lv.grad; o.touched = lv.touched;
+      o.X = lv.X; o.Y = lv.Y; o.Z = lv.Z; o.foff = lv.foff;
+      o.sX = lv.sX; o.sY = lv.sY; o.sZ = lv.sZ;
+      o.live = ((g.ignore_mask >> l) & 1u) ? 0 : 1;
       for (int a = 0; a < 3; ++a) {
-        pk.bdiv[pk.nl][a] = (size[a] % T[a] == 0) ? size[a] / T[a] : 0;
-        pk.inv_size[pk.nl][a] = 1.0f / (float)size[a];
+        o.bdiv[a] = (size[a] % T[a] == 0) ? size[a] / T[a] : 0;
+        o.inv_size[a] = 1.0f / (float)size[a];
       }
-      pk.lev[pk.nl++] = l;
     }
   pk.overwrite = overwrite;
   pk.drow_bytes = (unsigned int)(n * ld * 4);
@@ -755,7 +795,7 @@ hipError_t launch_grad_pull_mc(const GridK& g, int C, const int T[3], const int*
   }();
   pk.prof = prof;
   pk.prof_wave = prof ? atoi(getenv("MISO_MC_PROF")) - 1 : 0;
-  void (*k)(GridK, McK) = nullptr;
+  void (*k)(McK) = nullptr;
   size_t words = 0;
 #define PICK(c, n)                                                      \
   if (C == c && ((pk.nl <= 2 && n == 2) || pk.nl == n)) {               \
@@ -768,7 +808,7 @@ hipError_t launch_grad_pull_mc(const GridK& g, int C, const int T[3], const int*
   const size_t lds = words * sizeof(float);
   hipError_t e = allow_dynamic_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
-  k<<<dim3((unsigned)pk.nb[0], (unsigned)pk.nb[1], (unsigned)pk.nb[2]), 64 * MC_WAVES, lds, s>>>(g, pk);
+  k<<<dim3((unsigned)pk.nb[0], (unsigned)pk.nb[1], (unsigned)pk.nb[2]), 64 * MC_WAVES, lds, s>>>(pk);
   if (prof) {
     static int calls = 0;
     if (++calls % 64 == 0) {
