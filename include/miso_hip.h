@@ -168,12 +168,18 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
  * *_sorted calls are identical to the unsorted ones up to fp32 summation order;
  * sdf, grad_sdf (unless MISO_F_GRAD_SDF_SORTED) and grad_x stay in the caller's
  * (original) point order. */
+/* tiles_per_axis (here and wherever a binning is named): a plain count 1..16 (cubic binning), or per-axis counts of 1..32
+ * packed with MISO_TILES_XYZ -- e.g. (25, 13, 25) puts at most 8 vertices of a 200 x 100 x 200 level (ScanNet's fine
+ * level, configs/rgbd/scannet.yaml:23-24) on a tile and axis, which is what the owner-computes gradient can own.  A packed
+ * binning is served by the matrix-core pull only: miso_grad_pull_levels reports which levels it takes (at least 2/3 as many
+ * vertices as tiles on every axis, 4 or 8 channels); second-order gradients (miso_grad_pull with gg_x) need a plain count. */
+#define MISO_TILES_XYZ(tx, ty, tz) ((int32_t)((tx) | ((ty) << 8) | ((tz) << 16)))
 typedef struct {
-  int32_t tiles_per_axis;      /* 1..16 */
+  int32_t tiles_per_axis;      /* 1..16, or MISO_TILES_XYZ(tx, ty, tz) */
   const float* x_sorted;       /* (N,3) points grouped by tile                   */
   const float* xn_sorted;      /* (N,4) the same normalised to [-1,1] as {x,y,z,0}, 16-B aligned; NULL = absent */
   const int32_t* perm;         /* (N) sorted position -> original index          */
-  const int32_t* tile_offsets; /* (tiles^3 + 1) start of every tile in x_sorted  */
+  const int32_t* tile_offsets; /* (number of tiles + 1) start of every tile in x_sorted; tile (tx,ty,tz) = (tz Ty + ty) Tx + tx */
   /* Optional scratch of the owner-computes gradient (miso_grad_pull, miso_sdf_bwd_sorted):
    * miso_pull_queue_ints(n) int32, ZEROED ONCE by the caller when allocated (the library leaves it
    * zeroed after every call).  With it, tiles that hold far more points than the average are cut

@@ -360,19 +360,19 @@ static int check_sorted(const miso_sorted_t* s, int64_t n) {
   if (!s || !s->tile_offsets) return MISO_E_BADARG;
   if (n > 0 && ((!s->x_sorted && !s->xn_sorted) || !s->perm)) return MISO_E_BADARG;   // an empty batch has no buffers
   if (((uintptr_t)s->xn_sorted & 15u) != 0) return MISO_E_BADARG;
-  if (s->tiles_per_axis < 1 || s->tiles_per_axis > 16) return MISO_E_BADARG;
+  { int t3_[3]; if (!tiles_xyz(s->tiles_per_axis, t3_)) return MISO_E_BADARG; }
   return MISO_OK;
 }
 
 int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis) {
-  if (n < 0 || tiles_per_axis < 1 || tiles_per_axis > 16) return 0;
+  if (n < 0) return 0;
   return sort_workspace_bytes(n, tiles_per_axis);
 }
 
 int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,
                      void* workspace, float* x_sorted, float* xn_sorted, int32_t* perm,
                      int32_t* tile_offsets, void* stream) {
-  if (n < 0 || n >= ((int64_t)1 << 31) || tiles_per_axis < 1 || tiles_per_axis > 16) return MISO_E_BADARG;
+  { int t3_[3]; if (n < 0 || n >= ((int64_t)1 << 31) || !tiles_xyz(tiles_per_axis, t3_)) return MISO_E_BADARG; }
   if (!workspace || !tile_offsets || (n > 0 && (!x || (!x_sorted && !xn_sorted) || !perm))) return MISO_E_BADARG;
   if (((uintptr_t)xn_sorted & 15u) != 0) return MISO_E_BADARG;
   GridK g;
@@ -447,7 +447,7 @@ static int pull_plan(const miso_grid_t* grid, int32_t tiles_per_axis, GridK* g, 
   if (rc) return rc;
   *mask = 0;
   *C = g->lv[0].C;
-  if (tiles_per_axis < 1 || tiles_per_axis > 16) return MISO_E_BADARG;
+  { int t3_[3]; if (!tiles_xyz(tiles_per_axis, t3_)) return MISO_E_BADARG; }
   if (!v4 || (*C != 4 && *C != 8)) return MISO_OK;
   for (int l = 0; l < g->n_levels; ++l)
     if (g->lv[l].C != *C) return MISO_OK;

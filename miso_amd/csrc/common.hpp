@@ -45,6 +45,17 @@ __device__ __forceinline__ void load_point(const GridK& g, const float* __restri
   }
 }
 
+// miso_sorted_t.tiles_per_axis: a plain count (1..16: cubic binning) or MISO_TILES_XYZ(tx, ty, tz), 1..32 per axis
+inline bool tiles_xyz(int32_t code, int T[3]) {
+  if (code >= 1 && code <= 16) { T[0] = T[1] = T[2] = code; return true; }
+  if (code < 256 || (code >> 24) != 0) return false;
+  T[0] = code & 255; T[1] = (code >> 8) & 255; T[2] = (code >> 16) & 255;
+  for (int a = 0; a < 3; ++a)
+    if (T[a] < 1 || T[a] > 32) return false;
+  return true;
+}
+inline bool tiles_cubic16(int32_t code) { return code >= 1 && code <= 16; }
+
 // clears n_words 32-bit words with a kernel (loss.hip; see there why not hipMemsetAsync)
 hipError_t launch_zero_words(void* p, int n_words, hipStream_t s);
 

@@ -1009,16 +1009,27 @@ __global__ __launch_bounds__(64 * PUSH_WAVES) void grad_push_mfma_kernel(GridK g
 // 200 x 100 x 200 over 16 tiles: 13 x 7 x 13) are scattered with float atomics from the backward kernel: owner-computes
 // was built for them four ways over two rounds (tools/experiments/README.md) and every version cost at least what the
 // 4.3 M atomic requests cost.
-uint32_t plan_grad_pull(const GridK& g, int T) {
+uint32_t plan_grad_pull(const GridK& g, int tiles) {
   if (g.flags & (MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER)) return 0;
+  int T3[3];
+  if (!tiles_xyz(tiles, T3)) return 0;
+  // a per-axis or finer-than-16 binning is served by the matrix-core pull only (grad_pull_mc.hip): its levels must be
+  // at least as fine as the binning and share the channel count it is compiled for
+  const bool mc_only = !tiles_cubic16(tiles);
   uint32_t mask = 0;
   int cnt = 0;
   for (int l = 0; l < g.n_levels; ++l) {
     const LevelK& lv = g.lv[l];
     if (!lv.grad) continue;
-    auto bmax = [&](int size) { return (size + T - 1) / T; };
-    if (bmax(lv.X) > PULL_BMAX || bmax(lv.Y) > PULL_BMAX || bmax(lv.Z) > PULL_BMAX) continue;
-    if ((int64_t)lv.X * T >= (1 << 30) || (int64_t)lv.Y * T >= (1 << 30) || (int64_t)lv.Z * T >= (1 << 30)) continue;
+    const int size[3] = {lv.X, lv.Y, lv.Z};
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+      if ((size[a] + T3[a] - 1) / T3[a] > PULL_BMAX) ok = false;
+      if ((int64_t)size[a] * T3[a] >= (1 << 28)) ok = false;
+      if (mc_only && 3 * size[a] < 2 * T3[a]) ok = false;
+    }
+    if (mc_only && ((lv.C != 4 && lv.C != 8) || lv.sC != 1 || lv.C != g.lv[0].C)) ok = false;
+    if (!ok) continue;
     if (cnt++ >= PULL_MAXL) continue;
     mask |= 1u << l;
   }
@@ -1027,7 +1038,9 @@ uint32_t plan_grad_pull(const GridK& g, int T) {
 
 // levels (subset of `pull`) for the matrix-core push: a crowd of at least MISO_DENSE_MIN (100) samples per tile on
 // average, 4 or 8 channels, and every tile's region within PUSH_R vertices per axis
-uint32_t plan_push(const GridK& g, int T, int64_t n, uint32_t pull) {
+uint32_t plan_push(const GridK& g, int tiles, int64_t n, uint32_t pull) {
+  if (!tiles_cubic16(tiles)) return 0;      // (a finer binning: the matrix-core pull takes crowded levels as they come)
+  const int T = tiles;
   static const int dense_min = [] { const char* e = getenv("MISO_DENSE_MIN"); return e ? atoi(e) : 100; }();
   // MISO_F_CROWDED: the caller knows the batch piles up on a few tiles (ray samples: a 54 000-sample batch of the
   // synthetic RGB-D demo put 112 us of pull + drain launches on the 40 x 20 x 40 level, the push 46 us), where the
@@ -1074,10 +1087,13 @@ static hipError_t launch_push(const GridK& g, int C, int T, const int* tile_off,
   return hipGetLastError();
 }
 
-hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, const float* xn,
+hipError_t launch_grad_pull(const GridK& g, int C, int tiles, const int* tile_off, const float* xn,
                             const float* dfeat, int64_t ld, const int* perm, uint32_t level_mask,
                             int overwrite, const float* ggx, int32_t* queue, int64_t queue_ints, hipStream_t s,
                             uint32_t push_mask, int64_t n) {
+  int T3[3];
+  if (!tiles_xyz(tiles, T3)) return hipErrorInvalidValue;
+  const int T = T3[0];       // (the vector kernels below: cubic binning only)
   // push_mask: levels of plan_push the caller has zero-filled (overwrite) -- added to with atomics
   push_mask &= level_mask;
   if (push_mask && !ggx) {
@@ -1091,9 +1107,9 @@ hipError_t launch_grad_pull(const GridK& g, int C, int T, const int* tile_off, c
   if (!level_mask) return hipSuccess;
   {
     // first-order gradients on grids at least as fine as the binning: the matrix-core pull (grad_pull_mc.hip)
-    const int T3[3] = {T, T, T};
     if (!ggx && mc_pull_ok(g, C, T3, level_mask, n, ld))
       return launch_grad_pull_mc(g, C, T3, tile_off, xn, dfeat, ld, perm, level_mask, overwrite, n, s);
+    if (!tiles_cubic16(tiles)) return hipErrorInvalidValue;      // plan_grad_pull admits such a binning for that kernel only
   }
   PullK pk;
   memset(&pk, 0, sizeof(pk));

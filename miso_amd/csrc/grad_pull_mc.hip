@@ -26,8 +26,8 @@
 //       the distribution; a lane stages one pair (three cell_of, 12 weights, the d-feat row: 20 floats in LDS), four
 //       pairs feed one MFMA; a sub-brick that ends inside a share is stored straight from the accumulators, one that
 //       straddles a boundary leaves partial tiles in LDS that the wavefront where it starts sums and stores.
-// Used when no pulled level has fewer vertices than tiles on an axis (the sweep then stays within two tiles of the
-// block); everything else -- second-order weights (MODE 1), grids coarser than the binning -- keeps grad_pull.hip.
+// Used when no pulled level has fewer than 2/3 as many vertices as tiles on an axis (the sweep then stays within 7 tile
+// rows per axis); everything else -- second-order weights (MODE 1), grids coarser than the binning -- keeps grad_pull.hip.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
     }
     const bool any_rows = thi[0] >= tlo[0] && thi[1] >= tlo[1] && thi[2] >= tlo[2];
     const int ny = any_rows ? thi[1] - tlo[1] + 1 : 0;
-    const int nrows = any_rows ? ny * (thi[2] - tlo[2] + 1) : 0;      // <= 64 (launcher: size >= T on every axis)
+    const int nrows = any_rows ? ny * (thi[2] - tlo[2] + 1) : 0;      // <= 49 (launcher: 3 size >= 2 T on every axis)
     int rs_v = 0, re_v = 0;
     if (lane < nrows) {
       const int ry = tlo[1] + lane % ny, rz = tlo[2] + lane / ny;
@@ -753,7 +753,8 @@ bool mc_pull_ok(const GridK& g, int C, const int T[3], uint32_t level_mask, int6
       const int size[3] = {lv.X, lv.Y, lv.Z};
       if (lv.C != C || lv.sC != 1) return false;
       for (int a = 0; a < 3; ++a) {
-        if (size[a] < T[a]) return false;                        // a cell wider than a tile: the sweep would widen
+        if (3 * size[a] < 2 * T[a]) return false;                // cells much wider than tiles: the sweep (<= 7 tile rows per axis,
+                                                                 // 64 in all: the lane table of row bounds) would not cover them
         if ((size[a] + T[a] - 1) / T[a] > PULL_BMAX) return false;
         if ((int64_t)size[a] * T[a] >= (1 << 28)) return false;
       }

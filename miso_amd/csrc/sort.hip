@@ -23,29 +23,31 @@
 
 namespace miso {
 
-__device__ __forceinline__ int tile_of(float px, float py, float pz, const GridK& g, int T) {
+struct Tiles3 { int t[3]; };   // tiles per axis (x, y, z)
+
+__device__ __forceinline__ int tile_of(float px, float py, float pz, const GridK& g, const Tiles3& T) {
   float u[3] = {px, py, pz};
   int t[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     float v = (g.flags & MISO_F_COORDS_NORMALIZED) ? 0.5f * (u[a] + 1.0f)
                                                     : (u[a] - g.bmin[a]) / (g.bmax[a] - g.bmin[a]);
-    v = v * (float)T;
+    v = v * (float)T.t[a];
     if (!(v == v)) v = 0.0f;
-    v = fminf(fmaxf(floorf(v), 0.0f), (float)(T - 1));
+    v = fminf(fmaxf(floorf(v), 0.0f), (float)(T.t[a] - 1));
     t[a] = (int)v;
   }
-  return (t[2] * T + t[1]) * T + t[0];
+  return (t[2] * T.t[1] + t[1]) * T.t[0] + t[0];
 }
 
 constexpr int SORT_THREADS = 1024;
 constexpr int SORT_MAX_BLOCKS = 256;
 
 __global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(GridK g, const float* __restrict__ x, int64_t n,
-                                                                int T, int64_t seg, int* __restrict__ bh,
+                                                                Tiles3 T, int64_t seg, int* __restrict__ bh,
                                                                 uint16_t* __restrict__ tile_id) {
   extern __shared__ int hist[];
-  const int nt = T * T * T;
+  const int nt = T.t[0] * T.t[1] * T.t[2];
   for (int i = threadIdx.x; i < nt; i += blockDim.x) hist[i] = 0;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * seg, hi = min(n, lo + seg);
@@ -194,20 +196,29 @@ static inline int sort_blocks(int64_t n) {
 
 static inline int64_t a256(int64_t v) { return (v + 255) / 256 * 256; }
 
-int64_t sort_workspace_bytes(int64_t n, int T) {
-  int64_t nt = (int64_t)T * T * T;
+int64_t sort_workspace_bytes(int64_t n, int tiles) {
+  int T3[3];
+  if (!tiles_xyz(tiles, T3)) return 0;
+  int64_t nt = (int64_t)T3[0] * T3[1] * T3[2];
   return a256((int64_t)sort_blocks(n) * nt * sizeof(int)) + a256(nt * sizeof(int)) + a256(n * 2);
 }
 
-hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int T, void* ws, float* xs, float* xn,
+hipError_t launch_sort(const GridK& g, const float* x, int64_t n, int tiles, void* ws, float* xs, float* xn,
                        int* perm, int* tile_off, hipStream_t s) {
-  const int nt = T * T * T;
+  Tiles3 T;
+  if (!tiles_xyz(tiles, T.t)) return hipErrorInvalidValue;
+  const int nt = T.t[0] * T.t[1] * T.t[2];
   const int nb = sort_blocks(n);
   const int64_t seg = (n + nb - 1) / nb;
   char* w = reinterpret_cast<char*>(ws);
   int* bh = reinterpret_cast<int*>(w);            w += a256((int64_t)nb * nt * sizeof(int));
   int* count = reinterpret_cast<int*>(w);         w += a256(nt * sizeof(int));
   uint16_t* tid = reinterpret_cast<uint16_t*>(w);
+  {   // a fine binning's histogram (32^3 tiles: 128 KB) is past the default dynamic-LDS limit
+    hipError_t e = allow_dynamic_lds((const void*)sort_hist_kernel, (size_t)nt * sizeof(int));
+    if (e == hipSuccess) e = allow_dynamic_lds((const void*)sort_scatter_kernel, (size_t)(nt + 16) * sizeof(int));
+    if (e != hipSuccess) return e;
+  }
   sort_hist_kernel<<<nb, SORT_THREADS, nt * sizeof(int), s>>>(g, x, n, T, seg, bh, tid);
   sort_prefix_kernel<<<(nt + 63) / 64, 64 * PREFIX_WAVES, 0, s>>>(bh, nb, nt, count);
   sort_scatter_kernel<<<nb, SORT_THREADS, (nt + 16) * sizeof(int), s>>>(g, x, n, nt, seg, bh, count, tid, xs, xn,

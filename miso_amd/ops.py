@@ -394,6 +394,35 @@ def sdf_fused_supported(features, meta: GridMeta, pack: DecoderPack) -> bool:
     return bool(_lib.load().miso_sdf_supported(C.byref(g), C.byref(m)))
 
 
+def pack_tiles(tiles) -> int:
+    """include/miso_hip.h MISO_TILES_XYZ: a count stays a count, (tx, ty, tz) is packed (a cubic one of <= 16 as a count)."""
+    if isinstance(tiles, (tuple, list)):
+        tx, ty, tz = (int(v) for v in tiles)
+        assert all(1 <= v <= 32 for v in (tx, ty, tz)), tiles
+        if tx == ty == tz and tx <= 16:
+            return tx
+        return tx | (ty << 8) | (tz << 16)
+    return int(tiles)
+
+
+def n_tiles(code: int) -> int:
+    return code ** 3 if code < 256 else (code & 255) * ((code >> 8) & 255) * ((code >> 16) & 255)
+
+
+def choose_tiles(features) -> int:
+    """Binning for a training step over these levels ((1,C,Z,Y,X) tensors): 16 tiles per axis, and more (up to 32) on an
+    axis where the finest level would otherwise put more than 8 vertices on a tile -- what the owner-computes gradient can
+    own (ScanNet's 200 x 100 x 200 level: (25, 16, 25)).  A level too fine even for 32 tiles stays scattered."""
+    t = []
+    for a in (4, 3, 2):                       # x, y, z
+        sizes = [int(f.shape[a]) for f in features]
+        need = -(-max(sizes) // 8)
+        # the matrix-core pull (the only kernel of a binning finer than 16) wants 3 size >= 2 tiles of every level
+        cap = (3 * min(sizes)) // 2
+        t.append(need if 16 < need <= min(32, cap) else 16)
+    return pack_tiles(t)
+
+
 class SortedBatch:
     """A point batch binned by coarse spatial tile (miso_sort_points).  Buffers are
     reused across calls with the same n (graph-capture friendly)."""
@@ -406,14 +435,15 @@ class SortedBatch:
     # too few points for the sweep to pay.  None = never automatic.
     AUTO_MIN_POINTS = int(os.environ.get("MISO_SORT_MIN_POINTS", 65536)) or None
 
-    def __init__(self, n: int, device, tiles: int = TILES, keep_metric: bool = False):
-        self.n, self.tiles = int(n), int(tiles)
+    def __init__(self, n: int, device, tiles=TILES, keep_metric: bool = False):
+        """tiles: tiles per axis -- a count (1..16) or per-axis counts (tx, ty, tz) of 1..32 (MISO_TILES_XYZ)."""
+        self.n, self.tiles = int(n), pack_tiles(tiles)
         i32 = dict(device=device, dtype=torch.int32)
         # the kernels read the normalised float4 copy; the metric copy is optional
         self.x_sorted = torch.empty((self.n, 3), device=device, dtype=torch.float32) if keep_metric else None
         self.xn_sorted = torch.empty((self.n, 4), device=device, dtype=torch.float32)
         self.perm = torch.empty(self.n, **i32)
-        self.tile_offsets = torch.empty(self.tiles ** 3 + 1, **i32)
+        self.tile_offsets = torch.empty(n_tiles(self.tiles) + 1, **i32)
         ws = _lib.load().miso_sort_workspace_bytes(self.n, self.tiles)
         self.workspace = torch.empty(max(ws, 1), device=device, dtype=torch.uint8)
         self.struct = _lib.Sorted()
@@ -518,11 +548,12 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
     return gx, grads
 
 
-def sdf_bwd_scattered_levels(features, meta, grads, n: int) -> int:
+def sdf_bwd_scattered_levels(features, meta, grads, n: int, tiles=None) -> int:
     """Bit l set: sdf_bwd_raw(sorted_batch=..., overwrite=True) forms level l's gradient by adding with atomics (and
-    zero-fills it first) rather than by the pull's plain stores (miso_sdf_bwd_scattered_levels)."""
+    zero-fills it first) rather than by the pull's plain stores (miso_sdf_bwd_scattered_levels).  tiles: the batch's
+    binning (SortedBatch.tiles; default the 16-tile one)."""
     g = _fill_grid(features, meta, grads, data=False)
-    return int(_lib.load().miso_sdf_bwd_scattered_levels(C.byref(g), SortedBatch.TILES, n))
+    return int(_lib.load().miso_sdf_bwd_scattered_levels(C.byref(g), pack_tiles(tiles or SortedBatch.TILES), n))
 
 
 def sdf_mask_words(pack: DecoderPack) -> int:
@@ -564,10 +595,12 @@ def sdf_train_supported(features, meta, grads) -> bool:
     return any(gr is not None and not (meta.ignore_mask >> l) & 1 for l, gr in enumerate(grads))
 
 
-def sdf_train_scattered_levels(features, meta, grads) -> int:
-    """Bit mask of the levels sdf_train_raw scatters with atomics from its kernel (bricks beyond the pull's reach)."""
+def sdf_train_scattered_levels(features, meta, grads, tiles=None) -> int:
+    """Bit mask of the levels sdf_train_raw scatters with atomics from its kernel (bricks beyond the pull's reach under
+    the binning `tiles`: SortedBatch.tiles, default the 16-tile one)."""
     want = sum(1 << l for l, gr in enumerate(grads) if gr is not None and not (meta.ignore_mask >> l) & 1)
-    pulled = int(_lib.load().miso_grad_pull_levels(C.byref(_fill_grid(features, meta, grads, data=False)), SortedBatch.TILES))
+    pulled = int(_lib.load().miso_grad_pull_levels(C.byref(_fill_grid(features, meta, grads, data=False)),
+                                                   pack_tiles(tiles or SortedBatch.TILES)))
     return want & ~pulled
 
 

@@ -106,7 +106,16 @@ class MappingStep:
         if sort is None:   # default: bin when the batch is large enough for it to pay
             floor = self.CROWDED_MIN_POINTS if self.meta.flags & ops._lib.F_CROWDED else ops.SortedBatch.AUTO_MIN_POINTS
             sort = ops.SortedBatch.AUTO_MIN_POINTS is not None and self.n >= floor
-        self.sorted = ops.SortedBatch(self.n, dev) if sort else None
+        # Binning: 16 tiles per axis.  MISO_STEP_TILES=auto (dev / tests) lets it follow the grids -- more tiles on an axis
+        # where the finest level needs them to be owned by the pull (ops.choose_tiles: (25, 16, 25) for a ScanNet submap,
+        # every level then goes through the matrix-core pull).  Measured at the ScanNet shape (540 000 samples on 18 % of
+        # the bound): 412 us per trainer step against 324 us with the fine level scattered from the train kernel and the
+        # coarse one pushed -- a crowded block works its table off in epochs on ONE workgroup while most of the chip has
+        # no block to work on (tools/experiments/README.md) -- so it is not the default.
+        import os
+        env = os.environ.get("MISO_STEP_TILES")
+        self.tiles = ops.choose_tiles(self.features) if env == "auto" else ops.pack_tiles(int(env or ops.SortedBatch.TILES))
+        self.sorted = ops.SortedBatch(self.n, dev, tiles=self.tiles) if sort else None
         if getattr(self, "_shared_grads", False) and self.sorted is None:
             # the small-batch path accumulates onto buffers it expects zeroed; the previous owner may have been a
             # binned step, which overwrites and never clears
@@ -122,7 +131,7 @@ class MappingStep:
         # the Adam launch that consumes them instead of by a fill in front of every backward (64 MB at the ScanNet shape)
         self._adam_clears = 0
         if adam_device is not None and self.sorted is not None:
-            self._adam_clears = ops.sdf_bwd_scattered_levels(self.features, meta, self.grads, self.n)
+            self._adam_clears = ops.sdf_bwd_scattered_levels(self.features, meta, self.grads, self.n, tiles=self.tiles)
             for l, g in enumerate(self.grads):
                 if g is not None and (self._adam_clears >> l) & 1:
                     g.zero_()

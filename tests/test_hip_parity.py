@@ -403,15 +403,18 @@ def test_native_library_is_loaded():
 # --------------------------------------------------------------------------- #
 # spatially binned (sorted) path
 # --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("tiles", [16, (25, 13, 25), (32, 32, 32), (5, 1, 9)])
 @pytest.mark.parametrize("n", [1, 777, 40000, 300001])
-def test_sort_points_is_a_tile_grouped_permutation(n):
+def test_sort_points_is_a_tile_grouped_permutation(n, tiles):
+    """tiles: a count (cubic binning) or per-axis counts packed as MISO_TILES_XYZ (include/miso_hip.h)."""
     from miso_amd import ops
+    tx, ty, tz = (tiles,) * 3 if isinstance(tiles, int) else tiles
     bound = [[-1.0, 1.3], [-0.7, 0.9], [0.0, 2.1]]
     meta = ops.GridMeta.from_bound(bound)
     g = torch.Generator().manual_seed(n)
     x = torch.rand(n, 3, generator=g) * torch.tensor([2.5, 1.8, 2.3]) + torch.tensor([-1.1, -0.8, -0.1])
     x[0] = float("nan")
-    sb = ops.SortedBatch(n, DEV, keep_metric=True).sort(x.to(DEV), meta)
+    sb = ops.SortedBatch(n, DEV, tiles=tiles, keep_metric=True).sort(x.to(DEV), meta)
     perm = sb.perm.cpu().long()
     assert torch.equal(torch.sort(perm).values, torch.arange(n))
     xs = sb.x_sorted.cpu()
@@ -421,16 +424,17 @@ def test_sort_points_is_a_tile_grouped_permutation(n):
     xn = (2.0 * (xs - b_[:, 0])) / (b_[:, 1] - b_[:, 0]) - 1.0
     assert torch.equal(torch.nan_to_num(sb.xn_sorted.cpu()[:, :3], nan=7.0), torch.nan_to_num(xn, nan=7.0))
     # metric copy is optional: same permutation class without it
-    sb2 = ops.SortedBatch(n, DEV).sort(x.to(DEV), meta)
+    sb2 = ops.SortedBatch(n, DEV, tiles=tiles).sort(x.to(DEV), meta)
     assert torch.equal(sb2.tile_offsets.cpu(), sb.tile_offsets.cpu())
     assert torch.equal(torch.sort(sb2.perm.cpu().long()).values, torch.arange(n))
     off = sb.tile_offsets.cpu().long()
     assert off[0] == 0 and off[-1] == n and torch.all(off[1:] >= off[:-1])
     b = torch.tensor(bound)
     u = torch.nan_to_num((xs - b[:, 0]) / (b[:, 1] - b[:, 0]), nan=0.0)
-    t = torch.clamp(torch.floor(u * 16), 0, 15).long()
-    tid = (t[:, 2] * 16 + t[:, 1]) * 16 + t[:, 0]
-    expect = torch.repeat_interleave(torch.arange(4096), off[1:] - off[:-1])
+    tt = torch.tensor([tx, ty, tz])
+    t = torch.minimum(torch.clamp(torch.floor(u * tt), min=0), (tt - 1).float()).long()
+    tid = (t[:, 2] * ty + t[:, 1]) * tx + t[:, 0]
+    expect = torch.repeat_interleave(torch.arange(tx * ty * tz), off[1:] - off[:-1])
     assert torch.equal(tid, expect)
 
 

@@ -385,3 +385,47 @@ def test_matrix_core_push_random_shapes_and_clusters(seed):
     for a, b in zip(got, want):
         scale = b.abs().max().item()
         assert scale > 0 and (a - b).abs().max().item() <= 2e-4 * scale + 1e-12
+
+
+@pytest.mark.parametrize("shape", ["scannet", "uneven"])
+def test_per_axis_binning_lets_the_pull_own_fine_levels(shape, monkeypatch):
+    """ScanNet's submap (configs/rgbd/scannet.yaml:23-24: 40 x 20 x 40 and 200 x 100 x 200 vertices) under the 16-tile
+    binning puts 12.5 vertices of the fine level on a tile and axis -- beyond what the pull owns, so that level was
+    scattered with float atomics.  With MISO_STEP_TILES=auto MappingStep bins such grids per axis (ops.choose_tiles: (25, 16, 25)), every level
+    goes through the matrix-core pull, and the gradients equal those of the 16-tile step (atomics for the fine level,
+    push for the coarse one) to fp32 summation order, crowded batch and points outside the bound included."""
+    from miso_amd import ops
+    from miso_amd.step import MappingStep
+    g = torch.Generator().manual_seed(17)
+    if shape == "scannet":
+        C, dims, bound, want = 4, [(40, 20, 40), (200, 100, 200)], [[-10.0, 10.0], [-5.0, 5.0], [-10.0, 10.0]], (25, 16, 25)
+    else:     # sizes no tile count divides, 8 channels, three levels
+        C, dims, bound, want = 8, [(23, 31, 17), (91, 130, 70), (182, 250, 141)], [[-1.0, 2.0], [0.0, 4.0], [-3.0, 0.5]], \
+            (23, 32, 18)
+    feats = [(torch.randn(1, C, z, y, x, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+             for (x, y, z) in dims]
+    F = C * len(dims)
+    lin = [torch.nn.Linear(F, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 1)]
+    pack = ops.DecoderPack([m.weight.detach().to(DEV) for m in lin], [m.bias.detach().to(DEV) for m in lin])
+    meta = ops.GridMeta.from_bound(bound)
+    assert ops.choose_tiles(feats) == ops.pack_tiles(want)
+    n = 140000
+    b = torch.tensor(bound)
+    x = torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) * 1.06 + b[:, 0] - 0.03 * (b[:, 1] - b[:, 0])
+    x[: n // 2] = b.mean(1) + (torch.rand(n // 2, 3, generator=g) - 0.5) * (b[:, 1] - b[:, 0]) * 0.08       # a crowd
+    aux = torch.stack((torch.randn(n, generator=g) * 0.1, (torch.rand(n, generator=g) > 0.1).float(),
+                       (torch.rand(n, generator=g) > 0.6).float(), torch.rand(n, generator=g) + 0.5), dim=1).to(DEV)
+    out = {}
+    for tiles in ("auto", "16"):
+        monkeypatch.setenv("MISO_STEP_TILES", tiles)
+        st = MappingStep(feats, meta, pack, n, "L1", 1.0, 0.1, 0.15, keep_sdf=False, sort=True)
+        grads = [torch.full_like(f, 3.0) for f in feats]
+        scat = ops.sdf_train_scattered_levels(feats, meta, grads, tiles=st.tiles)
+        assert (scat == 0) == (tiles == "auto"), (tiles, scat)         # per-axis: every level pulled
+        st.set_batch(x.to(DEV), aux[:, 0:1], aux[:, 1:2], aux[:, 2:3], aux[:, 3:4])
+        st.run(); st.run()
+        torch.cuda.synchronize()
+        out[tiles] = (st.loss.clone(), [g_.clone() for g_ in st.grads])
+    assert (out["auto"][0] - out["16"][0]).abs().max().item() <= 2e-6 * out["16"][0].abs().max().item()
+    for a, c in zip(out["auto"][1], out["16"][1]):
+        assert relerr(a, c) < 2e-5
