@@ -5,10 +5,14 @@ order -- over the fused shape table, both losses, free-space term, invalid / NaN
 a crowded batch whose coarse level goes through the matrix-core push, and an ignored level.  Plus: a level the pull
 cannot own is scattered from the train kernel itself, and unbinned batches (miso_sdf_train) against their two launches.
 The two-launch form itself is pinned to the reference goldens and the CPU oracle elsewhere (test_hip_parity.py,
-test_config_shapes.py)."""
+test_config_shapes.py); test_train_kernel_vs_cpu_oracle below compares the one-launch kernel with the oracle DIRECTLY
+(stock ATen grid_sample per level, cat, nn.Linear chain, the reference's two loss terms, autograd), every shape of the
+table, the scattering variant and the unbinned form included."""
 import numpy as np
 import pytest
 import torch
+
+from oracle import ref_torch as R          # checker only (CPU restatement of the reference, pinned by tests/golden)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -23,7 +27,7 @@ SHAPES = [  # (C, level sizes (cubic), hidden)
 ]
 
 
-def _setup(C, sizes, H, n, seed, crowded=False, ignore=None, bound=None):
+def _setup(C, sizes, H, n, seed, crowded=False, ignore=None, bound=None, want_lin=False):
     from miso_amd import ops
     g = torch.Generator().manual_seed(seed)
     feats = [(torch.randn(1, C, s, s, s, generator=g) * 0.05).to(DEV).contiguous(memory_format=torch.channels_last_3d)
@@ -47,7 +51,8 @@ def _setup(C, sizes, H, n, seed, crowded=False, ignore=None, bound=None):
                        (torch.rand(n, generator=g) > 0.6).float(), torch.rand(n, generator=g) + 0.5), dim=1)
     if n > 7:
         aux[7, 0] = float("nan")
-    return feats, meta, pack, x.to(DEV).contiguous(), aux.to(DEV).contiguous()
+    out = (feats, meta, pack, x.to(DEV).contiguous(), aux.to(DEV).contiguous())
+    return out + (lin,) if want_lin else out
 
 
 def _both(feats, meta, pack, x, aux, lt, ws, wf, td, n_live=None, need=None):
@@ -207,3 +212,106 @@ def test_stream_launches_and_graph_replays_give_the_same_step():
         assert (out[mode][0] - out[True][0]).abs().max().item() <= 2e-6 * out[True][0].abs().max().item()
         for a, b in zip(out[mode][1], out[True][1]):
             assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
+
+
+def _oracle(feats, meta_bound, lin, x, aux, lt, ws, wf, td, n_live=None):
+    """Loss terms and grid gradients of the reference on the host: GridNet.forward (grid_net.py:306-325) ->
+    miso_loss_regression + miso_loss_free_space (loss.py:594-635, :668-700), weights as MisoLossMapping applies them."""
+    fc = [f.detach().cpu().contiguous().clone().requires_grad_(True) for f in feats]
+    w = [m.weight.detach().clone() for m in lin]
+    b = [m.bias.detach().clone() for m in lin]
+    xc, ac = x.cpu(), aux.cpu()
+    if n_live is not None:                    # the reference sees the exact-size batch
+        xc, ac = xc[:n_live], ac[:n_live]
+    pred = R.sdf_stock(fc, torch.tensor(meta_bound), xc, w, b)
+    t_sdf = ws * R.miso_loss_regression(pred, ac[:, 0:1], ac[:, 1:2], ac[:, 3:4], lt)
+    t_fs = wf * R.miso_loss_free_space(pred, ac[:, 0:1], ac[:, 2:3], td)
+    grads = torch.autograd.grad(t_sdf + t_fs, fc)
+    return pred.detach(), torch.stack((t_sdf.detach(), t_fs.detach())), grads
+
+
+def _check_vs_oracle(sdf, loss, grads, ref, n_live=None):
+    pred, terms, gref = ref
+    if sdf is not None:
+        d = (sdf.cpu()[: pred.shape[0]] - pred).abs()
+        assert d.max().item() <= 1e-5, d.max().item()
+    assert (loss.cpu() - terms).abs().max().item() <= 1e-6 * max(1.0, terms.abs().max().item())
+    for a, r in zip(grads, gref):
+        a = a.cpu()
+        scale = r.abs().max().item()
+        assert scale > 0
+        # (a sample whose ReLU pre-activation lies within fp32 rounding of zero may be gated differently by two
+        # implementations -- ~1 in 6 000 samples, tests/test_config_shapes.py counts them at full size -- and moves the eight
+        # vertices around it by one sample's share: the Euclidean norm and the fraction of entries bound the rest)
+        assert ((a - r).double().norm() / r.double().norm()).item() < 5e-4
+        # ... at most a handful of tie samples' 8 corners x C channels beyond 1e-4 of the largest entry
+        assert int(((a - r).abs() > 1e-4 * scale).sum()) <= max(2e-4 * a.numel(), 8 * a.shape[1] * 6)
+
+
+_BOUND = [[-1.0, 1.0], [-0.5, 1.5], [0.0, 2.0]]
+
+
+def _setup_lin(C, sizes, H, n, seed, **kw):
+    """_setup plus the nn.Linear modules its DecoderPack was made from (the oracle needs the weights)."""
+    return _setup(C, sizes, H, n, seed, want_lin=True, **kw)
+
+
+@pytest.mark.parametrize("lt", ["L1", "L2"])
+@pytest.mark.parametrize("shape", list(range(len(SHAPES))) + ["scat"])
+def test_train_kernel_vs_cpu_oracle(shape, lt):
+    """miso_sdf_train_sorted (sdf_train_kernel: forward + mapping loss + decoder backward in one launch, then the pull /
+    push; `scat`: a 200-vertex level the pull cannot own is scattered from the kernel, sdf_train_kernel<..,SCAT>) against
+    the oracle: SDF to 1e-5, both loss terms to 1e-6, every level's gradient to 1e-4 of its largest entry (ReLU ties
+    apart), with invalid rows, free-space rows, per-sample weights and points outside the bound."""
+    from miso_amd import ops
+    C, sizes, H = (4, (40, 200), 64) if shape == "scat" else SHAPES[shape]
+    n = 70001
+    feats, meta, pack, x, aux, lin = _setup_lin(C, sizes, H, n, seed=100 + (7 if shape == "scat" else shape))
+    aux[7, 0] = 0.05
+    ws, wf, td = 1.0, 0.2, 0.15
+    sb = ops.SortedBatch(n, DEV).sort(x, meta)
+    slots, sdf = torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), torch.empty(n, 1, device=DEV)
+    grads = [torch.full_like(f, -3.0) for f in feats]
+    if shape == "scat":
+        assert ops.sdf_train_scattered_levels(feats, meta, grads) == 2
+        grads[1].zero_()                      # a scattered level is added to: the caller clears it (MappingStep: Adam does)
+    ops.sdf_train_raw(feats, meta, pack, sb, aux, slots, grads, lt, ws, wf, td, sdf_out=sdf)
+    torch.cuda.synchronize()
+    _check_vs_oracle(sdf, slots.sum(0), grads, _oracle(feats, _BOUND, lin, x, aux, lt, ws, wf, td))
+
+
+def test_train_kernel_padded_batch_vs_cpu_oracle():
+    """A fixed-capacity batch whose rows past n_live are neutral padding (miso_sample_rays leaves them so): the means divide
+    by the live count, as the reference's do over its exact-size batch."""
+    from miso_amd import ops
+    C, sizes, H = SHAPES[0]
+    n, live = 66000, 60000
+    feats, meta, pack, x, aux, lin = _setup_lin(C, sizes, H, n, seed=131)
+    aux[7, 0] = 0.05
+    aux[live:] = 0.0
+    x[live:] = x[:n - live]                   # padding rows are parked on live samples
+    sb = ops.SortedBatch(n, DEV).sort(x, meta)
+    slots = torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV)
+    grads = [torch.empty_like(f) for f in feats]
+    nl = torch.tensor([live], device=DEV, dtype=torch.int32)
+    ops.sdf_train_raw(feats, meta, pack, sb, aux, slots, grads, "L1", 0.7, 0.2, 0.1, n_live=nl)
+    torch.cuda.synchronize()
+    _check_vs_oracle(None, slots.sum(0), grads, _oracle(feats, _BOUND, lin, x, aux, "L1", 0.7, 0.2, 0.1, n_live=live))
+
+
+@pytest.mark.parametrize("n", [65, 3000])
+def test_unbinned_train_kernel_vs_cpu_oracle(n):
+    """miso_sdf_train (unbinned: every level scattered with float atomics from the one launch) against the oracle."""
+    from miso_amd import ops
+    C, sizes, H = SHAPES[1]
+    feats, meta, pack, x, aux, lin = _setup_lin(C, sizes, H, n, seed=150 + n)
+    aux[7, 0] = 0.05
+    slots, sdf = torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), torch.empty(n, 1, device=DEV)
+    grads = [torch.zeros_like(f) for f in feats]
+    ops.sdf_train_unsorted_raw(x, feats, meta, pack, aux, slots, grads, "L2", 1.0, 0.3, 0.15, sdf_out=sdf)
+    torch.cuda.synchronize()
+    pred, terms, gref = _oracle(feats, _BOUND, lin, x, aux, "L2", 1.0, 0.3, 0.15)
+    assert (sdf.cpu() - pred).abs().max().item() <= 1e-5
+    assert (slots.sum(0).cpu() - terms).abs().max().item() <= 1e-6 * max(1.0, terms.abs().max().item())
+    for a, r in zip(grads, gref):
+        assert (a.cpu() - r).abs().max().item() <= 1e-4 * r.abs().max().item()
