@@ -355,22 +355,50 @@ def _maybe_fail(where):
 
 
 class Watchdog:
-    """Keeps the headline line safe from the collective-bearing extras.  One thread per rank: when the wall-clock
-    budget runs out, or ANY rank has raised the abort flag (a file next to the rendezvous port: one node, so every
-    rank sees it), rank 0 prints the finished headline record with extras_multi_gpu = {"error": ...} and every rank
-    leaves with os._exit -- a rank blocked in an all-reduce whose peer threw would otherwise sit there until the
-    process-group timeout.  (Exiting is all it does: no re-exec of a GPU process.)"""
+    """Keeps the headline line safe from the collective-bearing extras.  One thread per rank: when the shared wall-clock
+    deadline passes, or ANY rank has raised the abort flag (a file named after the rendezvous: one node, so every rank
+    sees it), rank 0 prints the finished headline record with extras_multi_gpu = {"error": ...}, writes `<flag>.done`
+    and leaves; the other ranks wait for that file (a few seconds at most) before they leave, and leave with status 0
+    when they saw it -- a launcher that ends every rank at the first non-zero status must not get one before rank 0
+    has printed.  A rank blocked in an all-reduce whose peer threw would otherwise sit there until the process-group
+    timeout.  (Exiting is all it does: no re-exec of a GPU process.)
 
-    def __init__(self, rank, budget_s):
+    Lifecycle of the flag: its name carries the rendezvous port AND a per-run token (the launcher's, or rank 0's start
+    time broadcast at construction), rank 0 removes leftovers at CONSTRUCTION -- which callers place right after the
+    process group is up and before a barrier, i.e. before any rank can raise it -- and again when it expires or stops."""
+
+    PEER_GRACE_S = 5.0
+
+    def __init__(self, rank, budget_s, dist=None):
         import threading
-        self.rank, self.deadline = rank, time.time() + budget_s
-        self.flag = os.path.join("/tmp", f"miso_bench_abort_{os.environ.get('MASTER_PORT', '0')}")
+        self.rank = rank
+        t0 = time.time()
+        token = os.environ.get("MISO_BENCH_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+        if dist is not None and dist.is_initialized():
+            import torch
+            t = torch.tensor([t0], dtype=torch.float64)
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = t.to(dev)
+            dist.broadcast(t, src=0)              # one clock for the deadline, one token for the flag's name
+            t0 = float(t.item())
+            token = f"{token}_{int(t0 * 1e3)}"
+        # rank 0 expires at the deadline, the peers a grace period later: its print comes first
+        self.deadline = t0 + budget_s + (0.0 if rank == 0 else self.PEER_GRACE_S)
+        self.flag = os.path.join("/tmp", f"miso_bench_abort_{os.environ.get('MASTER_PORT', '0')}_{token}")
+        self.done = self.flag + ".done"
         self.headline = None          # rank 0: the finished record
         self.partial = {}             # extras that did finish
         self._off = threading.Event()
-        if rank == 0 and os.path.exists(self.flag):
-            os.remove(self.flag)      # a stale flag of an earlier run on this port
+        if rank == 0:
+            self._cleanup()
         self._th = threading.Thread(target=self._watch, daemon=True)
+
+    def _cleanup(self):
+        for f in (self.flag, self.done):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
 
     def start(self):
         self._th.start()
@@ -390,26 +418,39 @@ class Watchdog:
                     reason = open(self.flag).read() or "a rank failed"
                 except OSError:
                     reason = "a rank failed"
+            elif self.rank != 0 and os.path.exists(self.done):
+                reason = "rank 0 has printed the record and left"       # (it removes the flag as it goes)
             elif time.time() > self.deadline:
                 reason = "wall-clock budget of the multi-GPU extras exceeded"
             if reason is not None:
                 self.expire(reason)
 
     def expire(self, reason):
-        if self.rank == 0 and self.headline is not None:
-            out = dict(self.headline)
-            out["extras_multi_gpu"] = dict(self.partial, error=reason)
-            sys.stdout.write(json.dumps(out) + "\n")
-            sys.stdout.flush()
-        os._exit(0 if self.rank == 0 else 3)
-
-    def stop(self):
-        self._off.set()
-        if self.rank == 0 and os.path.exists(self.flag):
+        if self.rank == 0:
+            if self.headline is not None:
+                out = dict(self.headline)
+                out["extras_multi_gpu"] = dict(self.partial, error=reason)
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            try:
+                open(self.done, "w").close()
+            except OSError:
+                pass
             try:
                 os.remove(self.flag)
             except OSError:
                 pass
+            os._exit(0)
+        # a peer: let rank 0 print first
+        t_end = time.time() + self.PEER_GRACE_S
+        while time.time() < t_end and not os.path.exists(self.done):
+            time.sleep(0.05)
+        os._exit(0 if os.path.exists(self.done) else 3)
+
+    def stop(self):
+        self._off.set()
+        if self.rank == 0:
+            self._cleanup()
 
 
 def extras_multi(dev, dist, dog):
@@ -769,9 +810,11 @@ def spawn_ranks(args):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    token = f"{os.getpid()}_{int(time.time() * 1e3)}"         # a per-run name for the watchdog's flag file
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), MISO_BENCH_TOKEN=token,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -784,8 +827,14 @@ def spawn_ranks(args):
             live.remove(pr)
             if code != 0 and rc == 0:
                 rc = code
-                for other in live:          # a dead rank leaves the others waiting in a collective: end them (exact PIDs)
-                    other.terminate()
+                # a dead rank leaves the others waiting in a collective: end them (exact PIDs) -- rank 0 last and only
+                # after a grace period: its watchdog prints the headline record within a second of a peer's failure
+                t_end = time.time() + 10.0
+                while procs[0] in live and procs[0].poll() is None and time.time() < t_end:
+                    time.sleep(0.1)
+                for other in live:
+                    if other.poll() is None:
+                        other.terminate()
         time.sleep(0.2)
     raise SystemExit(rc)
 
@@ -885,7 +934,8 @@ def main():
         out.update(collective)
     multi = None
     if dist is not None and not args.no_extras:
-        dog = Watchdog(rank, float(os.environ.get("MISO_BENCH_EXTRAS_BUDGET_S", "150")))
+        dog = Watchdog(rank, float(os.environ.get("MISO_BENCH_EXTRAS_BUDGET_S", "150")), dist)
+        dist.barrier()                # rank 0 has cleared leftovers of the flag: from here on a rank may raise it
         dog.headline = out
         dog.start()
         multi = extras_multi(dev, dist, dog)
@@ -965,13 +1015,19 @@ def headline_record(args, step, dev, world, elapsed):
         t_pull = time_kernel(lambda: ops.grad_pull_raw(feats, meta, sb, ws, step.grads, overwrite=True))
         kernels_us["grad_pull_kernel"] = t_pull
         kernels_us["sdf_bwd_kernel(MFMA pass)"] = t_bwd - t_pull
+        kernels_us["grad_pull_kernel"] = t_pull
         if t_train is not None:
             kernels_us["sdf_train_kernel(forward + loss + decoder backward, one launch: what the step runs)"] = t_train - t_pull
+            # the two-launch forward / backward are timed for reference only -- the step does not launch them
+            kernels_us = {"in_the_step": {"sort_points(3 launches)": t_sort, "sdf_train_kernel": t_train - t_pull,
+                                          "grad_pull_mc_kernel": t_pull},
+                          "not_in_the_step(two-launch form, for reference)": {
+                              "sdf_fwd_kernel(+mapping loss)": t_fwd, "sdf_bwd_kernel(MFMA pass)": t_bwd - t_pull},
+                          **kernels_us}
         # algorithmic bytes of the pull: the gradient of 8 corners x C channels per level, counted
         # once as a write (SURVEY 8d backward figure without the 4 B of dL/dsdf the MFMA pass reads)
-        # (at cfg-2 the pull is grad_pull_block_kernel -- one workgroup per 2x2x2 tiles -- followed by the drain launch
-        # of grad_pull_kernel for sliced tiles, which finds an empty queue on this uniform batch)
-        dom = ("grad_pull_block_kernel", t_pull, 32 * L * C)
+        # (at cfg-2 the pull is grad_pull_mc_kernel -- one workgroup per 2x2x2 tiles, the sums on the fp32 matrix cores)
+        dom = ("grad_pull_mc_kernel", t_pull, 32 * L * C)
     if t_train is not None and t_train - t_pull > dom[1]:
         # the fused kernel moves the bytes of both passes except the gradient write (the pull's): corners read once
         dom = ("sdf_train_kernel", t_train - t_pull, b_fwd)
@@ -992,7 +1048,7 @@ def headline_record(args, step, dev, world, elapsed):
         except Exception:
             continue
         if js.get("_meta", {}).get("source_hash") == source_hash():
-            if dom[0] == "grad_pull_block_kernel":      # kernel_us covers both launches of the pull: so does the traffic
+            if dom[0].startswith("grad_pull"):          # kernel_us covers every launch of the pull: so does the traffic
                 parts = [v.get("hbm_bytes_per_launch") for k, v in js.items() if k.startswith("grad_pull") and isinstance(v, dict)]
                 traffic = sum(p for p in parts if p is not None) if parts else None
             else:
@@ -1011,12 +1067,21 @@ def headline_record(args, step, dev, world, elapsed):
             "definition": "decoder matrix FLOPs / kernel time / fp32 MFMA peak (live, HIP events)"}
     if mfma_pmc:
         mfma["pmc_busy_frac"] = mfma_pmc
-    roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                "traffic_source": pmc_note, "algorithmic_bytes_per_point": dom[2], "kernel_us": dom[1],
-                "mfma_frac": mfma}
-    if dom[0] == "grad_pull_block_kernel":
-        roofline["launches"] = ("grad_pull_block_kernel + the drain launch grad_pull_kernel<..,true> (slices of over-full "
-                                "tiles; finds an empty queue on this uniform batch, ~3 us); kernel_us and traffic cover both")
+    # Both roofs of the dominant kernel, and which one binds: the fused kernels run the decoder on v_mfma_f32_32x32x2_f32
+    # (exact fp32, 157.3 TFLOP/s), and at cfg-2 that roof is closer than HBM's (0.52 vs 0.35)
+    frac_hbm = achieved / 8000.0
+    frac_mfma = mfma.get(dom[0])
+    if frac_mfma is not None and frac_mfma > frac_hbm:
+        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": frac_mfma * 157.3, "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": frac_mfma, "flop_per_point": (2 if dom[0] == "sdf_train_kernel" else 1) * mlp_flop / N_POINTS}
+    else:
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": frac_hbm}
+    roofline.update({"frac_hbm": frac_hbm, "frac_mfma": frac_mfma, "achieved_hbm_GBps": achieved, "peak_hbm_GBps": 8000.0,
+                     "traffic": traffic, "traffic_source": pmc_note, "algorithmic_bytes_per_point": dom[2],
+                     "kernel_us": dom[1], "mfma_frac": mfma})
+    if dom[0].startswith("grad_pull"):
+        roofline["launches"] = ("grad_pull_mc_kernel: one launch (crowded blocks are worked off in epochs inside it; the "
+                                "vector kernels' drain launch is gone)")
 
     out = {
         "metric": "3D point-samples/sec (encode+decode fwd+bwd), 262144-pt batch",
