@@ -222,18 +222,29 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
     iteration (no per-pair Python, no host sync on the overlap test or the NaN guard), the 6S + 1 floats of pose
     gradients + loss are all-reduced, and the identical regulariser / NaN guard / Adam step runs on every rank, so
     the replicas stay bit-identical.  Results equal the single-process run up to fp32 summation order of the pair
-    sums.  The pair loss must carry ``fused`` (align.miso.latent_loss_for_level).  always_reduce: keep the
-    all-reduce hook live in a group of one rank (exercises RCCL on a single GPU)."""
+    sums.  A pair loss that carries ``fused`` (align.miso.latent_loss_for_level) runs as that loop; one that does not
+    (the SDF fine-tune stage) runs the op-by-op loop with the same sharding (generic_align_multiple_submaps, my_pairs /
+    reduce).  always_reduce: keep the all-reduce hook live in a group of one rank (exercises RCCL on a single GPU)."""
     from miso_amd.grid_opt.align.base import fused_alignment_loop
     rank, world = rank_world()
     loss_name, loss_func = pairwise_loss_tuple
     fused = getattr(loss_func, 'fused', None)
-    if fused is None:
-        raise ValueError("align_multiple_submaps_distributed needs a fused pair loss "
-                         "(miso_amd.grid_opt.align.miso.latent_loss_for_level); the SDF fine-tune stage is not sharded")
     if submap_pairs is None:
         n = grid_atlas.num_submaps
         submap_pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
+    if fused is None:
+        # a pair loss without a fused plan -- the SDF fine-tune stage (align/miso.py pairwise_loss_sdf; reference
+        # miso.py:283-319, `--use_sdf`): the op-by-op loop with the pair list dealt round-robin, every rank evaluating its
+        # pairs through autograd, one all-reduce of the pose gradients + loss per iteration, the same Adam step everywhere
+        from miso_amd.grid_opt.align.base import generic_align_multiple_submaps
+        red = all_reduce_sum if world > 1 else ((lambda t: all_reduce_sum(t, always=True)) if always_reduce and
+                                                 dist.is_available() and dist.is_initialized() else None)
+        return generic_align_multiple_submaps(grid_atlas, dataset, pairwise_loss_tuple, num_iters=num_iters, lr=lr,
+                                              rel_change_thresh=rel_change_thresh, submap_pairs=submap_pairs,
+                                              check_intersection=check_intersection, pose_reg_weight=pose_reg_weight,
+                                              pose_thresh_rad=pose_thresh_rad, pose_thresh_m=pose_thresh_m,
+                                              verbose=verbose and rank == 0, save_iterations=save_iterations,
+                                              my_pairs=partition_pairs(submap_pairs, rank, world), reduce=red)
     my_pairs = partition_pairs(submap_pairs, rank, world, costs=pair_costs(grid_atlas, submap_pairs) if world > 1 else None)
     timer = utils.PerfTimer(activate=True)
     reduce = None

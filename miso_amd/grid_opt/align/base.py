@@ -49,6 +49,33 @@ def _adam_step(optimizer, loss_dict, what):
     return total
 
 
+def _adam_step_reduced(optimizer, params, loss_dict, reduce, what):
+    """_adam_step with the pair list sharded over ranks: backward of THIS rank's losses, the pose gradients and the loss
+    packed into one flat tensor, ``reduce`` (an all-reduce SUM) over the ranks, then the reference's NaN guard
+    (base.py:147-151) and the optimizer step on the summed gradient -- the same on every rank.  A rank without a loss
+    of its own (all its pairs gated out) contributes zeros; a NaN anywhere reaches every rank through the sum."""
+    dev = params[0].device
+    total = sum(loss_dict.values()) if loss_dict else torch.zeros((), device=dev)
+    total = total if torch.is_tensor(total) else torch.tensor(float(total), device=dev)
+    if total.requires_grad and not bool(torch.isnan(total)):
+        total.backward(retain_graph=False)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
+                     + [total.detach().reshape(1).to(params[0].dtype)])
+    if reduce is not None:
+        reduce(flat)
+    total_all = flat[-1]
+    if bool(torch.isnan(total_all)) or bool(torch.isnan(flat[:-1]).any()):
+        logger.warning(f"Loss at {what} is nan! Skip backward step.")
+        return total_all
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[o:o + n].reshape(p.shape).clone()
+        o += n
+    optimizer.step()
+    return total_all
+
+
 def generic_align_submap_pair(grid_atlas: GridAtlas, dataset: Dataset, src_id: int, dst_id: int,
                               pairwise_loss_tuple, num_iters=10, lr=1e-2, rel_change_thresh=0, verbose=True):
     """Align dst to src by optimising dst's pose only (reference :41-87)."""
@@ -204,9 +231,15 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
 def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pairwise_loss_tuple, num_iters=10,
                                    lr=1e-2, rel_change_thresh=0, submap_pairs=None, check_intersection=True,
                                    pose_reg_weight=0, pose_thresh_rad=1.0, pose_thresh_m=1.0, verbose=True,
-                                   save_iterations=False):
+                                   save_iterations=False, my_pairs=None, reduce=None):
     """Adam over the pose corrections of submaps 1..S-1 (submap 0 stays fixed) on the sum of
-    pairwise losses (reference :89-163)."""
+    pairwise losses (reference :89-163).
+
+    my_pairs / reduce: the multi-rank hook of miso_amd.dist for pair losses WITHOUT a fused plan (the SDF fine-tune
+    stage, align/miso.py pairwise_loss_sdf; reference miso.py:283-319): this rank evaluates ``my_pairs`` only -- the
+    trust-region term on the rank that holds the first pair of the list, so that it is counted once -- and
+    ``reduce(flat)`` sums the pose gradients and the loss over the ranks before the NaN guard and the identical Adam
+    step on every rank (replicas stay equal; results equal the single-process loop up to the order of the sum)."""
     def pose_params():
         return [p for s in range(1, grid_atlas.num_submaps) for p in grid_atlas.params_for_submap_pose(s)]
 
@@ -222,7 +255,11 @@ def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pair
     it = 0
     params = pose_params()
     fused = getattr(loss_func, 'fused', None)
-    if (fused is not None and params and all(p.requires_grad for p in params)
+    sharded = reduce is not None or my_pairs is not None
+    local_pairs = submap_pairs if my_pairs is None else list(my_pairs)
+    adds_reg = my_pairs is None or (len(submap_pairs) > 0 and submap_pairs[0] in local_pairs) or \
+        (len(submap_pairs) == 0)
+    if (fused is not None and params and all(p.requires_grad for p in params) and not sharded
             and not getattr(grid_atlas, 'no_fused_alignment', False)):
         iteration_results = fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr, num_iters,
                                                  rel_change_thresh, pose_reg_weight, pose_thresh_rad, pose_thresh_m,
@@ -237,9 +274,9 @@ def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pair
         # graph through so3_exp_map) are shared by all pairs
         batched = getattr(loss_func, 'batched', None)
         if batched is not None:
-            loss_dict.update(batched(grid_atlas, submap_pairs, check_intersection))
+            loss_dict.update(batched(grid_atlas, local_pairs, check_intersection))
         with grid_atlas.pose_cache():
-            for src_id, dst_id in (submap_pairs if batched is None else ()):
+            for src_id, dst_id in (local_pairs if batched is None else ()):
                 gate = None
                 if check_intersection:
                     inter = grid_atlas.check_submap_intersection(src_id, dst_id)
@@ -252,10 +289,13 @@ def generic_align_multiple_submaps(grid_atlas: GridAtlas, dataset: Dataset, pair
                 pair = loss_func(grid_atlas, loader, src_id, dst_id)
                 loss_dict.update({k: torch.nan_to_num(v) * gate if gate is not None else torch.nan_to_num(v)
                                   for k, v in pair.items()})
-        if pose_reg_weight > 0:
+        if pose_reg_weight > 0 and adds_reg:
             loss_dict.update(grid_atlas_pose_trust_region_loss(grid_atlas, thresh_rad=pose_thresh_rad,
                                                                thresh_m=pose_thresh_m, weight=pose_reg_weight))
-        total = _adam_step(optimizer, loss_dict, f"iter {it}")
+        if sharded:
+            total = _adam_step_reduced(optimizer, params, loss_dict, reduce, f"iter {it}")
+        else:
+            total = _adam_step(optimizer, loss_dict, f"iter {it}")
         cur = [p.clone().detach() for p in pose_params()]
         change = utils.relative_param_change(cur, prev)
         prev = cur

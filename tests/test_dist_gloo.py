@@ -80,8 +80,29 @@ def _worker(rank, world, port, out_dir):
             res["snap0"] = torch.stack([info["iteration_results"][i] for i in range(4)]).numpy()
         res[f"dr{l}"] = torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy()
         res[f"dt{l}"] = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
+    # --- SDF fine-tune stage (reference align/miso.py:283-319, --use_sdf): a pair loss WITHOUT a fused plan, sharded ---
+    res.update(_sdf_stage(mdist.align_multiple_submaps_distributed))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     torch.distributed.destroy_process_group()
+
+
+def _sdf_stage(align):
+    """Three iterations of the SDF-space alignment of the two-keyframe atlas on its fixed batch; `align` is the sharded
+    entry point (workers) or the single-process loop (reference run)."""
+    import golden_cases as gc
+    from test_grid_opt_mirror import make_atlas_two_kf, _OneBatch
+    import miso_amd.grid_opt.align.miso as AM
+    atlas = make_atlas_two_kf("cpu")
+    mi, gt = gc.atlas_sdf_batch()
+    ds = _OneBatch(mi, gt)
+
+    def sdf(at, loader, a, b):
+        return AM.pairwise_loss_sdf(at, loader, a, b, align_loss="L2", device="cpu")
+    info = align(atlas, ds, ("hier_sdf_L2", sdf), num_iters=2, lr=1e-3, pose_reg_weight=1.0, pose_thresh_rad=1e-3,
+                 pose_thresh_m=1e-3, verbose=False, check_intersection=False)
+    assert set(info) >= {"cpu_time_sec", "gpu_time_sec", "iteration_results"}
+    return {"sdf_dr": torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy(),
+            "sdf_dt": torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()}
 
 
 @pytest.mark.timeout(300)
@@ -125,6 +146,11 @@ def test_submap_parallel_world2_matches_single_process(tmp_path, monkeypatch):
         dt = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
         np.testing.assert_allclose(a[f"dr{l}"], dr, rtol=0, atol=2e-5)
         np.testing.assert_allclose(a[f"dt{l}"], dt, rtol=0, atol=2e-5)
+    # the SDF fine-tune stage: the sharded op-by-op loop == the single-process one (poses moved, and by the same amounts)
+    ref = _sdf_stage(AB.generic_align_multiple_submaps)
+    assert np.abs(ref["sdf_dr"]).max() > 1e-4
+    np.testing.assert_allclose(a["sdf_dr"], ref["sdf_dr"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a["sdf_dt"], ref["sdf_dt"], rtol=0, atol=2e-6)
 
 
 def test_shard_helpers():

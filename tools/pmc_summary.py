@@ -51,6 +51,32 @@ for k, d in acc.items():
         b, a = sum(busy) / len(busy), sum(act) / len(act)
         out[k].update({"SQ_VALU_MFMA_BUSY_CYCLES_avg": b, "GRBM_GUI_ACTIVE_avg": a,
                        "mfma_busy_frac": b / (a / 8.0 * 1024.0) if a else None})
+# cfg-4: the alignment's batched kernels, per alignment level.  The two levels launch the same kernels with different
+# grids (28 pairs x the workgroups the level's vertex count needs): launches are grouped by grid size, ascending = level.
+align = {}
+for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    import glob
+    paths = glob.glob(f"{src}/align_pmc_{kind}/**/align_counter_collection.csv", recursive=True)
+    if not paths:
+        continue
+    for r in csv.DictReader(open(paths[0])):
+        nm = short(r["Kernel_Name"])
+        if nm not in ("pair_latent_batch_kernel", "overlap_count_batch_kernel"):
+            continue
+        align.setdefault(nm, {}).setdefault(int(r["Grid_Size"]), {}).setdefault(cname, []).append(float(r["Counter_Value"]))
+if align:
+    out["cfg4_align"] = {}
+    for nm, by_grid in align.items():
+        for lvl, grid in enumerate(sorted(by_grid)):
+            d = by_grid[grid]
+            f = sum(d.get("FETCH_SIZE", [0.0])) / max(len(d.get("FETCH_SIZE", [])), 1)
+            w = sum(d.get("WRITE_SIZE", [0.0])) / max(len(d.get("WRITE_SIZE", [])), 1)
+            out["cfg4_align"][f"{nm}_level{lvl}"] = {
+                "grid_size": grid, "launches_sampled": len(d.get("FETCH_SIZE", [])), "FETCH_SIZE_KiB_avg": f,
+                "WRITE_SIZE_KiB_avg": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
+                "hbm_bytes_per_launch_if_fetch_is_not_halved": (f + w) * 1024,
+                "note": "one launch = all 28 pairs of an iteration; the x2 on FETCH_SIZE is the guide's calibration for wide "
+                        "coalesced reads -- this kernel's 16-byte corner gathers may not share it: both figures given"}
 # Stamp the summary with the kernel-source hash of the library the counters were COLLECTED with: every pass's log holds
 # the bench line, whose "library" field is miso_version() ("... src=<hash>").  (Stamping the hash of the tree the
 # summary is made in would label stale counters as current after a failed or skipped collection run.)
