@@ -106,7 +106,7 @@ constexpr int MC_FLUSH = 5;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Geometry of level d for the block, in its LDS record (wave-uniform address: broadcast reads):
-//   [0..2] size X Y Z   [3] foff   [4..6] v0   [8..10] E   [12..14] size / 2   [16..18] (size - 1) / 2 - v0  (floats)
+//   [0..2] size X Y Z   [3] foff   [4..6] v0   [7] live   [8..10] E   [12..14] size / 2   [16..18] (size - 1) / 2 - v0  (floats)
 struct McLevel { int size[3], v0[3], E[3], foff; };
 __device__ __forceinline__ McLevel mc_level(const int* lvl, int d) {
   const int4 r0 = *reinterpret_cast<const int4*>(lvl + d * MC_LVL);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           }
           if (threadIdx.x == 0) {
             lvl[d * MC_LVL + a] = sz; lvl[d * MC_LVL + 4 + a] = v0; lvl[d * MC_LVL + 8 + a] = E;
-            if (a == 0) lvl[d * MC_LVL + 3] = foff_[d];
+            if (a == 0) { lvl[d * MC_LVL + 3] = foff_[d]; lvl[d * MC_LVL + 7] = live_[d]; }
             // the routing's position relative to the block, one fma: xn size/2 + ((size - 1)/2 - v0)
             reinterpret_cast<float*>(lvl)[d * MC_LVL + 12 + a] = 0.5f * (float)sz;
             reinterpret_cast<float*>(lvl)[d * MC_LVL + 16 + a] = 0.5f * (float)(sz - 1) - (float)v0;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           const float xs[3] = {c4.x, c4.y, c4.z};
 #pragma unroll
           for (int d = 0; d < NLV; ++d) {
-            if (d >= pk.nl || !pk.lv[d].live) continue;
+            if (d >= pk.nl || !lvl[d * MC_LVL + 7]) continue;
             // (cell relative to the block by ONE fma: a sample within an ulp of a cell face may be routed by the neighbouring
             // cell -- the sub-brick it then misses would have got a weight of that ulp)
             const int4 re = *reinterpret_cast<const int4*>(lvl + d * MC_LVL + 8);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           const bool act = t < hi;
 #pragma unroll
           for (int d = 0; d < NLV; ++d) {
-            if (d >= pk.nl || !pk.lv[d].live) continue;
+            if (d >= pk.nl || !lvl[d * MC_LVL + 7]) continue;
             const int code = act ? (int)codes[d * MC_CAND + t] : 0;
             const bool ok = (code & 0x8000) != 0;
             const int s0x = code & 3, s0y = (code >> 2) & 3, s0z = (code >> 4) & 7;
@@ -481,25 +481,35 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
         // the first range also zero-fills the sub-bricks nothing touches (the gradient buffer is not cleared): wavefront w
         // looks at codes 16 w .. 16 w + 15 of every level
         if (first && pk.overwrite && !(pk.debug & 4)) {
+          // (all levels' reads first, one round trip: the usual answer is "nothing to fill")
+          const int j = 16 * wave + (lane & 15);
+          const int sx = j & 3, sy = (j >> 2) & 3, sz = j >> 4;
+          unsigned long long em[NLV];
 #pragma unroll
           for (int d = 0; d < NLV; ++d) {
+            em[d] = 0ull;
             if (d >= pk.nl) continue;
+            const int4 v0l = *reinterpret_cast<const int4*>(lvl + d * MC_LVL + 4);      // v0, live
+            const int4 e = *reinterpret_cast<const int4*>(lvl + d * MC_LVL + 8);
+            const int c = cnt[(d << 7) | j];
+            const bool valid = lane < 16 && 4 * sx < e.x && 4 * sy < e.y && ZS * sz < e.z;
+            em[d] = __ballot(valid && !(v0l.w != 0 && c != 0));
+          }
+#pragma unroll
+          for (int d = 0; d < NLV; ++d) {
+            if (em[d] == 0ull) continue;
             const McLevel m = mc_level(lvl, d);
-            const bool live = pk.lv[d].live != 0;
-            const int j = 16 * wave + (lane & 15);
-            const int sx = j & 3, sy = (j >> 2) & 3, sz = j >> 4;
-            const bool valid = lane < 16 && 4 * sx < m.E[0] && 4 * sy < m.E[1] && ZS * sz < m.E[2];
-            unsigned long long em = __ballot(valid && !(live && cnt[(d << 7) | j] != 0));
-            while (em) {
-              const int jj = 16 * wave + (int)__builtin_ctzll(em);
-              em &= em - 1;
+            const int4 gq = *reinterpret_cast<const int4*>(lvg + d * 8);                 // grad, sX, sY
+            float* gp = *reinterpret_cast<float* const*>(lvg + d * 8);
+            const int sZ_ = lvg[d * 8 + 4];
+            unsigned long long e_ = em[d];
+            while (e_) {
+              const int jj = 16 * wave + (int)__builtin_ctzll(e_);
+              e_ &= e_ - 1;
               const int lx = 4 * (jj & 3) + a_vx, ly = 4 * ((jj >> 2) & 3) + a_vy, lz = ZS * (jj >> 4) + a_vz;
-              if (lx < m.E[0] && ly < m.E[1] && lz < m.E[2]) {
-                const int4 gq = *reinterpret_cast<const int4*>(lvg + d * 8);                 // grad, sX, sY
-                float* gp = *reinterpret_cast<float* const*>(lvg + d * 8);
-                *reinterpret_cast<float4*>(gp + (m.v0[2] + lz) * lvg[d * 8 + 4] + (m.v0[1] + ly) * gq.w + (m.v0[0] + lx) * gq.z + a_c0) =
+              if (lx < m.E[0] && ly < m.E[1] && lz < m.E[2])
+                *reinterpret_cast<float4*>(gp + (m.v0[2] + lz) * sZ_ + (m.v0[1] + ly) * gq.w + (m.v0[0] + lx) * gq.z + a_c0) =
                     make_float4(0.f, 0.f, 0.f, 0.f);
-              }
             }
           }
         }

@@ -189,7 +189,9 @@ def pair_costs(grid_atlas, pairs) -> List[float]:
             q = (world_pts[a] - tb) @ Rb
             fracs.append(((q >= bd[:, 0]) & (q <= bd[:, 1])).all(dim=1).float().mean())
         fracs = torch.stack(fracs).cpu().tolist()
-    return [1.0 + 30.0 * f for f in fracs]
+    # quantised: every rank must arrive at the SAME deal (partition_pairs sorts by cost), and two GPUs may differ in the
+    # last bits of a mean -- a pair dropped or counted twice would go unnoticed in the all-reduced gradient
+    return [1.0 + 30.0 * (round(f * 1024.0) / 1024.0) for f in fracs]
 
 
 def partition_pairs(pairs: Sequence[Tuple[int, int]], rank: Optional[int] = None,
