@@ -637,8 +637,8 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
         }
 #define MC_GROUP(GI, AV, BV)                                                                      \
         {                                                                                         \
-          const int code = __builtin_amdgcn_readlane(codev, 4 * (GI));                            \
-          if (code != cur_code) {                                                                 \
+          if ((chg >> (4 * (GI))) & 1ull) {         /* a new sub-brick starts with this group */  \
+            const int code = __builtin_amdgcn_readlane(codev, 4 * (GI));                          \
             if (cur_code >= 0) {                                                                  \
               if (in_first && sh_before) part_a = acc;                                            \
               else store_tile(cur_code, acc);                                                     \
@@ -663,6 +663,10 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
 #pragma unroll
           for (int c = 0; c < C; ++c) stg[(8 + ZS + c) * MC_CS + wr_p] = rd[c];
           const int codev = rcode;
+          // where the sub-brick changes inside the chunk: one ballot per chunk instead of a lane read + compare per group
+          // (bit 4 g: group g's code differs from its predecessor's; group 0's predecessor is the running sub-brick)
+          const int prevc = __shfl_up(codev, 4);
+          const unsigned long long chg = __ballot((lane & 3) == 0 && codev != (lane < 4 ? cur_code : prevc));
           wave_sync_lds();
           MC_STAMP(12)
           const bool has_next = g0 + 16 < g_end;
