@@ -69,6 +69,8 @@ struct McK {
   unsigned int drow_bytes;   // bytes of the d-feat rows: n * ld * 4 (< 2^31: row offsets are 32-bit buffer offsets)
   int debug;                 // dev ablation (MISO_DEBUG_PULL): 1 no MFMAs, 2 no staging loads, 4 no stores, 8 no multiply
                              // phase, 16 nothing after the sweep
+  int cand_cap, pool_cap;    // table entries / pool pairs in use: MC_CAND / MC_POOL (tests: MISO_MC_SMALL shrinks them so that the
+                             // epoch and pool-overflow paths run on ordinary batches)
   int prof_wave;             // dev: the wavefront that stamps (MISO_MC_PROF=1+wave)
   unsigned long long* prof;  // dev (MISO_MC_PROF): clocks per phase, or nullptr
   McLv lv[MC_MAXL];
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           for (int u = 0; u < MC_UN; ++u) {
             if (u >= done) continue;
             const int nin = (int)__popcll(m[u]);
-            if (run + nin > MC_CAND) { done = u; continue; }      // table full: steps u.. are redone next epoch
+            if (run + nin > pk.cand_cap) { done = u; continue; }   // table full: steps u.. are redone next epoch
             if ((m[u] >> lane) & 1ull)
               cand[run + (int)__popcll(m[u] & lt_mask)] =
                   make_float4(c4[u].x, c4[u].y, c4[u].z, __int_as_float(p_cur + u * 64 + lane));
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           }
           if (done < nstep) {
             // what was reserved beyond the steps that fitted becomes null entries (outside every box)
-            for (int i = run + lane; i < min(base + tot, MC_CAND); i += 64) cand[i] = make_float4(2e30f, 2e30f, 2e30f, 0.f);
+            for (int i = run + lane; i < min(base + tot, pk.cand_cap); i += 64) cand[i] = make_float4(2e30f, 2e30f, 2e30f, 0.f);
             if (lane == 0) misc[M_FULL] = 1;
           }
         }
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
       if (r_cur < nrows && lane == 0) misc[M_MORE] = 1;
       __syncthreads();
       MC_STAMP(2)
-      const int ncand = (pk.debug & 16) ? 0 : min(__builtin_amdgcn_readfirstlane(misc[M_NSURV]), MC_CAND);
+      const int ncand = (pk.debug & 16) ? 0 : min(__builtin_amdgcn_readfirstlane(misc[M_NSURV]), pk.cand_cap);
       const bool more = __builtin_amdgcn_readfirstlane(misc[M_MORE]) != 0;
 
       // ---- (2) + (3): route and multiply the table, in one range unless the pool overflows --------------------------
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
         __syncthreads();
         MC_STAMP(5)
         const int ptot = __builtin_amdgcn_readfirstlane(misc[M_PTOT]);
-        if (ptot > MC_POOL) {          // a crowd on few sub-bricks: half the range at a time
+        if (ptot > pk.pool_cap) {      // a crowd on few sub-bricks: half the range at a time
           hi = lo + max(1, (hi - lo) >> 1);
           for (int i = threadIdx.x; i < MC_ITEMS; i += NT) cnt[i] = 0;
           __syncthreads();
@@ -800,6 +802,9 @@ hipError_t launch_grad_pull_mc(const GridK& g, int C, const int T[3], const int*
     }
   pk.overwrite = overwrite;
   pk.drow_bytes = (unsigned int)(n * ld * 4);
+  const bool small = getenv("MISO_MC_SMALL") != nullptr;      // tests: epochs and halved ranges on ordinary batches
+  pk.cand_cap = small ? 192 : MC_CAND;
+  pk.pool_cap = small ? 640 : MC_POOL;
   static const int dbg = [] { const char* e = getenv("MISO_DEBUG_PULL"); return e ? atoi(e) : 0; }();   // dev ablation
   pk.debug = dbg;
   // dev: MISO_MC_PROF=1 prints the clocks wavefront 0 of every workgroup spent per phase, averaged, every 64 launches

@@ -429,3 +429,46 @@ def test_per_axis_binning_lets_the_pull_own_fine_levels(shape, monkeypatch):
     assert (out["auto"][0] - out["16"][0]).abs().max().item() <= 2e-6 * out["16"][0].abs().max().item()
     for a, c in zip(out["auto"][1], out["16"][1]):
         assert relerr(a, c) < 2e-5
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_matrix_core_pull_epochs_and_halved_ranges(seed, monkeypatch):
+    """The matrix-core pull's rarely taken paths on ordinary batches: with MISO_MC_SMALL its survivor table holds 192
+    entries and its pair pool 640, so EVERY block is worked off in several epochs (first stores, later ones
+    read-add-store) and ranges whose pairs would overflow the pool are halved.  Same gradients as the full-size
+    kernel and as the atomic scatter; random level shapes (sizes no tile count divides among them), C = 4 / 8, 1-4 levels,
+    an ignored level, accumulate mode (grad += through autograd's second call), clusters and points outside the bound."""
+    from miso_amd import ops
+    rs = np.random.RandomState(4200 + seed)
+    L = int(rs.randint(1, 5))
+    C = int(rs.choice([4, 8]))
+    dims = [tuple(int(v) for v in rs.choice([16, 20, 24, 33, 48, 64, 100, 128], size=3)) for _ in range(L)]
+    bound = [[-1.0, 1.5], [0.0, 2.0], [-2.0, 0.0]]
+    n = int(rs.choice([20011, 70000]))
+    g = torch.Generator().manual_seed(seed)
+    feats = [(torch.randn(1, C, z, y, x, generator=g) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+             .requires_grad_(True) for (z, y, x) in dims]
+    b = torch.tensor(bound)
+    x = torch.rand(n, 3, generator=g) * (b[:, 1] - b[:, 0]) * 1.1 + b[:, 0] - 0.05 * (b[:, 1] - b[:, 0])
+    if seed % 2:
+        x[: n // 3] = x[: n // 3] * 0.03 + b.mean(dim=1)
+    ignore = [L > 1 and l == 1 and seed % 3 == 0 for l in range(L)]
+    meta = ops.GridMeta.from_bound(bound, ignore_level=ignore)
+    go = torch.randn(n, C * L, generator=g).to(DEV)
+
+    def run():
+        out = ops.encode(x.to(DEV), feats, meta)
+        return torch.autograd.grad(out, feats, go, allow_unused=True)
+
+    monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", 16384)
+    g_full = run()
+    monkeypatch.setenv("MISO_MC_SMALL", "1")
+    g_small = run()
+    monkeypatch.delenv("MISO_MC_SMALL")
+    monkeypatch.setattr(ops, "ENCODE_PULL_MIN_POINTS", None)
+    g_atomic = run()
+    for l, (a, s_, c) in enumerate(zip(g_full, g_small, g_atomic)):
+        if c is None:
+            assert a is None and s_ is None
+            continue
+        assert relerr(s_, c) < 5e-5 and relerr(a, c) < 5e-5, (seed, l, dims, C)
