@@ -379,7 +379,8 @@ typedef struct {
   int32_t loss_type;         /* 1 = L1 (row-wise 2-norm), 2 = L2 */
   int32_t ring_iters, save_poses;
   int32_t vec4;              /* set by miso_align_plan_build */
-  int64_t max_n, max_gate_n, max_gate_rows; /* set by miso_align_plan_build */
+  int64_t max_n, max_gate_n, max_gate_rows; /* set by miso_align_plan_build: longest source list, longest point-list gate,
+                                             * most lattice rows (ny nz) of a lattice gate */
   float align_weight, overlap_thresh;
   float reg_weight, reg_thresh_rad, reg_thresh_m; /* grid_atlas_pose_trust_region_loss, base.py:20-27; 0 = off */
   float rel_change_thresh;
@@ -388,6 +389,12 @@ typedef struct {
   const float* t0;           /* (S,3) base translations, device */
   const void* plan;          /* device copy of the plan blob */
   float* state;              /* device */
+  /* miso_align_iteration_a only.  Non-zero: the previous call on this state was miso_align_iteration_b, which leaves the
+   * poses of the next iteration (R0 Exp(dr), t0 + dt of the stepped corrections), their snapshot in the ring and cleared
+   * pair accumulators behind -- iteration_a then skips its prologue launch (four launches per iteration instead of five).
+   * Zero: iteration_a forms them itself (first iteration; after the caller wrote the corrections; a repeated
+   * iteration_a). */
+  int32_t poses_ready;
 } miso_align_t;
 
 int64_t miso_align_plan_bytes(int32_t n_pairs);

@@ -105,7 +105,8 @@ class Align(C.Structure):
                 ("reg_weight", C.c_float), ("reg_thresh_rad", C.c_float), ("reg_thresh_m", C.c_float),
                 ("rel_change_thresh", C.c_float),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("R0", C.c_void_p), ("t0", C.c_void_p), ("plan", C.c_void_p), ("state", C.c_void_p)]
+                ("R0", C.c_void_p), ("t0", C.c_void_p), ("plan", C.c_void_p), ("state", C.c_void_p),
+                ("poses_ready", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/miso_hip.h declares

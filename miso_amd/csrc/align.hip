@@ -49,10 +49,12 @@ AlignLayout align_layout(int S, int P, int ring_iters, int save_poses) {
   return L;
 }
 
-__global__ __launch_bounds__(256) void align_prologue_kernel(AlignK k) {
-  int32_t* ctrl = reinterpret_cast<int32_t*>(k.state + k.L.ctrl);
-  if (ctrl[CTRL_STOPPED]) return;
-  const int it = ctrl[CTRL_ITER];
+// What an iteration starts from: every submap's pose from its corrections, the (S,4,4) snapshot of
+// iteration_results_helper for iteration `it`, cleared pair accumulators.  Run by align_prologue_kernel, and (round 4) by
+// the tail of align_epilogue_b_kernel for the NEXT iteration, so that a loop pays four launches per iteration, not five.
+// full_clear: also the reduction buffer `flat` and the pair losses (epilogue A overwrites both: only for tidiness of a
+// state nobody has run yet).
+__device__ __forceinline__ void align_prologue_body(const AlignK& k, int it, bool full_clear) {
   for (int s = threadIdx.x; s < k.S; s += blockDim.x) {
     const float* prm = k.state + k.L.params + 6 * s;
     const float w[3] = {prm[0], prm[1], prm[2]};
@@ -80,10 +82,16 @@ __global__ __launch_bounds__(256) void align_prologue_kernel(AlignK k) {
       m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
     }
   }
-  // accumulators of the pair stage and the reduction buffer (out, cnt, pair_loss are adjacent; flat follows)
+  // accumulators of the pair stage (out, cnt: added to with atomics) [and pair_loss, flat, which follow them]
   float* z = k.state + k.L.out;
-  const int64_t nz = (k.L.flat + up4(7 * k.S + 2)) - k.L.out;
+  const int64_t nz = full_clear ? (k.L.flat + up4(7 * k.S + 2)) - k.L.out : k.L.pair_loss - k.L.out;
   for (int64_t i = threadIdx.x; i < nz; i += blockDim.x) z[i] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void align_prologue_kernel(AlignK k) {
+  int32_t* ctrl = reinterpret_cast<int32_t*>(k.state + k.L.ctrl);
+  if (ctrl[CTRL_STOPPED]) return;
+  align_prologue_body(k, ctrl[CTRL_ITER], true);
 }
 
 // torch.relu keeps a NaN (fmaxf would drop it, and with it the reference's "loss is nan" skip)
@@ -261,14 +269,18 @@ __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
     if (rel < k.rel_thresh) ctrl[CTRL_STOPPED] = 1;
     ctrl[CTRL_ITER] = it + 1;
   }
+  // the next iteration's poses (from the corrections just stepped), their snapshot, cleared pair accumulators: what
+  // align_prologue_kernel would do in a launch of its own (miso_align_t.poses_ready)
+  __syncthreads();
+  if (!ctrl[CTRL_STOPPED]) align_prologue_body(k, ctrl[CTRL_ITER], false);
 }
 
 hipError_t launch_pair_batch(const AlignPairK*, int, int64_t, int64_t, bool, const float*, int, double*, float*,
                              const int32_t*, int64_t, hipStream_t);
 
 hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, int64_t max_gate_rows, bool vec4,
-                          hipStream_t s) {
-  align_prologue_kernel<<<1, 256, 0, s>>>(k);
+                          bool poses_ready, hipStream_t s) {
+  if (!poses_ready) align_prologue_kernel<<<1, 256, 0, s>>>(k);
   const int32_t* stopped = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl) + CTRL_STOPPED;
   hipError_t e = launch_pair_batch(k.plan, k.P, max_n, max_gate_n, vec4, k.state + k.L.pose, k.loss_type,
                                    reinterpret_cast<double*>(k.state + k.L.out), k.state + k.L.cnt, stopped,

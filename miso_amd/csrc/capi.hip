@@ -70,7 +70,7 @@ hipError_t launch_adam_active(float*, float*, float*, float*, unsigned char*, in
                               int, const float*, hipStream_t, const float*, const int32_t*, int);
 hipError_t launch_mapping_loss(int, float, float, float, const float*, const float*, const float*,
                                const float*, const float*, int64_t, float*, float*, float*, hipStream_t);
-hipError_t launch_align_a(const AlignK&, int64_t, int64_t, int64_t, bool, hipStream_t);
+hipError_t launch_align_a(const AlignK&, int64_t, int64_t, int64_t, bool, bool, hipStream_t);
 hipError_t launch_align_b(const AlignK&, hipStream_t);
 }  // namespace miso
 
@@ -668,7 +668,7 @@ int miso_align_plan_build(const miso_align_pair_t* pairs, miso_align_t* cfg, voi
     }
     d.src = in.src; d.dst = in.dst; d.n_ch = (float)d.g.F;
     if (in.n > max_n) max_n = in.n;
-    if (d.gate_p && in.gate_n > max_gate) max_gate = in.gate_n;
+    if (d.gate_p && !d.gate_ax[0] && in.gate_n > max_gate) max_gate = in.gate_n;      // point-list gates only (grid sizing)
   }
   cfg->vec4 = v4_all ? 1 : 0;
   cfg->max_n = max_n;
@@ -709,7 +709,8 @@ int miso_align_iteration_a(const miso_align_t* cfg, void* stream) {
   AlignK k;
   int rc = align_k(cfg, &k);
   if (rc) return rc;
-  return (int)launch_align_a(k, cfg->max_n, cfg->max_gate_n, cfg->max_gate_rows, cfg->vec4 != 0, (hipStream_t)stream);
+  return (int)launch_align_a(k, cfg->max_n, cfg->max_gate_n, cfg->max_gate_rows, cfg->vec4 != 0, cfg->poses_ready != 0,
+                             (hipStream_t)stream);
 }
 
 int miso_align_iteration_b(const miso_align_t* cfg, void* stream) {

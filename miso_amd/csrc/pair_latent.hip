@@ -14,6 +14,8 @@
 // and reduces  sum term, sum m, sum g, sum (w - t_d) g^T, sum (R_d g) p^T  -- everything the
 // chain rule needs for d/dR_s, d/dt_s, d/dR_d, d/dt_d (SURVEY App. B "pose chain").  The source
 // features are read-only inputs (cached by the caller: they depend on no pose).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace miso {
@@ -273,22 +275,21 @@ constexpr int GATE_ROWS = 256;          // rows (lanes) per workgroup
 constexpr float GATE_SLACK = 2e-3f;     // metres; fp32 rounding of the map is ~1e-5 at 100 m
 constexpr float GATE_ERR = 2e-4f;       // metres: bound on the rounding of one mapped coordinate, generous
 
-__global__ __launch_bounds__(256) void overlap_count_batch_kernel(const AlignPairK* __restrict__ plan,
-                                                                 const float* __restrict__ pose_all,
-                                                                 float* __restrict__ cnt_all,
-                                                                 const int32_t* __restrict__ stopped) {
-  if (stopped && *stopped) return;
-  const AlignPairK& d = plan[blockIdx.y];
+// bx of nbx workgroups on pair `pair` (the standalone kernel: blockIdx.x of gridDim.x; the merged pair stage: the
+// workgroups behind the pair kernel's own)
+__device__ __forceinline__ void overlap_batch_body(const AlignPairK* __restrict__ plan, const float* __restrict__ pose_all,
+                                                   float* __restrict__ cnt_all, unsigned pair, unsigned bx, unsigned nbx) {
+  const AlignPairK& d = plan[pair];
   if (!d.gate_p) return;
   if (!d.gate_ax[0]) {
-    if ((int64_t)blockIdx.x * blockDim.x >= d.gate_n) return;
+    if ((int64_t)bx * blockDim.x >= d.gate_n) return;
     overlap_count_body(pose_all + 12 * d.src, pose_all + 12 * d.dst, d.gate_p, d.gate_n, d.g.bmin[0], d.g.bmin[1],
-                       d.g.bmin[2], d.g.bmax[0], d.g.bmax[1], d.g.bmax[2], cnt_all + blockIdx.y, blockIdx.x, gridDim.x);
+                       d.g.bmin[2], d.g.bmax[0], d.g.bmax[1], d.g.bmax[2], cnt_all + pair, bx, nbx);
     return;
   }
   const int nx = d.gate_dim[0], ny = d.gate_dim[1], nz = d.gate_dim[2];
   const int nrows = ny * nz;
-  const int row0 = blockIdx.x * GATE_ROWS;
+  const int row0 = bx * GATE_ROWS;
   if (row0 >= nrows) return;
   const float* ps = pose_all + 12 * d.src;
   const float* pd = pose_all + 12 * d.dst;
@@ -393,8 +394,37 @@ __global__ __launch_bounds__(256) void overlap_count_batch_kernel(const AlignPai
   __syncthreads();
   if (threadIdx.x == 0) {
     const float v = (red[0] + red[1]) + (red[2] + red[3]);
-    if (v != 0.0f) atomic_add_f32(cnt_all + blockIdx.y, v);
+    if (v != 0.0f) atomic_add_f32(cnt_all + pair, v);
   }
+}
+
+__global__ __launch_bounds__(256) void overlap_count_batch_kernel(const AlignPairK* __restrict__ plan,
+                                                                 const float* __restrict__ pose_all,
+                                                                 float* __restrict__ cnt_all,
+                                                                 const int32_t* __restrict__ stopped) {
+  if (stopped && *stopped) return;
+  overlap_batch_body(plan, pose_all, cnt_all, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+// The pair stage of an alignment iteration as ONE launch (round 4): workgroups [0, pair_blocks) of a pair run the
+// latent residual (pair_latent_batch_kernel's body), the gate_blocks behind them the overlap gate
+// (overlap_count_batch_kernel's) -- the two do not depend on each other (epilogue A applies the gate), and at level 0
+// each is a few tens of microseconds of latency on a mostly idle chip: side by side they take the longer of the two
+// instead of the sum plus a launch boundary (cfg-4 level 0: 31 + 25 + ~5 us -> see DESIGN 4.6).
+template <bool VEC4>
+__global__ __launch_bounds__(256, 4) void pair_stage_kernel(const AlignPairK* __restrict__ plan,
+                                                           const float* __restrict__ pose_all, int loss_type,
+                                                           double* __restrict__ out_all, float* __restrict__ cnt_all,
+                                                           const int32_t* __restrict__ stopped, unsigned pair_blocks) {
+  if (stopped && *stopped) return;
+  if (blockIdx.x >= pair_blocks) {
+    overlap_batch_body(plan, pose_all, cnt_all, blockIdx.y, blockIdx.x - pair_blocks, gridDim.x - pair_blocks);
+    return;
+  }
+  const AlignPairK& d = plan[blockIdx.y];
+  if ((int64_t)blockIdx.x * blockDim.x * 8 >= d.n) return;
+  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y};
+  pair_latent_body<VEC4>(d.g, pose_all + 12 * d.src, pose_all + 12 * d.dst, k, blockIdx.x, pair_blocks);
 }
 
 hipError_t launch_overlap_count(const float* pose, const float* p, int64_t n, const float* bmin, const float* bmax,
@@ -427,14 +457,21 @@ hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t ma
                              const float* pose_all, int loss_type, double* out_all, float* cnt_all,
                              const int32_t* stopped, int64_t max_gate_rows, hipStream_t s) {
   if (n_pairs <= 0) return hipSuccess;
+  // gate workgroups per pair: point-list gates (max_gate_n: the longest list) grid-stride whatever the count, lattice
+  // gates (max_gate_rows) want one workgroup per GATE_ROWS rows -- and no more: sized by the lattice's VERTEX count (4 M)
+  // the launch carried 512 workgroups per pair of which 79 had rows, 12 000 idle workgroups per iteration at cfg-4
+  unsigned gate_blocks = 0;
   if (max_gate_n > 0) {
-    unsigned blocks = (unsigned)((max_gate_n + 2047) / 2048);
-    if (blocks > 512u) blocks = 512u;
-    // lattice gates: one workgroup per GATE_ROWS rows (point-list gates grid-stride whatever the block count)
-    const unsigned lat = (unsigned)((max_gate_rows + GATE_ROWS - 1) / GATE_ROWS);
-    if (lat > blocks) blocks = lat;
-    overlap_count_batch_kernel<<<dim3(blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, cnt_all, stopped);
+    gate_blocks = (unsigned)((max_gate_n + 2047) / 2048);
+    if (gate_blocks > 512u) gate_blocks = 512u;
   }
+  {
+    const unsigned lat = (unsigned)((max_gate_rows + GATE_ROWS - 1) / GATE_ROWS);
+    if (lat > gate_blocks) gate_blocks = lat;
+  }
+  static const bool split = getenv("MISO_PAIR_STAGE_SPLIT") != nullptr;      // dev / tests: the two launches of rounds 2-3
+  if (gate_blocks && (max_n <= 0 || split))
+    overlap_count_batch_kernel<<<dim3(gate_blocks, (unsigned)n_pairs), 256, 0, s>>>(plan_dev, pose_all, cnt_all, stopped);
   if (max_n > 0) {
     unsigned blocks = (unsigned)((max_n + 2047) / 2048);
     // ~7000 workgroups in all (seven rounds of the 1024 that are resident at four waves per SIMD), at least 128 and at
@@ -444,9 +481,15 @@ hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t ma
     unsigned cap = (unsigned)(7168 / n_pairs);
     cap = cap < 128u ? 128u : (cap > 2048u ? 2048u : cap);
     if (blocks > cap) blocks = cap;
-    const dim3 grid(blocks, (unsigned)n_pairs);
-    if (vec4) pair_latent_batch_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
-    else pair_latent_batch_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
+    if (gate_blocks && !split) {
+      const dim3 grid(blocks + gate_blocks, (unsigned)n_pairs);
+      if (vec4) pair_stage_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, cnt_all, stopped, blocks);
+      else pair_stage_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, cnt_all, stopped, blocks);
+    } else {
+      const dim3 grid(blocks, (unsigned)n_pairs);
+      if (vec4) pair_latent_batch_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
+      else pair_latent_batch_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
+    }
   }
   return hipGetLastError();
 }

@@ -1124,7 +1124,10 @@ class AlignPlan:
 
     @property
     def params(self) -> torch.Tensor:
-        """(S,6) = (dr, dt) per submap: write the initial corrections here, read the final ones back."""
+        """(S,6) = (dr, dt) per submap: write the initial corrections here, read the final ones back.  (Handing the
+        tensor out counts as a write: the next iteration_a forms the poses itself instead of trusting those the last
+        iteration_b left.)"""
+        self._poses_ready = False
         return self._view(0, 6 * self.S).view(self.S, 6)
 
     @property
@@ -1165,10 +1168,14 @@ class AlignPlan:
         return self._view(11, self.S).view(torch.int32)
 
     def iteration_a(self):
+        # iteration_b leaves the next iteration's poses, their ring snapshot and cleared accumulators: no prologue launch
+        self.cfg.poses_ready = 1 if getattr(self, "_poses_ready", False) else 0
+        self._poses_ready = False
         _lib.check(_lib.load().miso_align_iteration_a(C.byref(self.cfg), _stream(self.state)), "miso_align_iteration_a")
 
     def iteration_b(self):
         _lib.check(_lib.load().miso_align_iteration_b(C.byref(self.cfg), _stream(self.state)), "miso_align_iteration_b")
+        self._poses_ready = True
 
     def ctrl(self) -> dict:
         """Host copy of the counters (one sync): Adam steps taken, stopped flag, iterations run, NaN-skipped."""
