@@ -3,8 +3,9 @@
 // Reference: generic_align_multiple_submaps, grid_opt/align/base.py:89-163, driving pairwise_loss_latent
 // (grid_opt/align/miso.py:116-211).  One iteration there is, per pair, two so3_exp_map chains, two affine maps, a
 // nonzero compaction, two multi-level grid_sample calls and their autograd backward, then torch.optim.Adam on the
-// 2(S-1) pose tensors -- ~200 tiny launches and several host syncs per pair.  Here an iteration is five launches
-// whatever the number of pairs:
+// 2(S-1) pose tensors -- ~200 tiny launches and several host syncs per pair.  Here an iteration is three launches
+// whatever the number of pairs (five in rounds 2-3: the prologue now runs in the tail of the previous iteration's
+// epilogue B -- miso_align_t.poses_ready -- and the overlap gate in the pair kernel's launch, pair_stage_kernel):
 //
 //   prologue    (dr_s, dt_s) -> R_s = R0_s Exp(dr_s), t_s = t0_s + dt_s for every submap (GridAtlas.updated_submap_pose,
 //               grid_atlas.py:250-268, utils_geometry.apply_pose_correction :78-99); clears the accumulators; writes
@@ -116,9 +117,11 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
   float* pl = k.state + k.L.pair_loss;
   // Pass structure: (1) one thread per pair normalises it -- loss value, overlap gate, the scale of its cotangents --
   // into LDS (the descriptors live in global memory: read in parallel, not P times in a row by every submap's
-  // thread); (2) one thread per submap sums the cotangents of its pairs IN LIST ORDER (deterministic) and pulls
-  // them back through R0 Exp(dr).  The pairs' 24 sums are staged in LDS too: read from global memory inside the
-  // per-submap loop they were seven dependent round trips per thread (16 us for the whole kernel, 5 with the copy).
+  // thread); (2) FOUR threads per submap sum the cotangents of its pairs, each every fourth pair of the list in list
+  // order, and are then added in a fixed tree ((0 + 2) + (1 + 3)): deterministic; thread 0 of the four pulls the sum
+  // back through R0 Exp(dr).  (One thread per submap walked all P pairs in double precision: 14 us at cfg-4's 28
+  // pairs, the longest kernel of a level-0 iteration after the pair stage.)  The pairs' 24 sums are staged in LDS too:
+  // read from global memory inside the per-submap loop they were seven dependent round trips per thread.
   __shared__ double s_out[EPI_A_PAIRS * 24];
   __shared__ float s_sc[EPI_A_PAIRS], s_loss[EPI_A_PAIRS];
   __shared__ int s_src[EPI_A_PAIRS], s_dst[EPI_A_PAIRS];
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
   __shared__ float s_total;
   double gR[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.}, gt[3] = {0., 0., 0.};
   float total = 0.0f;
-  const int s = threadIdx.x;      // submap of this thread in pass (2) (S <= 64 < EPI_A_THREADS)
+  const int s = threadIdx.x >> 2, part = threadIdx.x & 3;      // pass (2): submap and quarter of this thread (S <= 64)
   for (int p0 = 0; p0 < k.P; p0 += EPI_A_PAIRS) {
     const int np = min(EPI_A_PAIRS, k.P - p0);
     for (int i = threadIdx.x; i < np * 24; i += blockDim.x) s_out[i] = out[(int64_t)24 * p0 + i];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
     }
     __syncthreads();
     if (s < k.S) {
-      for (int i = 0; i < np; ++i) {
+      for (int i = part; i < np; i += 4) {
         const bool is_src = s_src[i] == s, is_dst = s_dst[i] == s;
         const float scf = s_sc[i];
         if (!(is_src || is_dst)) continue;
@@ -175,7 +178,17 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
       for (int i = 0; i < np; ++i) total += s_loss[i];
     __syncthreads();
   }
-  if (s < k.S) {
+  // the four quarters of a submap: lanes 4 s .. 4 s + 3 of one wavefront
+#pragma unroll
+  for (int o = 2; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) gR[q] += __shfl_xor(gR[q], o);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gt[q] += __shfl_xor(gt[q], o);
+    const int had_o = __shfl_xor(had ? 1 : 0, o);      // (not inside the ||: every lane must take part in the exchange)
+    had = had || had_o != 0;
+  }
+  if (s < k.S && part == 0) {
     const float* R0 = k.R0 + 9 * s;
     double G[9];
     for (int i = 0; i < 3; ++i)
