@@ -148,3 +148,46 @@ def test_gradient_plans_are_host_logic():
     assert lib.miso_grad_pull_levels(ctypes.byref(ncd), T) == 0b01                   # 38 vertices per tile and axis
     border = grid([(32, 32, 32)], 8, flags=2)                                         # padding_mode='border'
     assert lib.miso_grad_pull_levels(ctypes.byref(border), T) == 0
+
+
+def test_struct_sizes_and_offsets_equal_the_headers_as_a_c_compiler_sees_it(tmp_path):
+    """include/miso_hip.h compiled by gcc: sizeof of every struct the ctypes binding mirrors and the offsets of the
+    fields added last (a binding that drifts from the header corrupts arguments silently)."""
+    import ctypes
+    import os
+    import subprocess
+    from miso_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    names = [("miso_level_t", _lib.Level), ("miso_grid_t", _lib.Grid), ("miso_mlp_t", _lib.Mlp),
+             ("miso_sorted_t", _lib.Sorted), ("miso_align_pair_t", _lib.AlignPair), ("miso_align_t", _lib.Align),
+             ("miso_lm_track_t", _lib.LmTrack), ("miso_track_adam_t", _lib.TrackAdam)]
+    offs = [("miso_align_t", "poses_ready", _lib.Align), ("miso_align_t", "state", _lib.Align),
+            ("miso_sorted_t", "pull_queue_ints", _lib.Sorted), ("miso_level_t", "grad_touched", _lib.Level)]
+    body = "".join(f'  printf("%zu\\n", sizeof({n}));\n' for n, _ in names)
+    body += "".join(f'  printf("%zu\\n", offsetof({n}, {f}));\n' for n, f, _ in offs)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "miso_hip.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [ctypes.sizeof(c) for _, c in names] + [getattr(c, f).offset for _, f, c in offs]
+    assert got == want, list(zip([n for n, _ in names] + [f"{n}.{f}" for n, f, _ in offs], got, want))
+    assert _lib is not None
+
+
+def test_tile_codes_pack_and_choose():
+    """MISO_TILES_XYZ on the Python side (ops.pack_tiles / n_tiles / choose_tiles): a count stays a count, per-axis counts
+    are packed as the header's macro packs them, and the policy follows the finest level within what the matrix-core
+    pull accepts (3 size >= 2 tiles for every level)."""
+    import torch
+    from miso_amd import ops
+    assert ops.pack_tiles(16) == 16 and ops.pack_tiles((16, 16, 16)) == 16 and ops.n_tiles(16) == 4096
+    code = ops.pack_tiles((25, 13, 25))
+    assert code == 25 | (13 << 8) | (25 << 16) and ops.n_tiles(code) == 25 * 13 * 25
+    assert ops.pack_tiles((32, 32, 32)) == 32 | (32 << 8) | (32 << 16)          # cubic but beyond 16: packed
+    f = lambda z, y, x: torch.empty(1, 4, z, y, x)                                # noqa: E731
+    assert ops.choose_tiles([f(32, 32, 32), f(128, 128, 128)]) == 16             # cfg-2: 8 vertices per tile already
+    assert ops.choose_tiles([f(40, 20, 40), f(200, 100, 200)]) == ops.pack_tiles((25, 16, 25))      # ScanNet submap
+    # a coarse level of 16 vertices caps the binning at 24 tiles: the 200-vertex axis cannot be owned, stays at 16
+    assert ops.choose_tiles([f(16, 16, 16), f(200, 100, 200)]) == 16
+    assert ops.choose_tiles([f(20, 120, 120), f(100, 600, 600)]) == 16           # Newer College: too fine even for 32
