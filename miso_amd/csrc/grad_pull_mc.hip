@@ -67,8 +67,10 @@ struct McK {
   int nl;                    // pulled levels
   int overwrite;             // 1: grad = sum, 0: grad += sum
   unsigned int drow_bytes;   // bytes of the d-feat rows: n * ld * 4 (< 2^31: row offsets are 32-bit buffer offsets)
-  int debug;                 // dev ablation (MISO_DEBUG_PULL): 1 no MFMAs, 2 no staging loads, 4 no stores, 8 no multiply
-                             // phase, 16 nothing after the sweep
+  int debug;                 // dev ablation (MISO_DEBUG_PULL): 8 no multiply phase, 16 nothing after the sweep, 64 / 128 half the
+                             // workgroups.  (Bits 1 2 4 -- no MFMAs / staging loads / stores -- sat inside the multiply loop
+                             // and are gone: the branch around the loads alone made the compiler wait for them at every
+                             // later join)
   int cand_cap, pool_cap;    // table entries / pool pairs in use: MC_CAND / MC_POOL (tests: MISO_MC_SMALL shrinks them so that the
                              // epoch and pool-overflow paths run on ordinary batches)
   int prof_wave;             // dev: the wavefront that stamps (MISO_MC_PROF=1+wave)
@@ -172,6 +174,11 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
       *reinterpret_cast<unsigned char**>(lvg + d * 8 + 6) = lv.touched;
     }
   }
+  {
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);      // (workgroup i runs on XCD i % 8)
+    if ((pk.debug & 64) && ((lin >> 3) & 1)) return;       // dev: half the workgroups of every XCD, alternating
+    if ((pk.debug & 128) && lin >= (int)(gridDim.x * gridDim.y * gridDim.z) / 2) return;      // dev: the first half only
+  }      // dev: half the workgroups (one per CU): latency- or throughput-bound?
   if (pk.prof && threadIdx.x < 16) misc[M_PROF + threadIdx.x] = 0;
   unsigned long long t_prev = pk.prof ? __builtin_readcyclecounter() : 0ull;
   {
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
         MC_STAMP(6)
         // the first range also zero-fills the sub-bricks nothing touches (the gradient buffer is not cleared): wavefront w
         // looks at codes 16 w .. 16 w + 15 of every level
-        if (first && pk.overwrite && !(pk.debug & 4)) {
+        if (first && pk.overwrite) {
           // (all levels' reads first, one round trip: the usual answer is "nothing to fill")
           const int j = 16 * wave + (lane & 15);
           const int sx = j & 3, sy = (j >> 2) & 3, sz = j >> 4;
@@ -543,7 +550,6 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
         float* fl_grad = nullptr;
         unsigned char* fl_touched = nullptr;
         auto store_tile = [&](int code, const f32x4& v) {
-          if (pk.debug & 4) return;
           const int d = code >> 7;
           if (d != fl_d) {
             fl_d = d;
@@ -565,14 +571,16 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           const int sx = code & 3, sy = (code >> 2) & 3, sz = (code >> 4) & 7;
           if (!fl_full && (a_vx >= fl_e0 - 4 * sx || a_vy >= fl_e1 - 4 * sy || a_vz >= fl_e2 - ZS * sz)) return;
           const int eo = fl_lane + ZS * sz * fl_sZ + 4 * sy * fl_sY + 4 * sx * fl_sX;
-          float* dst = fl_grad + eo;
-          float4 o = make_float4(v[0], v[1], v[2], v[3]);
-          if (fl_touched && (o.x != 0.0f || o.y != 0.0f || o.z != 0.0f || o.w != 0.0f)) fl_touched[eo >> ADAM_CHUNK_SHIFT] = 1;
-          if (add_mode) {
-            const float4 q = *reinterpret_cast<const float4*>(dst);
-            o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
-          }
-          *reinterpret_cast<float4*>(dst) = o;
+          // (pointers rebuilt from LDS words are generic to the compiler: say they are global, or every store is a flat one
+          // that also holds the LDS counter)
+          typedef __attribute__((address_space(1))) f32x4 gf32x4;
+          typedef __attribute__((address_space(1))) unsigned char gu8;
+          gf32x4* dst = (gf32x4*)(fl_grad + eo);
+          f32x4 o = v;
+          if (fl_touched && (o[0] != 0.0f || o[1] != 0.0f || o[2] != 0.0f || o[3] != 0.0f))
+            *(gu8*)(fl_touched + (eo >> ADAM_CHUNK_SHIFT)) = 1;
+          if (add_mode) o += *dst;
+          *dst = o;
         };
 
         // one staged pair per lane, in registers until the previous chunk's MFMAs are through with the LDS area.  Two
@@ -596,16 +604,11 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           if (pk.perm && row >= 0) row = pk.perm[row];
           const int boff = row * (int)(pk.ld * 4) + foff * 4;
           typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          if (!(pk.debug & 2)) {
 #pragma unroll
-            for (int c = 0; c < C; c += 4) {
-              const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(drows, boff + 4 * c, 0, 0);
-              rd[c] = __uint_as_float(t4[0]); rd[c + 1] = __uint_as_float(t4[1]);
-              rd[c + 2] = __uint_as_float(t4[2]); rd[c + 3] = __uint_as_float(t4[3]);
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < C; ++c) rd[c] = 0.0f;
+          for (int c = 0; c < C; c += 4) {
+            const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(drows, boff + 4 * c, 0, 0);
+            rd[c] = __uint_as_float(t4[0]); rd[c + 1] = __uint_as_float(t4[1]);
+            rd[c + 2] = __uint_as_float(t4[2]); rd[c + 3] = __uint_as_float(t4[3]);
           }
         };
         auto stage_w = [&]() {
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
             cur_code = code;                                                                      \
             acc = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
           }                                                                                       \
-          if (!(pk.debug & 1)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, BV, acc, 0, 0, 0);  \
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, BV, acc, 0, 0, 0);                       \
         }
 #define MC_DUO(P, X, Y, Z, D)                                                                     \
         {                                                                                         \
@@ -662,6 +665,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           const int ng = min(16, g_end - g0);
 #pragma unroll
           for (int o = 0; o < 8 + ZS; ++o) stg[o * MC_CS + wr_p] = rw[o];
+          MC_STAMP(9)
 #pragma unroll
           for (int c = 0; c < C; ++c) stg[(8 + ZS + c) * MC_CS + wr_p] = rd[c];
           const int codev = rcode;
@@ -684,6 +688,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           __builtin_amdgcn_sched_barrier(0);
           MC_DUO(1, x1, y1, z1, d1)
           MC_DREAD(3, x1, y1, z1, d1)
+          if (has_next) stage_l();
           __builtin_amdgcn_sched_barrier(0);
           MC_DUO(2, x0, y0, z0, d0)
           MC_DREAD(4, x0, y0, z0, d0)
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           MC_DUO(6, x0, y0, z0, d0)
           __builtin_amdgcn_sched_barrier(0);
           MC_STAMP(13)
-          if (has_next) { stage_l(); stage_w(); }
+          if (has_next) stage_w();
           __builtin_amdgcn_sched_barrier(0);
           MC_STAMP(14)
           MC_DUO(7, x1, y1, z1, d1)
@@ -837,7 +842,7 @@ hipError_t launch_grad_pull_mc(const GridK& g, int C, const int T[3], const int*
       (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
       (void)hipMemset(prof, 0, sizeof(h));
       static const char* nm[16] = {"setup", "sweep", "barrier", "count", "barrier", "prefix+b", "fill", "zero", "barrier",
-                                   "multiply", "tail+b", "combine+b", "m:lds-write", "m:stage_a+duo0-6", "m:stage_b", "m:duo7"};
+                                   "m:write-w", "tail+b", "combine+b", "m:write-d+sync", "m:duo0-6+loads", "m:weights", "m:duo7"};
       fprintf(stderr, "[mc prof] clocks per workgroup:");
       for (int i = 0; i < 16; ++i) {
         double t = 0.0;
