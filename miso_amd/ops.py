@@ -592,7 +592,23 @@ def sdf_train_supported(features, meta, grads) -> bool:
     """True when sdf_train_raw / sdf_train_unsorted_raw cover this gradient request: a level with a gradient exists
     (the fused decoder shape itself is sdf_fused_supported's business).  Levels the pull / push cannot form from the
     d-feat rows are scattered with float atomics from the same launch (sdf_train_scattered_levels)."""
-    return any(gr is not None and not (meta.ignore_mask >> l) & 1 for l, gr in enumerate(grads))
+    if not any(gr is not None and not (meta.ignore_mask >> l) & 1 for l, gr in enumerate(grads)):
+        return False
+    # (ADVICE r3) the scattering variant keeps cell records beside the weights: make sure the widest form of the launch
+    # fits a workgroup's LDS, so that a shape that does not is routed to the two-launch path instead of failing there
+    return sdf_train_lds_bytes(features[0].shape[1], len(features), 64, scat=True) <= LDS_PER_WORKGROUP
+
+
+LDS_PER_WORKGROUP = 160 * 1024      # gfx950
+
+
+def sdf_train_lds_bytes(C: int, L: int, H: int, scat: bool, hidden_layers: int = 1) -> int:
+    """Dynamic LDS of sdf_train_kernel<C, L, H, NH, SCAT> (sdf_fused.hip: PackLayout + four wavefronts' d-feat tiles
+    [64][FP] and, scattering, their cell records [64][L][8])."""
+    F, RT, KS0, KS1 = C * L, H // 32, (C * L + 1) // 2, H // 2
+    pack = KS0 * 64 * RT + 2 * hidden_layers * KS1 * 64 * RT + H + hidden_layers * H + H + 4 + KS1 * 64
+    FP = (F + 3) // 4 * 4 + 4
+    return 4 * ((pack + 3) // 4 * 4 + 4 * (64 * FP + (64 * L * 8 if scat else 0)))
 
 
 def sdf_train_scattered_levels(features, meta, grads, tiles=None) -> int:

@@ -191,3 +191,19 @@ def test_tile_codes_pack_and_choose():
     # a coarse level of 16 vertices caps the binning at 24 tiles: the 200-vertex axis cannot be owned, stays at 16
     assert ops.choose_tiles([f(16, 16, 16), f(200, 100, 200)]) == 16
     assert ops.choose_tiles([f(20, 120, 120), f(100, 600, 600)]) == 16           # Newer College: too fine even for 32
+
+
+def test_train_kernel_lds_fits_for_every_fused_shape():
+    """the scattering form of the one-launch training kernel needs the weights + four d-feat tiles + four
+    record blocks in LDS; sdf_train_supported routes a shape that would not fit to the two-launch path.  The formula
+    (ops.sdf_train_lds_bytes) follows sdf_fused.hip's PackLayout; every shape the library instantiates fits 160 KB."""
+    from miso_amd import ops
+    shapes = [(4, 1, 32), (4, 1, 64), (4, 2, 32), (4, 2, 64), (4, 3, 64), (4, 4, 64), (8, 1, 64), (8, 2, 64), (8, 3, 64),
+              (8, 4, 64), (8, 3, 32)]                                     # MISO_FUSED_SHAPES (sdf_fused.hip)
+    for C, L, H in shapes:
+        assert ops.sdf_train_lds_bytes(C, L, H, scat=True) <= ops.LDS_PER_WORKGROUP, (C, L, H)
+    assert ops.sdf_train_lds_bytes(8, 3, 64, scat=False) == 4 * (11972 + 4 * 64 * 28)       # the headline launch: 76.6 KB
+    assert ops.sdf_train_lds_bytes(8, 4, 64, scat=True) == 4 * (12484 + 4 * (64 * 36 + 64 * 4 * 8))
+    feats = [torch.zeros(1, 8, 4, 4, 4)] * 3
+    meta = ops.GridMeta((-1.0,) * 3, (1.0,) * 3, 0, 0)
+    assert ops.sdf_train_supported(feats, meta, [feats[0], None, None]) and not ops.sdf_train_supported(feats, meta, [None] * 3)
