@@ -191,7 +191,8 @@ def scannet_atlas(dev, n_submaps=8, perturb=True):
 
 
 def cfg4_pmc_traffic(level):
-    """HBM bytes per launch of pair_latent_batch_kernel at an alignment level, from the committed PMC summary -- only
+    """HBM bytes per launch of pair_stage_kernel (gate + residual in one launch; pair_latent_batch_kernel where the stage
+    is split) at an alignment level, from the committed PMC summary -- only
     while that summary was collected on the kernel sources of this library (the hash miso_version() embeds)."""
     import glob
     from miso_amd.csrc_hash import source_hash
@@ -201,7 +202,8 @@ def cfg4_pmc_traffic(level):
         except Exception:
             continue
         if js.get("_meta", {}).get("source_hash") == source_hash():
-            e = js.get("cfg4_align", {}).get(f"pair_latent_batch_kernel_level{level}")
+            e = js.get("cfg4_align", {}).get(f"pair_stage_kernel_level{level}") or \
+                js.get("cfg4_align", {}).get(f"pair_latent_batch_kernel_level{level}")
             return None if e is None else {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
                                            "if_fetch_is_not_halved": e["hbm_bytes_per_launch_if_fetch_is_not_halved"],
                                            "source": os.path.basename(pmc)}
@@ -288,7 +290,7 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
             # on these; the no-reuse figure (8 corner fetches per in-bound vertex, SURVEY 8d's convention) is kept beside it.
             b_comp = 12 * nv + inb * (4 + 4) * C_ * (level + 1)
             traffic = cfg4_pmc_traffic(level)
-            rec["roofline"] = {"bound": "hbm", "kernel": "pair_latent_batch_kernel (+ overlap_count_batch_kernel, "
+            rec["roofline"] = {"bound": "hbm", "kernel": "pair_stage_kernel (gates + residuals; + "
                                "prologue, epilogue A)", "achieved": b_comp / (t_k * 1e-6) / 1e9, "peak": 8000.0,
                                "unit": "GB/s", "frac": b_comp / (t_k * 1e-6) / 8e12,
                                "compulsory_bytes": b_comp, "traffic": traffic,

@@ -61,7 +61,7 @@ for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         continue
     for r in csv.DictReader(open(paths[0])):
         nm = short(r["Kernel_Name"])
-        if nm not in ("pair_latent_batch_kernel", "overlap_count_batch_kernel"):
+        if nm not in ("pair_stage_kernel", "pair_latent_batch_kernel", "overlap_count_batch_kernel"):
             continue
         align.setdefault(nm, {}).setdefault(int(r["Grid_Size"]), {}).setdefault(cname, []).append(float(r["Counter_Value"]))
 if align:
