@@ -125,7 +125,21 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, con
   const int per = (nt + SORT_THREADS - 1) / SORT_THREADS;
   const int b0 = threadIdx.x * per;
   int sum = 0;
-  for (int i = 0; i < per; ++i) if (b0 + i < nt) sum += count[b0 + i];
+  // (this block's prefixes are requested together with the counts: one round trip in front of the scan, not one more
+  // behind it; 16^3 tiles: four per thread)
+  constexpr int PER_REG = 4;
+  int cnt_r[PER_REG], bh_r[PER_REG];
+#pragma unroll
+  for (int i = 0; i < PER_REG; ++i) {
+    cnt_r[i] = bh_r[i] = 0;
+    if (per <= PER_REG && i < per && b0 + i < nt) { cnt_r[i] = count[b0 + i]; bh_r[i] = bh[(int64_t)blockIdx.x * nt + b0 + i]; }
+  }
+  if (per <= PER_REG) {
+#pragma unroll
+    for (int i = 0; i < PER_REG; ++i) sum += cnt_r[i];
+  } else {
+    for (int i = 0; i < per; ++i) if (b0 + i < nt) sum += count[b0 + i];
+  }
   int inc = sum;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -135,12 +149,22 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, con
   int wbase = 0;
   for (int w = 0; w < wave; ++w) wbase += wsum[w];
   int run = wbase + inc - sum;
-  for (int i = 0; i < per; ++i)
-    if (b0 + i < nt) {
-      cursor[b0 + i] = run + bh[(int64_t)blockIdx.x * nt + b0 + i];
-      if (blockIdx.x == 0) tile_off[b0 + i] = run;
-      run += count[b0 + i];
-    }
+  if (per <= PER_REG) {
+#pragma unroll
+    for (int i = 0; i < PER_REG; ++i)
+      if (i < per && b0 + i < nt) {
+        cursor[b0 + i] = run + bh_r[i];
+        if (blockIdx.x == 0) tile_off[b0 + i] = run;
+        run += cnt_r[i];
+      }
+  } else {
+    for (int i = 0; i < per; ++i)
+      if (b0 + i < nt) {
+        cursor[b0 + i] = run + bh[(int64_t)blockIdx.x * nt + b0 + i];
+        if (blockIdx.x == 0) tile_off[b0 + i] = run;
+        run += count[b0 + i];
+      }
+  }
   if (blockIdx.x == 0 && threadIdx.x == SORT_THREADS - 1) tile_off[nt] = run;
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * seg, hi = min(n, lo + seg);
