@@ -694,8 +694,8 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
 // every level of an unbinned batch, perm == nullptr) are scattered from here with float atomics exactly as
 // sdf_bwd_kernel<.., true, false> does it -- per-point cell records kept in LDS from the forward's gather, lanes
 // (point slot, dx, channel) walking the chunk's d-feat tile.  dfeat_out may then be null (nothing deferred).
-template <int C, int L, int H, int NH, bool SCAT>
-__global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kernel(GridK g, const float* __restrict__ packed,
+template <int C, int L, int H, int NH, bool SCAT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kernel(GridK g, const float* __restrict__ packed,
                                                           const float* __restrict__ x, int64_t n,
                                                           float* __restrict__ sdf, const int* __restrict__ perm,
                                                           LossInK lin, float* __restrict__ dfeat_out,
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kerne
   float loss_sdf = 0.0f, loss_fs = 0.0f;
   float inv_n = lin.inv_n;
   if (lin.n_live) { const int live = *lin.n_live; inv_n = 1.0f / (float)(live > 1 ? live : 1); }
-  ChunkSched sched(nchunks, wave, 4, true);
+  ChunkSched sched(nchunks, wave, NW, true);
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     asm volatile("" ::: "memory");      // see sdf_fwd_kernel: keeps the LDS reads of weights / biases inside the loop
     const int64_t p = chunk * 64 + lane;
@@ -1013,7 +1013,11 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kerne
   if (lane == 0) { smem[2 * wave] = loss_sdf; smem[2 * wave + 1] = loss_fs; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float a = (smem[0] + smem[2]) + (smem[4] + smem[6]), b = (smem[1] + smem[3]) + (smem[5] + smem[7]);
+    float a = (smem[0] + smem[2]) + (smem[4] + smem[6]), b = (smem[1] + smem[3]) + (smem[5] + smem[7]);
+    if (NW == 8) {
+      a += (smem[8] + smem[10]) + (smem[12] + smem[14]);
+      b += (smem[9] + smem[11]) + (smem[13] + smem[15]);
+    }
     float2* slots = reinterpret_cast<float2*>(lin.loss_out);
     slots[blockIdx.x] = make_float2(lin.p.w_sdf * a * inv_n, lin.p.w_fs * b * inv_n);
     for (int sl = blockIdx.x + gridDim.x; sl < MISO_LOSS_SLOTS; sl += gridDim.x) slots[sl] = make_float2(0.f, 0.f);
@@ -1081,6 +1085,21 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
   constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4;
   size_t lds = (size_t)(((pl.total + 3) / 4) * 4 + 4 * (64 * FP + (scat ? 64 * L * 8 : 0))) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
+  // Nothing scattered from the kernel (the mapping step): ONE workgroup of eight wavefronts per CU instead of two of
+  // four -- the same two wavefronts per SIMD, half the copies of the 48 KB pack out of L2 at the start of the launch,
+  // one barrier per CU (cfg-2: 72.9 -> 72.0 us, A/B in one process; MISO_TRAIN_NW4 keeps the four-wavefront form).
+  // The scattering variant keeps four: its cell records would not fit beside eight d-feat tiles.
+  static const bool nw8 = getenv("MISO_TRAIN_NW4") == nullptr;
+  if (nw8 && !scat) {
+    size_t lds8 = (size_t)(((pl.total + 3) / 4) * 4 + 8 * 64 * FP) * sizeof(float);
+    unsigned blocks8 = (unsigned)((nchunks + 7) / 8);
+    if (blocks8 > 256u) blocks8 = 256u;
+    auto k8 = sdf_train_kernel<C, L, H, NH, false, 8>;
+    hipError_t e8 = allow_lds((const void*)k8, lds8);
+    if (e8 != hipSuccess) return e8;
+    k8<<<blocks8, 512, lds8, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
+    return hipGetLastError();
+  }
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   if (blocks > 512u) blocks = 512u;      // persistent: two workgroups per CU (256 .. 1024 measured: 512 and up equal)
   if (blocks > MISO_LOSS_SLOTS) blocks = MISO_LOSS_SLOTS;   // one loss slot per block

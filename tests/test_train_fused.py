@@ -76,7 +76,12 @@ def _both(feats, meta, pack, x, aux, lt, ws, wf, td, n_live=None, need=None):
 
 def _check(a, b):
     (s1, sdf1, g1), (s2, sdf2, g2) = a, b
-    assert torch.equal(torch.nan_to_num(s1, nan=123.0), torch.nan_to_num(s2, nan=123.0))
+    # the per-workgroup loss slots: the two forms group the wavefronts' sums differently (eight per workgroup in the
+    # one-launch kernel, four in the forward kernel) -- the totals agree to the rounding of that regrouping
+    t1, t2 = s1.double().sum(0), s2.double().sum(0)
+    assert torch.equal(torch.isnan(t1), torch.isnan(t2))
+    ok = ~torch.isnan(t2)
+    assert torch.allclose(t1[ok], t2[ok], rtol=2e-6, atol=1e-12), (t1, t2)
     assert torch.equal(sdf1, sdf2)
     for x1, x2 in zip(g1, g2):
         if x1 is None:
