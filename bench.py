@@ -1009,6 +1009,9 @@ def headline_record(args, step, dev, world, elapsed):
     mask = torch.empty(((N_POINTS + 63) // 64) * 64 * ops.sdf_mask_words(pack), device=dev, dtype=torch.int32)
     t_sort = time_kernel(lambda: sb.sort(step.x, meta)) if sb is not None else 0.0
     fused = sb is not None and step._fused_train()
+    if sb is not None and sb.perm is None:
+        # the step's own batch carries no perm[] (the fused step does not need one); the two-launch reference below does
+        sb = ops.SortedBatch(N_POINTS, dev, tiles=step.tiles).sort(step.x, meta)
     t_train = None
     if sb is not None:
         # the two-launch form of forward and backward, each timed alone (the generic entry points; what runs when a

@@ -177,8 +177,11 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
 typedef struct {
   int32_t tiles_per_axis;      /* 1..16, or MISO_TILES_XYZ(tx, ty, tz) */
   const float* x_sorted;       /* (N,3) points grouped by tile                   */
-  const float* xn_sorted;      /* (N,4) the same normalised to [-1,1] as {x,y,z,0}, 16-B aligned; NULL = absent */
-  const int32_t* perm;         /* (N) sorted position -> original index          */
+  const float* xn_sorted;      /* (N,4) the same normalised to [-1,1] as {x, y, z, i}, 16-B aligned; NULL = absent.  i = the
+                                  point's ORIGINAL index as a 32-bit integer bit pattern (what perm[] holds) */
+  const int32_t* perm;         /* (N) sorted position -> original index.  NULL is accepted by miso_sdf_train_sorted only
+                                  (it takes the index from xn_sorted[p].w): a mapping step that runs nothing else on the
+                                  batch saves the sort one scattered 4-byte store per point */
   const int32_t* tile_offsets; /* (number of tiles + 1) start of every tile in x_sorted; tile (tx,ty,tz) = (tz Ty + ty) Tx + tx */
   /* Optional scratch of the owner-computes gradient (miso_grad_pull, miso_sdf_bwd_sorted):
    * miso_pull_queue_ints(n) int32, ZEROED ONCE by the caller when allocated (the library leaves it
@@ -193,7 +196,7 @@ int64_t miso_pull_queue_ints(int64_t n);
 int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis);
 int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,
                      void* workspace, float* x_sorted /* may be NULL */, float* xn_sorted /* may be NULL */,
-                     int32_t* perm, int32_t* tile_offsets, void* stream);
+                     int32_t* perm /* may be NULL when xn_sorted is given */, int32_t* tile_offsets, void* stream);
 /* miso_encode_fwd over a binned batch: the gathers of neighbouring lanes share cache lines
  * (105 -> 39 us at 262144 points); feats rows are written in the caller's order. */
 int miso_encode_fwd_sorted(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, float* feats,

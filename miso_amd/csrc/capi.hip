@@ -161,7 +161,7 @@ int miso_encode_fwd(const miso_grid_t* grid, const float* x, int64_t n, float* f
 }
 
 static const float* sorted_points(GridK* g, const miso_sorted_t* sorted);
-static int check_sorted(const miso_sorted_t* s, int64_t n);
+static int check_sorted(const miso_sorted_t* s, int64_t n, bool perm_optional = false);
 
 static int encode_bwd_impl(const miso_grid_t* grid, const float* x, int64_t n, const float* grad_feats,
                            int64_t ld_g, float* grad_x, const miso_sorted_t* sorted, void* stream) {
@@ -356,9 +356,11 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
   return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, stream);
 }
 
-static int check_sorted(const miso_sorted_t* s, int64_t n) {
+// perm_optional: the entry point can take the original index from xn_sorted[p].w (miso_sdf_train_sorted)
+static int check_sorted(const miso_sorted_t* s, int64_t n, bool perm_optional) {
   if (!s || !s->tile_offsets) return MISO_E_BADARG;
-  if (n > 0 && ((!s->x_sorted && !s->xn_sorted) || !s->perm)) return MISO_E_BADARG;   // an empty batch has no buffers
+  if (n > 0 && (!s->x_sorted && !s->xn_sorted)) return MISO_E_BADARG;   // an empty batch has no buffers
+  if (n > 0 && !s->perm && !(perm_optional && s->xn_sorted)) return MISO_E_BADARG;
   if (((uintptr_t)s->xn_sorted & 15u) != 0) return MISO_E_BADARG;
   { int t3_[3]; if (!tiles_xyz(s->tiles_per_axis, t3_)) return MISO_E_BADARG; }
   return MISO_OK;
@@ -373,7 +375,8 @@ int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t
                      void* workspace, float* x_sorted, float* xn_sorted, int32_t* perm,
                      int32_t* tile_offsets, void* stream) {
   { int t3_[3]; if (n < 0 || n >= ((int64_t)1 << 31) || !tiles_xyz(tiles_per_axis, t3_)) return MISO_E_BADARG; }
-  if (!workspace || !tile_offsets || (n > 0 && (!x || (!x_sorted && !xn_sorted) || !perm))) return MISO_E_BADARG;
+  if (!workspace || !tile_offsets || (n > 0 && (!x || (!x_sorted && !xn_sorted)))) return MISO_E_BADARG;
+  if (n > 0 && !perm && !xn_sorted) return MISO_E_BADARG;      // without perm the index lives in xn_sorted[p].w only
   if (((uintptr_t)xn_sorted & 15u) != 0) return MISO_E_BADARG;
   GridK g;
   int rc = convert_grid(grid, &g, false, nullptr);
@@ -576,6 +579,7 @@ static int sdf_train_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const 
     lin.n_live = n_live;
     GridK gp = g;
     if (sorted) x = sorted_points(&gp, sorted);
+    if (sorted && !sorted->perm) gp.flags |= MISO_F_INDEX_IN_XN;
     rc = (int)launch_sdf_train(C, L, H, NH, gp, packed, x, n, sdf, sorted ? sorted->perm : nullptr, lin,
                                pull ? workspace : nullptr, pull, scat != 0, st);
     if (rc) return rc;
@@ -590,7 +594,7 @@ int miso_sdf_train_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const 
                           const miso_sorted_t* sorted, int64_t n, int loss_type, float weight_sdf, float weight_fs,
                           float trunc_dist, const float* loss_inputs, float* sdf, float* loss_slots,
                           const int32_t* n_live, float* workspace, void* stream) {
-  int rc = check_sorted(sorted, n);
+  int rc = check_sorted(sorted, n, true);
   if (rc) return rc;
   if (n > 0 && !workspace) return MISO_E_BADARG;
   return sdf_train_impl(grid, mlp, packed, nullptr, sorted, n, loss_type, weight_sdf, weight_fs, trunc_dist,

@@ -21,6 +21,10 @@ struct LevelK {
   int32_t foff;            // first output column of this level
 };
 
+// internal GridK::flags bit (not part of the ABI): the batch is binned, there is no perm[] and the original index of
+// sorted point p is the integer in xn[p].w (miso_sort_points with perm == NULL; sdf_train_kernel)
+constexpr uint32_t MISO_F_INDEX_IN_XN = 1u << 20;
+
 struct GridK {
   int32_t n_levels;
   uint32_t ignore_mask;

@@ -736,7 +736,10 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     asm volatile("" ::: "memory");      // see sdf_fwd_kernel: keeps the LDS reads of weights / biases inside the loop
     const int64_t p = chunk * 64 + lane;
     const bool valid = p < n;
-    const int64_t po = (valid && perm) ? (int64_t)perm[p] : p;
+    int64_t po = p;
+    if (valid && perm) po = (int64_t)perm[p];
+    // (a binned batch without perm[]: the sort left the original index in xn[p].w)
+    else if (valid && (g.flags & MISO_F_INDEX_IN_XN)) po = (int64_t)__float_as_int(reinterpret_cast<const float4*>(x)[p].w);
     float4 l_in = make_float4(0.f, 1.f, 0.f, 1.f);
     if (valid) l_in = lin.aux[po];
     float f[2 * KS0];

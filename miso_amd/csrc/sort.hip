@@ -190,7 +190,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, con
     for (int u = 0; u < UP; ++u) {
       if (t[u] < 0) continue;
       const int64_t i = i0 + (int64_t)u * blockDim.x;
-      perm[pos[u]] = (int)i;
+      if (perm) perm[pos[u]] = (int)i;      // (optional: the index also rides in xn[pos].w)
       if (xs) {
         xs[(int64_t)pos[u] * 3 + 0] = v[u][0]; xs[(int64_t)pos[u] * 3 + 1] = v[u][1];
         xs[(int64_t)pos[u] * 3 + 2] = v[u][2];
@@ -204,7 +204,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(GridK g, con
           w[a] = (g.flags & MISO_F_COORDS_NORMALIZED)
                      ? v[u][a]
                      : __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(v[u][a], g.bmin[a])), __fsub_rn(g.bmax[a], g.bmin[a])), 1.0f);
-        reinterpret_cast<float4*>(xn)[pos[u]] = make_float4(w[0], w[1], w[2], 0.0f);
+        // .w: the point's original index as an integer bit pattern -- a consumer that has the float4 in hand anyway
+        // (sdf_train_kernel) needs no perm[] then, and the sort one 4-byte scattered store per point less
+        reinterpret_cast<float4*>(xn)[pos[u]] = make_float4(w[0], w[1], w[2], __int_as_float((int)i));
       }
     }
   }

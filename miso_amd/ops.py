@@ -435,14 +435,15 @@ class SortedBatch:
     # too few points for the sweep to pay.  None = never automatic.
     AUTO_MIN_POINTS = int(os.environ.get("MISO_SORT_MIN_POINTS", 65536)) or None
 
-    def __init__(self, n: int, device, tiles=TILES, keep_metric: bool = False):
-        """tiles: tiles per axis -- a count (1..16) or per-axis counts (tx, ty, tz) of 1..32 (MISO_TILES_XYZ)."""
+    def __init__(self, n: int, device, tiles=TILES, keep_metric: bool = False, need_perm: bool = True):
+        """tiles: tiles per axis -- a count (1..16) or per-axis counts (tx, ty, tz) of 1..32 (MISO_TILES_XYZ).
+        need_perm=False: no perm[] array (the index rides in xn_sorted[:, 3]); only sdf_train_raw takes such a batch."""
         self.n, self.tiles = int(n), pack_tiles(tiles)
         i32 = dict(device=device, dtype=torch.int32)
         # the kernels read the normalised float4 copy; the metric copy is optional
         self.x_sorted = torch.empty((self.n, 3), device=device, dtype=torch.float32) if keep_metric else None
         self.xn_sorted = torch.empty((self.n, 4), device=device, dtype=torch.float32)
-        self.perm = torch.empty(self.n, **i32)
+        self.perm = torch.empty(self.n, **i32) if need_perm else None
         self.tile_offsets = torch.empty(n_tiles(self.tiles) + 1, **i32)
         ws = _lib.load().miso_sort_workspace_bytes(self.n, self.tiles)
         self.workspace = torch.empty(max(ws, 1), device=device, dtype=torch.uint8)
@@ -450,7 +451,7 @@ class SortedBatch:
         self.struct.tiles_per_axis = self.tiles
         self.struct.x_sorted = self.x_sorted.data_ptr() if keep_metric else None
         self.struct.xn_sorted = self.xn_sorted.data_ptr()
-        self.struct.perm = self.perm.data_ptr()
+        self.struct.perm = self.perm.data_ptr() if need_perm else None
         self.struct.tile_offsets = self.tile_offsets.data_ptr()
         # slice queue of the owner-computes gradient (heavy tiles are cut and spread): zeroed once, the
         # library rewinds it after every use

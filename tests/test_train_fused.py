@@ -320,3 +320,35 @@ def test_unbinned_train_kernel_vs_cpu_oracle(n):
     assert (slots.sum(0).cpu() - terms).abs().max().item() <= 1e-6 * max(1.0, terms.abs().max().item())
     for a, r in zip(grads, gref):
         assert (a.cpu() - r).abs().max().item() <= 1e-4 * r.abs().max().item()
+
+
+def test_train_kernel_takes_the_index_from_xn_when_the_batch_has_no_perm_array():
+    """miso_sort_points leaves the original index in xn_sorted[p].w; miso_sdf_train_sorted accepts a batch without perm[]
+    (MappingStep's fused step: one scattered store per point less in the sort).  Same results bit for bit as with
+    perm[]; every other entry point refuses such a batch."""
+    from miso_amd import ops
+    feats, meta, pack, x, aux = _setup(8, (32, 64, 128), 64, 70001, seed=21)
+    aux[7, 0] = 0.0
+    n = x.shape[0]
+    sb_p = ops.SortedBatch(n, DEV).sort(x, meta)
+    sb_n = ops.SortedBatch(n, DEV, need_perm=False).sort(x, meta)
+    assert sb_n.perm is None
+    assert torch.equal(sb_p.xn_sorted[:, 3].view(torch.int32), sb_p.perm)          # the index rides in .w either way
+    assert torch.equal(sb_p.xn_sorted[:, :3][torch.argsort(sb_p.perm)], sb_n.xn_sorted[:, :3][torch.argsort(
+        sb_n.xn_sorted[:, 3].view(torch.int32))])                                   # (orders inside a tile may differ)
+    outs = []
+    for sb in (sb_p, sb_n):
+        slots, sdf = torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), torch.full((n, 1), 9.0, device=DEV)
+        grads = [torch.full_like(f, -3.0) for f in feats]
+        ops.sdf_train_raw(feats, meta, pack, sb, aux, slots, grads, "L1", 1.0, 0.1, 0.15, sdf_out=sdf)
+        outs.append((slots, sdf, grads))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][1], outs[1][1])                                      # sdf in the caller's order
+    assert torch.allclose(outs[0][0].double().sum(0), outs[1][0].double().sum(0), rtol=2e-6, atol=0)
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()           # the pull's summation order only
+    mask = torch.empty(((n + 63) // 64) * 64 * ops.sdf_mask_words(pack), device=DEV, dtype=torch.int32)
+    with pytest.raises(RuntimeError):
+        ops.sdf_fwd_raw(x, feats, meta, pack, True, mask=mask, sorted_batch=sb_n)
+    with pytest.raises(RuntimeError):
+        ops.encode_fwd_raw(x, feats, meta, sorted_batch=sb_n)

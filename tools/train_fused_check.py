@@ -17,19 +17,19 @@ def main():
     step, _ = bench.build_workload(dev, 0)
     assert step._fused_train()
     # same sorted batch for both forms: sort once, call the two paths by hand
-    step.sorted.sort(step.x, step.meta)
+    sb = ops.SortedBatch(step.n, dev, tiles=step.tiles).sort(step.x, step.meta)      # with perm[]: the two-launch form needs it
     L = len(step.features)
     mw = ops.sdf_mask_words(step.pack)
     mask = torch.empty(((step.n + 63) // 64) * 64 * mw, device=dev, dtype=torch.int32)
     g2 = [torch.empty_like(f) for f in step.features]
     slots2 = torch.zeros_like(step.loss_slots)
-    ops.sdf_fwd_loss_raw(step.features, step.meta, step.pack, step.sorted, step.aux, mask, step.gpred, slots2, "L1", 1.0, 0.0, 0.0)
+    ops.sdf_fwd_loss_raw(step.features, step.meta, step.pack, sb, step.aux, mask, step.gpred, slots2, "L1", 1.0, 0.0, 0.0)
     ops.sdf_bwd_raw(step.x, step.features, step.meta, step.pack, step.gpred, mask, False, [True] * L, g2,
-                    sorted_batch=step.sorted, overwrite=True, gsdf_sorted=True)
+                    sorted_batch=sb, overwrite=True, gsdf_sorted=True)
     g1 = [torch.empty_like(f) for f in step.features]
     slots1 = torch.zeros_like(step.loss_slots)
     sdf1 = torch.empty(step.n, 1, device=dev)
-    ops.sdf_train_raw(step.features, step.meta, step.pack, step.sorted, step.aux, slots1, g1, "L1", 1.0, 0.0, 0.0, sdf_out=sdf1)
+    ops.sdf_train_raw(step.features, step.meta, step.pack, sb, step.aux, slots1, g1, "L1", 1.0, 0.0, 0.0, sdf_out=sdf1)
     torch.cuda.synchronize()
     print("loss", slots1.sum(0).tolist(), slots2.sum(0).tolist(), "slots equal:", torch.equal(slots1, slots2))
     for l in range(L):
