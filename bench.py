@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Headline benchmark: 3-D point-samples/s, encode+decode forward+backward.
 
 Workload (BASELINE.json configs[1], "cfg-2"): one submap per GPU, 3-level

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Dense Adam over one level (dev): miso_adam_active (finds the moving chunks by reading the gradient) against
 miso_adam_touched (reads the flags the scatter kernels left), by level size and fraction of moving chunks."""
 import os

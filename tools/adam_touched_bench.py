@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: miso_adam_touched on a 145 M-float level (the Newer College fine level) for synthetic flag patterns -- what
 bounds it: the flag scan, the number of stepped chunks, or where they lie?"""
 import os

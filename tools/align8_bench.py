@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """cfg-4 alone (dev / profiling): 8 ScanNet-shaped submaps, 28 pairs, the fused alignment loop at levels 0 and 1."""
 import json
 import os

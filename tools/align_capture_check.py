@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Dev: wall time per alignment iteration, captured loop vs op-by-op (same setup as tools/align_bench.py)."""
 import logging
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: pose gradients of one level-1 pair (4 M vertices): HIP fused plan vs the oracle loop in fp32 and in fp64."""
 import os, sys, time
 import torch

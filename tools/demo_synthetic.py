@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """The two MISO demos end to end on synthetic RGB-D frames, through the reference's import names.
 
 demo/build_submaps.py (main_scannet, :125-141) and demo/align_submaps.py (main_scannet, :240-317) need a ScanNet

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: where the wall time of one sharded alignment run goes (2 ranks on one GPU over gloo, or 1 rank over nccl).
    MISO_BENCH_BACKEND=gloo python tools/dist_probe.py 2      (spawns the ranks itself)"""
 import cProfile

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: per-step host enqueue time of the stream-launched headline step, to find the slow stretch seen in
 tools/graph_vs_eager.py (third run of 200)."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev probe: the headline MappingStep as a graph replay vs as plain stream launches (cfg-2), same protocol as bench.py."""
 import os
 import sys

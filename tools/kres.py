@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: per-kernel register / LDS / spill counts of a compiled HIP object.
    python tools/kres.py miso_amd/csrc/grad_pull.o [regex]"""
 import re

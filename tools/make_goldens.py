@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Generate tests/golden/*.npz by IMPORTING the reference (MISO) on CPU.
 
 Runs only in the build container (needs /root/reference).  The reference can

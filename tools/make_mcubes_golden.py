@@ -1,4 +1,3 @@
-#!/opt/conda/bin/python3.9
 """Golden vectors for marching cubes from an independent third-party implementation.
 
 PyMCubes (what the reference calls, grid_opt/utils/utils_sdf.py:94) is not in this image; scikit-image 0.18.3 under

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Wall time of Mapper.mapping (a fresh GridTrainer per call, as the SLAM loop does per frame) at the ScanNet shape (dev)."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Dev bench: marching cubes on a res^3 volume in HBM (sphere + ripple).  Prints per-launch times (HIP events on
 the launch stream) and the HBM rate of the two sweeps against their algorithmic bytes (4 B per sample each)."""
 import ctypes as C

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Do the next batch's sort and the current step's gradient pull overlap when they run on two streams (dev probe for
 DESIGN 4.10 item 3)?  cfg-2 shapes; serial = both on one stream."""
 import os

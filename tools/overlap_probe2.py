@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev probe: does the NEXT batch's sort hide behind the current batch's sdf_train_kernel + pull when it runs on a
 second stream?  cfg-2 shapes.  serial = one stream."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev probe (cfg-3 shapes): does the forward of one batch overlap with the atomic-bound backward of another when the
 two run on two streams?  If the pair takes ~max instead of ~sum, a fused forward + backward (atomics included) kernel
 would hide the fine level's atomics behind matrix work."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev probe: the NEXT batch's sort (small workgroups, MISO_SORT_SMALL=1) on a second stream under the current batch's
 training kernel -- stream launches only, for a kernel trace (tools/ovl_trace.py prints a window of it)."""
 import os

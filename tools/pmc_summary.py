@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Turn the rocprofv3 outputs of tools/profile_bench.sh into the committed summaries:
 profiles/<tag>_kernel_stats.csv (verbatim --stats table) and
 profiles/<tag>_pmc_summary.json (per kernel: FETCH_SIZE / WRITE_SIZE averages and HBM bytes

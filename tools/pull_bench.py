@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """grad_pull_kernel alone at cfg-2 (dev tool): all levels together, each level alone, pairs of levels, and the sort."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Kernel-level timing of the hot path at BASELINE cfg-2 (dev tool, not the contract bench)."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: us per headline step in blocks of 250 steps from the very first step of a process on a box whose GPU has been idle
 for a while -- how long until the sustained rate?"""
 import gc

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: duration of consecutive blocks of 5 headline steps (a) from a cold device, (b) after 40 ms of steps followed by a
 synchronize and an idle gap of X ms -- how long does the device keep its clocks?"""
 import gc

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd SQLite database (kernel-trace) into a per-kernel
 stats table (calls, total/avg/min/max us) and, with --timeline N, the last N
 dispatches with start offsets -- the text that gets committed under profiles/."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Submaps that CAN be aligned: every level of every submap samples ONE analytic feature field of the world.
 
 The golden atlas of the tests and bench.py's cfg-4 atlas carry random features -- good for pinning gradients and

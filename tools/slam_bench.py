@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Wall time of System.run on the synthetic lidar room of tests/test_datasets.py (7 keyframes, two submaps; LM or Adam
 tracking, coordinate+joint mapping), with the round-2 fast paths on and off (dev)."""
 import os

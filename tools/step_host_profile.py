@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: cProfile of the host side of the stream-launched headline step (where do its 35 us go?)."""
 import cProfile
 import os

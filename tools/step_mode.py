@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: run the headline step N times as graph replays or as stream launches (for a kernel trace of either)."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Wall time of Tracker.lm_step / track_window at a SLAM-sized batch (dev)."""
 import os
 import sys

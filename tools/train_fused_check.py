@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: the one-launch training kernel (sdf_train_kernel) against the two-launch form on the cfg-2 step: same loss, same
 gradients (one sorted order), and the step time of both as graph replays."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: cfg-2 step time (graph replays) under the environment it is started with."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Wall time per GridTrainer.train_step at cfg-2 (dev): captured graph replay vs op-by-op autograd."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """dev: cProfile of the host side of GridTrainer.train_step at the Newer College shape (6 144 samples: host-bound)."""
 import cProfile
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Dev: print the kernel timeline of the last captured GridTrainer.train_step found in a rocprofv3 kernel trace of
 tools/trainer_bench.py (start offset, duration, gap to the previous kernel's end; microseconds)."""
 import csv
