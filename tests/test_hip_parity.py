@@ -438,6 +438,48 @@ def test_sort_points_is_a_tile_grouped_permutation(n, tiles):
     assert torch.equal(tid, expect)
 
 
+def _check_sorted_batch(sb, x, bound, tiles3):
+    n = x.shape[0]
+    tx, ty, tz = tiles3
+    perm = sb.perm.cpu().long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(n))
+    assert torch.equal(sb.xn_sorted.cpu()[:, 3].view(torch.int32).long(), perm)      # the index also rides in .w
+    off = sb.tile_offsets.cpu().long()
+    assert off[0] == 0 and off[-1] == n and torch.all(off[1:] >= off[:-1])
+    b = torch.tensor(bound)
+    u = torch.nan_to_num((x[perm] - b[:, 0]) / (b[:, 1] - b[:, 0]), nan=0.0)
+    tt = torch.tensor([tx, ty, tz])
+    t = torch.minimum(torch.clamp(torch.floor(u * tt), min=0), (tt - 1).float()).long()
+    tid = (t[:, 2] * ty + t[:, 1]) * tx + t[:, 0]
+    assert torch.equal(tid, torch.repeat_interleave(torch.arange(tx * ty * tz), off[1:] - off[:-1]))
+
+
+@pytest.mark.gpu
+def test_sort_reuses_its_buffers_batch_after_batch():
+    """The SAME SortedBatch (workspace, outputs) sorts batch after batch -- uniform, everything in one tile, a thin slab
+    (most tiles empty), more than a million points -- and every result is a tile-grouped permutation with the original
+    index in xn_sorted[:, 3]: nothing of one call leaks into the next."""
+    from miso_amd import ops
+    bound = [[-1.0, 1.0], [-2.0, 2.0], [0.0, 3.0]]
+    meta = ops.GridMeta.from_bound(bound)
+    lo, ln = torch.tensor([-1.0, -2.0, 0.0]), torch.tensor([2.0, 4.0, 3.0])
+    g = torch.Generator().manual_seed(11)
+    for n, tiles in [(70001, 16), (3000, (25, 16, 25)), ((1 << 20) + 4097, 16)]:
+        sb = ops.SortedBatch(n, DEV, tiles=tiles)
+        t3 = (tiles,) * 3 if isinstance(tiles, int) else tiles
+        for kind in ("uniform", "one_tile", "uniform", "slab", "uniform"):
+            x = torch.rand(n, 3, generator=g) * ln + lo
+            if kind == "one_tile":
+                x = x * 1e-3 + torch.tensor([0.3, 0.3, 1.1])
+            if kind == "slab":
+                x[:, 2] = x[:, 2] * 0.01 + 2.0
+            sb.sort(x.to(DEV), meta)
+            _check_sorted_batch(sb, x, bound, t3)
+    sb0 = ops.SortedBatch(0, DEV)
+    sb0.sort(torch.empty(0, 3, device=DEV), meta)
+    assert int(sb0.tile_offsets.cpu().abs().sum()) == 0
+
+
 @pytest.mark.parametrize("name,n", [("small", 5000), ("cfg2", 50000)])
 def test_sorted_path_matches_unsorted(name, n):
     """Binned forward/backward (LDS pre-reduction per tile) == plain path up to fp32
