@@ -232,16 +232,20 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
     for level in levels:
         loss = AM.latent_loss_for_level(atlas, level, device=dev)
 
-        def run(n_it, lr=1e-2):
+        dist_info = {}
+
+        def run(n_it, lr=1e-2, one_rank=False):
             for s in range(S):
                 atlas.set_submap_pose_correction(s, *start[s])
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
             t0 = time.perf_counter()
-            if dist is not None:
-                mdist.align_multiple_submaps_distributed(atlas, _DS(), (f"latent{level}", loss), num_iters=n_it - 1,
-                                                         lr=lr, verbose=True, save_iterations=True)
+            if dist is not None and not one_rank:
+                info = mdist.align_multiple_submaps_distributed(atlas, _DS(), (f"latent{level}", loss),
+                                                                num_iters=n_it - 1, lr=lr, verbose=True,
+                                                                save_iterations=True)
+                dist_info.update(info["dist"])
             else:
                 AB.generic_align_multiple_submaps(atlas, _DS(), (f"latent{level}", loss), num_iters=n_it - 1, lr=lr,
                                                   verbose=True, save_iterations=True)
@@ -313,7 +317,15 @@ def align_cfg4(dev, atlas, levels=(0, 1), iters=20, dist=None):
             torch.cuda.synchronize()
             rec["all_reduce_us"] = (time.perf_counter() - t0) / 50 * 1e6
             rec["all_reduce_share"] = rec["all_reduce_us"] * 1e-6 / per_it
-            rec["pairs_this_rank"] = len(mdist.partition_pairs([(a, b) for a in range(S) for b in range(a + 1, S)]))
+            # the policy of miso_amd.dist (alignment_mode): a level cheaper than its collective runs replicated
+            rec["mode"] = dist_info.get("mode")
+            rec["policy"] = {k: dist_info.get(k) for k in ("pair_stage_estimate_us", "all_reduce_us", "costs_agree",
+                                                           "pairs_this_rank", "world")}
+            rec["pairs_this_rank"] = dist_info.get("pairs_this_rank")
+            # the same level on ONE rank's GPU (every rank runs the single-process loop side by side, no collective)
+            one = min(run(6 * iters, one_rank=True)[1] for _ in range(2))
+            rec["ms_per_iteration_one_rank"] = one * 1e3
+            rec["speedup_vs_one_rank"] = one / per_it
         out[f"level{level}"] = rec
     for s in range(S):
         atlas.set_submap_pose_correction(s, *start[s])

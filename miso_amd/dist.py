@@ -15,7 +15,10 @@ grids, keyframe poses and optimiser state (grid_opt/models/grid_atlas.py:146-150
             least loaded rank: a gated pair costs a fraction of an overlapping one); each
             iteration ends with ONE all-reduce(SUM) of a flat fp32 buffer holding the pose
             gradients and the loss (6S+1 floats: latency bound, xGMI bandwidth irrelevant)
-            between two captured halves, then the identical Adam step everywhere.
+            between two captured halves, then the identical Adam step everywhere.  A level whose whole
+            iteration is cheaper than what sharding adds (the all-reduce + a second graph replay; cfg-4's
+            level 0 is 82 us on ONE GPU) runs REPLICATED instead: every rank all pairs, no collective,
+            bit-identical by construction (``alignment_mode``).  The deal itself is rank 0's, broadcast.
 """
 from __future__ import annotations
 
@@ -194,6 +197,109 @@ def pair_costs(grid_atlas, pairs) -> List[float]:
     return [1.0 + 30.0 * (round(f * 1024.0) / 1024.0) for f in fracs]
 
 
+# Calibration of the iteration-time estimate (1xMI355X, cfg-4: 8 ScanNet-shaped submaps, 28 pairs, profiles/r04_bench.json):
+# level 0 (0.9 M source vertices) 82 us, level 1 (112 M source vertices, 21 % in bound) 877 us per iteration.  In the cost
+# unit of pair_costs (1 per source vertex, 30 more per in-bound one) level 1 is 112e6 x (1 + 30 x 0.21) = 8.2e8 units for
+# ~800 us of pair stage: 1e-6 us per unit, on top of ~75 us that do not depend on the pair list (three launches, the
+# gate, the epilogues).  Only the first part shrinks when the pairs are dealt over ranks.
+PAIR_US_PER_UNIT = 1.0e-6
+ITERATION_FIXED_US = 75.0
+SHARD_OVERHEAD_US = 15.0       # two graph replays per iteration instead of one eighth of an 8x unrolled one, + the hook
+
+
+def pair_stage_estimate_us(grid_atlas, pairs, costs, level) -> float:
+    """Estimated time of ONE rank's pair stage over `pairs` (us): source vertices of the level x pair_costs."""
+    units = 0.0
+    for (a, _), c in zip(pairs, costs):
+        units += float(grid_atlas.coordinates_for_alignment(a, level).shape[0]) * c
+    return PAIR_US_PER_UNIT * units
+
+
+_ALLREDUCE_US = {}
+
+
+def measured_all_reduce_us(n_floats: int, device) -> float:
+    """Latency of one all-reduce(SUM) of n_floats fp32 on this process group (us), probed once per (backend, world,
+    device type): 5 warm-up + 20 timed collectives on a scratch buffer, then MAX over ranks so that every rank holds the
+    same figure (the policy below must come out the same everywhere).  A collective: every rank must call it."""
+    import time
+    key = (dist.get_backend(), dist.get_world_size(), torch.device(device).type, int(n_floats))
+    if key in _ALLREDUCE_US:
+        return _ALLREDUCE_US[key]
+    buf = torch.zeros(int(n_floats), device=device)
+    sync = torch.cuda.synchronize if buf.is_cuda else (lambda: None)
+    for _ in range(5):
+        all_reduce_sum(buf)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        all_reduce_sum(buf)
+    sync()
+    us = torch.tensor([(time.perf_counter() - t0) / 20 * 1e6], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        us = us.to(device)
+    dist.all_reduce(us, op=dist.ReduceOp.MAX)
+    _ALLREDUCE_US[key] = float(us.item())
+    return _ALLREDUCE_US[key]
+
+
+def alignment_mode(pair_stage_us: float, all_reduce_us: float, world: int, mode: Optional[str] = None) -> str:
+    """'replicated' or 'sharded' for one alignment level.  Sharding divides the pair stage by `world` (at best) and adds
+    an all-reduce and a second graph replay to EVERY iteration; it is taken only when that is a gain:
+
+        pair_stage_us (1 - 1 / world)  >  all_reduce_us + SHARD_OVERHEAD_US
+
+    cfg-4 on 8 ranks with a ~25 us RCCL all-reduce: level 0 (7 us of pair stage) stays replicated -- sharded it would run
+    at ~1.5x the single-GPU time -- and level 1 (800 us) is sharded.  mode / MISO_ALIGN_DIST_MODE force either."""
+    mode = mode or os.environ.get("MISO_ALIGN_DIST_MODE") or "auto"
+    if mode in ("replicated", "sharded"):
+        return mode
+    if mode != "auto":
+        raise ValueError(f"alignment mode {mode!r}: expected auto, replicated or sharded")
+    if world <= 1:
+        return "replicated"
+    return "sharded" if pair_stage_us * (1.0 - 1.0 / world) > all_reduce_us + SHARD_OVERHEAD_US else "replicated"
+
+
+def _deal(pairs, costs, world) -> List[int]:
+    """owner[i] of every pair: longest first onto the least loaded rank (ties: lower rank)."""
+    load = [0.0] * world
+    owner = [0] * len(pairs)
+    for i in sorted(range(len(pairs)), key=lambda i: (-costs[i], i)):
+        k = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = k
+        load[k] += costs[i]
+    return owner
+
+
+def agree_on_plan(owner: Sequence[int], mode: str, costs: Sequence[float], device) -> Tuple[List[int], str, bool]:
+    """Rank 0's deal and mode become everybody's: ONE broadcast of len(owner) + 1 integers.  Every rank derives costs
+    from its own GPU's floats, and although they are quantised a mean that sits at a rounding boundary can still come out
+    one step apart on two devices -- a pair evaluated twice or by nobody would vanish in the all-reduced gradient
+    without a trace.  So the ranks do not each trust their own deal.  Returns (owner, mode, costs_agree): the last says
+    whether every rank had computed the same quantised costs (an all-reduce MIN / MAX of a checksum) -- False is logged,
+    not fatal: the broadcast plan is consistent either way."""
+    rank, world = rank_world()
+    on_dev = dist.get_backend() == "nccl"
+    t = torch.tensor(list(owner) + [1 if mode == "sharded" else 0], dtype=torch.int64)
+    t = t.to(device) if on_dev else t
+    dist.broadcast(t, src=0)
+    vals = t.cpu().tolist()
+    # checksum of the quantised costs (exact integers: costs are 1 + 30 k / 1024)
+    q = [int(round((c - 1.0) / 30.0 * 1024.0)) for c in costs]
+    h = 0
+    for i, v in enumerate(q):
+        h = (h * 1000003 + v * 31 + i) % ((1 << 53) - 111)
+    cs = torch.tensor([float(h), -float(h)], dtype=torch.float64)
+    cs = cs.to(device) if on_dev else cs
+    dist.all_reduce(cs, op=dist.ReduceOp.MAX)
+    agree = float(cs[0].item()) == -float(cs[1].item())
+    if not agree and rank == 0:
+        logger.warning("pair costs differ between ranks (device-dependent rounding of the overlap estimate); "
+                       "rank 0's deal is used everywhere")
+    return [int(v) for v in vals[:-1]], ("sharded" if vals[-1] else "replicated"), agree
+
+
 def partition_pairs(pairs: Sequence[Tuple[int, int]], rank: Optional[int] = None,
                     world: Optional[int] = None, costs: Optional[Sequence[float]] = None) -> List[Tuple[int, int]]:
     """This rank's share of the pair list.  Without costs: round-robin.  With costs (pair_costs): longest first onto
@@ -204,19 +310,14 @@ def partition_pairs(pairs: Sequence[Tuple[int, int]], rank: Optional[int] = None
     if costs is None:
         return [p for i, p in enumerate(pairs) if i % world == rank]
     assert len(costs) == len(pairs)
-    load = [0.0] * world
-    owner = [0] * len(pairs)
-    for i in sorted(range(len(pairs)), key=lambda i: (-costs[i], i)):
-        k = min(range(world), key=lambda k: (load[k], k))
-        owner[i] = k
-        load[k] += costs[i]
+    owner = _deal(pairs, costs, world)
     return [p for i, p in enumerate(pairs) if owner[i] == rank]
 
 
 def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple, num_iters=10, lr=1e-2,
                                        rel_change_thresh=0, submap_pairs=None, check_intersection=True,
                                        pose_reg_weight=0, pose_thresh_rad=1.0, pose_thresh_m=1.0,
-                                       verbose=False, save_iterations=False, always_reduce=False):
+                                       verbose=False, save_iterations=False, always_reduce=False, mode=None):
     """generic_align_multiple_submaps (grid_opt/align/base.py:89-163) with the pair list sharded over ranks.
     Every rank must hold all submaps (sync_submaps) and identical pose parameters.
 
@@ -226,7 +327,14 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
     the replicas stay bit-identical.  Results equal the single-process run up to fp32 summation order of the pair
     sums.  A pair loss that carries ``fused`` (align.miso.latent_loss_for_level) runs as that loop; one that does not
     (the SDF fine-tune stage) runs the op-by-op loop with the same sharding (generic_align_multiple_submaps, my_pairs /
-    reduce).  always_reduce: keep the all-reduce hook live in a group of one rank (exercises RCCL on a single GPU)."""
+    reduce).  always_reduce: keep the all-reduce hook live in a group of one rank (exercises RCCL on a single GPU).
+
+    mode ('auto' | 'replicated' | 'sharded'; default auto, or MISO_ALIGN_DIST_MODE): a fused level whose pair stage is
+    cheaper than the collective it would need runs REPLICATED -- every rank evaluates all pairs with the single-process
+    loop (one graph, 8x unrolled), no collective inside the loop, bit-identical replicas by construction -- so that adding
+    GPUs can never make a level slower than one GPU (``alignment_mode``).  The decision and the deal are rank 0's,
+    broadcast once per call (``agree_on_plan``).  The returned dict carries ``dist``: mode, the estimate, the measured
+    all-reduce latency, this rank's pairs, and whether the ranks' own cost estimates agreed."""
     from miso_amd.grid_opt.align.base import fused_alignment_loop
     rank, world = rank_world()
     loss_name, loss_func = pairwise_loss_tuple
@@ -247,16 +355,29 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
                                               pose_thresh_rad=pose_thresh_rad, pose_thresh_m=pose_thresh_m,
                                               verbose=verbose and rank == 0, save_iterations=save_iterations,
                                               my_pairs=partition_pairs(submap_pairs, rank, world), reduce=red)
-    my_pairs = partition_pairs(submap_pairs, rank, world, costs=pair_costs(grid_atlas, submap_pairs) if world > 1 else None)
+    level = fused.get('level', 0)
+    info = {'mode': 'replicated', 'world': world, 'pairs_this_rank': len(submap_pairs)}
+    my_pairs = list(submap_pairs)
+    if world > 1:
+        dev = grid_atlas.rotation_corrections[0].device
+        costs = pair_costs(grid_atlas, submap_pairs)
+        est_us = pair_stage_estimate_us(grid_atlas, submap_pairs, costs, level)
+        ar_us = measured_all_reduce_us(7 * grid_atlas.num_submaps + 1, dev)
+        owner, want, agree = agree_on_plan(_deal(submap_pairs, costs, world), alignment_mode(est_us, ar_us, world, mode),
+                                           costs, dev)
+        info.update(mode=want, pair_stage_estimate_us=est_us, all_reduce_us=ar_us, costs_agree=agree)
+        if want == 'sharded':
+            my_pairs = [p for i, p in enumerate(submap_pairs) if owner[i] == rank]
+            info['pairs_this_rank'] = len(my_pairs)
     timer = utils.PerfTimer(activate=True)
     reduce = None
-    if world > 1:
+    if world > 1 and info['mode'] == 'sharded':
         reduce = all_reduce_sum
-    elif always_reduce and dist.is_available() and dist.is_initialized():      # the single-GPU RCCL smoke test
+    elif world == 1 and always_reduce and dist.is_available() and dist.is_initialized():      # the single-GPU RCCL smoke test
         reduce = lambda t: all_reduce_sum(t, always=True)                       # noqa: E731
     iteration_results = fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr, num_iters,
                                              rel_change_thresh, pose_reg_weight, pose_thresh_rad, pose_thresh_m,
                                              verbose and rank == 0, save_iterations, f"{loss_name}[rank {rank}/{world}]",
-                                             reduce=reduce, my_pairs=my_pairs)
+                                             reduce=reduce, my_pairs=my_pairs if reduce is not None else None)
     cpu_time, gpu_time = timer.check()
-    return {'cpu_time_sec': cpu_time, 'gpu_time_sec': gpu_time, 'iteration_results': iteration_results}
+    return {'cpu_time_sec': cpu_time, 'gpu_time_sec': gpu_time, 'iteration_results': iteration_results, 'dist': info}

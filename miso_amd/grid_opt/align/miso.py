@@ -256,7 +256,7 @@ def latent_loss_for_level(grid_atlas: GridAtlas, level: int, align_weight=3000, 
                                                 check_intersection=check_intersection, device=device)
         latent.batched = latent_all
     if on_gpu or (default_opts and getattr(_ops.AlignPlan, 'cpu_ok', False)):
-        latent.fused = dict(align_loss=align_loss, align_weight=align_weight,
+        latent.fused = dict(align_loss=align_loss, align_weight=align_weight, level=level,
                             inputs=lambda atlas, pairs, chk: latent_pair_inputs(
                                 atlas, pairs, level=level, fdim=atlas.get_submap(0).fdim, check_intersection=chk))
     return latent

@@ -68,18 +68,64 @@ def _worker(rank, world, port, out_dir):
             return 0
 
     res = {}
+    start = [(atlas.rotation_corrections[s].detach().clone(), atlas.translation_corrections[s].detach().clone())
+             for s in range(3)]
     for l in range(c["n_levels"]):
         # the sharded loop is the fused one (ops.AlignPlan; here its oracle stand-in): this rank's pairs in one
         # launch, ONE all-reduce of 6S + 1 floats per iteration, identical guard / Adam on every rank
         tup = (f"latent{l}", AM.latent_loss_for_level(atlas, l, align_loss="L2", device="cpu"))
         info = mdist.align_multiple_submaps_distributed(atlas, DS(), tup, num_iters=3, lr=1e-2, pose_reg_weight=1.0,
                                                         pose_thresh_rad=1e-3, pose_thresh_m=1e-3,
-                                                        save_iterations=(l == 0))
+                                                        save_iterations=(l == 0), mode="sharded")
+        assert info["dist"]["mode"] == "sharded" and info["dist"]["costs_agree"]
+        assert info["dist"]["pairs_this_rank"] in (1, 2) and info["dist"]["all_reduce_us"] > 0
         if l == 0:
             assert sorted(info["iteration_results"]) == [0, 1, 2, 3]
             res["snap0"] = torch.stack([info["iteration_results"][i] for i in range(4)]).numpy()
         res[f"dr{l}"] = torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy()
         res[f"dt{l}"] = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
+    # --- the policy: a level this small must come out REPLICATED (every rank all pairs, no collective in the loop) ------
+    after = [(atlas.rotation_corrections[s].detach().clone(), atlas.translation_corrections[s].detach().clone())
+             for s in range(3)]
+
+    def restart():
+        for s in range(3):
+            atlas.set_submap_pose_correction(s, *start[s])
+    restart()
+    calls = []
+    real_reduce = mdist.all_reduce_sum
+    mdist.all_reduce_sum = lambda t, always=False: (calls.append(t.numel()), real_reduce(t, always))[1]
+    try:
+        for l in range(c["n_levels"]):
+            tup = (f"latent{l}", AM.latent_loss_for_level(atlas, l, align_loss="L2", device="cpu"))
+            info = mdist.align_multiple_submaps_distributed(atlas, DS(), tup, num_iters=3, lr=1e-2, pose_reg_weight=1.0,
+                                                            pose_thresh_rad=1e-3, pose_thresh_m=1e-3)
+            assert info["dist"]["mode"] == "replicated", info["dist"]      # a few thousand vertices against a collective
+            assert info["dist"]["pairs_this_rank"] == 3
+            res[f"rep_dr{l}"] = torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy()
+            res[f"rep_dt{l}"] = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
+        assert not [n for n in calls if n == 7 * 3 + 1], "a replicated level must not all-reduce pose gradients"
+    finally:
+        mdist.all_reduce_sum = real_reduce
+    # --- ranks that disagree on the costs: detected, and harmless (rank 0's deal is everybody's) --------------------
+    restart()
+    real_costs = mdist.pair_costs
+    if rank == 1:       # what a rounding boundary on another GPU would do: one pair a quantum cheaper, the order of the deal flips
+        mdist.pair_costs = lambda at, pairs: [c_ - (30.0 / 1024.0 if i == 0 else 0.0) + (30.0 * (i == 2))
+                                              for i, c_ in enumerate(real_costs(at, pairs))]
+    try:
+        for l in range(c["n_levels"]):
+            tup = (f"latent{l}", AM.latent_loss_for_level(atlas, l, align_loss="L2", device="cpu"))
+            info = mdist.align_multiple_submaps_distributed(atlas, DS(), tup, num_iters=3, lr=1e-2, pose_reg_weight=1.0,
+                                                            pose_thresh_rad=1e-3, pose_thresh_m=1e-3, mode="sharded")
+            assert info["dist"]["costs_agree"] is False
+            res[f"dis_dr{l}"] = torch.stack([p.detach() for p in atlas.rotation_corrections]).numpy()
+            res[f"dis_dt{l}"] = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
+            res[f"dis_pairs{l}"] = np.array([info["dist"]["pairs_this_rank"]])
+    finally:
+        mdist.pair_costs = real_costs
+    for s in range(3):
+        atlas.set_submap_pose_correction(s, *after[s])
     # --- SDF fine-tune stage (reference align/miso.py:283-319, --use_sdf): a pair loss WITHOUT a fused plan, sharded ---
     res.update(_sdf_stage(mdist.align_multiple_submaps_distributed))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
@@ -112,6 +158,9 @@ def test_submap_parallel_world2_matches_single_process(tmp_path, monkeypatch):
     a = np.load(tmp_path / "rank0.npz")
     b = np.load(tmp_path / "rank1.npz")
     for k in a.files:
+        if k.startswith("dis_pairs"):
+            assert int(a[k][0]) + int(b[k][0]) == 3   # ranks that disagreed on the costs still deal every pair exactly once
+            continue
         np.testing.assert_array_equal(a[k], b[k])     # replicas stay bit-identical
     # single-process reference run of the same loop (with the same regulariser)
     sys.path.insert(0, HERE)
@@ -146,11 +195,28 @@ def test_submap_parallel_world2_matches_single_process(tmp_path, monkeypatch):
         dt = torch.stack([p.detach() for p in atlas.translation_corrections]).numpy()
         np.testing.assert_allclose(a[f"dr{l}"], dr, rtol=0, atol=2e-5)
         np.testing.assert_allclose(a[f"dt{l}"], dt, rtol=0, atol=2e-5)
+        # world-2 replicated == world-2 sharded == single process; a deal made under disagreeing costs too
+        for tag in ("rep", "dis"):
+            np.testing.assert_allclose(a[f"{tag}_dr{l}"], dr, rtol=0, atol=2e-5)
+            np.testing.assert_allclose(a[f"{tag}_dt{l}"], dt, rtol=0, atol=2e-5)
     # the SDF fine-tune stage: the sharded op-by-op loop == the single-process one (poses moved, and by the same amounts)
     ref = _sdf_stage(AB.generic_align_multiple_submaps)
     assert np.abs(ref["sdf_dr"]).max() > 1e-4
     np.testing.assert_allclose(a["sdf_dr"], ref["sdf_dr"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(a["sdf_dt"], ref["sdf_dt"], rtol=0, atol=2e-6)
+
+
+def test_alignment_mode_policy():
+    """Sharding must buy more than it costs: the pair stage divided by the ranks against one all-reduce + a second
+    replay per iteration.  cfg-4's level 0 (a few us of pair stage) stays replicated on any world size; level 1 is sharded."""
+    from miso_amd import dist as mdist
+    assert mdist.alignment_mode(7.0, 25.0, 8, "auto") == "replicated"
+    assert mdist.alignment_mode(800.0, 25.0, 8, "auto") == "sharded"
+    assert mdist.alignment_mode(800.0, 25.0, 1, "auto") == "replicated"
+    assert mdist.alignment_mode(60.0, 25.0, 2, "auto") == "replicated"      # 30 us saved < 40 us added
+    assert mdist.alignment_mode(7.0, 25.0, 8, "sharded") == "sharded" and mdist.alignment_mode(800.0, 25.0, 8, "replicated") == "replicated"
+    with pytest.raises(ValueError):
+        mdist.alignment_mode(1.0, 1.0, 2, "sometimes")
 
 
 def test_shard_helpers():
