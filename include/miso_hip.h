@@ -375,7 +375,18 @@ typedef struct {
   const float* gate_axis[3];
   int32_t gate_dims[3];
   int32_t src, dst;         /* submap indices */
+  /* Optional: miso_align_src_boxes(coords_src, n, ...) -- one axis-aligned box per run of MISO_ALIGN_BOX_VERTS
+   * consecutive source vertices.  With it the residual kernel maps a run's box into the destination frame first and
+   * skips the run unread when it cannot touch the destination bound (conservatively: a skipped run holds no in-bound
+   * vertex, so every sum is unchanged) -- the reference does the same per PAIR before any work
+   * (check_submap_intersection, grid_opt/align/base.py:132-135); here per 512 vertices, every iteration, at the
+   * current poses.  NULL: every vertex is read and tested. */
+  const float* src_boxes;
 } miso_align_pair_t;
+#define MISO_ALIGN_BOX_VERTS 512
+/* boxes: (ceil(n / MISO_ALIGN_BOX_VERTS), 6) floats {min x, y, z, max x, y, z} of coords[512 r .. 512 r + 511] (NaN
+ * coordinates are ignored by min / max; they fail the bound test anyway).  Poses do not enter: build once per source list. */
+int miso_align_src_boxes(const float* coords, int64_t n, float* boxes, void* stream);
 
 typedef struct {
   int32_t n_submaps, n_pairs;

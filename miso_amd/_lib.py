@@ -94,7 +94,7 @@ class AlignPair(C.Structure):
     _fields_ = [("dst_grid", Grid), ("coords_src", C.c_void_p), ("feats_src", C.c_void_p),
                 ("ld_feats", C.c_int64), ("n", C.c_int64), ("gate_coords", C.c_void_p), ("gate_n", C.c_int64),
                 ("gate_axis", C.c_void_p * 3), ("gate_dims", C.c_int32 * 3),
-                ("src", C.c_int32), ("dst", C.c_int32)]
+                ("src", C.c_int32), ("dst", C.c_int32), ("src_boxes", C.c_void_p)]
 
 
 class Align(C.Structure):
@@ -206,6 +206,7 @@ SIGNATURES = {
     "miso_mc_case_table": (C.c_int, [C.c_void_p]),
     "miso_align_plan_bytes": (C.c_int64, [C.c_int32]),
     "miso_align_plan_build": (C.c_int, [C.POINTER(AlignPair), C.POINTER(Align), C.c_void_p]),
+    "miso_align_src_boxes": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "miso_align_state_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "miso_align_iteration_a": (C.c_int, [C.POINTER(Align), C.c_void_p]),
     "miso_align_iteration_b": (C.c_int, [C.POINTER(Align), C.c_void_p]),

@@ -56,6 +56,7 @@ hipError_t launch_mc_vertices(const float*, int32_t, int32_t, int32_t, float, vo
                               float*, hipStream_t);
 void mc_copy_table(int8_t*);
 hipError_t launch_overlap_count(const float*, const float*, int64_t, const float*, const float*, float*, hipStream_t);
+hipError_t launch_src_boxes(const float*, int64_t, float*, hipStream_t);
 hipError_t launch_lm_normal_eq(const float*, const float*, const float*, const float*, const float*, int64_t, int,
                                float, float*, hipStream_t);
 size_t sample_rays_workspace_bytes(int64_t, int32_t);
@@ -630,6 +631,11 @@ int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, co
   return (int)launch_overlap_count(pose, coords_src, n, bound_min, bound_max, count_out, (hipStream_t)stream);
 }
 
+int miso_align_src_boxes(const float* coords, int64_t n, float* boxes, void* stream) {
+  if (n < 0 || (n > 0 && (!coords || !boxes))) return MISO_E_BADARG;
+  return (int)launch_src_boxes(coords, n, boxes, (hipStream_t)stream);
+}
+
 int64_t miso_align_plan_bytes(int32_t n_pairs) {
   return n_pairs < 0 ? 0 : (int64_t)(n_pairs > 0 ? n_pairs : 1) * (int64_t)sizeof(AlignPairK);
 }
@@ -671,6 +677,7 @@ int miso_align_plan_build(const miso_align_pair_t* pairs, miso_align_t* cfg, voi
       return MISO_E_BADARG;
     }
     d.src = in.src; d.dst = in.dst; d.n_ch = (float)d.g.F;
+    d.boxes = in.n > 0 ? in.src_boxes : nullptr;
     if (in.n > max_n) max_n = in.n;
     if (d.gate_p && !d.gate_ax[0] && in.gate_n > max_gate) max_gate = in.gate_n;      // point-list gates only (grid sizing)
   }

@@ -209,7 +209,11 @@ struct AlignPairK {
   int32_t gate_dim[3];
   int32_t src, dst;
   float n_ch;           // channels compared (the L2 mean divides by count * n_ch)
+  // axis-aligned boxes {min xyz, max xyz} (source frame) of every run of ALIGN_BOX_VERTS consecutive source vertices, or
+  // nullptr: a wavefront whose run cannot reach the destination bound under the current poses skips it unread
+  const float* boxes;
 };
+constexpr int ALIGN_BOX_VERTS = 512;
 
 // One torch.optim.Adam update (amsgrad=False, weight_decay=0) as torch forms it op by op; shared by adam.hip
 // (dense grids) and align.hip (the 6(S-1) pose numbers of the alignment loop).

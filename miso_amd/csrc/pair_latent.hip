@@ -28,7 +28,9 @@ struct PairK {
   int64_t n;
   int loss_type;       // 1 = L1 (vector norm), 2 = L2
   double* out;         // 24 doubles, zeroed by the launcher
+  const float* boxes;  // per run of ALIGN_BOX_VERTS vertices {min xyz, max xyz}, or nullptr (AlignPairK::boxes)
 };
+constexpr float BOX_SLACK = 2e-3f;      // metres: the exact test rounds a mapped coordinate by ~1e-5 at 100 m
 
 // hardware fp64 add at L2 (global_atomic_add_f64, no return value)
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
@@ -57,12 +59,46 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
   // tests PAIR_K x 64 consecutive vertices and compacts the in-bound ones into a per-wave LDS list (ballot + prefix:
   // a deterministic order, no block barrier); pass 2 walks that list with all lanes busy.
   constexpr int PAIR_K = 8;
+  static_assert(PAIR_K * 64 == ALIGN_BOX_VERTS, "a wavefront's run of a chunk is one box");
   __shared__ uint16_t s_in[4][PAIR_K * 64];
-  const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+  const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long lt_mask = (lane_ == 0) ? 0ull : (~0ull >> (64 - lane_));
   const int64_t chunk = (int64_t)blockDim.x * PAIR_K;
+  // A run's box in the destination frame: centre q_c = Rd^T (Rs c + ts - td), half-extent along destination axis a
+  // sum_b |M[a][b]| e_b with M = Rd^T Rs.  Outside the bound by more than BOX_SLACK on any axis: no vertex of the run
+  // can pass the exact test below, the run is skipped unread (the sums are those of reading it).  NaN poses compare
+  // false: nothing is skipped.
+  float Mabs[9], Mq[9], q0c[3];
+  // (the exact test forms w = Rs p + ts first: its rounding grows with the size of the world coordinates)
+  const float box_slack = BOX_SLACK + 4e-6f * (fabsf(ts[0]) + fabsf(ts[1]) + fabsf(ts[2]) + fabsf(td[0]) + fabsf(td[1]) + fabsf(td[2]));
+  if (k.boxes) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        Mq[a * 3 + b] = Rd[a] * Rs[b] + Rd[3 + a] * Rs[3 + b] + Rd[6 + a] * Rs[6 + b];
+        Mabs[a * 3 + b] = fabsf(Mq[a * 3 + b]);
+      }
+      q0c[a] = Rd[a] * (ts[0] - td[0]) + Rd[3 + a] * (ts[1] - td[1]) + Rd[6 + a] * (ts[2] - td[2]);
+    }
+  }
   for (int64_t c0 = (int64_t)bx * chunk; c0 < k.n; c0 += (int64_t)nbx * chunk) {
     const int64_t w0 = c0 + (int64_t)wave_ * (PAIR_K * 64);
+    if (w0 >= k.n) continue;
+    if (k.boxes) {
+      const float* bb = k.boxes + (w0 / ALIGN_BOX_VERTS) * 6;      // (wave-uniform address)
+      const float c[3] = {0.5f * (bb[0] + bb[3]), 0.5f * (bb[1] + bb[4]), 0.5f * (bb[2] + bb[5])};
+      const float e[3] = {0.5f * (bb[3] - bb[0]), 0.5f * (bb[4] - bb[1]), 0.5f * (bb[5] - bb[2])};
+      bool outside = false;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float qc = Mq[a * 3] * c[0] + Mq[a * 3 + 1] * c[1] + Mq[a * 3 + 2] * c[2] + q0c[a];
+        const float r = Mabs[a * 3] * e[0] + Mabs[a * 3 + 1] * e[1] + Mabs[a * 3 + 2] * e[2] +
+                        box_slack + 1e-6f * (fabsf(qc) + fabsf(q0c[a]));
+        outside = outside || qc - r > g.bmax[a] || qc + r < g.bmin[a];
+      }
+      if (outside) continue;
+    }
     int n_in = 0;
 #pragma unroll
     for (int u = 0; u < PAIR_K; ++u) {
@@ -215,7 +251,7 @@ __global__ __launch_bounds__(256, 4) void pair_latent_batch_kernel(const AlignPa
   if (stopped && *stopped) return;
   const AlignPairK& d = plan[blockIdx.y];
   if ((int64_t)blockIdx.x * blockDim.x * 8 >= d.n) return;
-  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y};
+  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y, d.boxes};
   pair_latent_body<VEC4>(d.g, pose_all + 12 * d.src, pose_all + 12 * d.dst, k, blockIdx.x, gridDim.x);
 }
 
@@ -423,8 +459,32 @@ __global__ __launch_bounds__(256, 4) void pair_stage_kernel(const AlignPairK* __
   }
   const AlignPairK& d = plan[blockIdx.y];
   if ((int64_t)blockIdx.x * blockDim.x * 8 >= d.n) return;
-  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y};
+  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y, d.boxes};
   pair_latent_body<VEC4>(d.g, pose_all + 12 * d.src, pose_all + 12 * d.dst, k, blockIdx.x, pair_blocks);
+}
+
+// boxes[r] = {min, max} over source vertices [512 r, 512 r + 512): one wavefront per run (fminf / fmaxf drop NaNs)
+__global__ __launch_bounds__(256) void src_boxes_kernel(const float* __restrict__ p, int64_t n, float* __restrict__ boxes) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i0 = r * ALIGN_BOX_VERTS;
+  if (i0 >= n) return;
+  float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+  for (int64_t i = i0 + lane; i < min(n, i0 + ALIGN_BOX_VERTS); i += 64)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const float v = p[i * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+  if (lane < 3) boxes[r * 6 + lane] = lane == 0 ? lo[0] : (lane == 1 ? lo[1] : lo[2]);
+  else if (lane < 6) boxes[r * 6 + lane] = lane == 3 ? hi[0] : (lane == 4 ? hi[1] : hi[2]);
+}
+
+hipError_t launch_src_boxes(const float* p, int64_t n, float* boxes, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const int64_t runs = (n + ALIGN_BOX_VERTS - 1) / ALIGN_BOX_VERTS;
+  src_boxes_kernel<<<(unsigned)((runs + 3) / 4), 256, 0, s>>>(p, n, boxes);
+  return hipGetLastError();
 }
 
 hipError_t launch_overlap_count(const float* pose, const float* p, int64_t n, const float* bmin, const float* bmax,
@@ -444,7 +504,7 @@ hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, cons
                               int64_t ld, int64_t n, int loss_type, double* out, hipStream_t s) {
   hipError_t e = launch_zero_words(out, 48, s);
   if (e != hipSuccess || n == 0) return e;
-  PairK k{pose, p, fsrc, ld, n, loss_type, out};
+  PairK k{pose, p, fsrc, ld, n, loss_type, out, nullptr};
   unsigned blocks = (unsigned)((n + 2047) / 2048);      // a workgroup takes 256 x PAIR_K vertices per trip
   if (blocks > 2048u) blocks = 2048u;
   if (vec4) pair_latent_kernel<true><<<blocks, 256, 0, s>>>(g, k);

@@ -1056,6 +1056,9 @@ def pair_latent_multi(R_all, t_all, plan) -> torch.Tensor:
     return _PairLatentMulti.apply(R_all, t_all, plan)
 
 
+ALIGN_BOX_VERTS = 512        # MISO_ALIGN_BOX_VERTS
+
+
 class AlignPlan:
     """Device-resident state of one fused alignment run (miso_align_iteration_a / _b): Adam over the pose
     corrections of submaps 1..S-1 on the summed latent pair losses, generic_align_multiple_submaps
@@ -1073,7 +1076,10 @@ class AlignPlan:
 
     def __init__(self, R0, t0, pairs, *, loss_type="L2", align_weight=3000.0, overlap_thresh=1e-2, lr=1e-2,
                  betas=(0.9, 0.999), eps=1e-8, reg_weight=0.0, reg_thresh_rad=1.0, reg_thresh_m=1.0,
-                 rel_change_thresh=0.0, ring_iters=0, save_poses=False):
+                 rel_change_thresh=0.0, ring_iters=0, save_poses=False, cull=None):
+        """cull (default on; MISO_ALIGN_CULL=0 switches it off): one box per run of 512 source vertices
+        (miso_align_src_boxes, built once per source list) lets the residual kernel skip runs that cannot reach the
+        destination bound at the current poses without reading them -- same sums, fewer bytes."""
         _require_hip(R0, t0)
         lib = _lib.load()
         dev = R0.device
@@ -1089,6 +1095,9 @@ class AlignPlan:
         cfg.rel_change_thresh = float(rel_change_thresh)
         cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
         self._keep = []
+        if cull is None:
+            cull = os.environ.get("MISO_ALIGN_CULL", "1") != "0"
+        boxes_of = {}                                 # one table per source list (a submap is the source of up to S-1 pairs)
         descs = (_lib.AlignPair * max(P, 1))()
         for i, pr in enumerate(pairs):
             feats_dst = [f.detach() for f in pr["feats_dst"]]
@@ -1122,7 +1131,15 @@ class AlignPlan:
                             d.gate_axis[a], d.gate_dims[a] = axes[a].data_ptr(), (nx, ny, nz)[a]
                         gate = (gate, axes)
             d.src, d.dst = int(pr["src"]), int(pr["dst"])
-            self._keep.append((feats_dst, coords, fsrc, gate))
+            if cull and d.n > 0:
+                key = (coords.data_ptr(), int(d.n))
+                if key not in boxes_of:
+                    bx = torch.empty(((int(d.n) + ALIGN_BOX_VERTS - 1) // ALIGN_BOX_VERTS, 6), device=dev, dtype=torch.float32)
+                    _lib.check(lib.miso_align_src_boxes(_ptr(coords), int(d.n), _ptr(bx), _stream(coords)),
+                               "miso_align_src_boxes")
+                    boxes_of[key] = bx
+                d.src_boxes = boxes_of[key].data_ptr()
+            self._keep.append((feats_dst, coords, fsrc, gate, boxes_of))
         nbytes = int(lib.miso_align_plan_bytes(P))
         blob = (C.c_uint8 * nbytes)()
         _lib.check(lib.miso_align_plan_build(descs, C.byref(cfg), blob), "miso_align_plan_build")

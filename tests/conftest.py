@@ -33,3 +33,28 @@ def device_backend(request, monkeypatch):
         oracle_backend.install(monkeypatch)
         return "cpu"
     return "cuda:0"
+
+
+# --- wall-time budget of the GPU suite -------------------------------------------------------------------------------
+# The driver gives `pytest -m gpu` 1 200 s; past that every row counts as untested.  The suite is to stay well inside
+# (target <= 450 s on the driver's box; ~170 s on a dev box): a session that runs GPU tests for longer than
+# MISO_GPU_SUITE_BUDGET_S (default 900) FAILS, loudly, so that the builder sees it a round before the driver does.
+import time as _time
+
+_T0 = _time.time()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import torch
+    budget = float(os.environ.get("MISO_GPU_SUITE_BUDGET_S", "900"))
+    took = _time.time() - _T0
+    ran_gpu = torch.cuda.is_available() and any("gpu" in it.keywords for it in getattr(session, "items", []))
+    if ran_gpu and took > budget:
+        tr = session.config.pluginmanager.get_plugin("terminalreporter")
+        msg = (f"GPU suite took {took:.0f} s > budget {budget:.0f} s (driver limit 1 200 s): trim it "
+               f"(pytest --durations=40) before adding tests")
+        if tr is not None:
+            tr.write_line("ERROR: " + msg, red=True)
+        else:
+            print("ERROR: " + msg, file=sys.stderr)
+        session.exitstatus = 1

@@ -47,11 +47,18 @@ def test_alignment_trajectory_hip_equals_the_oracle_loop(n_submaps, monkeypatch)
     """Same construction, HIP fused loop on the GPU against the oracle loop on the host: per-iteration (S,4,4) pose
     snapshots of both levels."""
     import oracle_backend
-    _, after_gpu, info_gpu, atlas_gpu = SF.run("cuda:0", n_submaps, DEG, METRES)
+    # two submaps: the reference's whole schedule (2 x 101 iterations) to convergence.  Four submaps (six pairs): the
+    # first 2 x 26 iterations -- the host loop costs ~0.25 s per iteration there and this test was a twelfth of the GPU
+    # suite's wall time; convergence of four submaps is test_alignment_converges_on_a_shared_field[hip-4]'s business,
+    # here the two loops only have to walk the same trajectory (set MISO_TEST_FULL=1 for the whole schedule)
+    full = n_submaps == 2 or os.environ.get("MISO_TEST_FULL")
+    cfg = dict(SF.ALIGN_CFG) if full else dict(SF.ALIGN_CFG, level_iters=25)
+    _, after_gpu, info_gpu, atlas_gpu = SF.run("cuda:0", n_submaps, DEG, METRES, align_cfg=cfg)
     oracle_backend.install(monkeypatch)
-    _, after_cpu, info_cpu, atlas_cpu = SF.run("cpu", n_submaps, DEG, METRES)
-    assert after_gpu[0] <= 0.1 * DEG and after_gpu[1] <= 0.1 * METRES
-    assert after_cpu[0] <= 0.1 * DEG and after_cpu[1] <= 0.1 * METRES
+    _, after_cpu, info_cpu, atlas_cpu = SF.run("cpu", n_submaps, DEG, METRES, align_cfg=cfg)
+    if full:
+        assert after_gpu[0] <= 0.1 * DEG and after_gpu[1] <= 0.1 * METRES
+        assert after_cpu[0] <= 0.1 * DEG and after_cpu[1] <= 0.1 * METRES
     worst = {}
     for level in (0, 1):
         a, b = _losses(info_gpu, level), _losses(info_cpu, level)

@@ -874,6 +874,17 @@ def test_full_size_training_step_vs_cpu_oracle_cfg2():
     for a, b in zip(step.grads, gref):
         a = a.cpu()
         assert ((a - b).double().norm() / b.double().norm()).item() < 5e-4
+    # ... and the EXACT configuration bench.py times (the headline): stream launches, no SDF write-back, a batch sorted
+    # without perm[] (the index rides in xn_sorted[:, 3]) -- against the same host evaluation
+    head = MappingStep(fd, meta, pack, n, "L1", 1.0, 0.0, 0.0, sort=True, keep_sdf=False, use_graph=False)
+    assert head._fused_train() and head.sorted is not None and head.sorted.perm is None
+    head.set_batch(x.to(DEV), target.to(DEV))
+    head.run(); head.run()
+    torch.cuda.synchronize()
+    assert abs(head.loss.sum().item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+    for a, b in zip(head.grads, gref):
+        a = a.cpu()
+        assert ((a - b).double().norm() / b.double().norm()).item() < 5e-4
 
 
 @pytest.mark.parametrize("lt", ["L2", "L1"])
@@ -1218,6 +1229,70 @@ def test_lattice_overlap_gate_counts_equal_the_point_list_gate(case):
         q = (w - t0[b_].cpu().reshape(1, 3)) @ R0[b_].cpu()
         ref = int(((q >= b[:, 0]) & (q <= b[:, 1])).all(dim=1).sum())
         assert abs(int(c[idx]) - ref) <= max(2, int(2e-4 * ref)), (idx, int(c[idx]), ref)     # matmul order differs
+
+
+@pytest.mark.gpu
+def test_box_culled_pair_stage_equals_reading_every_vertex():
+    """miso_align_src_boxes + miso_align_pair_t.src_boxes: the residual kernel skips a run of 512 source vertices when its
+    box, mapped into the destination frame, cannot touch the destination bound.  The skip is conservative, so all 24
+    sums of every pair are those of the kernel that reads every vertex (same lanes add the same terms; only the fp64
+    atomics' order is free): identity, faces touching, rotated overlaps, no overlap at all, far-away world origins (the
+    slack has to cover the rounding of w = Rs p + ts), a NaN pose.  Both lists are checked: a lattice in z-major order
+    (what precompute_coordinates_for_alignment leaves) and a shuffled one (boxes of scattered vertices: nothing may be
+    skipped wrongly, little is skipped at all)."""
+    from miso_amd import ops, _lib
+    from miso_amd.so3 import so3_exp_map
+    torch.manual_seed(7)
+    nx, ny, nz = 50, 24, 40
+    bound = [[-2.5, 2.5], [-1.2, 1.2], [-2.0, 2.0]]
+    half = [(b[1] - b[0]) / (2 * n) for b, n in zip(bound, (nx, ny, nz))]
+    axes = [torch.linspace(b[0] + h, b[1] - h, n) for b, h, n in zip(bound, half, (nx, ny, nz))]
+    zz, yy, xx = torch.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
+    pts = torch.stack([xx, yy, zz], dim=-1).reshape(-1, 3)
+    pts = pts[torch.rand(pts.shape[0]) > 0.3].contiguous()           # compacted, as the norm threshold leaves it
+    rots = [torch.zeros(3), torch.tensor([0.0, 0.0, math.pi / 2]), torch.tensor([0.02, -0.01, 0.03]),
+            torch.tensor([0.4, 0.2, -0.7]), torch.tensor([1.2, -2.0, 0.6]), torch.randn(3), torch.zeros(3), torch.zeros(3)]
+    trans = [torch.zeros(3), torch.tensor([4.98, 0.0, 0.0]), torch.tensor([0.0, 2.39, 0.0]), torch.tensor([0.3, -0.2, 0.1]),
+             torch.tensor([1.0, 0.9, -1.5]), torch.randn(3), torch.tensor([40.0, 0.0, 0.0]), torch.tensor([2.0, 0.5, 3.9])]
+    S = len(rots)
+    C_ = 4
+    feats = [(torch.randn(1, C_, 8, 6, 10) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d),
+             (torch.randn(1, C_, 16, 12, 20) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d)]
+    meta = ops.GridMeta.from_bound(bound)
+    pairs = [(a, b) for a in range(S) for b in range(S) if a != b]
+    for order, far in (("zmajor", 0.0), ("shuffled", 0.0), ("zmajor", 3000.0)):
+        coords = (pts if order == "zmajor" else pts[torch.randperm(pts.shape[0])]).to(DEV).contiguous()
+        n = coords.shape[0]
+        fsrc = torch.randn(n, 2 * C_, device=DEV)
+        # the box table itself
+        bx = torch.empty(((n + 511) // 512, 6), device=DEV)
+        assert _lib.load().miso_align_src_boxes(ops._ptr(coords), n, ops._ptr(bx), ops._stream(coords)) == 0
+        pad = torch.cat([coords, coords[-1:].expand(bx.shape[0] * 512 - n, 3)]).view(-1, 512, 3)
+        assert torch.equal(bx, torch.cat([pad.amin(1), pad.amax(1)], dim=1))
+        R0 = so3_exp_map(torch.stack(rots)).to(DEV)
+        t0 = (torch.stack(trans) + far).reshape(S, 3, 1).to(DEV)      # far: every submap 3 km from the world origin
+        out = {}
+        for cull in (False, True):
+            descr = [dict(src=a, dst=b, coords=coords, feats_src=fsrc, feats_dst=feats, meta_dst=meta, gate_pts=None)
+                     for a, b in pairs]
+            plan = ops.AlignPlan(R0, t0, descr, loss_type="L2", cull=cull)
+            plan.iteration_a()
+            o = [plan.pair_out.clone().cpu()]
+            plan.params[2, 0] = 0.3
+            plan.params[4, 3:] = torch.tensor([0.2, -0.1, 0.05], device=DEV)
+            plan.iteration_a()
+            o.append(plan.pair_out.clone().cpu())
+            plan.params[3, 1] = float("nan")
+            plan.iteration_a()
+            o.append(plan.pair_out.clone().cpu())
+            out[cull] = o
+        for a_, b_ in zip(out[False], out[True]):
+            assert torch.equal(torch.isnan(a_), torch.isnan(b_))
+            assert torch.equal(a_[:, 1], b_[:, 1])                      # in-bound counts: exact
+            torch.testing.assert_close(torch.nan_to_num(b_), torch.nan_to_num(a_), rtol=1e-12, atol=1e-12)
+        cnt = out[True][0][:, 1]
+        assert (cnt == 0).any() and (cnt > 0).any()
+    # (that runs ARE skipped shows in the time of the cfg-4 level-1 iteration: bench.py, DESIGN 4.6)
 
 
 @pytest.mark.gpu
