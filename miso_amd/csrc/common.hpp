@@ -210,10 +210,10 @@ struct AlignPairK {
   int32_t src, dst;
   float n_ch;           // channels compared (the L2 mean divides by count * n_ch)
   // axis-aligned boxes {min xyz, max xyz} (source frame) of every run of ALIGN_BOX_VERTS consecutive source vertices, or
-  // nullptr: a wavefront whose run cannot reach the destination bound under the current poses skips it unread
+  // nullptr: a run that cannot reach the destination bound under the current poses is not read
   const float* boxes;
 };
-constexpr int ALIGN_BOX_VERTS = 512;
+constexpr int ALIGN_BOX_VERTS = 64;
 
 // One torch.optim.Adam update (amsgrad=False, weight_decay=0) as torch forms it op by op; shared by adam.hip
 // (dense grids) and align.hip (the 6(S-1) pose numbers of the alignment loop).

@@ -59,52 +59,58 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
   // tests PAIR_K x 64 consecutive vertices and compacts the in-bound ones into a per-wave LDS list (ballot + prefix:
   // a deterministic order, no block barrier); pass 2 walks that list with all lanes busy.
   constexpr int PAIR_K = 8;
-  static_assert(PAIR_K * 64 == ALIGN_BOX_VERTS, "a wavefront's run of a chunk is one box");
+  static_assert(ALIGN_BOX_VERTS == 64 && PAIR_K == 8, "one box per 64-vertex step, eight steps per wavefront and chunk");
   __shared__ uint16_t s_in[4][PAIR_K * 64];
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long lt_mask = (lane_ == 0) ? 0ull : (~0ull >> (64 - lane_));
   const int64_t chunk = (int64_t)blockDim.x * PAIR_K;
-  // A run's box in the destination frame: centre q_c = Rd^T (Rs c + ts - td), half-extent along destination axis a
-  // sum_b |M[a][b]| e_b with M = Rd^T Rs.  Outside the bound by more than BOX_SLACK on any axis: no vertex of the run
-  // can pass the exact test below, the run is skipped unread (the sums are those of reading it).  NaN poses compare
-  // false: nothing is skipped.
-  float Mabs[9], Mq[9], q0c[3];
+  // A step's box in the destination frame: centre q_c = Rd^T (Rs c + ts - td), half-extent along destination axis a
+  // sum_b |M[a][b]| e_b with M = Rd^T Rs.  Outside the bound by more than the slack on any axis: no vertex of the step
+  // can pass the exact test below, and the step is not read (the sums are those of reading it).  Lane u < 8 tests the
+  // box of step u -- one test per 512 vertices of wavefront time, not per 64.  NaN poses compare false: nothing is skipped.
+  // (M and q_0 are formed where they are used, once per 512 vertices: kept across the loop they would be 21 more
+  // live registers in a kernel that sits at its 128-register budget)
   // (the exact test forms w = Rs p + ts first: its rounding grows with the size of the world coordinates)
-  const float box_slack = BOX_SLACK + 4e-6f * (fabsf(ts[0]) + fabsf(ts[1]) + fabsf(ts[2]) + fabsf(td[0]) + fabsf(td[1]) + fabsf(td[2]));
-  if (k.boxes) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        Mq[a * 3 + b] = Rd[a] * Rs[b] + Rd[3 + a] * Rs[3 + b] + Rd[6 + a] * Rs[6 + b];
-        Mabs[a * 3 + b] = fabsf(Mq[a * 3 + b]);
-      }
-      q0c[a] = Rd[a] * (ts[0] - td[0]) + Rd[3 + a] * (ts[1] - td[1]) + Rd[6 + a] * (ts[2] - td[2]);
-    }
-  }
   for (int64_t c0 = (int64_t)bx * chunk; c0 < k.n; c0 += (int64_t)nbx * chunk) {
     const int64_t w0 = c0 + (int64_t)wave_ * (PAIR_K * 64);
     if (w0 >= k.n) continue;
+    unsigned live_steps = 0xffu;
     if (k.boxes) {
-      const float* bb = k.boxes + (w0 / ALIGN_BOX_VERTS) * 6;      // (wave-uniform address)
-      const float c[3] = {0.5f * (bb[0] + bb[3]), 0.5f * (bb[1] + bb[4]), 0.5f * (bb[2] + bb[5])};
-      const float e[3] = {0.5f * (bb[3] - bb[0]), 0.5f * (bb[4] - bb[1]), 0.5f * (bb[5] - bb[2])};
-      bool outside = false;
+      const int64_t s0 = w0 + (int64_t)(lane_ & 7) * 64;
+      bool reach = false;
+      if (s0 < k.n) {
+        const float* bb = k.boxes + (s0 / ALIGN_BOX_VERTS) * 6;
+        const float c[3] = {0.5f * (bb[0] + bb[3]), 0.5f * (bb[1] + bb[4]), 0.5f * (bb[2] + bb[5])};
+        const float e[3] = {0.5f * (bb[3] - bb[0]), 0.5f * (bb[4] - bb[1]), 0.5f * (bb[5] - bb[2])};
+        bool outside = false;
+        // (an opaque 1.0: without it the compiler hoists the nine products of M and q_0 out of the chunk loop and keeps
+        // them live across pass 2 -- 12 more spilled registers there)
+        float one = 1.0f;
+        asm volatile("" : "+v"(one));
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float qc = Mq[a * 3] * c[0] + Mq[a * 3 + 1] * c[1] + Mq[a * 3 + 2] * c[2] + q0c[a];
-        const float r = Mabs[a * 3] * e[0] + Mabs[a * 3 + 1] * e[1] + Mabs[a * 3 + 2] * e[2] +
-                        box_slack + 1e-6f * (fabsf(qc) + fabsf(q0c[a]));
-        outside = outside || qc - r > g.bmax[a] || qc + r < g.bmin[a];
+        for (int a = 0; a < 3; ++a) {
+          const float rda = Rd[a] * one, rdb = Rd[3 + a] * one, rdc = Rd[6 + a] * one;
+          const float m0 = rda * Rs[0] + rdb * Rs[3] + rdc * Rs[6];
+          const float m1 = rda * Rs[1] + rdb * Rs[4] + rdc * Rs[7];
+          const float m2 = rda * Rs[2] + rdb * Rs[5] + rdc * Rs[8];
+          const float q0 = rda * (ts[0] * one - td[0]) + rdb * (ts[1] * one - td[1]) + rdc * (ts[2] * one - td[2]);
+          const float qc = m0 * c[0] + m1 * c[1] + m2 * c[2] + q0;
+          // (the exact test forms w = Rs p + ts first: its rounding grows with the size of the world coordinates)
+          const float slack = BOX_SLACK + 4e-6f * (fabsf(ts[0] * one) + fabsf(ts[1]) + fabsf(ts[2]) + fabsf(td[0]) + fabsf(td[1]) + fabsf(td[2]));
+          const float r = fabsf(m0) * e[0] + fabsf(m1) * e[1] + fabsf(m2) * e[2] + slack + 1e-6f * (fabsf(qc) + fabsf(q0));
+          outside = outside || qc - r > g.bmax[a] || qc + r < g.bmin[a];
+        }
+        reach = !outside;
       }
-      if (outside) continue;
+      live_steps = (unsigned)(__ballot(reach) & 0xffull);
+      if (live_steps == 0u) continue;
     }
     int n_in = 0;
 #pragma unroll
     for (int u = 0; u < PAIR_K; ++u) {
       const int64_t i = w0 + u * 64 + lane_;
       bool inb = false;
-      if (i < k.n) {
+      if (i < k.n && ((live_steps >> u) & 1u)) {
         const float px = k.p[i * 3 + 0], py = k.p[i * 3 + 1], pz = k.p[i * 3 + 2];
         const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
                             Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(256, 4) void pair_stage_kernel(const AlignPairK* __
   pair_latent_body<VEC4>(d.g, pose_all + 12 * d.src, pose_all + 12 * d.dst, k, blockIdx.x, pair_blocks);
 }
 
-// boxes[r] = {min, max} over source vertices [512 r, 512 r + 512): one wavefront per run (fminf / fmaxf drop NaNs)
+// boxes[r] = {min, max} over source vertices [64 r, 64 r + 64): one wavefront per run (fminf / fmaxf drop NaNs)
 __global__ __launch_bounds__(256) void src_boxes_kernel(const float* __restrict__ p, int64_t n, float* __restrict__ boxes) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);

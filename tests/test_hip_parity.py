@@ -1233,7 +1233,7 @@ def test_lattice_overlap_gate_counts_equal_the_point_list_gate(case):
 
 @pytest.mark.gpu
 def test_box_culled_pair_stage_equals_reading_every_vertex():
-    """miso_align_src_boxes + miso_align_pair_t.src_boxes: the residual kernel skips a run of 512 source vertices when its
+    """miso_align_src_boxes + miso_align_pair_t.src_boxes: the residual kernel skips a run of 64 source vertices when its
     box, mapped into the destination frame, cannot touch the destination bound.  The skip is conservative, so all 24
     sums of every pair are those of the kernel that reads every vertex (same lanes add the same terms; only the fp64
     atomics' order is free): identity, faces touching, rotated overlaps, no overlap at all, far-away world origins (the
@@ -1265,9 +1265,9 @@ def test_box_culled_pair_stage_equals_reading_every_vertex():
         n = coords.shape[0]
         fsrc = torch.randn(n, 2 * C_, device=DEV)
         # the box table itself
-        bx = torch.empty(((n + 511) // 512, 6), device=DEV)
+        bx = torch.empty(((n + 63) // 64, 6), device=DEV)
         assert _lib.load().miso_align_src_boxes(ops._ptr(coords), n, ops._ptr(bx), ops._stream(coords)) == 0
-        pad = torch.cat([coords, coords[-1:].expand(bx.shape[0] * 512 - n, 3)]).view(-1, 512, 3)
+        pad = torch.cat([coords, coords[-1:].expand(bx.shape[0] * 64 - n, 3)]).view(-1, 64, 3)
         assert torch.equal(bx, torch.cat([pad.amin(1), pad.amax(1)], dim=1))
         R0 = so3_exp_map(torch.stack(rots)).to(DEV)
         t0 = (torch.stack(trans) + far).reshape(S, 3, 1).to(DEV)      # far: every submap 3 km from the world origin
