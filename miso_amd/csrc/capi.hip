@@ -297,6 +297,15 @@ static int sdf_fwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   return (int)launch_sdf_fwd(C, L, H, NH, g, packed, x, n, sdf, relu_mask, perm, lin, (hipStream_t)stream);
 }
 
+// A per-axis (or finer than 16) binning is served by the matrix-core pull alone, and that kernel addresses the d-feat
+// rows with 32-bit byte offsets: a batch whose rows pass 2 GB cannot be pulled under such a binning.  Said here, BEFORE
+// the step's first kernel is launched (the launch used to fail after the backward had already deferred the
+// levels to the pull).
+static bool pull_serviceable(const miso_sorted_t* sorted, int64_t n, int64_t ld) {
+  if (!sorted || tiles_cubic16(sorted->tiles_per_axis)) return true;
+  return n * ld * 4 < ((int64_t)1 << 31);
+}
+
 // levels the brick push (grad_brick.hip) takes in this call: what plan_brick wants, provided the caller's binned batch
 // carries a stage buffer large enough (miso_brick_stage_floats); without one the call behaves as before round 5
 static uint32_t brick_levels(const GridK& g, const miso_sorted_t* sorted, int64_t n, uint32_t pull) {
@@ -335,6 +344,7 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   // their d-feat rows go through the workspace like a pulled level's
   const uint32_t brick = (sorted && sorted->xn_sorted && workspace && want_grid && ((uintptr_t)workspace & 15u) == 0)
                              ? brick_levels(g, sorted, n, pull) : 0u;
+  if ((pull & ~brick) && !pull_serviceable(sorted, n, g.F)) return MISO_E_UNSUPPORTED;
   pull |= brick; push &= ~brick;
   hipStream_t st = (hipStream_t)stream;
   if (overwrite && !(grid->flags & MISO_F_GRAD_ZEROED)) {
@@ -523,6 +533,7 @@ static int grad_pull_impl(const miso_grid_t* grid, const miso_sorted_t* sorted, 
   rc = pull_plan(grid, sorted->tiles_per_axis, &g, &C, &pull);
   if (rc) return rc;
   if (ld_d < g.F) return MISO_E_BADARG;
+  if (pull && !gg_x && !pull_serviceable(sorted, n, ld_d)) return MISO_E_UNSUPPORTED;
   for (int l = 0; l < g.n_levels; ++l)
     if (g.lv[l].grad && !((pull >> l) & 1u)) return MISO_E_UNSUPPORTED;   // every requested level must be pullable
   if (gg_x && !(g.flags & MISO_F_COORDS_NORMALIZED))
@@ -588,6 +599,7 @@ static int sdf_train_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const 
   uint32_t push = pull ? plan_push(g, sorted->tiles_per_axis, n, pull) : 0u;
   // levels beyond the pull's reach (and what fits beside them): the brick push, from the d-feat rows as well
   const uint32_t brick = (sorted && workspace) ? brick_levels(g, sorted, n, pull) : 0u;
+  if ((pull & ~brick) && !pull_serviceable(sorted, n, g.F)) return MISO_E_UNSUPPORTED;
   pull |= brick; push &= ~brick;
   const uint32_t scat = want & ~pull;
   hipStream_t st = (hipStream_t)stream;

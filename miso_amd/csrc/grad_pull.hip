@@ -1087,6 +1087,7 @@ static hipError_t launch_push(const GridK& g, int C, int T, const int* tile_off,
   return hipGetLastError();
 }
 
+hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
 hipError_t launch_brick(const GridK& g, int C, int tiles, const int* tile_off, const float* xn, const float* dfeat,
                         int64_t ld, const int* perm, uint32_t mask, int overwrite, int zeroed, float* stage,
                         int64_t stage_floats, hipStream_t s);
@@ -1123,7 +1124,22 @@ hipError_t launch_grad_pull(const GridK& g, int C, int tiles, const int* tile_of
     // first-order gradients on grids at least as fine as the binning: the matrix-core pull (grad_pull_mc.hip)
     if (!ggx && mc_pull_ok(g, C, T3, level_mask, n, ld))
       return launch_grad_pull_mc(g, C, T3, tile_off, xn, dfeat, ld, perm, level_mask, overwrite, n, s);
-    if (!tiles_cubic16(tiles)) return hipErrorInvalidValue;      // plan_grad_pull admits such a binning for that kernel only
+    if (!tiles_cubic16(tiles)) {
+      // plan_grad_pull admits a per-axis binning for the matrix-core kernel only.  What it cannot serve: an empty batch
+      // (the gradient of nothing is zero -- written here when the caller asked for overwrite, as the vector
+      // kernels of a cubic binning do) and d-feat rows past its 32-bit offsets (pull_serviceable: refused by the entry
+      // points before anything is launched)
+      if (n > 0) return hipErrorInvalidValue;
+      for (int l = 0; overwrite && l < g.n_levels; ++l)
+        if ((level_mask >> l) & 1u) {
+          const LevelK& lv = g.lv[l];
+          const size_t span = (size_t)(lv.C - 1) * lv.sC + (size_t)(lv.X - 1) * lv.sX + (size_t)(lv.Y - 1) * lv.sY +
+                              (size_t)(lv.Z - 1) * lv.sZ + 1;
+          hipError_t e = launch_zero_fill(lv.grad, (int64_t)span, s);
+          if (e != hipSuccess) return e;
+        }
+      return hipSuccess;
+    }
   }
   PullK pk;
   memset(&pk, 0, sizeof(pk));

@@ -922,16 +922,18 @@ def test_pair_latent_kernel_vs_oracle_large(lt, level):
         assert relerr(a.cpu(), b) < 2e-3
 
 
+@pytest.mark.parametrize("tiles", [16, (20, 16, 24)])
 @pytest.mark.parametrize("n", [0, 1, 64, 65])
-def test_binned_path_ragged_and_empty(n):
+def test_binned_path_ragged_and_empty(n, tiles):
     """Binned entry points at the edges: an empty batch (every gradient must come back exactly zero
-    -- MISO_F_GRAD_OVERWRITE promises no stale values), one point, one chunk, one chunk + 1."""
+    -- MISO_F_GRAD_OVERWRITE promises no stale values), one point, one chunk, one chunk + 1.  Also under a per-axis
+    binning, which the matrix-core pull alone serves (an empty batch used to come back as an error there)."""
     from miso_amd import ops
     case, feats, bound, ws, bs, x0, meta, fd, pack = setup_case("cfg2")
     fdd = [f.detach() for f in fd]
     L = len(fdd)
     x = x0[:n].to(DEV)
-    sb = ops.SortedBatch(n, DEV).sort(x, meta)
+    sb = ops.SortedBatch(n, DEV, tiles=tiles).sort(x, meta)
     off = sb.tile_offsets.cpu()
     assert off[0] == 0 and off[-1] == n
     sdf, mask = ops.sdf_fwd_raw(x, fdd, meta, pack, True, sorted_batch=sb)
