@@ -190,22 +190,8 @@ typedef struct {
    * bound would otherwise be limited by its heaviest tile.  NULL / 0: tiles are never cut. */
   int32_t* pull_queue;
   int64_t pull_queue_ints;
-  /* Optional scratch of the brick push (round 5): miso_brick_stage_floats(grid, tiles, n) floats, 16-byte aligned,
-   * contents unspecified.  With it, levels whose bricks are beyond the owner-computes pull (more than 8 vertices per tile
-   * and axis: ScanNet's 200 x 100 x 200 level over 16 tiles) are no longer scattered with float atomics from the
-   * backward kernel: every tile accumulates its samples into an LDS copy of its region in double (ds_add_f64), leaves
-   * the rounded region in this buffer, and a second launch lets every tile sum the regions that cover the vertices it
-   * owns -- no atomics in HBM, no zero-fill, sums independent of the sample order.  miso_grad_brick_levels reports the
-   * levels that move (they leave miso_sdf_bwd_scattered_levels / miso_sdf_bwd_push_levels).  NULL / too small: as before. */
-  float* brick_stage;
-  int64_t brick_stage_floats;
 } miso_sorted_t;
 int64_t miso_pull_queue_ints(int64_t n);
-/* levels (bit l) of a binned miso_sdf_bwd_sorted / miso_sdf_train_sorted call over n points that go through the brick
- * push when miso_sorted_t.brick_stage is given, and the floats that buffer needs (0: no level qualifies -- every level is
- * within the pull's reach, or none fits a workgroup's LDS, or the grid does not use the default sampling convention) */
-uint32_t miso_grad_brick_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n);
-int64_t miso_brick_stage_floats(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n);
 
 int64_t miso_sort_workspace_bytes(int64_t n, int32_t tiles_per_axis);
 int miso_sort_points(const miso_grid_t* grid, const float* x, int64_t n, int32_t tiles_per_axis,

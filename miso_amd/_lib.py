@@ -74,8 +74,7 @@ class Mlp(C.Structure):
 class Sorted(C.Structure):
     _fields_ = [("tiles_per_axis", C.c_int32), ("x_sorted", C.c_void_p), ("xn_sorted", C.c_void_p),
                 ("perm", C.c_void_p), ("tile_offsets", C.c_void_p),
-                ("pull_queue", C.c_void_p), ("pull_queue_ints", C.c_int64),
-                ("brick_stage", C.c_void_p), ("brick_stage_floats", C.c_int64)]
+                ("pull_queue", C.c_void_p), ("pull_queue_ints", C.c_int64)]
 
 
 class RayFrames(C.Structure):
@@ -129,8 +128,6 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_sdf_bwd": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "miso_grad_brick_levels": (C.c_uint32, [C.POINTER(Grid), C.c_int32, C.c_int64]),
-    "miso_brick_stage_floats": (C.c_int64, [C.POINTER(Grid), C.c_int32, C.c_int64]),
     "miso_sort_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "miso_sort_points": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

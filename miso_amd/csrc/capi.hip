@@ -43,10 +43,7 @@ hipError_t launch_mapping_loss_rows(int, float, float, float, const float*, cons
                                     hipStream_t);
 uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
-                            uint32_t, int, const float*, int32_t*, int64_t, hipStream_t, uint32_t push_mask, int64_t n,
-                            uint32_t brick_mask, float* stage, int64_t stage_floats, int zeroed);
-uint32_t plan_brick(const GridK&, int, int64_t, uint32_t);
-int64_t brick_stage_floats(const GridK&, int, uint32_t);
+                            uint32_t, int, const float*, int32_t*, int64_t, hipStream_t, uint32_t push_mask, int64_t n);
 uint32_t plan_push(const GridK&, int, int64_t, uint32_t);
 int64_t pull_queue_ints(int64_t);
 hipError_t launch_rigid_by_index(const float*, const float*, const int64_t*, const float*, int64_t, int32_t, int, float*,
@@ -306,15 +303,6 @@ static bool pull_serviceable(const miso_sorted_t* sorted, int64_t n, int64_t ld)
   return n * ld * 4 < ((int64_t)1 << 31);
 }
 
-// levels the brick push (grad_brick.hip) takes in this call: what plan_brick wants, provided the caller's binned batch
-// carries a stage buffer large enough (miso_brick_stage_floats); without one the call behaves as before round 5
-static uint32_t brick_levels(const GridK& g, const miso_sorted_t* sorted, int64_t n, uint32_t pull) {
-  if (!sorted || !sorted->brick_stage || ((uintptr_t)sorted->brick_stage & 15u) != 0) return 0u;
-  const uint32_t want = plan_brick(g, sorted->tiles_per_axis, n, pull);
-  if (!want || sorted->brick_stage_floats < brick_stage_floats(g, sorted->tiles_per_axis, want)) return 0u;
-  return want;
-}
-
 static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,
                         const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
                         float* grad_x, const miso_sorted_t* sorted, float* workspace, void* stream) {
@@ -339,13 +327,8 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
     pull = plan_grad_pull(g, sorted->tiles_per_axis);
   // coarse levels under a crowd: the matrix-core push (grad_pull.hip; its d-feat rows go through the workspace like a
   // pulled level's, so it stays in `pull`)
-  uint32_t push = (pull && sorted) ? plan_push(g, sorted->tiles_per_axis, n, pull) : 0u;
-  // levels beyond the pull's reach (and whatever fits beside them): accumulated per tile in LDS, gathered by the owners --
-  // their d-feat rows go through the workspace like a pulled level's
-  const uint32_t brick = (sorted && sorted->xn_sorted && workspace && want_grid && ((uintptr_t)workspace & 15u) == 0)
-                             ? brick_levels(g, sorted, n, pull) : 0u;
-  if ((pull & ~brick) && !pull_serviceable(sorted, n, g.F)) return MISO_E_UNSUPPORTED;
-  pull |= brick; push &= ~brick;
+  const uint32_t push = (pull && sorted) ? plan_push(g, sorted->tiles_per_axis, n, pull) : 0u;
+  if (pull && !pull_serviceable(sorted, n, g.F)) return MISO_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (overwrite && !(grid->flags & MISO_F_GRAD_ZEROED)) {
     // levels that are scattered or pushed with atomics start from zero; pulled levels need no fill
@@ -370,8 +353,7 @@ static int sdf_bwd_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const fl
   if (!pull) return MISO_OK;
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace,
                                g.F, nullptr, pull, overwrite ? 1 : 0, nullptr, sorted->pull_queue,
-                               sorted->pull_queue_ints, st, push, n, brick, sorted->brick_stage,
-                               sorted->brick_stage_floats, (grid->flags & MISO_F_GRAD_ZEROED) ? 1 : 0);
+                               sorted->pull_queue_ints, st, push, n);
 }
 
 int miso_sdf_fwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x,
@@ -503,20 +485,6 @@ uint32_t miso_sdf_bwd_push_levels(const miso_grid_t* grid, int32_t tiles_per_axi
   return plan_push(g, tiles_per_axis, n, mask);
 }
 
-uint32_t miso_grad_brick_levels(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n) {
-  GridK g; int C; uint32_t mask;
-  if (pull_plan(grid, tiles_per_axis, &g, &C, &mask)) return 0;
-  if (C != 4 && C != 8) return 0;
-  return plan_brick(g, tiles_per_axis, n, mask);
-}
-
-int64_t miso_brick_stage_floats(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n) {
-  GridK g; int C; uint32_t mask;
-  if (pull_plan(grid, tiles_per_axis, &g, &C, &mask)) return 0;
-  if (C != 4 && C != 8) return 0;
-  return brick_stage_floats(g, tiles_per_axis, plan_brick(g, tiles_per_axis, n, mask));
-}
-
 uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis) {
   GridK g; int C; uint32_t mask;
   if (pull_plan(grid, tiles_per_axis, &g, &C, &mask)) return 0;
@@ -541,7 +509,7 @@ static int grad_pull_impl(const miso_grid_t* grid, const miso_sorted_t* sorted, 
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, dfeat, ld_d,
                                rows_in_caller_order ? sorted->perm : nullptr, pull,
                                (grid->flags & MISO_F_GRAD_OVERWRITE) ? 1 : 0, gg_x, sorted->pull_queue,
-                               sorted->pull_queue_ints, (hipStream_t)stream, 0u, n, 0u, nullptr, 0, 0);
+                               sorted->pull_queue_ints, (hipStream_t)stream, 0u, n);
 }
 
 int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
@@ -595,12 +563,9 @@ static int sdf_train_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const 
   if (!want) return MISO_E_UNSUPPORTED;
   // levels formed from the d-feat rows (pull or push); the rest is scattered from the kernel
   // (an ignored level with a gradient buffer stays in `pull`: the pull writes its zeros, as miso_sdf_bwd_sorted does)
-  uint32_t pull = (sorted && workspace) ? plan_grad_pull(g, sorted->tiles_per_axis) : 0u;
-  uint32_t push = pull ? plan_push(g, sorted->tiles_per_axis, n, pull) : 0u;
-  // levels beyond the pull's reach (and what fits beside them): the brick push, from the d-feat rows as well
-  const uint32_t brick = (sorted && workspace) ? brick_levels(g, sorted, n, pull) : 0u;
-  if ((pull & ~brick) && !pull_serviceable(sorted, n, g.F)) return MISO_E_UNSUPPORTED;
-  pull |= brick; push &= ~brick;
+  const uint32_t pull = (sorted && workspace) ? plan_grad_pull(g, sorted->tiles_per_axis) : 0u;
+  const uint32_t push = pull ? plan_push(g, sorted->tiles_per_axis, n, pull) : 0u;
+  if (pull && !pull_serviceable(sorted, n, g.F)) return MISO_E_UNSUPPORTED;
   const uint32_t scat = want & ~pull;
   hipStream_t st = (hipStream_t)stream;
   const bool overwrite = sorted && (grid->flags & MISO_F_GRAD_OVERWRITE) != 0;
@@ -635,8 +600,7 @@ static int sdf_train_impl(const miso_grid_t* grid, const miso_mlp_t* mlp, const 
   if (!pull) return MISO_OK;
   return (int)launch_grad_pull(g, C, sorted->tiles_per_axis, sorted->tile_offsets, sorted->xn_sorted, workspace, g.F,
                                nullptr, pull, overwrite ? 1 : 0, nullptr, sorted->pull_queue, sorted->pull_queue_ints,
-                               st, push, n, brick, sorted->brick_stage, sorted->brick_stage_floats,
-                               (grid->flags & MISO_F_GRAD_ZEROED) ? 1 : 0);
+                               st, push, n);
 }
 
 int miso_sdf_train_sorted(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed,

@@ -1088,27 +1088,13 @@ static hipError_t launch_push(const GridK& g, int C, int T, const int* tile_off,
 }
 
 hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
-hipError_t launch_brick(const GridK& g, int C, int tiles, const int* tile_off, const float* xn, const float* dfeat,
-                        int64_t ld, const int* perm, uint32_t mask, int overwrite, int zeroed, float* stage,
-                        int64_t stage_floats, hipStream_t s);
-
 hipError_t launch_grad_pull(const GridK& g, int C, int tiles, const int* tile_off, const float* xn,
                             const float* dfeat, int64_t ld, const int* perm, uint32_t level_mask,
                             int overwrite, const float* ggx, int32_t* queue, int64_t queue_ints, hipStream_t s,
-                            uint32_t push_mask, int64_t n, uint32_t brick_mask, float* stage, int64_t stage_floats,
-                            int zeroed) {
+                            uint32_t push_mask, int64_t n) {
   int T3[3];
   if (!tiles_xyz(tiles, T3)) return hipErrorInvalidValue;
   const int T = T3[0];       // (the vector kernels below: cubic binning only)
-  // brick_mask: levels of plan_brick (grad_brick.hip) -- accumulated per tile in LDS, gathered by the owners
-  brick_mask &= level_mask;
-  if (brick_mask && !ggx) {
-    hipError_t e = launch_brick(g, C, tiles, tile_off, xn, dfeat, ld, perm, brick_mask, overwrite, zeroed, stage,
-                                stage_floats, s);
-    if (e != hipSuccess) return e;
-    level_mask &= ~brick_mask;
-    push_mask &= ~brick_mask;
-  }
   // push_mask: levels of plan_push the caller has zero-filled (overwrite) -- added to with atomics
   push_mask &= level_mask;
   if (push_mask && !ggx) {

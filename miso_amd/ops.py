@@ -434,9 +434,6 @@ class SortedBatch:
     # 157 us (MFMA pass + owner-computes pull, no zero-fill).  Below ~64 K points the tiles hold
     # too few points for the sweep to pay.  None = never automatic.
     AUTO_MIN_POINTS = int(os.environ.get("MISO_SORT_MIN_POINTS", 65536)) or None
-    # Levels beyond the pull's reach go through the brick push (LDS accumulation per tile, grad_brick.hip) instead of float
-    # atomics from the backward kernel.  False (tests, A/B timing): no stage buffer is handed over and they are scattered.
-    use_brick = os.environ.get("MISO_BRICK", "1") != "0"
 
     def __init__(self, n: int, device, tiles=TILES, keep_metric: bool = False, need_perm: bool = True):
         """tiles: tiles per axis -- a count (1..16) or per-axis counts (tx, ty, tz) of 1..32 (MISO_TILES_XYZ).
@@ -461,20 +458,6 @@ class SortedBatch:
         self.pull_queue = torch.zeros(int(_lib.load().miso_pull_queue_ints(self.n)), **i32)
         self.struct.pull_queue = self.pull_queue.data_ptr()
         self.struct.pull_queue_ints = self.pull_queue.numel()
-
-    def ensure_brick_stage(self, g) -> None:
-        """The stage buffer of the brick push (miso_sorted_t.brick_stage) for the grid `g` (a filled _lib.Grid with its
-        gradient pointers), allocated on first need: levels beyond the pull's reach are then accumulated per tile in
-        LDS and gathered by their owners instead of being scattered with float atomics (miso_grad_brick_levels)."""
-        if not self.use_brick:                       # tests / A-B runs: the atomic scatter and the push, as before round 5
-            self.struct.brick_stage, self.struct.brick_stage_floats = None, 0
-            return
-        need = int(_lib.load().miso_brick_stage_floats(C.byref(g), self.tiles, self.n))
-        have = getattr(self, "_brick_stage", None)
-        if need and (have is None or have.numel() < need):
-            self._brick_stage = torch.empty(need, device=self.xn_sorted.device, dtype=torch.float32)
-            self.struct.brick_stage = self._brick_stage.data_ptr()
-            self.struct.brick_stage_floats = need
 
     def bwd_workspace(self, floats: int) -> torch.Tensor:
         """(N,F) d-feat rows handed from the MFMA backward to the per-tile reduction."""
@@ -557,8 +540,6 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
         g.flags |= _lib.F_GRAD_SDF_SORTED
     if sorted_batch is not None:
         ws = sorted_batch.bwd_workspace(n * _feature_dim(features)) if any(gr is not None for gr in grads) else None
-        if ws is not None:
-            sorted_batch.ensure_brick_stage(g)
         _lib.check(_lib.load().miso_sdf_bwd_sorted(C.byref(g), C.byref(m), _ptr(packed),
                                                    C.byref(sorted_batch.struct), n, _ptr(gsdf), _ptr(mask),
                                                    _ptr(gx), _ptr(ws), _stream(x)), "miso_sdf_bwd_sorted")
@@ -631,15 +612,12 @@ def sdf_train_lds_bytes(C: int, L: int, H: int, scat: bool, hidden_layers: int =
     return 4 * ((pack + 3) // 4 * 4 + 4 * (64 * FP + (64 * L * 8 if scat else 0)))
 
 
-def sdf_train_scattered_levels(features, meta, grads, tiles=None, n=None) -> int:
+def sdf_train_scattered_levels(features, meta, grads, tiles=None) -> int:
     """Bit mask of the levels sdf_train_raw scatters with atomics from its kernel (bricks beyond the pull's reach under
-    the binning `tiles`: SortedBatch.tiles, default the 16-tile one -- and, given the batch size n, beyond the brick
-    push's as well: a level whose region does not fit a workgroup's LDS)."""
+    the binning `tiles`: SortedBatch.tiles, default the 16-tile one)."""
     want = sum(1 << l for l, gr in enumerate(grads) if gr is not None and not (meta.ignore_mask >> l) & 1)
-    g = _fill_grid(features, meta, grads, data=False)
-    pulled = int(_lib.load().miso_grad_pull_levels(C.byref(g), pack_tiles(tiles or SortedBatch.TILES)))
-    if n is not None:      # with the batch size: the levels the brick push takes are not scattered either
-        pulled |= int(_lib.load().miso_grad_brick_levels(C.byref(g), pack_tiles(tiles or SortedBatch.TILES), int(n)))
+    pulled = int(_lib.load().miso_grad_pull_levels(C.byref(_fill_grid(features, meta, grads, data=False)),
+                                                   pack_tiles(tiles or SortedBatch.TILES)))
     return want & ~pulled
 
 
@@ -662,7 +640,6 @@ def sdf_train_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatch, 
     if zeroed:
         g.flags |= _lib.F_GRAD_ZEROED
     ws = sorted_batch.bwd_workspace(n * _feature_dim(features))
-    sorted_batch.ensure_brick_stage(g)
     _lib.check(_lib.load().miso_sdf_train_sorted(
         C.byref(g), C.byref(m), _ptr(packed), C.byref(sorted_batch.struct), n, _LOSS_TYPES[loss_type], float(weight_sdf),
         float(weight_fs), float(trunc_dist), _ptr(loss_inputs), _ptr(sdf_out), _ptr(loss_slots), _ptr(n_live), _ptr(ws),

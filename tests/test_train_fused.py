@@ -132,29 +132,19 @@ def test_train_kernel_with_the_matrix_core_push_on_a_crowded_batch():
     _check(*_both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.15))
 
 
-@pytest.mark.parametrize("brick", [False, True])
-def test_levels_the_pull_cannot_own_are_scattered_from_the_train_kernel(brick, monkeypatch):
+def test_levels_the_pull_cannot_own_are_scattered_from_the_train_kernel():
     """A level with bricks beyond the pull's reach (200 vertices over 16 tiles: 12.5 per tile and axis; cfg-3's fine
     level) no longer forces the two launches: sdf_train_kernel<.., SCAT> scatters it with float atomics itself, the
     other level still goes through the d-feat rows.  Against the two-launch form: SDF and loss bit for bit, the pulled
-    level to the pull's summation order, the scattered one to the order of the atomics.
-    brick (round 5): with a stage buffer on the binned batch neither form scatters -- both levels leave through the d-feat
-    rows and the brick push (grad_brick.hip: per-tile LDS accumulation in double, gathered by the owners)."""
+    level to the pull's summation order, the scattered one to the order of the atomics."""
     from miso_amd import ops
     from miso_amd.step import MappingStep
-    monkeypatch.setattr(ops.SortedBatch, "use_brick", brick)
-    fine = 160 if brick else 200      # (a cubic 200-vertex level needs 15^3 x 4 doubles of LDS: beyond the brick push as well)
-    feats, meta, pack, x, aux = _setup(4, (40, fine), 64, 70000, seed=31)
+    feats, meta, pack, x, aux = _setup(4, (40, 200), 64, 70000, seed=31)
     aux[7, 0] = 0.0
     grads = [torch.empty_like(f) for f in feats]
     assert ops.sdf_train_supported(feats, meta, grads) and ops.sdf_train_scattered_levels(feats, meta, grads) == 2
-    # ... unless the brick push takes them (given the batch size the query knows about it)
-    assert ops.sdf_train_scattered_levels(feats, meta, grads, n=x.shape[0]) == (0 if fine == 160 else 2)
     (s1, sdf1, g1), (s2, sdf2, g2) = _both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.15)
-    if brick:      # nothing is scattered: the kernel runs eight wavefronts per workgroup and groups its loss slots by eight
-        assert torch.allclose(s1.double().sum(0), s2.double().sum(0), rtol=2e-6, atol=1e-12) and torch.equal(sdf1, sdf2)
-    else:
-        assert torch.equal(s1, s2) and torch.equal(sdf1, sdf2)
+    assert torch.equal(s1, s2) and torch.equal(sdf1, sdf2)
     assert (g1[0] - g2[0]).abs().max().item() <= 2e-6 * g2[0].abs().max().item()
     assert (g1[1] - g2[1]).abs().max().item() <= 2e-5 * g2[1].abs().max().item() and float(g2[1].abs().max()) > 0
     # only the scattered level wanted: nothing goes through the workspace at all
@@ -272,25 +262,21 @@ def _setup_lin(C, sizes, H, n, seed, **kw):
 
 
 @pytest.mark.parametrize("lt", ["L1", "L2"])
-@pytest.mark.parametrize("shape", list(range(len(SHAPES))) + ["scat", "brick"])
-def test_train_kernel_vs_cpu_oracle(shape, lt, monkeypatch):
+@pytest.mark.parametrize("shape", list(range(len(SHAPES))) + ["scat"])
+def test_train_kernel_vs_cpu_oracle(shape, lt):
     """miso_sdf_train_sorted (sdf_train_kernel: forward + mapping loss + decoder backward in one launch, then the pull /
     push; `scat`: a 200-vertex level the pull cannot own is scattered from the kernel, sdf_train_kernel<..,SCAT>) against
     the oracle: SDF to 1e-5, both loss terms to 1e-6, every level's gradient to 1e-4 of its largest entry (ReLU ties
     apart), with invalid rows, free-space rows, per-sample weights and points outside the bound."""
     from miso_amd import ops
-    # `scat`: the 200-vertex level scattered from the kernel; `brick`: the same grid through the brick push
-    monkeypatch.setattr(ops.SortedBatch, "use_brick", shape != "scat")
-    C, sizes, H = (4, (40, 200), 64) if shape == "scat" else (4, (40, 160), 64) if shape == "brick" else SHAPES[shape]
+    C, sizes, H = (4, (40, 200), 64) if shape == "scat" else SHAPES[shape]
     n = 70001
-    feats, meta, pack, x, aux, lin = _setup_lin(C, sizes, H, n, seed=100 + (7 if shape in ("scat", "brick") else shape))
+    feats, meta, pack, x, aux, lin = _setup_lin(C, sizes, H, n, seed=100 + (7 if shape == "scat" else shape))
     aux[7, 0] = 0.05
     ws, wf, td = 1.0, 0.2, 0.15
     sb = ops.SortedBatch(n, DEV).sort(x, meta)
     slots, sdf = torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), torch.empty(n, 1, device=DEV)
     grads = [torch.full_like(f, -3.0) for f in feats]
-    if shape == "brick":
-        assert ops.sdf_train_scattered_levels(feats, meta, grads, n=n) == 0
     if shape == "scat":
         assert ops.sdf_train_scattered_levels(feats, meta, grads) == 2
         grads[1].zero_()                      # a scattered level is added to: the caller clears it (MappingStep: Adam does)
