@@ -1026,6 +1026,7 @@ def headline_record(args, step, dev, world, elapsed):
     mask = torch.empty(((N_POINTS + 63) // 64) * 64 * ops.sdf_mask_words(pack), device=dev, dtype=torch.int32)
     t_sort = time_kernel(lambda: sb.sort(step.x, meta)) if sb is not None else 0.0
     fused = sb is not None and step._fused_train()
+    sb_step = sb                      # what the step itself runs on: no perm[] when the step is the fused one
     if sb is not None and sb.perm is None:
         # the step's own batch carries no perm[] (the fused step does not need one); the two-launch reference below does
         sb = ops.SortedBatch(N_POINTS, dev, tiles=step.tiles).sort(step.x, meta)
@@ -1041,8 +1042,9 @@ def headline_record(args, step, dev, world, elapsed):
                                                     gsdf_sorted=True))
         if fused:
             # ... and what the step actually launches: forward + loss + decoder backward as ONE kernel, then the pull
-            t_train = time_kernel(lambda: ops.sdf_train_raw(feats, meta, pack, sb, step.aux, step.loss_slots, step.grads,
-                                                            "L1", 1.0, 0.0, 0.0))
+            # (on the step's OWN binned batch -- the index rides in xn.w, no perm[] -- not on the reference one)
+            t_train = time_kernel(lambda: ops.sdf_train_raw(feats, meta, pack, sb_step, step.aux, step.loss_slots,
+                                                            step.grads, "L1", 1.0, 0.0, 0.0))
     else:
         t_fwd = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, True, out=step.sdf, mask=mask))
         cols = [c.contiguous() for c in (step.target, step.valid, step.sign, step.weight)]
@@ -1050,34 +1052,35 @@ def headline_record(args, step, dev, world, elapsed):
         t_bwd = time_kernel(lambda: ops.sdf_bwd_raw(step.x, feats, meta, pack, step.gpred, mask, False,
                                                     [True] * L, step.grads))
     t_zero = time_kernel(lambda: [g.zero_() for g in step.grads]) if sb is None else 0.0
-    kernels_us = {"sort_points(3 launches)": t_sort,
-                  "sdf_fwd_kernel(+mapping loss)" if sb is not None else "sdf_fwd_kernel": t_fwd,
-                  "mapping_loss_kernel": t_loss,
-                  "backward(sdf_bwd_kernel + grad_pull_kernel)" if sb is not None else "sdf_bwd_kernel": t_bwd,
-                  "zero_grads": t_zero}
     b_fwd = 12 + 32 * L * C + 4        # xyz + 8 corners x C x 4 B per level + sdf
     b_bwd = 4 + 32 * L * C             # dL/dsdf + grad scatter counted once as a write
     dom = ("sdf_bwd_kernel", t_bwd, b_bwd)
-    if sb is not None:
+    t_pull = 0.0
+    if sb is None:
+        kernels_us = {"in_the_step": {"sdf_fwd_kernel": t_fwd, "mapping_loss_kernel": t_loss, "sdf_bwd_kernel": t_bwd,
+                                      "zero_grads": t_zero}}
+    else:
         # the backward is two launches: the MFMA pass that leaves the d-feat rows in the workspace,
         # and the owner-computes pull that forms the grid gradient from them; time the pull alone
         ws = sb.bwd_workspace(N_POINTS * L * C)
         t_pull = time_kernel(lambda: ops.grad_pull_raw(feats, meta, sb, ws, step.grads, overwrite=True))
-        kernels_us["grad_pull_kernel"] = t_pull
-        kernels_us["sdf_bwd_kernel(MFMA pass)"] = t_bwd - t_pull
-        kernels_us["grad_pull_kernel"] = t_pull
+        # which kernel that is (asked of the library, not assumed): the matrix-core pull, or the vector kernels
+        # (MISO_PULL_MC=0, or a grid the matrix-core kernel does not take)
+        from miso_amd import _lib as _l
+        on_mc = bool(_l.load().miso_grad_pull_on_matrix_cores(
+            ops.C.byref(ops._fill_grid(feats, meta, step.grads, data=False)), sb.tiles, N_POINTS, L * C))
+        pull_name = "grad_pull_mc_kernel" if on_mc else "grad_pull_block_kernel(+drain)"
+        two_launch = {"sdf_fwd_kernel(+mapping loss)": t_fwd, "sdf_bwd_kernel(MFMA pass)": t_bwd - t_pull, pull_name: t_pull}
         if t_train is not None:
-            kernels_us["sdf_train_kernel(forward + loss + decoder backward, one launch: what the step runs)"] = t_train - t_pull
             # the two-launch forward / backward are timed for reference only -- the step does not launch them
             kernels_us = {"in_the_step": {"sort_points(3 launches)": t_sort, "sdf_train_kernel": t_train - t_pull,
-                                          "grad_pull_mc_kernel": t_pull},
-                          "not_in_the_step(two-launch form, for reference)": {
-                              "sdf_fwd_kernel(+mapping loss)": t_fwd, "sdf_bwd_kernel(MFMA pass)": t_bwd - t_pull},
-                          **kernels_us}
+                                          pull_name: t_pull},
+                          "not_in_the_step(two-launch form, for reference)": two_launch}
+        else:
+            kernels_us = {"in_the_step": {"sort_points(3 launches)": t_sort, **two_launch}}
         # algorithmic bytes of the pull: the gradient of 8 corners x C channels per level, counted
         # once as a write (SURVEY 8d backward figure without the 4 B of dL/dsdf the MFMA pass reads)
-        # (at cfg-2 the pull is grad_pull_mc_kernel -- one workgroup per 2x2x2 tiles, the sums on the fp32 matrix cores)
-        dom = ("grad_pull_mc_kernel", t_pull, 32 * L * C)
+        dom = (pull_name, t_pull, 32 * L * C)
     if t_train is not None and t_train - t_pull > dom[1]:
         # the fused kernel moves the bytes of both passes except the gradient write (the pull's): corners read once
         dom = ("sdf_train_kernel", t_train - t_pull, b_fwd)
@@ -1110,7 +1113,7 @@ def headline_record(args, step, dev, world, elapsed):
     # decoder: forward 2(F H + H H + H), backward the same w.r.t. activations) over v_mfma_f32_32x32x2_f32 peak
     F_ = L * C
     mlp_flop = 2.0 * (F_ * HIDDEN + HIDDEN * HIDDEN + HIDDEN) * N_POINTS
-    t_bwd_mfma = kernels_us.get("sdf_bwd_kernel(MFMA pass)", t_bwd)
+    t_bwd_mfma = t_bwd - t_pull
     mfma = {"peak_TFLOPs": 157.3, "sdf_fwd_kernel": mlp_flop / (t_fwd * 1e-6) / 157.3e12,
             "sdf_bwd_kernel": mlp_flop / (t_bwd_mfma * 1e-6) / 157.3e12,
             **({"sdf_train_kernel": 2 * mlp_flop / ((t_train - t_pull) * 1e-6) / 157.3e12} if t_train is not None else {}),
@@ -1130,8 +1133,9 @@ def headline_record(args, step, dev, world, elapsed):
                      "traffic": traffic, "traffic_source": pmc_note, "algorithmic_bytes_per_point": dom[2],
                      "kernel_us": dom[1], "mfma_frac": mfma})
     if dom[0].startswith("grad_pull"):
-        roofline["launches"] = ("grad_pull_mc_kernel: one launch (crowded blocks are worked off in epochs inside it; the "
-                                "vector kernels' drain launch is gone)")
+        roofline["launches"] = ("grad_pull_mc_kernel: one launch (crowded blocks are worked off in epochs inside it)"
+                                if dom[0] == "grad_pull_mc_kernel" else
+                                "grad_pull_block_kernel + its drain launch for queued slices of crowded tiles")
 
     out = {
         "metric": "3D point-samples/sec (encode+decode fwd+bwd), 262144-pt batch",
@@ -1144,7 +1148,7 @@ def headline_record(args, step, dev, world, elapsed):
                    "points_per_gpu": N_POINTS, "levels": list(LEVELS), "feature_dim": C,
                    "decoder": [C * L, HIDDEN, HIDDEN, 1], "parallelism": f"submap-parallel x{world}",
                    "launch": "one graph replay per step" if step._use_graph else
-                             "six stream launches per step (a graph replay leaves the device idle ~6 us between replays)"},
+                             "five stream launches per step (a graph replay leaves the device idle ~6 us between replays)"},
         "roofline": roofline,
         "step_fraction_of_hbm_roofline": value / world * (20 + 64 * L * C) / 8e12,
         "kernels_us": kernels_us,

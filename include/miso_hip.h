@@ -145,6 +145,11 @@ int64_t miso_mlp_packed_floats(const miso_mlp_t* mlp);
 int miso_mlp_pack(const miso_mlp_t* mlp, float* packed, void* stream);
 /* 1 if (grid, mlp) is covered by miso_sdf_fwd/bwd, else 0 */
 int miso_sdf_supported(const miso_grid_t* grid, const miso_mlp_t* mlp);
+/* Dynamic LDS (bytes) of the one-launch training kernel (miso_sdf_train / miso_sdf_train_sorted) for this (levels, C,
+ * hidden width, hidden layers) shape -- scattering != 0: the form that scatters some level from the kernel (cell records
+ * beside the d-feat tiles); 0: every level deferred to the pull.  0 = shape not covered.  A caller routes a shape whose
+ * figure exceeds the device's LDS per workgroup (160 KB on gfx950) to the two-launch path instead of failing in the launch. */
+int64_t miso_sdf_train_lds_bytes(const miso_grid_t* grid, const miso_mlp_t* mlp, int32_t scattering);
 
 /* uint32 words of ReLU sign bits per point: (n_linear-1) * hidden_dim/32 */
 int64_t miso_sdf_mask_words(const miso_mlp_t* mlp);
@@ -263,6 +268,10 @@ int miso_sdf_fwd_loss(const miso_grid_t* grid, const miso_mlp_t* mlp, const floa
  * miso_encode_bwd.  Replaces the grad_input half of aten::grid_sampler_3d_backward
  * (third_party/cuda_gridsample_grad2/cuda_gridsample.py:102-105). */
 uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis);
+/* 1 when the pull of those levels over n points with d-feat rows of pitch ld_d runs as grad_pull_mc_kernel (the sums on the
+ * fp32 matrix cores, grad_pull_mc.hip), 0 when the vector kernels of grad_pull.hip take it (second-order weights are always
+ * theirs): what a profile of the call will show -- bench.py names its dominant kernel by this, not by assumption. */
+int miso_grad_pull_on_matrix_cores(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n, int64_t ld_d);
 int miso_grad_pull(const miso_grid_t* grid, const miso_sorted_t* sorted, int64_t n, const float* dfeat,
                    int64_t ld_d, int32_t rows_in_caller_order, void* stream);
 /* miso_encode_bwd over a binned batch: grad_x (and any level the pull cannot own) with

@@ -128,6 +128,8 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_sdf_bwd": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_sdf_train_lds_bytes": (C.c_int64, [C.POINTER(Grid), C.POINTER(Mlp), C.c_int32]),
+    "miso_grad_pull_on_matrix_cores": (C.c_int, [C.POINTER(Grid), C.c_int32, C.c_int64, C.c_int64]),
     "miso_sort_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "miso_sort_points": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

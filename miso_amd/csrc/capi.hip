@@ -14,6 +14,7 @@ hipError_t launch_encode_bwd(const GridK&, bool, const float*, int64_t, const fl
 hipError_t launch_encode_bwd2(const GridK&, bool, const float*, int64_t, const float*, int64_t, const float*, float*,
                               int64_t, float*, const int*, hipStream_t);
 bool fused_shape_supported(int C, int L, int H, int NH);
+int64_t sdf_train_lds_bytes(int C, int L, int H, int NH, bool scat);
 hipError_t launch_sdf_fwd(int, int, int, int, const GridK&, const float*, const float*, int64_t, float*,
                           uint32_t*, const int*, const LossInK&, hipStream_t);
 hipError_t launch_sdf_bwd(int, int, int, int, const GridK&, const float*, const float*, int64_t,
@@ -45,6 +46,7 @@ uint32_t plan_grad_pull(const GridK&, int);
 hipError_t launch_grad_pull(const GridK&, int, int, const int*, const float*, const float*, int64_t, const int*,
                             uint32_t, int, const float*, int32_t*, int64_t, hipStream_t, uint32_t push_mask, int64_t n);
 uint32_t plan_push(const GridK&, int, int64_t, uint32_t);
+bool mc_pull_ok(const GridK& g, int C, const int T[3], uint32_t level_mask, int64_t n, int64_t ld);
 int64_t pull_queue_ints(int64_t);
 hipError_t launch_rigid_by_index(const float*, const float*, const int64_t*, const float*, int64_t, int32_t, int, float*,
                                  hipStream_t);
@@ -254,6 +256,14 @@ int miso_mlp_pack(const miso_mlp_t* mlp, float* packed, void* stream) {
   }
   return (int)launch_mlp_pack(k, mlp->in_dim, mlp->hidden_dim, mlp->n_linear - 2, packed,
                               (hipStream_t)stream);
+}
+
+int64_t miso_sdf_train_lds_bytes(const miso_grid_t* grid, const miso_mlp_t* mlp, int32_t scattering) {
+  GridK g; bool v4;
+  if (convert_grid(grid, &g, false, &v4)) return 0;
+  int C, L, H, NH;
+  if (fused_shape(g, v4, mlp, &C, &L, &H, &NH) != MISO_OK) return 0;
+  return sdf_train_lds_bytes(C, L, H, NH, scattering != 0);
 }
 
 int miso_sdf_supported(const miso_grid_t* grid, const miso_mlp_t* mlp) {
@@ -483,6 +493,14 @@ uint32_t miso_sdf_bwd_push_levels(const miso_grid_t* grid, int32_t tiles_per_axi
   GridK g; int C; uint32_t mask;
   if (pull_plan(grid, tiles_per_axis, &g, &C, &mask)) return 0;
   return plan_push(g, tiles_per_axis, n, mask);
+}
+
+int miso_grad_pull_on_matrix_cores(const miso_grid_t* grid, int32_t tiles_per_axis, int64_t n, int64_t ld_d) {
+  GridK g; int C; uint32_t mask;
+  if (pull_plan(grid, tiles_per_axis, &g, &C, &mask) || !mask) return 0;
+  int T3[3];
+  if (!tiles_xyz(tiles_per_axis, T3)) return 0;
+  return mc_pull_ok(g, C, T3, mask & ~plan_push(g, tiles_per_axis, n, mask), n, ld_d) ? 1 : 0;
 }
 
 uint32_t miso_grad_pull_levels(const miso_grid_t* grid, int32_t tiles_per_axis) {

@@ -1173,4 +1173,15 @@ hipError_t launch_mlp_pack(const MlpK& m, int F, int H, int NH, float* out, hipS
 
 int64_t mlp_packed_floats(int F, int H, int NH) { return PackLayout(F, H, NH).total; }
 
+// dynamic LDS of the sdf_train_kernel launch for this shape (launch_train_t above): the pack, then per wavefront a d-feat
+// tile [64][FP] and, scattering, its cell records [64][L][8] -- four wavefronts, or eight when nothing is scattered
+int64_t sdf_train_lds_bytes(int C, int L, int H, int NH, bool scat) {
+  if (!fused_shape_supported(C, L, H, NH)) return 0;
+  const PackLayout pl(C * L, H, NH);
+  const int F = C * L, FP = ((F + 3) / 4) * 4 + 4;
+  const int64_t pack = ((pl.total + 3) / 4) * 4;
+  const int64_t four = pack + 4 * (64 * FP + (scat ? 64 * L * 8 : 0)), eight = pack + 8 * 64 * FP;
+  return (int64_t)sizeof(float) * (scat ? four : (eight > four ? eight : four));
+}
+
 }  // namespace miso

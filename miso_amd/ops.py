@@ -589,15 +589,26 @@ def sdf_fwd_loss_raw(features, meta, pack: DecoderPack, sorted_batch: SortedBatc
         _ptr(gsdf_sorted), _ptr(loss_slots), _ptr(n_live), _stream(gsdf_sorted)), "miso_sdf_fwd_sorted_loss")
 
 
-def sdf_train_supported(features, meta, grads) -> bool:
+def sdf_train_supported(features, meta, grads, pack: Optional["DecoderPack"] = None) -> bool:
     """True when sdf_train_raw / sdf_train_unsorted_raw cover this gradient request: a level with a gradient exists
     (the fused decoder shape itself is sdf_fused_supported's business).  Levels the pull / push cannot form from the
-    d-feat rows are scattered with float atomics from the same launch (sdf_train_scattered_levels)."""
+    d-feat rows are scattered with float atomics from the same launch (sdf_train_scattered_levels).
+    pack: the decoder (its hidden width and depth size the kernel's LDS; without it 64 x 1, the reference's decoder)."""
     if not any(gr is not None and not (meta.ignore_mask >> l) & 1 for l, gr in enumerate(grads)):
         return False
-    # (ADVICE r3) the scattering variant keeps cell records beside the weights: make sure the widest form of the launch
-    # fits a workgroup's LDS, so that a shape that does not is routed to the two-launch path instead of failing there
-    return sdf_train_lds_bytes(features[0].shape[1], len(features), 64, scat=True) <= LDS_PER_WORKGROUP
+    # (ADVICE r3 / r4) the scattering variant keeps cell records beside the weights: make sure the widest form of the launch
+    # fits a workgroup's LDS, so that a shape that does not is routed to the two-launch path instead of failing there --
+    # asked of the library itself (miso_sdf_train_lds_bytes: computed from the kernel's own PackLayout) when the decoder
+    # is at hand
+    if pack is not None and features[0].is_cuda:
+        m, _ = pack.get()
+        if m is None:
+            return False
+        need = int(_lib.load().miso_sdf_train_lds_bytes(C.byref(_fill_grid(features, meta, grads, data=False)), C.byref(m), 1))
+        return 0 < need <= LDS_PER_WORKGROUP
+    H = pack.weights[0].shape[0] if pack is not None else 64
+    NH = len(pack.weights) - 2 if pack is not None else 1
+    return sdf_train_lds_bytes(features[0].shape[1], len(features), H, scat=True, hidden_layers=NH) <= LDS_PER_WORKGROUP
 
 
 LDS_PER_WORKGROUP = 160 * 1024      # gfx950

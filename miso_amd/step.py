@@ -232,7 +232,7 @@ class MappingStep:
         if ok is None:
             import os
             ok = self._fused_train_ok = (os.environ.get("MISO_NO_FUSED_TRAIN") is None      # dev: the two-launch form
-                                         and ops.sdf_train_supported(self.features, self.meta, self.grads))
+                                         and ops.sdf_train_supported(self.features, self.meta, self.grads, self.pack))
         return ok
 
     @property

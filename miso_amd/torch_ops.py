@@ -143,17 +143,27 @@ encode_bwd.register_autograd(_encode_bwd_backward, setup_context=_encode_bwd_set
 # --------------------------------------------------------------------------- #
 # encode + frozen decoder
 # --------------------------------------------------------------------------- #
-_packs = {}
+import collections
+
+_PACKS_MAX = 16
+_packs = collections.OrderedDict()      # least recently used first
 
 
 def _pack(weights, biases) -> ops.DecoderPack:
-    """One DecoderPack per set of weight tensors (the pack re-permutes itself when a weight's version changes)."""
-    key = tuple(w.data_ptr() for w in weights) + tuple(b.data_ptr() for b in biases)
+    """One DecoderPack per set of weight tensors (the pack re-permutes itself when a weight's version changes).
+    Keyed by storage AND layout -- two views of one buffer (same base pointer, another shape or stride) are different
+    decoders -- and by device; a small LRU: the oldest entry goes when the 17th arrives, so discarded models' weights
+    are not kept alive indefinitely and nothing is dropped in the middle of a forward / backward pair."""
+    def k(t):
+        return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.device.index if t.is_cuda else -1)
+    key = tuple(k(w) for w in weights) + tuple(k(b) for b in biases)
     p = _packs.get(key)
-    if p is None:
-        if len(_packs) > 64:
-            _packs.clear()
-        p = _packs[key] = ops.DecoderPack(list(weights), [b if b.numel() else None for b in biases])
+    if p is not None:
+        _packs.move_to_end(key)
+        return p
+    while len(_packs) >= _PACKS_MAX:
+        _packs.popitem(last=False)
+    p = _packs[key] = ops.DecoderPack(list(weights), [b if b.numel() else None for b in biases])
     return p
 
 

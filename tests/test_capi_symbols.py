@@ -200,8 +200,30 @@ def test_train_kernel_lds_fits_for_every_fused_shape():
     from miso_amd import ops
     shapes = [(4, 1, 32), (4, 1, 64), (4, 2, 32), (4, 2, 64), (4, 3, 64), (4, 4, 64), (8, 1, 64), (8, 2, 64), (8, 3, 64),
               (8, 4, 64), (8, 3, 32)]                                     # MISO_FUSED_SHAPES (sdf_fused.hip)
+    from miso_amd import _lib
+    lib = _lib.load()
     for C, L, H in shapes:
         assert ops.sdf_train_lds_bytes(C, L, H, scat=True) <= ops.LDS_PER_WORKGROUP, (C, L, H)
+        #  ... and the formula is what the library computes from the kernel's own PackLayout
+        # (miso_sdf_train_lds_bytes: what sdf_train_supported asks when it has the decoder) -- it cannot drift unnoticed
+        g = _lib.Grid()
+        g.n_levels = L
+        for a in range(3):
+            g.bound_min[a], g.bound_max[a] = -1.0, 1.0
+        for l in range(L):
+            lv = g.level[l]
+            lv.C, lv.X, lv.Y, lv.Z = C, 8, 8, 8
+            lv.sC, lv.sX, lv.sY, lv.sZ = 1, C, C * 8, C * 64
+            lv.data, lv.grad = None, 0x100000 * (l + 1)
+        m = _lib.Mlp()
+        m.n_linear, m.in_dim, m.hidden_dim, m.out_dim = 3, C * L, H, 1
+        for scat in (True, False):
+            want = ops.sdf_train_lds_bytes(C, L, H, scat=scat)
+            if not scat:      # nothing scattered: eight wavefronts' tiles beside the pack (the four-wavefront form is smaller)
+                want = max(want, want + 4 * 4 * 64 * ((C * L + 3) // 4 * 4 + 4))
+            assert lib.miso_sdf_train_lds_bytes(ctypes.byref(g), ctypes.byref(m), int(scat)) == want, (C, L, H, scat)
+    m.hidden_dim = 48
+    assert lib.miso_sdf_train_lds_bytes(ctypes.byref(g), ctypes.byref(m), 1) == 0          # a shape outside the table
     assert ops.sdf_train_lds_bytes(8, 3, 64, scat=False) == 4 * (11972 + 4 * 64 * 28)       # the headline launch: 76.6 KB
     assert ops.sdf_train_lds_bytes(8, 4, 64, scat=True) == 4 * (12484 + 4 * (64 * 36 + 64 * 4 * 8))
     feats = [torch.zeros(1, 8, 4, 4, 4)] * 3

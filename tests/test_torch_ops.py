@@ -138,3 +138,20 @@ def test_opcheck_encode_and_adam():
     p, g, m, v = (torch.randn(100, device="cuda") for _ in range(4))
     torch.library.opcheck(torch.ops.miso.adam_dense.default, (p, g, m, v.abs(), 1, 1e-2, 0.9, 0.999, 1e-8, True),
                           test_utils=("test_schema", "test_faketensor"))
+
+
+def test_decoder_pack_cache_keys_on_layout_and_stays_small():
+    """the operator layer keeps one DecoderPack per decoder.  Two views of ONE buffer (same base pointer,
+    another shape) are different decoders and must not share a pack; the cache is a small LRU (the oldest entry goes,
+    nothing is cleared wholesale in the middle of a forward / backward pair).  Host logic: no kernel runs here."""
+    buf = torch.zeros(64 * 64)
+    w_a = [buf[: 64 * 8].view(64, 8), buf.view(64, 64), buf[:64].view(1, 64)]
+    w_b = [buf[: 32 * 16].view(32, 16), buf[: 32 * 32].view(32, 32), buf[:32].view(1, 32)]       # the same storage, reshaped
+    none = [torch.empty(0)] * 3
+    T._packs.clear()
+    p_a, p_b = T._pack(w_a, none), T._pack(w_b, none)
+    assert p_a is not p_b and p_a is T._pack(w_a, none) and len(T._packs) == 2
+    for i in range(3 * T._PACKS_MAX):
+        T._pack([torch.zeros(8, 8), torch.zeros(1, 8)], [torch.empty(0)] * 2)
+        T._pack(w_a, none)                                             # in use: never the oldest
+    assert len(T._packs) <= T._PACKS_MAX and T._pack(w_a, none) is p_a
