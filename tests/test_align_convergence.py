@@ -48,11 +48,11 @@ def test_alignment_trajectory_hip_equals_the_oracle_loop(n_submaps, monkeypatch)
     snapshots of both levels."""
     import oracle_backend
     # two submaps: the reference's whole schedule (2 x 101 iterations) to convergence.  Four submaps (six pairs): the
-    # first 2 x 26 iterations -- the host loop costs ~0.25 s per iteration there and this test was a twelfth of the GPU
+    # first 2 x 16 iterations -- the host loop costs ~0.25 s per iteration there and this test was a twelfth of the GPU
     # suite's wall time; convergence of four submaps is test_alignment_converges_on_a_shared_field[hip-4]'s business,
     # here the two loops only have to walk the same trajectory (set MISO_TEST_FULL=1 for the whole schedule)
     full = n_submaps == 2 or os.environ.get("MISO_TEST_FULL")
-    cfg = dict(SF.ALIGN_CFG) if full else dict(SF.ALIGN_CFG, level_iters=25)
+    cfg = dict(SF.ALIGN_CFG) if full else dict(SF.ALIGN_CFG, level_iters=15)
     _, after_gpu, info_gpu, atlas_gpu = SF.run("cuda:0", n_submaps, DEG, METRES, align_cfg=cfg)
     oracle_backend.install(monkeypatch)
     _, after_cpu, info_cpu, atlas_cpu = SF.run("cpu", n_submaps, DEG, METRES, align_cfg=cfg)

@@ -203,13 +203,13 @@ def test_cfg4_eight_submaps_alignment_vs_oracle_loop():
         return out
 
     kw = dict(loss_type="L2", align_weight=3000.0, lr=1e-2, ring_iters=3)
-    # ---- level 0, all 28 pairs, 3 iterations ----------------------------------------------------------------------
+    # ---- level 0, all 28 pairs, 2 iterations ----------------------------------------------------------------------
     inp = AM.latent_pair_inputs(atlas, pairs, level=0, fdim=4, check_intersection=True)
     plan = ops.AlignPlan(R0, t0, inp, **kw)
     ref = oracle_backend.AlignPlan(R0.cpu(), t0.cpu(), host(inp), **kw)
     plan.params.copy_(prm0)
     ref.params.copy_(prm0.cpu())
-    for it in range(3):
+    for it in range(2):
         plan.iteration_a()
         ref.iteration_a()
         f_gpu, f_ref = plan.flat.cpu(), ref.flat
@@ -236,7 +236,9 @@ def test_cfg4_eight_submaps_alignment_vs_oracle_loop():
     # much (1.5e-3 ... 2.2e-3).  The bar is therefore "the same order as the reference's own fp32 arithmetic"; on a
     # field that is actually alignable the gradient is coherent and the kernel is within 1e-4 of fp64
     # (tests/test_align_convergence.py).
-    some = [(0, 1), (2, 3)]
+    # (one pair: the two host evaluations of 4 M vertices each are what this test costs -- 25 s per pair on a dev box, several
+    # times that on a busy one; rounds 3-4 ran two pairs)
+    some = [(0, 1)]
     inp = AM.latent_pair_inputs(atlas, some, level=1, fdim=4, check_intersection=True)
     assert all(p["coords"].shape[0] == 4000000 for p in inp)
     plan = ops.AlignPlan(R0, t0, inp, **kw)
