@@ -426,9 +426,6 @@ int64_t miso_align_state_layout(int32_t n_submaps, int32_t n_pairs, int32_t ring
                                 int64_t* offsets /* [11] or NULL */);
 int miso_align_iteration_a(const miso_align_t* cfg, void* stream);
 int miso_align_iteration_b(const miso_align_t* cfg, void* stream);
-/* _a followed by _b as ONE call with one launch fewer (both epilogues in a kernel): for a caller with nothing to do between
- * the two -- a single rank, or a level every rank runs in full.  Same results, bit for bit. */
-int miso_align_iteration_ab(const miso_align_t* cfg, void* stream);
 
 /* --- tracker: Gauss-Newton normal equations ------------------------------
  * coords_frame (N,3): samples in the keyframe frame; R_frame (9 floats, DEVICE, row-major):

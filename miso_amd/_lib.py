@@ -212,7 +212,6 @@ SIGNATURES = {
     "miso_align_state_layout": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "miso_align_iteration_a": (C.c_int, [C.POINTER(Align), C.c_void_p]),
     "miso_align_iteration_b": (C.c_int, [C.POINTER(Align), C.c_void_p]),
-    "miso_align_iteration_ab": (C.c_int, [C.POINTER(Align), C.c_void_p]),
     "miso_adam_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int,
                                   C.c_void_p]),

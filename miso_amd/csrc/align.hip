@@ -107,7 +107,9 @@ __device__ __forceinline__ float nan_to_num_f(float v) {
 constexpr int EPI_A_THREADS = 256;
 constexpr int EPI_A_PAIRS = 128;      // pairs staged in LDS per pass (S <= 64 => at most 2016 pairs: 16 passes)
 
-__device__ __forceinline__ void align_epilogue_a_body(const AlignK& k) {
+__global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK k) {
+  const int32_t* ctrl = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl);
+  if (ctrl[CTRL_STOPPED]) return;
   const double* out = reinterpret_cast<const double*>(k.state + k.L.out);
   const float* cnt = k.state + k.L.cnt;
   const float* pose = k.state + k.L.pose;
@@ -202,18 +204,12 @@ __device__ __forceinline__ void align_epilogue_a_body(const AlignK& k) {
   (void)s_total;
 }
 
-__global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK k) {
-  const int32_t* ctrl = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl);
-  if (ctrl[CTRL_STOPPED]) return;
-  align_epilogue_a_body(k);
-}
-
-// (any workgroup size up to EPI_A_THREADS: the standalone launch uses one wavefront, the fused one the 256 threads of A)
-__device__ __forceinline__ void align_epilogue_b_body(const AlignK& k) {
+__global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
   int32_t* ctrl = reinterpret_cast<int32_t*>(k.state + k.L.ctrl);
+  if (ctrl[CTRL_STOPPED]) return;
   __shared__ float s_total;
   __shared__ float s_nr[64], s_nt[64];           // |dr_s|, |dt_s| BEFORE the step (S <= 64, checked by the entry point)
-  __shared__ double s_num[EPI_A_THREADS], s_den[EPI_A_THREADS];
+  __shared__ double s_num[64], s_den[64];
   float* prm = k.state + k.L.params;
   const float* flat = k.state + k.L.flat;
   for (int s = threadIdx.x; s < k.S; s += blockDim.x) {
@@ -273,10 +269,8 @@ __device__ __forceinline__ void align_epilogue_b_body(const AlignK& k) {
   s_num[threadIdx.x] = num; s_den[threadIdx.x] = den;
   __syncthreads();
   if (threadIdx.x == 0) {
-    // (in thread order; threads past 6 (S - 1) hold zeros, so the sum -- and its rounding -- does not depend on how many
-    // threads the launch has)
     double n = 0., d = 0.;
-    for (int i = 0; i < (int)blockDim.x; ++i) { n += s_num[i]; d += s_den[i]; }
+    for (int i = 0; i < 64; ++i) { n += s_num[i]; d += s_den[i]; }
     const int it = ctrl[CTRL_ITER];
     // relative_param_change (utils.py:507-516): after iteration k against after iteration k-1; inf at k = 0
     const float rel = (it == 0) ? INFINITY : (float)sqrt(n / d);
@@ -294,24 +288,6 @@ __device__ __forceinline__ void align_epilogue_b_body(const AlignK& k) {
   if (!ctrl[CTRL_STOPPED]) align_prologue_body(k, ctrl[CTRL_ITER], false);
 }
 
-__global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
-  const int32_t* ctrl = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl);
-  if (ctrl[CTRL_STOPPED]) return;
-  align_epilogue_b_body(k);
-}
-
-// Both epilogues in one launch (round 5): a caller that has nothing to do between them -- no all-reduce: a single rank, or
-// a level that runs replicated -- saves a launch boundary per iteration, ~5 us of the 80 us of a cfg-4 level-0 iteration.
-// Same arithmetic in the same order as the two kernels (B reads what A wrote through global memory, behind a barrier).
-__global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_ab_kernel(AlignK k) {
-  const int32_t* ctrl = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl);
-  if (ctrl[CTRL_STOPPED]) return;
-  align_epilogue_a_body(k);
-  __threadfence_block();
-  __syncthreads();
-  align_epilogue_b_body(k);
-}
-
 hipError_t launch_pair_batch(const AlignPairK*, int, int64_t, int64_t, bool, const float*, int, double*, float*,
                              const int32_t*, int64_t, hipStream_t);
 
@@ -324,19 +300,6 @@ hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, in
                                    max_gate_rows, s);
   if (e != hipSuccess) return e;
   align_epilogue_a_kernel<<<1, EPI_A_THREADS, 0, s>>>(k);
-  return hipGetLastError();
-}
-
-// pair stage + both epilogues: the whole iteration in two launches (three with the prologue of the first one)
-hipError_t launch_align_ab(const AlignK& k, int64_t max_n, int64_t max_gate_n, int64_t max_gate_rows, bool vec4,
-                           bool poses_ready, hipStream_t s) {
-  if (!poses_ready) align_prologue_kernel<<<1, 256, 0, s>>>(k);
-  const int32_t* stopped = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl) + CTRL_STOPPED;
-  hipError_t e = launch_pair_batch(k.plan, k.P, max_n, max_gate_n, vec4, k.state + k.L.pose, k.loss_type,
-                                   reinterpret_cast<double*>(k.state + k.L.out), k.state + k.L.cnt, stopped,
-                                   max_gate_rows, s);
-  if (e != hipSuccess) return e;
-  align_epilogue_ab_kernel<<<1, EPI_A_THREADS, 0, s>>>(k);
   return hipGetLastError();
 }
 

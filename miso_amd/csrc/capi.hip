@@ -75,7 +75,6 @@ hipError_t launch_mapping_loss(int, float, float, float, const float*, const flo
                                const float*, const float*, int64_t, float*, float*, float*, hipStream_t);
 hipError_t launch_align_a(const AlignK&, int64_t, int64_t, int64_t, bool, bool, hipStream_t);
 hipError_t launch_align_b(const AlignK&, hipStream_t);
-hipError_t launch_align_ab(const AlignK&, int64_t, int64_t, int64_t, bool, bool, hipStream_t);
 }  // namespace miso
 
 using namespace miso;
@@ -753,14 +752,6 @@ int miso_align_iteration_a(const miso_align_t* cfg, void* stream) {
   if (rc) return rc;
   return (int)launch_align_a(k, cfg->max_n, cfg->max_gate_n, cfg->max_gate_rows, cfg->vec4 != 0, cfg->poses_ready != 0,
                              (hipStream_t)stream);
-}
-
-int miso_align_iteration_ab(const miso_align_t* cfg, void* stream) {
-  AlignK k;
-  int rc = align_k(cfg, &k);
-  if (rc) return rc;
-  return (int)launch_align_ab(k, cfg->max_n, cfg->max_gate_n, cfg->max_gate_rows, cfg->vec4 != 0, cfg->poses_ready != 0,
-                              (hipStream_t)stream);
 }
 
 int miso_align_iteration_b(const miso_align_t* cfg, void* stream) {

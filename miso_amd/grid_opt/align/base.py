@@ -136,12 +136,7 @@ def fused_alignment_loop(grid_atlas, fused, submap_pairs, check_intersection, lr
         dt = torch.cat([p.detach().reshape(1, 3) for p in grid_atlas.translation_corrections], dim=0)
         plan.params.copy_(torch.cat((dr, dt), dim=1))
 
-    fused_ab = reduce is None and hasattr(plan, "iteration_ab")      # (the CPU stand-in of the tests has the two halves only)
-
     def iteration():
-        if fused_ab:                      # nothing between the halves: one call, one launch fewer
-            plan.iteration_ab()
-            return
         plan.iteration_a()
         if reduce is not None:
             reduce(plan.flat_reduce)

@@ -1218,12 +1218,6 @@ class AlignPlan:
         self._poses_ready = False
         _lib.check(_lib.load().miso_align_iteration_a(C.byref(self.cfg), _stream(self.state)), "miso_align_iteration_a")
 
-    def iteration_ab(self):
-        """iteration_a + iteration_b with one launch fewer (miso_align_iteration_ab): nothing to all-reduce in between."""
-        self.cfg.poses_ready = 1 if getattr(self, "_poses_ready", False) else 0
-        _lib.check(_lib.load().miso_align_iteration_ab(C.byref(self.cfg), _stream(self.state)), "miso_align_iteration_ab")
-        self._poses_ready = True
-
     def iteration_b(self):
         _lib.check(_lib.load().miso_align_iteration_b(C.byref(self.cfg), _stream(self.state)), "miso_align_iteration_b")
         self._poses_ready = True

@@ -1234,51 +1234,6 @@ def test_lattice_overlap_gate_counts_equal_the_point_list_gate(case):
 
 
 @pytest.mark.gpu
-def test_fused_epilogue_iteration_equals_the_two_halves():
-    """miso_align_iteration_ab (pair stage + ONE kernel for both epilogues: what a single rank runs, nothing to all-reduce
-    in between) against miso_align_iteration_a followed by miso_align_iteration_b: the same arithmetic in the same order --
-    corrections, Adam moments, per-submap step counts, ring rows (losses, relative changes, pose snapshots) and counters
-    after five iterations, with the regulariser on, a gated pair and a NaN iteration in between.  (The pair sums come
-    from fp64 atomics in both: equal to ~1e-16 relative, the poses to the last bit or the one next to it.)"""
-    from miso_amd import ops
-    from miso_amd.so3 import so3_exp_map
-    torch.manual_seed(3)
-    bound = [[-2.0, 2.0], [-1.0, 1.0], [-1.5, 1.5]]
-    meta = ops.GridMeta.from_bound(bound)
-    feats = [(torch.randn(1, 4, 12, 8, 16) * 0.1).to(DEV).contiguous(memory_format=torch.channels_last_3d)]
-    n = 6000
-    coords = ((torch.rand(n, 3) - 0.5) * torch.tensor([4.0, 2.0, 3.0])).to(DEV)
-    fsrc = torch.randn(n, 4, device=DEV)
-    S = 4
-    R0 = so3_exp_map(torch.randn(S, 3) * 0.05).to(DEV)
-    t0 = (torch.randn(S, 3, 1) * 0.3).to(DEV)
-    t0[3, 0, 0] = 50.0                                   # submap 3 is far away: its pairs are gated off
-    pairs = [(a, b) for a in range(S) for b in range(a + 1, S)]
-    descr = [dict(src=a, dst=b, coords=coords, feats_src=fsrc, feats_dst=feats, meta_dst=meta, gate_pts=coords) for a, b in pairs]
-    kw = dict(loss_type="L2", lr=1e-2, reg_weight=1.0, reg_thresh_rad=1e-3, reg_thresh_m=1e-3, ring_iters=5, save_poses=True)
-    out = []
-    for fused in (False, True):
-        plan = ops.AlignPlan(R0, t0, descr, **kw)
-        plan.params[1:, :] = torch.tensor([0.01, -0.02, 0.015, 0.05, -0.03, 0.02], device=DEV)
-        for it in range(5):
-            if it == 2:
-                plan.params[2, 0] = float("nan")         # this iteration's loss is NaN: the step is skipped, counted
-            if it == 3:
-                plan.params[2, 0] = 0.01
-            if fused:
-                plan.iteration_ab()
-            else:
-                plan.iteration_a(); plan.iteration_b()
-        torch.cuda.synchronize()
-        out.append((plan.params.clone(), plan.ring().clone(), plan.ctrl(), plan.state.clone()))
-    (pa, ra, ca, sa), (pb, rb, cb, sb_) = out
-    assert ca == cb and ca["iterations"] == 5 and ca["skipped"] == 1
-    assert torch.equal(torch.isnan(ra), torch.isnan(rb))
-    torch.testing.assert_close(torch.nan_to_num(pb), torch.nan_to_num(pa), rtol=0, atol=2e-7)
-    torch.testing.assert_close(torch.nan_to_num(rb), torch.nan_to_num(ra), rtol=2e-6, atol=2e-7)
-
-
-@pytest.mark.gpu
 def test_box_culled_pair_stage_equals_reading_every_vertex():
     """miso_align_src_boxes + miso_align_pair_t.src_boxes: the residual kernel skips a run of 64 source vertices when its
     box, mapped into the destination frame, cannot touch the destination bound.  The skip is conservative, so all 24
