@@ -64,16 +64,40 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
   const int lane_ = threadIdx.x & 63, wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long lt_mask = (lane_ == 0) ? 0ull : (~0ull >> (64 - lane_));
   const int64_t chunk = (int64_t)blockDim.x * PAIR_K;
-  // A step's box in the destination frame: centre q_c = Rd^T (Rs c + ts - td), half-extent along destination axis a
-  // sum_b |M[a][b]| e_b with M = Rd^T Rs.  Outside the bound by more than the slack on any axis: no vertex of the step
-  // can pass the exact test below, and the step is not read (the sums are those of reading it).  Lane u < 8 tests the
-  // box of step u -- one test per 512 vertices of wavefront time, not per 64.  NaN poses compare false: nothing is skipped.
-  // (M and q_0 are formed where they are used, once per 512 vertices: kept across the loop they would be 21 more
-  // live registers in a kernel that sits at its 128-register budget)
-  // (the exact test forms w = Rs p + ts first: its rounding grows with the size of the world coordinates)
+  // The composed map q = M p + q_0 (M = Rd^T Rs, q_0 = Rd^T (ts - td)) once per workgroup, in LDS.  It serves two coarse
+  // filters, both followed by the exact test of pass 2 (the reference's operation order: w = Rs p + ts, w - td, Rd^T .):
+  //  * a step's box in the destination frame: centre M c + q_0, half-extent along destination axis a sum_b |M[a][b]| e_b.
+  //    Outside the bound by more than the slack on any axis: no vertex of the step can be in bound, the step is not read.
+  //    Lane u < 8 tests the box of step u -- one test per 512 vertices of wavefront time;
+  //  * pass 1 itself: a vertex is a candidate when M p + q_0 lies inside the bound widened by the slack -- 12 multiply-adds
+  //    on 12 values read back from LDS per chunk, where forming w, w - td and Rd^T . per vertex kept 24 pose values live
+  //    as scalar registers the compiler had to spill and reload inside every one of the eight unrolled steps.
+  // The slack covers the rounding of either form (~1e-5 m at 100 m, growing with the size of the world coordinates): a
+  // vertex the composed map puts inside the bound shrunk by the slack is in bound exactly, one outside the widened bound
+  // is out, and the few in between take the exact test.  NaN poses compare false: no candidates, as the exact test finds.
+  __shared__ float s_aff[16];
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    s_aff[a * 4 + 0] = Rd[a] * Rs[0] + Rd[3 + a] * Rs[3] + Rd[6 + a] * Rs[6];
+    s_aff[a * 4 + 1] = Rd[a] * Rs[1] + Rd[3 + a] * Rs[4] + Rd[6 + a] * Rs[7];
+    s_aff[a * 4 + 2] = Rd[a] * Rs[2] + Rd[3 + a] * Rs[5] + Rd[6 + a] * Rs[8];
+    s_aff[a * 4 + 3] = Rd[a] * (ts[0] - td[0]) + Rd[3 + a] * (ts[1] - td[1]) + Rd[6 + a] * (ts[2] - td[2]);
+  }
+  if (threadIdx.x == 3)
+    s_aff[12] = BOX_SLACK + 4e-6f * (fabsf(ts[0]) + fabsf(ts[1]) + fabsf(ts[2]) + fabsf(td[0]) + fabsf(td[1]) + fabsf(td[2]));
+  __syncthreads();
   for (int64_t c0 = (int64_t)bx * chunk; c0 < k.n; c0 += (int64_t)nbx * chunk) {
     const int64_t w0 = c0 + (int64_t)wave_ * (PAIR_K * 64);
     if (w0 >= k.n) continue;
+    // (read per chunk, dead after pass 1: kept across the loop they would be 13 more live registers in pass 2, which sits
+    // at the kernel's 128-register budget)
+    const float4 m0 = *reinterpret_cast<const float4*>(s_aff), m1 = *reinterpret_cast<const float4*>(s_aff + 4),
+                 m2 = *reinterpret_cast<const float4*>(s_aff + 8);
+    // (wave-uniform: as scalar registers they cost pass 1 no vector registers)
+    auto sc = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const float slack = sc(s_aff[12]);
+    const float M[3][4] = {{sc(m0.x), sc(m0.y), sc(m0.z), sc(m0.w)}, {sc(m1.x), sc(m1.y), sc(m1.z), sc(m1.w)},
+                           {sc(m2.x), sc(m2.y), sc(m2.z), sc(m2.w)}};
     unsigned live_steps = 0xffu;
     if (k.boxes) {
       const int64_t s0 = w0 + (int64_t)(lane_ & 7) * 64;
@@ -83,21 +107,11 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
         const float c[3] = {0.5f * (bb[0] + bb[3]), 0.5f * (bb[1] + bb[4]), 0.5f * (bb[2] + bb[5])};
         const float e[3] = {0.5f * (bb[3] - bb[0]), 0.5f * (bb[4] - bb[1]), 0.5f * (bb[5] - bb[2])};
         bool outside = false;
-        // (an opaque 1.0: without it the compiler hoists the nine products of M and q_0 out of the chunk loop and keeps
-        // them live across pass 2 -- 12 more spilled registers there)
-        float one = 1.0f;
-        asm volatile("" : "+v"(one));
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const float rda = Rd[a] * one, rdb = Rd[3 + a] * one, rdc = Rd[6 + a] * one;
-          const float m0 = rda * Rs[0] + rdb * Rs[3] + rdc * Rs[6];
-          const float m1 = rda * Rs[1] + rdb * Rs[4] + rdc * Rs[7];
-          const float m2 = rda * Rs[2] + rdb * Rs[5] + rdc * Rs[8];
-          const float q0 = rda * (ts[0] * one - td[0]) + rdb * (ts[1] * one - td[1]) + rdc * (ts[2] * one - td[2]);
-          const float qc = m0 * c[0] + m1 * c[1] + m2 * c[2] + q0;
-          // (the exact test forms w = Rs p + ts first: its rounding grows with the size of the world coordinates)
-          const float slack = BOX_SLACK + 4e-6f * (fabsf(ts[0] * one) + fabsf(ts[1]) + fabsf(ts[2]) + fabsf(td[0]) + fabsf(td[1]) + fabsf(td[2]));
-          const float r = fabsf(m0) * e[0] + fabsf(m1) * e[1] + fabsf(m2) * e[2] + slack + 1e-6f * (fabsf(qc) + fabsf(q0));
+          const float qc = M[a][0] * c[0] + M[a][1] * c[1] + M[a][2] * c[2] + M[a][3];
+          const float r = fabsf(M[a][0]) * e[0] + fabsf(M[a][1]) * e[1] + fabsf(M[a][2]) * e[2] + slack +
+                          1e-6f * (fabsf(qc) + fabsf(M[a][3]));
           outside = outside || qc - r > g.bmax[a] || qc + r < g.bmin[a];
         }
         reach = !outside;
@@ -105,23 +119,36 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
       live_steps = (unsigned)(__ballot(reach) & 0xffull);
       if (live_steps == 0u) continue;
     }
+    const float blo[3] = {sc(g.bmin[0] - slack), sc(g.bmin[1] - slack), sc(g.bmin[2] - slack)};
+    const float bhi[3] = {sc(g.bmax[0] + slack), sc(g.bmax[1] + slack), sc(g.bmax[2] + slack)};
     int n_in = 0;
 #pragma unroll
     for (int u = 0; u < PAIR_K; ++u) {
       const int64_t i = w0 + u * 64 + lane_;
-      bool inb = false;
+      bool cand = false;
       if (i < k.n && ((live_steps >> u) & 1u)) {
         const float px = k.p[i * 3 + 0], py = k.p[i * 3 + 1], pz = k.p[i * 3 + 2];
-        const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
-                            Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
-        const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
-        const float q[3] = {Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
-                            Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2]};
-        inb = q[0] >= g.bmin[0] && q[0] <= g.bmax[0] && q[1] >= g.bmin[1] && q[1] <= g.bmax[1] &&
-              q[2] >= g.bmin[2] && q[2] <= g.bmax[2];
+        const float q0 = M[0][0] * px + M[0][1] * py + M[0][2] * pz + M[0][3];
+        const float q1 = M[1][0] * px + M[1][1] * py + M[1][2] * pz + M[1][3];
+        const float q2 = M[2][0] * px + M[2][1] * py + M[2][2] * pz + M[2][3];
+        cand = q0 >= blo[0] && q0 <= bhi[0] && q1 >= blo[1] && q1 <= bhi[1] && q2 >= blo[2] && q2 <= bhi[2];
+        // inside the bound SHRUNK by the slack: in bound by the exact arithmetic as well.  Between the two (within the slack
+        // of a face: ~0.1 % of the candidates) the exact test decides, here -- a branch a wavefront takes in one step out of
+        // ~15; in pass 2 (a `continue`, or selects at the end) it cost 0.93 - 0.97 ms per cfg-4 level-1 iteration against 0.69
+        const bool sure = q0 >= blo[0] + 2.0f * slack && q0 <= bhi[0] - 2.0f * slack && q1 >= blo[1] + 2.0f * slack &&
+                          q1 <= bhi[1] - 2.0f * slack && q2 >= blo[2] + 2.0f * slack && q2 <= bhi[2] - 2.0f * slack;
+        if (cand && !sure) {
+          const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
+                              Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
+          const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
+          const float q[3] = {Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
+                              Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2]};
+          cand = q[0] >= g.bmin[0] && q[0] <= g.bmax[0] && q[1] >= g.bmin[1] && q[1] <= g.bmax[1] &&
+                 q[2] >= g.bmin[2] && q[2] <= g.bmax[2];
+        }
       }
-      const unsigned long long m = __ballot(inb);
-      if (inb) s_in[wave_][n_in + (int)__popcll(m & lt_mask)] = (uint16_t)(u * 64 + lane_);
+      const unsigned long long m = __ballot(cand);
+      if (cand) s_in[wave_][n_in + (int)__popcll(m & lt_mask)] = (uint16_t)(u * 64 + lane_);
       n_in += (int)__popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -207,9 +234,9 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
       }
     }
     // R_d g
+    const float pp[3] = {px, py, pz};
     const float h[3] = {Rd[0] * gq[0] + Rd[1] * gq[1] + Rd[2] * gq[2], Rd[3] * gq[0] + Rd[4] * gq[1] + Rd[5] * gq[2],
                         Rd[6] * gq[0] + Rd[7] * gq[1] + Rd[8] * gq[2]};
-    const float pp[3] = {px, py, pz};
     acc[0] += term; acc[1] += 1.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) acc[2 + a] += gq[a];
