@@ -194,12 +194,15 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
           float v[8][4];
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk) {
+            // (loaded whatever the flag -- an out-of-range corner's offset is 0, a valid address -- and zeroed afterwards: a
+            // load under `if (in range)` is a branch per corner, and the eight gathers of a level then issue one by one)
             if (VEC4) {
-              float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (inb8[kk]) t = *reinterpret_cast<const float4*>(lv.data + off[kk] + ch);
+              float4 t = *reinterpret_cast<const float4*>(lv.data + off[kk] + ch);
+              if (!inb8[kk]) t = make_float4(0.f, 0.f, 0.f, 0.f);
               v[kk][0] = t.x; v[kk][1] = t.y; v[kk][2] = t.z; v[kk][3] = t.w;
             } else {
-              v[kk][0] = inb8[kk] ? lv.data[(int64_t)ch * lv.sC + off[kk]] : 0.0f;
+              const float t = lv.data[(int64_t)ch * lv.sC + off[kk]];
+              v[kk][0] = inb8[kk] ? t : 0.0f;
             }
           }
 #pragma unroll
