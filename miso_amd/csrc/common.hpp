@@ -105,6 +105,36 @@ __device__ __forceinline__ Axis axis_coord(float x, float bmin, float bmax, int 
   return a;
 }
 
+// The two halves of axis_coord, for a kernel that evaluates several levels at one point: the normalised coordinate and
+// the factor 2 / len do not depend on the level (same operations, same order, same bits -- formed once instead of per level:
+// two IEEE divisions per axis and level otherwise).
+__device__ __forceinline__ void axis_norm(float x, float bmin, float bmax, uint32_t flags, float& xn, float& m) {
+  xn = x; m = 1.0f;
+  if (!(flags & MISO_F_COORDS_NORMALIZED)) {
+    const float len = __fsub_rn(bmax, bmin);
+    xn = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, __fsub_rn(x, bmin)), len), 1.0f);
+    m = __fdiv_rn(2.0f, len);
+  }
+}
+__device__ __forceinline__ Axis axis_from_norm(float xn, float m, int size, uint32_t flags) {
+  const float fs = (float)size;
+  float ix;
+  if (flags & MISO_F_ALIGN_CORNERS) {
+    ix = __fmul_rn(__fmul_rn(__fadd_rn(xn, 1.0f), 0.5f), (float)(size - 1));
+    m *= 0.5f * (float)(size - 1);
+  } else {
+    ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(xn, 1.0f), fs), 1.0f), 0.5f);
+    m *= 0.5f * fs;
+  }
+  if (flags & MISO_F_PAD_BORDER) {
+    const float hi = (float)(size - 1);
+    if (ix <= 0.0f) { ix = 0.0f; m = 0.0f; }
+    else if (ix >= hi) { ix = hi; m = 0.0f; }
+  }
+  Axis a; a.pos = ix; a.mult = m;
+  return a;
+}
+
 // Trilinear cell: base corner, the two 1-D weights per axis (ATen forms them
 // as (i0+1-ix) and (ix-i0), gridsample_cuda.cu:335-342) and in-range flags.
 struct Cell {

@@ -398,7 +398,11 @@ __global__ __launch_bounds__(256) void encode_bwd2_lean_kernel(GridK g, const fl
       float4 vv[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        vv[k] = inb[k] ? *reinterpret_cast<const float4*>(lv.data + off[k] + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+      {   // (loaded whatever the flag: offset 0 of an out-of-range corner is a valid address; a load under a condition is a
+          // branch per corner and the eight gathers then issue one by one -- pair_latent.hip, round 5)
+        vv[k] = *reinterpret_cast<const float4*>(lv.data + off[k] + ch);
+        if (!inb[k]) vv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       float ggv[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -414,7 +418,10 @@ __global__ __launch_bounds__(256) void encode_bwd2_lean_kernel(GridK g, const fl
       if (gg_here) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          vv[k] = inb[k] ? *reinterpret_cast<const float4*>(lv.gg + off[k] + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+          {
+            vv[k] = *reinterpret_cast<const float4*>(lv.gg + off[k] + ch);
+            if (!inb[k]) vv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v[8];

@@ -164,6 +164,10 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
     const float q[3] = {Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
                         Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2]};
     const float* fs = k.fsrc + idx * k.ld;
+    // the normalised coordinate is the same for every level (axis_coord op for op, its first half formed once)
+    float xn[3], mn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) axis_norm(q[a], g.bmin[a], g.bmax[a], g.flags, xn[a], mn[a]);
     // pass 1: residual norm (needed by L1 before the derivative weights are known)
     float term = 0.0f, gq[3] = {0.f, 0.f, 0.f};
     float inv_norm = 1.0f;
@@ -171,9 +175,9 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
       float ss = 0.0f;
       for (int l = 0; l < g.n_levels; ++l) {
         const LevelK& lv = g.lv[l];
-        Axis ax = axis_coord(q[0], g.bmin[0], g.bmax[0], lv.X, g.flags);
-        Axis ay = axis_coord(q[1], g.bmin[1], g.bmax[1], lv.Y, g.flags);
-        Axis az = axis_coord(q[2], g.bmin[2], g.bmax[2], lv.Z, g.flags);
+        Axis ax = axis_from_norm(xn[0], mn[0], lv.X, g.flags);
+        Axis ay = axis_from_norm(xn[1], mn[1], lv.Y, g.flags);
+        Axis az = axis_from_norm(xn[2], mn[2], lv.Z, g.flags);
         Cell c = make_cell(ax, ay, az, lv);
         const bool ign = (g.ignore_mask >> l) & 1u;
         // Corner values with zeros outside the grid (padding_mode = zeros), then the trilinear value and its three
