@@ -578,7 +578,8 @@ hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t ma
     // most 2048 per pair: a workgroup's fixed part -- poses, the 23-value reduction, 23 atomics -- is paid per
     // workgroup, and with 2048 of them for each of cfg-4's 28 pairs it was a fifth of the level-1 pair stage
     // (1.15 -> 0.89 ms per iteration at 256 per pair)
-    unsigned cap = (unsigned)(7168 / n_pairs);
+    static const int cap_all = [] { const char* e = getenv("MISO_PAIR_WGS"); return e ? atoi(e) : 7168; }();      // dev: scan
+    unsigned cap = (unsigned)(cap_all / n_pairs);
     cap = cap < 128u ? 128u : (cap > 2048u ? 2048u : cap);
     if (blocks > cap) blocks = cap;
     if (gate_blocks && !split) {
