@@ -167,6 +167,8 @@ SIGNATURES = {
                                           C.c_void_p]),
     "miso_adam_bump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_loss_total_bump": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_loss_total_bump_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_void_p]),
     "miso_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "miso_mapping_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -28,8 +28,11 @@ __global__ void adam_bump_kernel(int32_t* step, const float* __restrict__ guard)
 
 // The step's loss from its per-workgroup slots and the step count in one launch (a captured trainer step needs both
 // between the backward and the Adam launches): total = sum of n floats (pairwise in LDS, a fixed order), then the bump.
+// host_ring (pinned host memory, ring_len a power of two) also receives the total, in slot step[1] % ring_len with
+// step[1] counting the launches: the host reads the NaN guard from there without a copy on the stream.
 __global__ __launch_bounds__(256) void loss_total_bump_kernel(const float* __restrict__ slots, int n,
-                                                             float* __restrict__ total, int32_t* step) {
+                                                             float* __restrict__ total, int32_t* step,
+                                                             float* host_ring, int ring_len) {
   __shared__ float red[256];
   float acc = 0.0f;
   for (int i = threadIdx.x; i < n; i += 256) acc += slots[i];
@@ -43,6 +46,12 @@ __global__ __launch_bounds__(256) void loss_total_bump_kernel(const float* __res
     const float t = red[0];
     total[0] = t;
     if (step && t == t) step[0] += 1;
+    if (host_ring) {
+      const int it = step[1];
+      step[1] = it + 1;
+      host_ring[it & (ring_len - 1)] = t;
+      __threadfence_system();
+    }
   }
 }
 
@@ -296,8 +305,9 @@ static AdamScalars adam_scalars(double lr, double b1, double b2, double eps, int
   return a;
 }
 
-hipError_t launch_loss_total_bump(const float* slots, int n, float* total, int32_t* step, hipStream_t s) {
-  loss_total_bump_kernel<<<1, 256, 0, s>>>(slots, n, total, step);
+hipError_t launch_loss_total_bump(const float* slots, int n, float* total, int32_t* step, float* host_ring,
+                                  int ring_len, hipStream_t s) {
+  loss_total_bump_kernel<<<1, 256, 0, s>>>(slots, n, total, step, host_ring, ring_len);
   return hipGetLastError();
 }
 

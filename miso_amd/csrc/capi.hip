@@ -31,7 +31,7 @@ hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
 hipError_t launch_adam_touched(float*, float*, float*, float*, unsigned char*, unsigned char*, int64_t, double, double,
                                double, double, int, int, const float*, hipStream_t, const float*, const int32_t*, int);
 hipError_t launch_adam_bump(int32_t*, const float*, hipStream_t);
-hipError_t launch_loss_total_bump(const float*, int, float*, int32_t*, hipStream_t);
+hipError_t launch_loss_total_bump(const float*, int, float*, int32_t*, float*, int, hipStream_t);
 hipError_t launch_lm_track_head(const LmTrackK&, hipStream_t);
 hipError_t launch_track_loss(const TrackAdamK&, hipStream_t);
 hipError_t launch_track_tail(const TrackAdamK&, hipStream_t);
@@ -943,7 +943,14 @@ int miso_adam_scalars_table(double lr, double beta1, double beta2, double eps, i
 
 int miso_loss_total_bump(const float* loss_slots, int32_t n_floats, float* total, int32_t* step, void* stream) {
   if (!loss_slots || n_floats < 1 || !total) return MISO_E_BADARG;
-  return (int)launch_loss_total_bump(loss_slots, n_floats, total, step, (hipStream_t)stream);
+  return (int)launch_loss_total_bump(loss_slots, n_floats, total, step, nullptr, 0, (hipStream_t)stream);
+}
+
+int miso_loss_total_bump_host(const float* loss_slots, int32_t n_floats, float* total, int32_t* step2, float* host_ring,
+                              int32_t ring_len, void* stream) {
+  if (!loss_slots || n_floats < 1 || !total || !step2 || !host_ring || ring_len < 1 || (ring_len & (ring_len - 1)))
+    return MISO_E_BADARG;
+  return (int)launch_loss_total_bump(loss_slots, n_floats, total, step2, host_ring, ring_len, (hipStream_t)stream);
 }
 
 int miso_adam_bump(int32_t* step, const float* guard, void* stream) {

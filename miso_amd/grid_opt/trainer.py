@@ -242,8 +242,11 @@ class _FastMappingPlan:
             # no copy kernel on the launch stream (4 us per step)
             total, step.total = step.total, torch.empty_like(step.total)
         # guards resolved while making room: those steps were skipped on the device, whose counter never moved
-        self.dev.count -= opt.note_guarded_step(total, self.states)
+        self.dev.count -= opt.note_guarded_step(total, self.states, host=None if _GUARD_COPY else step.host_total)
         return total
+
+
+_GUARD_COPY = os.environ.get('MISO_GUARD_COPY') is not None      # dev: the guard through a copy on the stream
 
 
 def _mapping_base_compute():

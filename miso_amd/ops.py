@@ -815,12 +815,26 @@ class AdamDeviceStep:
                    "miso_adam_scalars_table")
         self.table = host.to(device)
         self.rows = rows
-        self.step = torch.zeros(1, dtype=torch.int32, device=device)
+        # [0] the Adam step count, [1] the launches of total_and_bump so far (the slot of ``ring`` a launch writes)
+        self.step = torch.zeros(2, dtype=torch.int32, device=device)
+        # the step's loss as the host sees it: written by the kernel itself (pinned memory mapped into the device), so
+        # the NaN guard costs the stream no copy.  ``launches`` mirrors step[1]: whoever EXECUTES total_and_bump (a
+        # stream launch or a graph replay, not a capture) calls note_launch().
+        self.ring = torch.empty(self.RING, dtype=torch.float32).pin_memory()
+        self.launches = 0
         self.set_count(count)
+
+    RING = 64
 
     def set_count(self, count: int):
         self.count = int(count)
-        self.step.fill_(self.count)
+        self.step[:1].fill_(self.count)
+
+    def note_launch(self) -> torch.Tensor:
+        """One total_and_bump has been put on the stream: the (1,) view of ``ring`` it will write."""
+        slot = self.launches & (self.RING - 1)
+        self.launches += 1
+        return self.ring[slot:slot + 1]
 
     def bump(self, guard: Optional[torch.Tensor]):
         """step += 1 on the device unless ``guard`` (device scalar) is NaN; the host mirror is the caller's business."""
@@ -829,8 +843,9 @@ class AdamDeviceStep:
     def total_and_bump(self, loss_slots: torch.Tensor, total: torch.Tensor):
         """total (0-d) = loss_slots.sum() and bump(total) in one launch (miso_loss_total_bump)."""
         assert loss_slots.is_contiguous() and loss_slots.dtype == torch.float32 and total.numel() == 1
-        _lib.check(_lib.load().miso_loss_total_bump(_ptr(loss_slots), loss_slots.numel(), _ptr(total), _ptr(self.step),
-                                                    _stream(self.step)), "miso_loss_total_bump")
+        _lib.check(_lib.load().miso_loss_total_bump_host(_ptr(loss_slots), loss_slots.numel(), _ptr(total),
+                                                         _ptr(self.step), C.c_void_p(self.ring.data_ptr()), self.RING,
+                                                         _stream(self.step)), "miso_loss_total_bump_host")
 
     def step_(self, param, grad, exp_avg, exp_avg_sq, active, touched=None, zero_grad=False, guard=None):
         _require_hip(param, grad, exp_avg, exp_avg_sq, guard)

@@ -44,13 +44,13 @@ class DenseAdam(torch.optim.Optimizer):
         pending = self.__dict__.get('_pending')
         skipped = 0
         while pending:
-            host, event, states, _src = pending[0]
+            host, event, states, _src, own = pending[0]
             if block:
                 event.synchronize()
             elif not event.query():
                 break
             pending.pop(0)
-            self.__dict__.setdefault('_guard_slots', []).append((host, event))
+            self.__dict__.setdefault('_guard_slots', []).append((host if own else None, event))
             if bool(torch.isnan(host[0])):
                 for st in states:
                     st['step'] -= 1
@@ -151,26 +151,30 @@ class DenseAdam(torch.optim.Optimizer):
             self.note_guarded_step(guard, stepped)
         return loss
 
-    def note_guarded_step(self, guard, stepped):
+    def note_guarded_step(self, guard, stepped, host=None):
         """A step guarded by the device scalar ``guard`` has been launched for the states ``stepped`` (their 'step'
         already counts it): remember to take the count back if the guard turns out NaN (resolve_guard).
         Returns the number of EARLIER steps found skipped while making room (a bounded number of guards is kept in
         flight): a caller that mirrors a device-side step counter subtracts it from its mirror -- the device counter
         never moved for those steps, and overwriting it with the host count while the step just launched is still
-        unresolved could leave it one ahead."""
+        unresolved could leave it one ahead.
+        host: a pinned (1,) tensor the step's own launches write the guard value to (ops.AdamDeviceStep.ring) -- then
+        no copy is put on the stream, only the event."""
         pending = self.__dict__.setdefault('_pending', [])        # (an unpickled optimizer has no such attributes)
         slots = self.__dict__.setdefault('_guard_slots', [])
         skipped = 0
         if len(pending) >= 8:
             skipped = self.resolve_guard(block=True)        # a bounded number of guards in flight
-        if slots:
-            host, event = slots.pop()
-        else:
-            host, event = torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event()
+        mine, event = slots.pop() if slots else (None, torch.cuda.Event())
         src = guard.detach().reshape(1)
-        host.copy_(src, non_blocking=True)
+        own = host is None
+        if own:
+            host = mine if mine is not None else torch.empty(1, dtype=torch.float32, pin_memory=True)
+            host.copy_(src, non_blocking=True)
+        else:
+            src = None                                      # nothing on the stream reads the device scalar for us
         event.record()
         # the device scalar stays referenced until the copy has been consumed: a caller that drops the loss
         # right away would hand its block back to the allocator while the asynchronous copy may still read it
-        pending.append((host, event, stepped, src))
+        pending.append((host, event, stepped, src, own))
         return skipped

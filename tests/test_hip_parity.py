@@ -1370,10 +1370,22 @@ def test_round2_entry_points_on_empty_and_tiny_batches():
     # loss total + step count: a NaN total leaves the count alone
     dev = ops.AdamDeviceStep(1e-3, 0.9, 0.999, 1e-8, DEV, count=3)
     tot = torch.zeros((), device=DEV)
+    host0 = dev.note_launch()
     dev.total_and_bump(torch.full((ops._lib.LOSS_SLOTS, 2), 0.25, device=DEV), tot)
-    assert float(tot) == 0.25 * 2 * ops._lib.LOSS_SLOTS and int(dev.step) == 4
+    assert float(tot) == 0.25 * 2 * ops._lib.LOSS_SLOTS and dev.step.tolist() == [4, 1]
     bad = torch.full((ops._lib.LOSS_SLOTS, 2), 0.25, device=DEV)
     bad[3, 1] = float("nan")
+    host1 = dev.note_launch()
     dev.total_and_bump(bad, tot)
-    assert bool(torch.isnan(tot)) and int(dev.step) == 4
+    # the count stays, the launch counter moves; the host ring (pinned memory the kernel writes) holds both totals
+    assert bool(torch.isnan(tot)) and dev.step.tolist() == [4, 2]
+    assert float(host0) == 0.25 * 2 * ops._lib.LOSS_SLOTS and bool(torch.isnan(host1))
+    assert host0.data_ptr() == dev.ring.data_ptr() and host1.data_ptr() == dev.ring.data_ptr() + 4
+    for _ in range(dev.RING - 1):                    # the ring wraps to the slot it started from
+        last = dev.note_launch()
+        dev.total_and_bump(torch.full((ops._lib.LOSS_SLOTS, 2), 0.5, device=DEV), tot)
+    torch.cuda.synchronize()
+    assert last.data_ptr() == host0.data_ptr() and float(host0) == 0.5 * 2 * ops._lib.LOSS_SLOTS
+    dev.set_count(7)
+    assert dev.step.tolist() == [7, dev.RING + 1]
     assert dev.table.shape[1] == 6 and dev.rows > 20000
