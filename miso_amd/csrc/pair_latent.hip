@@ -40,6 +40,24 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 // One workgroup's share (grid-stride from block bx of nbx) of one pair.  pose_s / pose_d: R[9] t[3] of the source
 // and the destination submap.  Shared by the single-pair kernel and the batched one (one launch for all pairs of an
 // alignment iteration, grid.y = pair, descriptors in device memory).
+// src -> world -> dst of one source vertex (transform_points_to, then transfrom_points_from: utils_geometry.py:214-240)
+// in ONE fixed arithmetic: d = (Rs p + ts) - td with the row sums as fma chains, q = Rd^T d likewise.  Every in-bound
+// decision -- pass 1 and pass 2 of the pair stage, the point-list and the lattice form of the overlap gate -- is taken on
+// these bits.  Written as plain products and sums, the copies of this expression came out of the compiler with different
+// contractions, and the two forms of the gate disagreed on one vertex of 4 M for two submaps 0.35 degrees apart
+// (test_lattice_overlap_gate_counts_equal_the_point_list_gate).
+__device__ __forceinline__ void src_to_dst(const float (&Rs)[9], const float (&ts)[3], const float (&Rd)[9],
+                                           const float (&td)[3], float px, float py, float pz, float (&d)[3],
+                                           float (&q)[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float w = __fadd_rn(__fmaf_rn(Rs[3 * r + 2], pz, __fmaf_rn(Rs[3 * r + 1], py, __fmul_rn(Rs[3 * r], px))), ts[r]);
+    d[r] = __fsub_rn(w, td[r]);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) q[c] = __fmaf_rn(Rd[6 + c], d[2], __fmaf_rn(Rd[3 + c], d[1], __fmul_rn(Rd[c], d[0])));
+}
+
 template <bool VEC4>
 __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __restrict__ pose_s,
                                                  const float* __restrict__ pose_d, const PairK& k, unsigned bx,
@@ -138,11 +156,8 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
         const bool sure = q0 >= blo[0] + 2.0f * slack && q0 <= bhi[0] - 2.0f * slack && q1 >= blo[1] + 2.0f * slack &&
                           q1 <= bhi[1] - 2.0f * slack && q2 >= blo[2] + 2.0f * slack && q2 <= bhi[2] - 2.0f * slack;
         if (cand && !sure) {
-          const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
-                              Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
-          const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
-          const float q[3] = {Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
-                              Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2]};
+          float d[3], q[3];
+          src_to_dst(Rs, ts, Rd, td, px, py, pz, d, q);
           cand = q[0] >= g.bmin[0] && q[0] <= g.bmax[0] && q[1] >= g.bmin[1] && q[1] <= g.bmax[1] &&
                  q[2] >= g.bmin[2] && q[2] <= g.bmax[2];
         }
@@ -158,11 +173,8 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
     const int64_t idx = w0 + s_in[wave_][e];
     // the same arithmetic as pass 1 (three loads from L2 and 30 flops are cheaper than carrying q through LDS)
     const float px = k.p[idx * 3 + 0], py = k.p[idx * 3 + 1], pz = k.p[idx * 3 + 2];
-    const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
-                        Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
-    const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
-    const float q[3] = {Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
-                        Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2]};
+    float d[3], q[3];
+    src_to_dst(Rs, ts, Rd, td, px, py, pz, d, q);
     const float* fs = k.fsrc + idx * k.ld;
     // the normalised coordinate is the same for every level (axis_coord op for op, its first half formed once)
     float xn[3], mn[3];
@@ -311,12 +323,10 @@ __device__ __forceinline__ void overlap_count_body(const float* __restrict__ pos
   float cnt = 0.0f;
   for (int64_t idx = (int64_t)bx * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)nbx * blockDim.x) {
     const float px = p[idx * 3 + 0], py = p[idx * 3 + 1], pz = p[idx * 3 + 2];
-    // same operation order as pair_latent_kernel, so both agree on which vertices are inside
-    const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
-                        Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
-    const float d[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
-    const float q0 = Rd[0] * d[0] + Rd[3] * d[1] + Rd[6] * d[2], q1 = Rd[1] * d[0] + Rd[4] * d[1] + Rd[7] * d[2],
-                q2 = Rd[2] * d[0] + Rd[5] * d[1] + Rd[8] * d[2];
+    // the pair stage's own arithmetic, so both agree on which vertices are inside
+    float d[3], q[3];
+    src_to_dst(Rs, ts, Rd, td, px, py, pz, d, q);
+    const float q0 = q[0], q1 = q[1], q2 = q[2];
     if (q0 >= bmin0 && q0 <= bmax0 && q1 >= bmin1 && q1 <= bmax1 && q2 >= bmin2 && q2 <= bmax2) cnt += 1.0f;
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(256) void overlap_count_kernel(const float* __restr
 // the gate of 28 pairs x 4 M vertices took 147 us of a 210 us level-0 alignment iteration.
 constexpr int GATE_ROWS = 256;          // rows (lanes) per workgroup
 constexpr float GATE_SLACK = 2e-3f;     // metres; fp32 rounding of the map is ~1e-5 at 100 m
+constexpr int GATE_AX_LDS = 512;        // x-table entries kept in LDS (ScanNet: 200; a longer table is read from global memory)
 constexpr float GATE_ERR = 2e-4f;       // metres: bound on the rounding of one mapped coordinate, generous
 
 // bx of nbx workgroups on pair `pair` (the standalone kernel: blockIdx.x of gridDim.x; the merged pair stage: the
@@ -375,14 +386,20 @@ __device__ __forceinline__ void overlap_batch_body(const AlignPairK* __restrict_
 #pragma unroll
   for (int i = 0; i < 3; ++i) { ts[i] = ps[9 + i]; td[i] = pd[9 + i]; }
   const float lo[3] = {d.g.bmin[0], d.g.bmin[1], d.g.bmin[2]}, hi[3] = {d.g.bmax[0], d.g.bmax[1], d.g.bmax[2]};
-  const float* __restrict__ ax = d.gate_ax[0];
+  const float* __restrict__ axg = d.gate_ax[0];
+  // the x table in LDS when it fits: the exact tests walk it vertex by vertex, a dependent read each
+  __shared__ float s_ax[GATE_AX_LDS];
+  const bool ax_lds = nx <= GATE_AX_LDS;
+  if (ax_lds) {
+    for (int i = threadIdx.x; i < nx; i += blockDim.x) s_ax[i] = axg[i];
+    __syncthreads();
+  }
+  auto ax = [&](int i) -> float { return ax_lds ? s_ax[i] : axg[i]; };
   // the exact test of one vertex: the arithmetic of overlap_count_body / the reference's tensor ops
   auto inside = [&](float px, float py, float pz) -> bool {
-    const float w[3] = {Rs[0] * px + Rs[1] * py + Rs[2] * pz + ts[0], Rs[3] * px + Rs[4] * py + Rs[5] * pz + ts[1],
-                        Rs[6] * px + Rs[7] * py + Rs[8] * pz + ts[2]};
-    const float e[3] = {w[0] - td[0], w[1] - td[1], w[2] - td[2]};
-    const float q0 = Rd[0] * e[0] + Rd[3] * e[1] + Rd[6] * e[2], q1 = Rd[1] * e[0] + Rd[4] * e[1] + Rd[7] * e[2],
-                q2 = Rd[2] * e[0] + Rd[5] * e[1] + Rd[8] * e[2];
+    float e[3], q[3];
+    src_to_dst(Rs, ts, Rd, td, px, py, pz, e, q);
+    const float q0 = q[0], q1 = q[1], q2 = q[2];
     return q0 >= lo[0] && q0 <= hi[0] && q1 >= lo[1] && q1 <= hi[1] && q2 >= lo[2] && q2 <= hi[2];
   };
   const int lane = threadIdx.x & 63;
@@ -394,12 +411,15 @@ __device__ __forceinline__ void overlap_batch_body(const AlignPairK* __restrict_
   bool whole = false;                     // this lane's row needs every vertex evaluated
   if (live) {
     if (nx <= 8) {
-      for (int i = 0; i < nx; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
+      for (int i = 0; i < nx; ++i) cnt += inside(ax(i), py, pz) ? 1.0f : 0.0f;
     } else {
       // q_c(px) = alpha_c px + beta_c;  interval of px with all six faces satisfied
-      const float x0 = ax[0], x1 = ax[nx - 1];
+      const float x0 = ax(0), x1 = ax(nx - 1);
       float pxl = x0, pxh = x1;           // the row itself
       float unc = 0.0f;                   // how far (in px) rounding can move an interval end: GATE_ERR / |alpha|
+      float wpx = 0.0f;                   // how far (in px) from an interval end a vertex can still be within GATE_SLACK of a
+                                          // face: GATE_SLACK / |alpha| -- a face the row meets at a shallow angle (two submaps
+                                          // a fraction of a degree apart) keeps many vertices that close
       bool empty = false;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -418,6 +438,7 @@ __device__ __forceinline__ void overlap_batch_body(const AlignPairK* __restrict_
         pxl = fmaxf(pxl, fminf(a, b));
         pxh = fminf(pxh, fmaxf(a, b));
         unc = fmaxf(unc, GATE_ERR / fabsf(al));
+        wpx = fmaxf(wpx, GATE_SLACK / fabsf(al));
       }
       pxl -= unc; pxh += unc;
       if (!(pxl == pxl) || !(pxh == pxh)) whole = true;          // NaN poses: let the exact path decide
@@ -428,12 +449,16 @@ __device__ __forceinline__ void overlap_batch_body(const AlignPairK* __restrict_
         int il = (int)fminf(fmaxf(floorf((pxl - x0) * inv_dx), -4.0f), (float)nx + 4.0f);
         int ih = (int)fminf(fmaxf(ceilf((pxh - x0) * inv_dx), -4.0f), (float)nx + 4.0f);
         il = max(il - 2, 0); ih = min(ih + 2, nx - 1);           // first / last vertex that could be in bound
-        if (ih - il < 12) {
-          for (int i = il; i <= ih; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
+        // m vertices either side exactly: 5 when every face is met at more than ~0.4 degrees (a 0.1 m lattice), more for
+        // shallower ones -- with a fixed 5 every row of such a pair failed the depth test below and went down the
+        // one-row-at-a-time path (cfg-4 level 0: five of the 56 ordered pairs, 28 of the iteration's 80 us)
+        const int m = 4 + (int)fminf(ceilf(wpx * inv_dx), 4096.0f);
+        if (ih - il < 2 * m + 2) {
+          for (int i = il; i <= ih; ++i) cnt += inside(ax(i), py, pz) ? 1.0f : 0.0f;
         } else {
-          // vertices il .. il+4 and ih-4 .. ih exactly; il+5 .. ih-5 counted if the analytic map keeps both ends of
+          // vertices il .. il+m-1 and ih-m+1 .. ih exactly; il+m .. ih-m counted if the analytic map keeps both ends of
           // that stretch GATE_SLACK inside every face (q is linear in px, so everything between is at least as deep)
-          const int a0 = il + 5, a1 = ih - 5;
+          const int a0 = il + m, a1 = ih - m;
           bool deep = true;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
@@ -441,14 +466,14 @@ __device__ __forceinline__ void overlap_batch_body(const AlignPairK* __restrict_
             const float be = Rd[c] * (Rs[1] * py + Rs[2] * pz + ts[0] - td[0]) +
                              Rd[3 + c] * (Rs[4] * py + Rs[5] * pz + ts[1] - td[1]) +
                              Rd[6 + c] * (Rs[7] * py + Rs[8] * pz + ts[2] - td[2]);
-            const float qa = al * ax[a0] + be, qb = al * ax[a1] + be;
+            const float qa = al * ax(a0) + be, qb = al * ax(a1) + be;
             deep = deep && fminf(qa, qb) >= lo[c] + GATE_SLACK && fmaxf(qa, qb) <= hi[c] - GATE_SLACK;
           }
           if (!deep) {
             whole = true;
           } else {
-            for (int i = il; i < a0; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
-            for (int i = a1 + 1; i <= ih; ++i) cnt += inside(ax[i], py, pz) ? 1.0f : 0.0f;
+            for (int i = il; i < a0; ++i) cnt += inside(ax(i), py, pz) ? 1.0f : 0.0f;
+            for (int i = a1 + 1; i <= ih; ++i) cnt += inside(ax(i), py, pz) ? 1.0f : 0.0f;
             cnt += (float)(a1 - a0 + 1);
           }
         }
@@ -462,7 +487,7 @@ __device__ __forceinline__ void overlap_batch_body(const AlignPairK* __restrict_
     const int src = __builtin_ctzll(todo);
     todo &= todo - 1;
     const float ry = __shfl(py, src, 64), rz = __shfl(pz, src, 64);
-    for (int i = lane; i < nx; i += 64) cnt += inside(ax[i], ry, rz) ? 1.0f : 0.0f;
+    for (int i = lane; i < nx; i += 64) cnt += inside(ax(i), ry, rz) ? 1.0f : 0.0f;
   }
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
   __shared__ float red[4];

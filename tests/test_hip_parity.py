@@ -1176,17 +1176,22 @@ def test_lattice_overlap_gate_counts_equal_the_point_list_gate(case):
         bound = [[-2.0, 2.0], [-0.9, 0.9], [-1.5, 1.5]]
         rots = [torch.zeros(3), torch.tensor([0.0, 0.0, math.pi / 2]), torch.tensor([math.pi / 2, 0.0, 0.0]),
                 torch.tensor([0.0, 1e-4, 0.0]), torch.tensor([0.02, -0.01, 0.03]), torch.tensor([0.4, 0.2, -0.7]),
-                torch.tensor([1.2, -2.0, 0.6]), torch.tensor([0.0, math.pi, 0.0]), torch.randn(3), torch.zeros(3)]
+                torch.tensor([1.2, -2.0, 0.6]), torch.tensor([0.0, math.pi, 0.0]), torch.randn(3), torch.zeros(3),
+                # faces met at a fraction of a degree: many vertices of a row lie within the gate's slack of the face
+                torch.tensor([0.0, 0.004, 0.0]), torch.tensor([0.002, -0.0007, 0.005])]
         trans = [torch.zeros(3), torch.tensor([0.05, 0.0, 0.0]), torch.tensor([3.95, 0.0, 0.0]), torch.tensor([0.0, 1.75, 0.0]),
                  torch.tensor([10.0, 0.0, 0.0]), torch.tensor([0.3, -0.2, 0.1]), torch.tensor([1.0, 0.9, -1.5]),
-                 torch.tensor([-2.0, 0.0, 2.95]), torch.randn(3), torch.zeros(3)]      # the last one coincides with the first
+                 torch.tensor([-2.0, 0.0, 2.95]), torch.randn(3), torch.zeros(3),      # (coincides with the first)
+                 torch.tensor([0.4, 0.1, -0.2]), torch.tensor([-1.0, 0.45, 0.7])]
     else:
         nx, ny, nz = 200, 100, 200
         bound = [[-10.0, 10.0], [-5.0, 5.0], [-10.0, 10.0]]
         rots = [torch.zeros(3), torch.tensor([0.0, 0.3, 0.0]), torch.tensor([0.01, -0.5, 0.02]), torch.tensor([0.0, 1e-5, 0.0]),
-                torch.tensor([0.0, math.pi / 2, 0.0]), torch.randn(3) * 0.2, torch.randn(3) * 0.05, torch.zeros(3)]
+                torch.tensor([0.0, math.pi / 2, 0.0]), torch.randn(3) * 0.2, torch.randn(3) * 0.05, torch.zeros(3),
+                torch.tensor([0.0, 0.004, 0.0]), torch.tensor([0.0015, -0.0004, 0.006])]      # 0.2 - 0.35 degrees
         trans = [torch.zeros(3), torch.tensor([6.0, 0.2, -3.0]), torch.tensor([-8.0, 0.0, 7.5]), torch.tensor([0.1, 0.0, 0.0]),
-                 torch.tensor([19.9, 0.0, 0.0]), torch.randn(3) * 4, torch.randn(3) * 4, torch.tensor([35.0, 0.0, 0.0])]
+                 torch.tensor([19.9, 0.0, 0.0]), torch.randn(3) * 4, torch.randn(3) * 4, torch.tensor([35.0, 0.0, 0.0]),
+                 torch.tensor([9.0, -0.3, 2.0]), torch.tensor([-4.0, 4.6, -11.0])]
     half = [(b[1] - b[0]) / (2 * n) for b, n in zip(bound, (nx, ny, nz))]
     axes = [torch.linspace(b[0] + h, b[1] - h, n) for b, h, n in zip(bound, half, (nx, ny, nz))]
     zz, yy, xx = torch.meshgrid(axes[2], axes[1], axes[0], indexing="ij")          # z-major, x fastest
