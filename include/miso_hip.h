@@ -611,11 +611,13 @@ int miso_adam_bump(int32_t* step, const float* guard /* or NULL */, void* stream
  * i.e. both terms of the mapping loss) and, with step != NULL, miso_adam_bump(step, total) in the same launch. */
 int miso_loss_total_bump(const float* loss_slots, int32_t n_floats, float* total, int32_t* step /* or NULL */,
                          void* stream);
-/* The same with the total ALSO stored to host_ring[step2[1] % ring_len] and step2[1] += 1 (step2: device int32[2] =
- * {Adam step count, launches so far}; host_ring: PINNED HOST memory mapped into the device, ring_len a power of two).
+/* The same with the total ALSO handed to the host: slot s = step2[1] % ring_len of host_ring receives
+ * host_ring[2 s] = total and then, behind a system-scope fence, ((int32_t*)host_ring)[2 s + 1] = step2[1] + 1 (the
+ * 1-based number of this launch); step2[1] += 1.  step2: device int32[2] = {Adam step count, launches so far};
+ * host_ring: PINNED HOST memory mapped into the device, 2 * ring_len words, zeroed once; ring_len a power of two.
  * The reference reads the loss on the host after every step to decide whether to skip it (grid_opt/trainer.py:213-219);
- * here the host finds it in the ring once an event recorded behind the launch has completed -- no copy on the
- * stream.  The launch counter moves on NaN too, so a skipped step does not alias the next one's slot. */
+ * here the host polls the slot for its launch's number -- no copy and no event on the stream.  The launch counter
+ * moves on NaN too, so a skipped step does not alias the next one's slot. */
 int miso_loss_total_bump_host(const float* loss_slots, int32_t n_floats, float* total, int32_t* step2,
                               float* host_ring, int32_t ring_len, void* stream);
 int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,

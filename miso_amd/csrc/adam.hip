@@ -28,8 +28,9 @@ __global__ void adam_bump_kernel(int32_t* step, const float* __restrict__ guard)
 
 // The step's loss from its per-workgroup slots and the step count in one launch (a captured trainer step needs both
 // between the backward and the Adam launches): total = sum of n floats (pairwise in LDS, a fixed order), then the bump.
-// host_ring (pinned host memory, ring_len a power of two) also receives the total, in slot step[1] % ring_len with
-// step[1] counting the launches: the host reads the NaN guard from there without a copy on the stream.
+// host_ring (pinned host memory, ring_len slots of two words, ring_len a power of two) also receives the total, in slot
+// step[1] % ring_len with step[1] counting the launches: the host reads the NaN guard from there without a copy on the
+// stream.
 __global__ __launch_bounds__(256) void loss_total_bump_kernel(const float* __restrict__ slots, int n,
                                                              float* __restrict__ total, int32_t* step,
                                                              float* host_ring, int ring_len) {
@@ -47,12 +48,31 @@ __global__ __launch_bounds__(256) void loss_total_bump_kernel(const float* __res
     total[0] = t;
     if (step && t == t) step[0] += 1;
     if (host_ring) {
+      // slot = {total, launch number}: the number is stored behind a system-scope fence, so a host that finds its
+      // launch's number in the slot finds the total there too -- it polls the slot, no event on the stream (an event
+      // record is a barrier packet: ~5.6 us between this step's last kernel and the next step's first)
       const int it = step[1];
       step[1] = it + 1;
-      host_ring[it & (ring_len - 1)] = t;
+      float* slot = host_ring + 2 * (it & (ring_len - 1));
+      __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __threadfence_system();
+      __hip_atomic_store(reinterpret_cast<int32_t*>(slot) + 1, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+// Streaming accesses (the `nt` bit) for the gradient and the moments: they are read and written once per step, 460 of
+// the step's 536 MB at cfg-2, and as ordinary accesses they pushed the parameters -- which the next step's forward
+// gathers -- out of the 256 MB Infinity Cache.  Measured on the cfg-2 trainer step (rocprofv3, same box): the next
+// sdf_train_kernel 83.3 -> 77.1 us, grad_pull_mc_kernel 65.9 -> 61.5 us, the three Adam launches 95.0 -> 90.6 us.
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* q) {
+  const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(q));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st4_stream(float* q, const float4& v) {
+  const f4v t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(q));
 }
 
 template <bool ZERO>
@@ -61,13 +81,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                   int64_t n4, int64_t n, AdamScalars a) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
-    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = ld4_stream(g + 4 * i);
+    float4 mm = ld4_stream(m + 4 * i), vv = ld4_stream(v + 4 * i);
     adam_one(pp.x, gg.x, mm.x, vv.x, a); adam_one(pp.y, gg.y, mm.y, vv.y, a);
     adam_one(pp.z, gg.z, mm.z, vv.z, a); adam_one(pp.w, gg.w, mm.w, vv.w, a);
     reinterpret_cast<float4*>(p)[i] = pp;
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
+    st4_stream(m + 4 * i, mm);
+    st4_stream(v + 4 * i, vv);
     if (ZERO) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // scalar tail (numel % 4), handled by the first threads of block 0
@@ -122,10 +142,10 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
       gg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (sl < nslab) {
         act[u] = active[sl * 4 + q] != 0;
-        gg[u] = *reinterpret_cast<const float4*>(g + i);
+        gg[u] = ld4_stream(g + i);
         if (act[u]) {
-          pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
-          vv[u] = *reinterpret_cast<float4*>(v + i);
+          pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = ld4_stream(m + i);
+          vv[u] = ld4_stream(v + i);
         }
       }
     }
@@ -142,15 +162,15 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
         continue;
       }
       if (!act[u]) {
-        pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = *reinterpret_cast<float4*>(m + i);
-        vv[u] = *reinterpret_cast<float4*>(v + i);
+        pp[u] = *reinterpret_cast<float4*>(p + i); mm[u] = ld4_stream(m + i);
+        vv[u] = ld4_stream(v + i);
         if ((lane & 15) == 0) active[sl * 4 + q] = 1;
       }
       adam_one(pp[u].x, gg[u].x, mm[u].x, vv[u].x, a); adam_one(pp[u].y, gg[u].y, mm[u].y, vv[u].y, a);
       adam_one(pp[u].z, gg[u].z, mm[u].z, vv[u].z, a); adam_one(pp[u].w, gg[u].w, mm[u].w, vv[u].w, a);
       *reinterpret_cast<float4*>(p + i) = pp[u];
-      *reinterpret_cast<float4*>(m + i) = mm[u];
-      *reinterpret_cast<float4*>(v + i) = vv[u];
+      st4_stream(m + i, mm[u]);
+      st4_stream(v + i, vv[u]);
       if (ZERO && any) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }

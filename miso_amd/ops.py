@@ -796,6 +796,21 @@ def adam_active_(param, grad, exp_avg, exp_avg_sq, active, step: int, lr: float,
                                             _ptr(guard), _stream(param)), "miso_adam_active")
 
 
+class HostTotal:
+    """A step's loss total as the device hands it to the host (AdamDeviceStep.ring): valid once the slot carries the
+    launch's number."""
+    __slots__ = ("slot", "seq_word", "seq")
+
+    def __init__(self, slot, seq_word, seq):
+        self.slot, self.seq_word, self.seq = slot, seq_word, seq
+
+    def ready(self) -> bool:
+        return int(self.seq_word[1]) == self.seq
+
+    def value(self) -> float:
+        return float(self.slot[0])
+
+
 class AdamDeviceStep:
     """What a captured step needs to take Adam steps without new kernel arguments (miso_adam_step_dev): the table of
     per-step scalars (computed by the library's own host code, so the captured step equals the launch-by-launch one
@@ -820,7 +835,9 @@ class AdamDeviceStep:
         # the step's loss as the host sees it: written by the kernel itself (pinned memory mapped into the device), so
         # the NaN guard costs the stream no copy.  ``launches`` mirrors step[1]: whoever EXECUTES total_and_bump (a
         # stream launch or a graph replay, not a capture) calls note_launch().
-        self.ring = torch.empty(self.RING, dtype=torch.float32).pin_memory()
+        # RING slots of {total, 1-based number of the launch that wrote it}: the host polls the number
+        self.ring = torch.zeros((self.RING, 2), dtype=torch.float32).pin_memory()
+        self.ring_seq = self.ring.view(torch.int32)
         self.launches = 0
         self.set_count(count)
 
@@ -830,11 +847,12 @@ class AdamDeviceStep:
         self.count = int(count)
         self.step[:1].fill_(self.count)
 
-    def note_launch(self) -> torch.Tensor:
-        """One total_and_bump has been put on the stream: the (1,) view of ``ring`` it will write."""
+    def note_launch(self):
+        """One total_and_bump has been put on the stream: (the (2,) int32 view of the ``ring`` slot it will write, the
+        number it will leave in word 1 once the total is in word 0).  HostTotal.ready / .value read them."""
         slot = self.launches & (self.RING - 1)
         self.launches += 1
-        return self.ring[slot:slot + 1]
+        return HostTotal(self.ring[slot], self.ring_seq[slot], ((self.launches + 2 ** 31) % 2 ** 32) - 2 ** 31)
 
     def bump(self, guard: Optional[torch.Tensor]):
         """step += 1 on the device unless ``guard`` (device scalar) is NaN; the host mirror is the caller's business."""

@@ -15,6 +15,7 @@ launched, by which time it has long completed) and takes the step count back, so
 of torch.optim.Adam."""
 import logging
 import math
+import time
 
 import torch
 
@@ -36,22 +37,41 @@ class DenseAdam(torch.optim.Optimizer):
         self._pending = []            # guarded steps not yet accounted for: [pinned loss copy, event, states, device scalar]
         self._guard_slots = []        # pinned floats + events, reused
 
-    def resolve_guard(self, block=True):
+    def resolve_guard(self, block=True, at_most=None):
         """Account for guarded steps whose loss has arrived: if it was NaN the device skipped the step -- take the step
         counts back.  block=True waits for every pending one (the launch-by-launch path computes the next step's bias
         corrections from the count, so it must be right); block=False looks only at those that have completed (a
-        captured step counts on the device).  Returns the number of steps found skipped."""
+        captured step counts on the device).  at_most: wait for that many of the oldest ones only, then go on without
+        waiting.  Returns the number of steps found skipped."""
         pending = self.__dict__.get('_pending')
         skipped = 0
         while pending:
-            host, event, states, _src, own = pending[0]
-            if block:
-                event.synchronize()
-            elif not event.query():
+            if at_most is not None:
+                if at_most <= 0:
+                    block = False
+                at_most -= 1
+            host, event, states, src, own = pending[0]
+            if own:
+                if block:
+                    event.synchronize()
+                elif not event.query():
+                    break
+                bad = bool(torch.isnan(host[0]))
+                self.__dict__.setdefault('_guard_slots', []).append((host, event))
+            elif host.ready():                     # ops.HostTotal: the step's own launch left the loss in pinned memory
+                bad = math.isnan(host.value())
+            elif not block:
                 break
+            else:
+                # wait for THIS step only: poll its slot (anything put on the stream -- an .item() of the device scalar --
+                # would queue up behind every step launched since and drain them all)
+                t0 = time.perf_counter()
+                while not host.ready() and time.perf_counter() - t0 < 2.0:
+                    pass
+                # (not after two seconds: the ring and the device counter disagree; the device scalar has the number)
+                bad = math.isnan(host.value()) if host.ready() else bool(torch.isnan(src).item())
             pending.pop(0)
-            self.__dict__.setdefault('_guard_slots', []).append((host if own else None, event))
-            if bool(torch.isnan(host[0])):
+            if bad:
                 for st in states:
                     st['step'] -= 1
                 skipped += 1
@@ -158,22 +178,23 @@ class DenseAdam(torch.optim.Optimizer):
         flight): a caller that mirrors a device-side step counter subtracts it from its mirror -- the device counter
         never moved for those steps, and overwriting it with the host count while the step just launched is still
         unresolved could leave it one ahead.
-        host: a pinned (1,) tensor the step's own launches write the guard value to (ops.AdamDeviceStep.ring) -- then
-        no copy is put on the stream, only the event."""
+        host: the ops.HostTotal of a step whose own launch hands the guard value to the host (AdamDeviceStep.ring) --
+        then nothing is put on the stream, neither a copy nor an event (an event record is a barrier packet: 5.6 us
+        between the step's last kernel and the next step's first)."""
         pending = self.__dict__.setdefault('_pending', [])        # (an unpickled optimizer has no such attributes)
         slots = self.__dict__.setdefault('_guard_slots', [])
         skipped = 0
         if len(pending) >= 8:
-            skipped = self.resolve_guard(block=True)        # a bounded number of guards in flight
-        mine, event = slots.pop() if slots else (None, torch.cuda.Event())
+            # a bounded number of guards in flight: wait for the oldest only -- waiting for all of them would drain the
+            # queue the host has filled and leave the device idle until the next step is launched
+            skipped = self.resolve_guard(block=True, at_most=len(pending) - 7)
         src = guard.detach().reshape(1)
         own = host is None
+        event = None
         if own:
-            host = mine if mine is not None else torch.empty(1, dtype=torch.float32, pin_memory=True)
+            host, event = slots.pop() if slots else (torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event())
             host.copy_(src, non_blocking=True)
-        else:
-            src = None                                      # nothing on the stream reads the device scalar for us
-        event.record()
+            event.record()
         # the device scalar stays referenced until the copy has been consumed: a caller that drops the loss
         # right away would hand its block back to the allocator while the asynchronous copy may still read it
         pending.append((host, event, stepped, src, own))

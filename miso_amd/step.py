@@ -243,7 +243,7 @@ class MappingStep:
     def run(self):
         """Launch one iteration on the current stream (asynchronous)."""
         if self.adam_device is not None:
-            self.host_total = self.adam_device.note_launch()      # where this iteration's loss lands on the host
+            self.host_total = self.adam_device.note_launch()      # where the host will find this iteration's loss
         if not self._use_graph:
             self._launch()
             return

@@ -1376,21 +1376,25 @@ def test_round2_entry_points_on_empty_and_tiny_batches():
     dev = ops.AdamDeviceStep(1e-3, 0.9, 0.999, 1e-8, DEV, count=3)
     tot = torch.zeros((), device=DEV)
     host0 = dev.note_launch()
+    assert not host0.ready()
     dev.total_and_bump(torch.full((ops._lib.LOSS_SLOTS, 2), 0.25, device=DEV), tot)
     assert float(tot) == 0.25 * 2 * ops._lib.LOSS_SLOTS and dev.step.tolist() == [4, 1]
     bad = torch.full((ops._lib.LOSS_SLOTS, 2), 0.25, device=DEV)
     bad[3, 1] = float("nan")
     host1 = dev.note_launch()
     dev.total_and_bump(bad, tot)
-    # the count stays, the launch counter moves; the host ring (pinned memory the kernel writes) holds both totals
+    # the count stays, the launch counter moves; the pinned ring (written by the kernel) holds both totals, each with the
+    # number of the launch that wrote it
     assert bool(torch.isnan(tot)) and dev.step.tolist() == [4, 2]
-    assert float(host0) == 0.25 * 2 * ops._lib.LOSS_SLOTS and bool(torch.isnan(host1))
-    assert host0.data_ptr() == dev.ring.data_ptr() and host1.data_ptr() == dev.ring.data_ptr() + 4
+    assert host0.ready() and host0.value() == 0.25 * 2 * ops._lib.LOSS_SLOTS
+    assert host1.ready() and math.isnan(host1.value()) and host1.seq == 2
+    assert host0.slot.data_ptr() == dev.ring.data_ptr() and host1.slot.data_ptr() == dev.ring.data_ptr() + 8
     for _ in range(dev.RING - 1):                    # the ring wraps to the slot it started from
         last = dev.note_launch()
         dev.total_and_bump(torch.full((ops._lib.LOSS_SLOTS, 2), 0.5, device=DEV), tot)
     torch.cuda.synchronize()
-    assert last.data_ptr() == host0.data_ptr() and float(host0) == 0.5 * 2 * ops._lib.LOSS_SLOTS
+    assert last.slot.data_ptr() == host0.slot.data_ptr() and last.ready() and not host0.ready()
+    assert last.value() == 0.5 * 2 * ops._lib.LOSS_SLOTS
     dev.set_count(7)
     assert dev.step.tolist() == [7, dev.RING + 1]
     assert dev.table.shape[1] == 6 and dev.rows > 20000
