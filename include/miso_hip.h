@@ -623,6 +623,22 @@ int miso_loss_total_bump_host(const float* loss_slots, int32_t n_floats, float* 
 int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
                        uint8_t* touched /* or NULL */, int64_t numel, const float* table, int32_t table_len,
                        const int32_t* step, int zero_grad, const float* guard, void* stream);
+/* miso_adam_step_dev (touched == NULL) for up to MISO_ADAM_MAX_TENSORS tensors in ONE launch, each bit-identical to its
+ * own call: the levels of a grid as one optimizer.step() (grid_opt/trainer.py:217), without a launch's ramp and tail per
+ * level.  `tensors` is a HOST array (copied into the kernel arguments). */
+#define MISO_ADAM_MAX_TENSORS 8
+typedef struct {
+  float* param; float* grad; float* exp_avg; float* exp_avg_sq;   /* DEVICE, 16-byte aligned, numel floats each */
+  uint8_t* active;                                                /* miso_adam_flag_bytes(numel) */
+  int64_t numel;
+  int32_t zero_grad;
+  int32_t reserved;
+} miso_adam_tensor_t;
+int miso_adam_step_dev_multi(const miso_adam_tensor_t* tensors, int32_t n_tensors, const float* table, int32_t table_len,
+                             const int32_t* step, const float* guard, void* stream);
+/* the same for miso_adam_active (the step's scalars from the host: lr .. eps, the 1-based step) */
+int miso_adam_active_multi(const miso_adam_tensor_t* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
+                           double eps, int32_t step, const float* guard, void* stream);
 
 /* --- per-keyframe rigid map of a sample batch ---------------------------------
  * y[i] = R[idx[i]] x[i] + t[idx[i]] (transpose = 0) or R[idx[i]]^T x[i] (+ t if given; transpose = 1: the cotangent

@@ -77,6 +77,14 @@ class Sorted(C.Structure):
                 ("pull_queue", C.c_void_p), ("pull_queue_ints", C.c_int64)]
 
 
+ADAM_MAX_TENSORS = 8
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("active", C.c_void_p), ("numel", C.c_int64), ("zero_grad", C.c_int32), ("reserved", C.c_int32)]
+
+
 class RayFrames(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("normals", C.c_void_p), ("T_WC", C.c_void_p), ("R_wk", C.c_void_p),
                 ("t_wk", C.c_void_p), ("frame_ids", C.c_void_p),
@@ -167,6 +175,10 @@ SIGNATURES = {
                                           C.c_void_p]),
     "miso_adam_bump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_loss_total_bump": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_adam_active_multi": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.c_int32, C.c_void_p, C.c_void_p]),
+    "miso_adam_step_dev_multi": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "miso_loss_total_bump_host": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_void_p]),
     "miso_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

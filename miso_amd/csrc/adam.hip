@@ -115,20 +115,12 @@ constexpr int ADAM_SLAB = 4 * ADAM_CHUNK;     // floats a wavefront takes per sl
 constexpr int ADAM_UN = 4;                    // slabs in flight per wavefront
 static_assert(ADAM_CHUNK == 64, "a chunk is the sixteen float4s of a quarter wavefront");
 
+// one tensor's step by the whole grid (wavefront `wave` of `nwaves`)
 template <bool ZERO>
-__global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p, float* __restrict__ g,
-                                                         float* __restrict__ m, float* __restrict__ v,
-                                                         unsigned char* __restrict__ active, int64_t n,
-                                                         AdamScalars a, const float* __restrict__ guard,
-                                                         AdamDevK dev) {
-  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];     // a captured step: see AdamDevK
+__device__ __forceinline__ void adam_active_body(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, unsigned char* __restrict__ active, int64_t n,
+                                                 const AdamScalars& a, bool skip, int64_t wave, int64_t nwaves) {
   const int lane = threadIdx.x & 63, q = lane >> 4;      // q: this lane's chunk within the slab
-  // guard (optional, device): the step's loss.  NaN => the reference skips backward and optimizer step
-  // (grid_opt/trainer.py:213-219); here the launch leaves parameters, moments and flags alone (and still clears
-  // the consumed gradients when asked), so the host need not read the loss back before launching.
-  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t nslab = n / ADAM_SLAB;             // whole slabs: float4 path
   for (int64_t s0 = wave * ADAM_UN; s0 < nslab; s0 += nwaves * ADAM_UN) {
     float4 gg[ADAM_UN], pp[ADAM_UN], mm[ADAM_UN], vv[ADAM_UN];
@@ -189,6 +181,48 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
         if (!skip && !was && lane == 0) active[c] = 1;
       }
     }
+  }
+}
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         unsigned char* __restrict__ active, int64_t n,
+                                                         AdamScalars a, const float* __restrict__ guard,
+                                                         AdamDevK dev) {
+  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];     // a captured step: see AdamDevK
+  // guard (optional, device): the step's loss.  NaN => the reference skips backward and optimizer step
+  // (grid_opt/trainer.py:213-219); here the launch leaves parameters, moments and flags alone (and still clears
+  // the consumed gradients when asked), so the host need not read the loss back before launching.
+  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  adam_active_body<ZERO>(p, g, m, v, active, n, a, skip, wave, nwaves);
+}
+
+// Several tensors in ONE launch (miso_adam_step_dev_multi): the levels of a grid differ by a factor of eight each, and as
+// launches of their own the two coarse ones of cfg-2 are 8.5 + 13.4 us of ramp and tail for 67 MB (the fine one: 74.5 us
+// for 469 MB).  Every wavefront walks the tensors in turn, the grid sized for the largest.
+struct AdamSegK {
+  float* p; float* g; float* m; float* v;
+  unsigned char* active;
+  int64_t n;
+  int zero;
+};
+struct AdamMultiK {
+  int count;
+  AdamSegK seg[MISO_ADAM_MAX_TENSORS];
+};
+__global__ __launch_bounds__(256) void adam_active_multi_kernel(AdamMultiK k, AdamScalars a, const float* __restrict__ guard,
+                                                               AdamDevK dev) {
+  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];
+  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int t = 0; t < k.count; ++t) {
+    const AdamSegK& sg = k.seg[t];
+    if (sg.zero) adam_active_body<true>(sg.p, sg.g, sg.m, sg.v, sg.active, sg.n, a, skip, wave, nwaves);
+    else adam_active_body<false>(sg.p, sg.g, sg.m, sg.v, sg.active, sg.n, a, skip, wave, nwaves);
   }
 }
 
@@ -355,6 +389,28 @@ hipError_t launch_adam_active(float* p, float* g, float* m, float* v, unsigned c
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (zero_grad) adam_active_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard, dev);
   else adam_active_kernel<false><<<(unsigned)blocks, 256, 0, s>>>(p, g, m, v, active, n, a, guard, dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_adam_active_multi(const miso_adam_tensor_t* t, int count, double lr, double b1, double b2, double eps,
+                                    int step, const float* table, int table_len, const int32_t* step_dev,
+                                    const float* guard, hipStream_t s) {
+  AdamMultiK k;
+  memset(&k, 0, sizeof(k));
+  int64_t most = 0;
+  for (int i = 0; i < count; ++i) {
+    if (t[i].numel == 0) continue;
+    AdamSegK& sg = k.seg[k.count++];
+    sg.p = t[i].param; sg.g = t[i].grad; sg.m = t[i].exp_avg; sg.v = t[i].exp_avg_sq; sg.active = t[i].active;
+    sg.n = t[i].numel; sg.zero = t[i].zero_grad;
+    most = t[i].numel > most ? t[i].numel : most;
+  }
+  if (k.count == 0) return hipSuccess;
+  const AdamDevK dev{reinterpret_cast<const AdamScalars*>(table), step_dev, table_len};
+  const int64_t nslabs = (most + ADAM_SLAB - 1) / ADAM_SLAB;
+  int64_t blocks = (nslabs + 4 * ADAM_UN - 1) / (4 * ADAM_UN);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  adam_active_multi_kernel<<<(unsigned)blocks, 256, 0, s>>>(k, adam_scalars(lr, b1, b2, eps, step), guard, dev);
   return hipGetLastError();
 }
 

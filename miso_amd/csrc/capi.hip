@@ -31,6 +31,8 @@ hipError_t launch_zero_fill(float*, int64_t, hipStream_t);
 hipError_t launch_adam_touched(float*, float*, float*, float*, unsigned char*, unsigned char*, int64_t, double, double,
                                double, double, int, int, const float*, hipStream_t, const float*, const int32_t*, int);
 hipError_t launch_adam_bump(int32_t*, const float*, hipStream_t);
+hipError_t launch_adam_active_multi(const miso_adam_tensor_t*, int, double, double, double, double, int, const float*, int,
+                                    const int32_t*, const float*, hipStream_t);
 hipError_t launch_loss_total_bump(const float*, int, float*, int32_t*, float*, int, hipStream_t);
 hipError_t launch_lm_track_head(const LmTrackK&, hipStream_t);
 hipError_t launch_track_loss(const TrackAdamK&, hipStream_t);
@@ -972,6 +974,30 @@ int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg
                                     zero_grad, guard, (hipStream_t)stream, table, step, table_len);
   return (int)launch_adam_active(param, grad, exp_avg, exp_avg_sq, active, numel, 1e-3, 0.9, 0.999, 1e-8, 1, zero_grad,
                                  guard, (hipStream_t)stream, table, step, table_len);
+}
+
+static int adam_tensors_ok(const miso_adam_tensor_t* tensors, int32_t n_tensors) {
+  if (!tensors || n_tensors < 1 || n_tensors > MISO_ADAM_MAX_TENSORS) return 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    const miso_adam_tensor_t& t = tensors[i];
+    if (t.numel < 0 || (t.numel > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq || !t.active))) return 0;
+    if ((((uintptr_t)t.param) | ((uintptr_t)t.grad) | ((uintptr_t)t.exp_avg) | ((uintptr_t)t.exp_avg_sq)) & 15u) return 0;
+  }
+  return 1;
+}
+
+int miso_adam_active_multi(const miso_adam_tensor_t* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
+                           double eps, int32_t step, const float* guard, void* stream) {
+  if (!adam_tensors_ok(tensors, n_tensors) || step < 1) return MISO_E_BADARG;
+  return (int)launch_adam_active_multi(tensors, n_tensors, lr, beta1, beta2, eps, step, nullptr, 0, nullptr, guard,
+                                       (hipStream_t)stream);
+}
+
+int miso_adam_step_dev_multi(const miso_adam_tensor_t* tensors, int32_t n_tensors, const float* table, int32_t table_len,
+                             const int32_t* step, const float* guard, void* stream) {
+  if (!adam_tensors_ok(tensors, n_tensors) || table_len < 1 || !table || !step) return MISO_E_BADARG;
+  return (int)launch_adam_active_multi(tensors, n_tensors, 1e-3, 0.9, 0.999, 1e-8, 1, table, table_len, step, guard,
+                                       (hipStream_t)stream);
 }
 
 int miso_mapping_batch(const float* R, const float* t, int32_t n_poses, const int64_t* table, int64_t table_len,

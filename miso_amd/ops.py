@@ -796,6 +796,30 @@ def adam_active_(param, grad, exp_avg, exp_avg_sq, active, step: int, lr: float,
                                             _ptr(guard), _stream(param)), "miso_adam_active")
 
 
+def adam_tensors(tensors):
+    """The argument block of adam_active_multi_ / AdamDeviceStep.step_multi_ for ``tensors`` = [(param, grad, exp_avg,
+    exp_avg_sq, active, zero_grad)]: built once for buffers whose addresses do not change.  Returns (block, keep-alive)."""
+    assert 1 <= len(tensors) <= _lib.ADAM_MAX_TENSORS
+    arr = (_lib.AdamTensor * len(tensors))()
+    for a, (p, g, m, v, act, zero) in zip(arr, tensors):
+        _require_hip(p, g, m, v)
+        for t in (g, m, v):
+            assert t.shape == p.shape and t.stride() == p.stride(), "Adam state must share the param layout"
+        assert act.dtype == torch.uint8 and act.numel() * _lib.ADAM_CHUNK >= p.numel()
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.active, a.numel, a.zero_grad = act.data_ptr(), p.numel(), int(bool(zero))
+    return arr, [t[:5] for t in tensors]
+
+
+def adam_active_multi_(packed, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                       guard: Optional[torch.Tensor] = None):
+    """adam_active_ for several tensors in ONE launch (miso_adam_active_multi), each bit-identical to its own call;
+    ``packed`` from adam_tensors()."""
+    arr, keep = packed
+    _lib.check(_lib.load().miso_adam_active_multi(arr, len(arr), lr, beta1, beta2, eps, step, _ptr(guard),
+                                                  _stream(keep[0][0])), "miso_adam_active_multi")
+
+
 class HostTotal:
     """A step's loss total as the device hands it to the host (AdamDeviceStep.ring): valid once the slot carries the
     launch's number."""
@@ -871,6 +895,17 @@ class AdamDeviceStep:
                                                   _ptr(touched), param.numel(), _ptr(self.table), self.rows,
                                                   _ptr(self.step), int(zero_grad), _ptr(guard), _stream(param)),
                    "miso_adam_step_dev")
+
+
+    def multi(self, tensors):
+        """adam_tensors(tensors): the argument block of step_multi_."""
+        return adam_tensors(tensors)
+
+    def step_multi_(self, packed, guard=None):
+        """step_ for several tensors in one launch (miso_adam_step_dev_multi); ``packed`` from multi()."""
+        arr = packed[0]
+        _lib.check(_lib.load().miso_adam_step_dev_multi(arr, len(arr), _ptr(self.table), self.rows, _ptr(self.step),
+                                                        _ptr(guard), _stream(self.step)), "miso_adam_step_dev_multi")
 
 
 def mapping_batch(R, t, table, frame_ids, coords_frame, target, valid, sign, weight, x_out, rows_out,

@@ -128,6 +128,7 @@ class DenseAdam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             lr, (b1, b2), eps = group['lr'], group['betas'], group['eps']
+            batch = []
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -147,9 +148,12 @@ class DenseAdam(torch.optim.Optimizer):
                         st['active'] = ops.adam_active_flags(p)
                         if t > 1:
                             st['active'].fill_(1)
-                    ops.adam_active_(p, g, m, v, st['active'], t, lr, b1, b2, eps, zero_grad=clear_grads,
-                                     guard=None if guard is None else guard.detach().reshape(1),
-                                     touched=None if touched is None else touched.get(id(p)))
+                    tch = None if touched is None else touched.get(id(p))
+                    if tch is None:
+                        batch.append((p, g, m, v, st['active'], t))      # launched together below
+                    else:
+                        ops.adam_active_(p, g, m, v, st['active'], t, lr, b1, b2, eps, zero_grad=clear_grads,
+                                         guard=None if guard is None else guard.detach().reshape(1), touched=tch)
                     # the kernel wrote through raw pointers: tell autograd / version-keyed caches (DecoderPack)
                     torch.autograd.graph.increment_version(p)
                     continue
@@ -167,9 +171,26 @@ class DenseAdam(torch.optim.Optimizer):
                         cur.copy_(torch.where(ok, cur, old))
                 if clear_grads:
                     g.zero_()
+            self._launch_batch(batch, lr, b1, b2, eps, clear_grads, None if guard is None else guard.detach().reshape(1))
         if guard is not None and stepped:
             self.note_guarded_step(guard, stepped)
         return loss
+
+    def _launch_batch(self, batch, lr, b1, b2, eps, clear_grads, guard):
+        """The kernel-sized tensors of one parameter group: ONE launch when they are at the same step (the levels of a
+        grid are; miso_adam_active_multi), else one each.  The argument block is kept while the addresses stay."""
+        if not batch:
+            return
+        same_t = all(b[5] == batch[0][5] for b in batch)
+        if len(batch) < 2 or len(batch) > ops._lib.ADAM_MAX_TENSORS or not same_t:
+            for p, g, m, v, act, t in batch:
+                ops.adam_active_(p, g, m, v, act, t, lr, b1, b2, eps, zero_grad=clear_grads, guard=guard)
+            return
+        key = tuple(x.data_ptr() for b in batch for x in b[:5]) + (bool(clear_grads),)
+        cache = self.__dict__.get('_multi_block')
+        if cache is None or cache[0] != key:
+            cache = self.__dict__['_multi_block'] = (key, ops.adam_tensors([b[:5] + (clear_grads,) for b in batch]))
+        ops.adam_active_multi_(cache[1], batch[0][5], lr, b1, b2, eps, guard=guard)
 
     def note_guarded_step(self, guard, stepped, host=None):
         """A step guarded by the device scalar ``guard`` has been launched for the states ``stepped`` (their 'step'

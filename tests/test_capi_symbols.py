@@ -161,7 +161,8 @@ def test_struct_sizes_and_offsets_equal_the_headers_as_a_c_compiler_sees_it(tmp_
     src = tmp_path / "layout.c"
     names = [("miso_level_t", _lib.Level), ("miso_grid_t", _lib.Grid), ("miso_mlp_t", _lib.Mlp),
              ("miso_sorted_t", _lib.Sorted), ("miso_align_pair_t", _lib.AlignPair), ("miso_align_t", _lib.Align),
-             ("miso_lm_track_t", _lib.LmTrack), ("miso_track_adam_t", _lib.TrackAdam)]
+             ("miso_lm_track_t", _lib.LmTrack), ("miso_track_adam_t", _lib.TrackAdam),
+             ("miso_adam_tensor_t", _lib.AdamTensor)]
     offs = [("miso_align_t", "poses_ready", _lib.Align), ("miso_align_t", "state", _lib.Align),
             ("miso_sorted_t", "pull_queue_ints", _lib.Sorted), ("miso_level_t", "grad_touched", _lib.Level)]
     body = "".join(f'  printf("%zu\\n", sizeof({n}));\n' for n, _ in names)

@@ -1398,3 +1398,40 @@ def test_round2_entry_points_on_empty_and_tiny_batches():
     dev.set_count(7)
     assert dev.step.tolist() == [7, dev.RING + 1]
     assert dev.table.shape[1] == 6 and dev.rows > 20000
+    # several tensors in one launch == one launch per tensor, bit for bit (ragged sizes, a gradient cleared or kept, chunks
+    # that never moved, a NaN guard that skips the step)
+    g = torch.Generator().manual_seed(3)
+    sizes = [70000, 4096 + 37, 64, 1 << 20]
+    def fresh():
+        ts = []
+        for i, nfl in enumerate(sizes):
+            p = torch.randn(nfl, generator=g).to(DEV)
+            gr = torch.randn(nfl, generator=g).to(DEV)
+            gr[nfl // 3: 2 * nfl // 3] = 0.0                                   # chunks without a gradient
+            m, v = torch.zeros(nfl, device=DEV), torch.zeros(nfl, device=DEV)
+            ts.append([p, gr, m, v, ops.adam_active_flags(p), i % 2 == 0])
+        return ts
+    g.manual_seed(3)
+    one = fresh()
+    g.manual_seed(3)
+    many = fresh()
+    devs = [ops.AdamDeviceStep(1e-3, 0.9, 0.999, 1e-8, DEV, count=0) for _ in range(2)]
+    packed = devs[1].multi([tuple(t) for t in many])
+    for it, guard_val in enumerate((0.5, 0.25, float("nan"), 0.125)):
+        guard = torch.full((1,), guard_val, device=DEV)
+        for d_ in devs:
+            d_.bump(guard)
+        for p, gr, m, v, act, zero in one:
+            devs[0].step_(p, gr, m, v, act, zero_grad=zero, guard=guard)
+        devs[1].step_multi_(packed, guard=guard)
+        for a_, b_ in zip(one, many):
+            for x_, y_ in zip(a_[:5], b_[:5]):
+                assert torch.equal(x_, y_)
+            if not a_[5]:      # a gradient that was kept: give both the next step's
+                new = torch.randn(a_[1].shape, generator=g).to(DEV)
+                a_[1].copy_(new), b_[1].copy_(new)
+            else:
+                assert int((a_[1] != 0).sum()) == 0
+                new = torch.randn(a_[1].shape, generator=g).to(DEV)
+                a_[1].copy_(new), b_[1].copy_(new)
+    assert devs[0].step.tolist()[0] == 3 and float(one[0][2].abs().sum()) > 0
