@@ -1372,6 +1372,14 @@ def test_round2_entry_points_on_empty_and_tiny_batches():
     e3, e4 = torch.empty(0, 3, device=DEV), torch.empty(0, 4, device=DEV)
     ops.mapping_batch(R, t, table, torch.empty(0, 1, dtype=torch.int64, device=DEV), e3, torch.empty(0, 1, device=DEV),
                       None, None, None, e3.clone(), e4, sanitize=True)
+
+
+@pytest.mark.gpu
+def test_adam_device_step_host_ring_and_multi_tensor_launch():
+    """ops.AdamDeviceStep: the loss total + step count launch (a NaN total leaves the count alone; the total reaches the
+    host through the pinned ring, each slot tagged with the number of the launch that wrote it -- what the trainer's NaN
+    guard polls instead of copying), and several tensors stepped by ONE launch equal one launch per tensor bit for bit."""
+    from miso_amd import ops
     # loss total + step count: a NaN total leaves the count alone
     dev = ops.AdamDeviceStep(1e-3, 0.9, 0.999, 1e-8, DEV, count=3)
     tot = torch.zeros((), device=DEV)
