@@ -67,9 +67,14 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
   for (int i = 0; i < 9; ++i) { Rs[i] = pose_s[i]; Rd[i] = pose_d[i]; }
 #pragma unroll
   for (int i = 0; i < 3; ++i) { ts[i] = pose_s[9 + i]; td[i] = pose_d[9 + i]; }
-  float acc[23];
+  // per lane: {term, in-bound count, G = sum g_q (3), S = sum p (x) g_q (9)}.  The two 3x3 sums the iteration needs --
+  // sum d (x) g_q with d = Rs p + ts - td, and sum (Rd g_q) (x) p -- are linear in S and G: Rs S + (ts - td) (x) G and
+  // Rd S^T, formed once per workgroup in double below.  (Accumulating both per vertex was 18 more multiply-adds, the
+  // product Rd g_q, and 9 more live accumulators in a kernel at its 128-register budget.)
+  constexpr int NACC = 14;
+  float acc[NACC];
 #pragma unroll
-  for (int i = 0; i < 23; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
 
   // Two passes per chunk, per wavefront.  Under a perturbed pose only a fraction of a source submap lands inside the
   // destination (cfg-4: 21 % of the level-1 vertices), and the heavy part -- 8 corner gathers per level, the source
@@ -140,6 +145,8 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
     const float blo[3] = {sc(g.bmin[0] - slack), sc(g.bmin[1] - slack), sc(g.bmin[2] - slack)};
     const float bhi[3] = {sc(g.bmax[0] + slack), sc(g.bmax[1] + slack), sc(g.bmax[2] + slack)};
     int n_in = 0;
+    // (this wavefront's vertices through 32-bit offsets from wave-uniform bases: a 64-bit index per vertex is a
+    // v_mad_u64_u32 -- quarter rate -- per address)
 #pragma unroll
     for (int u = 0; u < PAIR_K; ++u) {
       const int64_t i = w0 + u * 64 + lane_;
@@ -186,7 +193,10 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
     for (int pass = (k.loss_type == 1 ? 0 : 1); pass < 2; ++pass) {
       float ss = 0.0f;
       for (int l = 0; l < g.n_levels; ++l) {
-        const LevelK& lv = g.lv[l];
+        // the level's record by VALUE: one batch of scalar loads at the head of the level (the plan lives in device memory;
+        // through a reference every field was fetched where it is used, a dependent scalar round trip each: 0.651 ->
+        // 0.632 ms per cfg-4 level-1 iteration)
+        const LevelK lv = g.lv[l];
         Axis ax = axis_from_norm(xn[0], mn[0], lv.X, g.flags);
         Axis ay = axis_from_norm(xn[1], mn[1], lv.Y, g.flags);
         Axis az = axis_from_norm(xn[2], mn[2], lv.Z, g.flags);
@@ -198,11 +208,14 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
         // bound by the latency of its gathers and ran at two wavefronts per SIMD (225 VGPRs) with the weight form.
         int off[8];
         bool inb8[8];
+        // (the base corner's offset once, the others by additions: a 32-bit integer multiply is a quarter-rate instruction,
+        // and three per corner were 24 of them per level and vertex)
+        const int off0 = c.k0 * lv.sZ + c.j0 * lv.sY + c.i0 * lv.sX;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
           const int dx = kk & 1, dy = (kk >> 1) & 1, dz = kk >> 2;
           inb8[kk] = c.inx[dx] && c.iny[dy] && c.inz[dz] && !ign;
-          off[kk] = inb8[kk] ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+          off[kk] = inb8[kk] ? off0 + (dz ? lv.sZ : 0) + (dy ? lv.sY : 0) + (dx ? lv.sX : 0) : 0;
         }
         const float fx = c.wx[1], fy = c.wy[1], fz = c.wz[1];      // weight of the upper corner along each axis
         float ax_ = 0.f, ay_ = 0.f, az_ = 0.f;
@@ -252,17 +265,14 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
         term = ss;
       }
     }
-    // R_d g
     const float pp[3] = {px, py, pz};
-    const float h[3] = {Rd[0] * gq[0] + Rd[1] * gq[1] + Rd[2] * gq[2], Rd[3] * gq[0] + Rd[4] * gq[1] + Rd[5] * gq[2],
-                        Rd[6] * gq[0] + Rd[7] * gq[1] + Rd[8] * gq[2]};
     acc[0] += term; acc[1] += 1.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) acc[2 + a] += gq[a];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 3; ++b) { acc[5 + a * 3 + b] += d[a] * gq[b]; acc[14 + a * 3 + b] += h[a] * pp[b]; }
+      for (int b = 0; b < 3; ++b) acc[5 + a * 3 + b] += pp[a] * gq[b];
     }
     __builtin_amdgcn_wave_barrier();      // the list is rewritten by the next chunk's pass 1
   }
@@ -272,18 +282,36 @@ __device__ __forceinline__ void pair_latent_body(const GridK& g, const float* __
   // the order of the atomics changes from run to run); in double the fan-in adds nothing measurable and the result is
   // reproducible to ~1e-16.  (Shuffling doubles -- two ds_bpermute per step instead of one DPP move -- made the tail of
   // every workgroup three times as long and the level-1 pair stage 1.24 -> 1.9 ms: the tree stays fp32.)
-  __shared__ double red[4][24];
+  __shared__ double red[5][NACC + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < 23; ++i) {
+  for (int i = 0; i < NACC; ++i) {
     float v = acc[i];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if (lane == 0) red[wave][i] = (double)v;
   }
   __syncthreads();
+  if (threadIdx.x < NACC)
+    red[4][threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  __syncthreads();
   if (threadIdx.x < 23) {
-    const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (v != 0.0) atomic_add_f64(k.out + threadIdx.x, v);
+    // out[0] term, [1] count, [2..4] G, [5 + 3a + b] sum d_a g_b = (Rs S)_ab + (ts - td)_a G_b, [14 + 3a + b] sum (Rd g)_a p_b
+    // = sum_c Rd[a][c] S[b][c]
+    const double* T = red[4];
+    const int t = threadIdx.x;
+    double v;
+    if (t < 5) {
+      v = T[t];
+    } else if (t < 14) {
+      const int a = (t - 5) / 3, b = (t - 5) % 3;
+      // (the poses from memory: indexing the register copies by thread would move them into LDS for the whole kernel)
+      v = ((double)pose_s[3 * a] * T[5 + b] + (double)pose_s[3 * a + 1] * T[8 + b]) + (double)pose_s[3 * a + 2] * T[11 + b] +
+          ((double)pose_s[9 + a] - (double)pose_d[9 + a]) * T[2 + b];
+    } else {
+      const int a = (t - 14) / 3, b = (t - 14) % 3;
+      v = ((double)pose_d[3 * a] * T[5 + 3 * b] + (double)pose_d[3 * a + 1] * T[6 + 3 * b]) + (double)pose_d[3 * a + 2] * T[7 + 3 * b];
+    }
+    if (v != 0.0) atomic_add_f64(k.out + t, v);
   }
 }
 
