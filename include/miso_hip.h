@@ -366,7 +366,9 @@ int miso_overlap_count(const float* pose, const float* coords_src, int64_t n, co
  *                     NaN-skipped iterations), ring, ring row length, per-submap Adam step counts (S x int32)}.  Ring row k (ring_iters rows): {total loss, relative
  *                     pose change (inf at k = 0)} of iteration k [+ (S,4,4) poses BEFORE its step when save_poses:
  *                     iteration_results_helper, base.py:29-39].  The caller writes the initial corrections into
- *                     `params` and reads the final ones from there.
+ *                     `params` and reads the final ones from there.  Behind the ring the library keeps P int32 of its
+ *                     own (the order in which the next pair stage takes the pairs up: those with most in-bound
+ *                     vertices first -- scheduling only, zero = the list's order).
  * Once the relative change falls below rel_change_thresh (base.py:157-158) the stopped flag is set and further
  * iterations change nothing. */
 typedef struct {

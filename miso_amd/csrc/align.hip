@@ -45,7 +45,11 @@ AlignLayout align_layout(int S, int P, int ring_iters, int save_poses) {
   L.adam_t = o; o += up4(S);            // int32 per submap: Adam steps THIS submap has taken
   L.ctrl = o; o += 8;
   L.ring_row = 2 + (save_poses ? 16 * S : 0);
-  L.ring = o; o += (int64_t)ring_iters * L.ring_row;
+  L.ring = o; o += up4((int64_t)ring_iters * L.ring_row);
+  // int32 per launch slot: (pair + 1) the slot's workgroups work on, heaviest pair first (epilogue A, from the in-bound
+  // counts of the iteration before); 0 = not set yet: slot y works on pair y.  Behind everything else: the offsets the
+  // ABI publishes (miso_align_state_layout) do not move.
+  L.order = o; o += up4(P);
   L.total = o;
   return L;
 }
@@ -152,6 +156,21 @@ __global__ __launch_bounds__(EPI_A_THREADS) void align_epilogue_a_kernel(AlignK 
       s_gate[i] = gate != 0.0f;
     }
     __syncthreads();
+    if (k.P <= EPI_A_PAIRS) {
+      // the next iteration's launch order: pairs by the number of in-bound vertices they had in this one, most first (a
+      // pair's residual costs what it overlaps; with the list's own order a launch ended with its last pairs' workgroups
+      // alone on the chip).  Scheduling only: every pair's sums land in its own slot of `out` whatever the order.
+      int32_t* order = reinterpret_cast<int32_t*>(k.state + k.L.order);
+      for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        const double ci = s_out[24 * i + 1];
+        int rank = 0;
+        for (int j = 0; j < np; ++j) {
+          const double cj = s_out[24 * j + 1];
+          rank += (cj > ci || (cj == ci && j < i)) ? 1 : 0;
+        }
+        order[rank] = i + 1;
+      }
+    }
     if (s < k.S) {
       for (int i = part; i < np; i += 4) {
         const bool is_src = s_src[i] == s, is_dst = s_dst[i] == s;
@@ -289,7 +308,7 @@ __global__ __launch_bounds__(64) void align_epilogue_b_kernel(AlignK k) {
 }
 
 hipError_t launch_pair_batch(const AlignPairK*, int, int64_t, int64_t, bool, const float*, int, double*, float*,
-                             const int32_t*, int64_t, hipStream_t);
+                             const int32_t*, int64_t, const int32_t*, hipStream_t);
 
 hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, int64_t max_gate_rows, bool vec4,
                           bool poses_ready, hipStream_t s) {
@@ -297,7 +316,7 @@ hipError_t launch_align_a(const AlignK& k, int64_t max_n, int64_t max_gate_n, in
   const int32_t* stopped = reinterpret_cast<const int32_t*>(k.state + k.L.ctrl) + CTRL_STOPPED;
   hipError_t e = launch_pair_batch(k.plan, k.P, max_n, max_gate_n, vec4, k.state + k.L.pose, k.loss_type,
                                    reinterpret_cast<double*>(k.state + k.L.out), k.state + k.L.cnt, stopped,
-                                   max_gate_rows, s);
+                                   max_gate_rows, reinterpret_cast<const int32_t*>(k.state + k.L.order), s);
   if (e != hipSuccess) return e;
   align_epilogue_a_kernel<<<1, EPI_A_THREADS, 0, s>>>(k);
   return hipGetLastError();

@@ -5,7 +5,7 @@
 namespace miso {
 
 struct AlignLayout {
-  int64_t params, pose, out, cnt, pair_loss, flat, adam_m, adam_v, adam_t, ctrl, ring, ring_row, total;
+  int64_t params, pose, out, cnt, pair_loss, flat, adam_m, adam_v, adam_t, ctrl, ring, ring_row, order, total;
 };
 
 __host__ __device__ inline int64_t up4(int64_t v) { return (v + 3) / 4 * 4; }

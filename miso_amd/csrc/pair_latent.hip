@@ -544,15 +544,19 @@ template <bool VEC4>
 __global__ __launch_bounds__(256, 4) void pair_stage_kernel(const AlignPairK* __restrict__ plan,
                                                            const float* __restrict__ pose_all, int loss_type,
                                                            double* __restrict__ out_all, float* __restrict__ cnt_all,
-                                                           const int32_t* __restrict__ stopped, unsigned pair_blocks) {
+                                                           const int32_t* __restrict__ stopped, unsigned pair_blocks,
+                                                           const int32_t* __restrict__ order) {
   if (stopped && *stopped) return;
+  // launch slot blockIdx.y -> pair: heaviest first when epilogue A has ranked them (align.hip), the list's order until then
+  const int o_ = order ? order[blockIdx.y] : 0;
+  const unsigned pair = o_ > 0 ? (unsigned)(o_ - 1) : blockIdx.y;
   if (blockIdx.x >= pair_blocks) {
-    overlap_batch_body(plan, pose_all, cnt_all, blockIdx.y, blockIdx.x - pair_blocks, gridDim.x - pair_blocks);
+    overlap_batch_body(plan, pose_all, cnt_all, pair, blockIdx.x - pair_blocks, gridDim.x - pair_blocks);
     return;
   }
-  const AlignPairK& d = plan[blockIdx.y];
+  const AlignPairK& d = plan[pair];
   if ((int64_t)blockIdx.x * blockDim.x * 8 >= d.n) return;
-  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y, d.boxes};
+  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * pair, d.boxes};
   pair_latent_body<VEC4>(d.g, pose_all + 12 * d.src, pose_all + 12 * d.dst, k, blockIdx.x, pair_blocks);
 }
 
@@ -608,7 +612,7 @@ hipError_t launch_pair_latent(const GridK& g, bool vec4, const float* pose, cons
 // The pair stage of one fused alignment iteration (align.hip): overlap counts, then the pair residuals.
 hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t max_n, int64_t max_gate_n, bool vec4,
                              const float* pose_all, int loss_type, double* out_all, float* cnt_all,
-                             const int32_t* stopped, int64_t max_gate_rows, hipStream_t s) {
+                             const int32_t* stopped, int64_t max_gate_rows, const int32_t* order, hipStream_t s) {
   if (n_pairs <= 0) return hipSuccess;
   // gate workgroups per pair: point-list gates (max_gate_n: the longest list) grid-stride whatever the count, lattice
   // gates (max_gate_rows) want one workgroup per GATE_ROWS rows -- and no more: sized by the lattice's VERTEX count (4 M)
@@ -637,8 +641,8 @@ hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t ma
     if (blocks > cap) blocks = cap;
     if (gate_blocks && !split) {
       const dim3 grid(blocks + gate_blocks, (unsigned)n_pairs);
-      if (vec4) pair_stage_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, cnt_all, stopped, blocks);
-      else pair_stage_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, cnt_all, stopped, blocks);
+      if (vec4) pair_stage_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, cnt_all, stopped, blocks, order);
+      else pair_stage_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, cnt_all, stopped, blocks, order);
     } else {
       const dim3 grid(blocks, (unsigned)n_pairs);
       if (vec4) pair_latent_batch_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
