@@ -197,13 +197,13 @@ def pair_costs(grid_atlas, pairs) -> List[float]:
     return [1.0 + 30.0 * (round(f * 1024.0) / 1024.0) for f in fracs]
 
 
-# Calibration of the iteration-time estimate (1xMI355X, cfg-4: 8 ScanNet-shaped submaps, 28 pairs, profiles/r04_bench.json):
-# level 0 (0.9 M source vertices) 82 us, level 1 (112 M source vertices, 21 % in bound) 877 us per iteration.  In the cost
+# Calibration of the iteration-time estimate (1xMI355X, cfg-4: 8 ScanNet-shaped submaps, 28 pairs, profiles/r05_bench.json):
+# level 0 (0.9 M source vertices) 55 us, level 1 (112 M source vertices, 21 % in bound) 578 us per iteration.  In the cost
 # unit of pair_costs (1 per source vertex, 30 more per in-bound one) level 1 is 112e6 x (1 + 30 x 0.21) = 8.2e8 units for
-# ~800 us of pair stage: 1e-6 us per unit, on top of ~75 us that do not depend on the pair list (three launches, the
-# gate, the epilogues).  Only the first part shrinks when the pairs are dealt over ranks.
-PAIR_US_PER_UNIT = 1.0e-6
-ITERATION_FIXED_US = 75.0
+# ~530 us of pair stage: 0.65e-6 us per unit, on top of ~50 us that do not depend on the pair list (three launches, the
+# gate, the epilogues).  Only the first part shrinks when the pairs are dealt over ranks.  (Round 4: 1e-6 and 75.)
+PAIR_US_PER_UNIT = 0.65e-6
+ITERATION_FIXED_US = 50.0
 SHARD_OVERHEAD_US = 15.0       # two graph replays per iteration instead of one eighth of an 8x unrolled one, + the hook
 
 
