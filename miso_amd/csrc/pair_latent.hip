@@ -327,11 +327,14 @@ template <bool VEC4>
 __global__ __launch_bounds__(256, 4) void pair_latent_batch_kernel(const AlignPairK* __restrict__ plan,
                                                                const float* __restrict__ pose_all, int loss_type,
                                                                double* __restrict__ out_all,
-                                                               const int32_t* __restrict__ stopped) {
+                                                               const int32_t* __restrict__ stopped,
+                                                               const int32_t* __restrict__ order) {
   if (stopped && *stopped) return;
-  const AlignPairK& d = plan[blockIdx.y];
+  const int o_ = order ? order[blockIdx.y] : 0;      // launch slot -> pair, as in pair_stage_kernel
+  const unsigned pair = o_ > 0 ? (unsigned)(o_ - 1) : blockIdx.y;
+  const AlignPairK& d = plan[pair];
   if ((int64_t)blockIdx.x * blockDim.x * 8 >= d.n) return;
-  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * blockIdx.y, d.boxes};
+  PairK k{nullptr, d.p, d.fsrc, d.ld, d.n, loss_type, out_all + 24 * pair, d.boxes};
   pair_latent_body<VEC4>(d.g, pose_all + 12 * d.src, pose_all + 12 * d.dst, k, blockIdx.x, gridDim.x);
 }
 
@@ -645,8 +648,8 @@ hipError_t launch_pair_batch(const AlignPairK* plan_dev, int n_pairs, int64_t ma
       else pair_stage_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, cnt_all, stopped, blocks, order);
     } else {
       const dim3 grid(blocks, (unsigned)n_pairs);
-      if (vec4) pair_latent_batch_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
-      else pair_latent_batch_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped);
+      if (vec4) pair_latent_batch_kernel<true><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped, order);
+      else pair_latent_batch_kernel<false><<<grid, 256, 0, s>>>(plan_dev, pose_all, loss_type, out_all, stopped, order);
     }
   }
   return hipGetLastError();
