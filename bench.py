@@ -685,11 +685,13 @@ def trainer_steps(dev):
         torch.cuda.synchronize()
         import gc
         gc.disable()
-        t0 = time.perf_counter()
-        for _ in range(60):
-            tr.train_step(*batch)
-        torch.cuda.synchronize()
-        us = (time.perf_counter() - t0) / 60 * 1e6
+        us = float("inf")
+        for _ in range(3):                          # best of three loops: a one-off host hiccup once read 345 for 305 us
+            t0 = time.perf_counter()
+            for _ in range(60):
+                tr.train_step(*batch)
+            torch.cuda.synchronize()
+            us = min(us, (time.perf_counter() - t0) / 60 * 1e6)
         gc.enable()
         out[name] = {"us_per_step": us, "grid_floats": sum(f.feature.numel() for f in net.features),
                      "point_samples_per_s": n / (us * 1e-6),
