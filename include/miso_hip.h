@@ -625,13 +625,15 @@ int miso_loss_total_bump_host(const float* loss_slots, int32_t n_floats, float* 
 int miso_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint8_t* active,
                        uint8_t* touched /* or NULL */, int64_t numel, const float* table, int32_t table_len,
                        const int32_t* step, int zero_grad, const float* guard, void* stream);
-/* miso_adam_step_dev (touched == NULL) for up to MISO_ADAM_MAX_TENSORS tensors in ONE launch, each bit-identical to its
+/* miso_adam_step_dev for up to MISO_ADAM_MAX_TENSORS tensors in ONE launch, each bit-identical to its
  * own call: the levels of a grid as one optimizer.step() (grid_opt/trainer.py:217), without a launch's ramp and tail per
  * level.  `tensors` is a HOST array (copied into the kernel arguments). */
 #define MISO_ADAM_MAX_TENSORS 8
 typedef struct {
   float* param; float* grad; float* exp_avg; float* exp_avg_sq;   /* DEVICE, 16-byte aligned, numel floats each */
   uint8_t* active;                                                /* miso_adam_flag_bytes(numel) */
+  uint8_t* touched;                                               /* NULL: stepped by reading the gradient (miso_adam_active);
+                                                                     else the scatter kernels' flags, as miso_adam_touched */
   int64_t numel;
   int32_t zero_grad;
   int32_t reserved;

@@ -82,7 +82,8 @@ ADAM_MAX_TENSORS = 8
 
 class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("active", C.c_void_p), ("numel", C.c_int64), ("zero_grad", C.c_int32), ("reserved", C.c_int32)]
+                ("active", C.c_void_p), ("touched", C.c_void_p), ("numel", C.c_int64), ("zero_grad", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class RayFrames(C.Structure):

@@ -200,32 +200,6 @@ __global__ __launch_bounds__(256) void adam_active_kernel(float* __restrict__ p,
   adam_active_body<ZERO>(p, g, m, v, active, n, a, skip, wave, nwaves);
 }
 
-// Several tensors in ONE launch (miso_adam_step_dev_multi): the levels of a grid differ by a factor of eight each, and as
-// launches of their own the two coarse ones of cfg-2 are 8.5 + 13.4 us of ramp and tail for 67 MB (the fine one: 74.5 us
-// for 469 MB).  Every wavefront walks the tensors in turn, the grid sized for the largest.
-struct AdamSegK {
-  float* p; float* g; float* m; float* v;
-  unsigned char* active;
-  int64_t n;
-  int zero;
-};
-struct AdamMultiK {
-  int count;
-  AdamSegK seg[MISO_ADAM_MAX_TENSORS];
-};
-__global__ __launch_bounds__(256) void adam_active_multi_kernel(AdamMultiK k, AdamScalars a, const float* __restrict__ guard,
-                                                               AdamDevK dev) {
-  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];
-  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int t = 0; t < k.count; ++t) {
-    const AdamSegK& sg = k.seg[t];
-    if (sg.zero) adam_active_body<true>(sg.p, sg.g, sg.m, sg.v, sg.active, sg.n, a, skip, wave, nwaves);
-    else adam_active_body<false>(sg.p, sg.g, sg.m, sg.v, sg.active, sg.n, a, skip, wave, nwaves);
-  }
-}
-
 // The same step driven by flags instead of by reading the gradient (miso_adam_touched): the scatter kernels set
 // touched[c] when they put a non-zero into chunk c (common.hpp:touch_chunk), so a chunk is stepped iff
 // active[c] | touched[c].  A sparse level is latency, not bytes -- the Newer College fine level has 2.3 M flag bytes of
@@ -245,22 +219,16 @@ constexpr int ADAM_SLOTS = 4 * ADAM_LOADS;    // groups per wavefront and round
 constexpr int ADAM_TUN = 4;                   // slabs in flight per wavefront (8: 202 VGPRs and slower, 31 vs 25 us)
 
 template <bool ZERO>
-__global__ __launch_bounds__(256) void adam_touched_kernel(float* __restrict__ p, float* __restrict__ g,
-                                                          float* __restrict__ m, float* __restrict__ v,
-                                                          unsigned char* __restrict__ active,
-                                                          unsigned char* __restrict__ touched, int64_t n,
-                                                          AdamScalars a, const float* __restrict__ guard,
-                                                          AdamDevK dev) {
+__device__ __forceinline__ void adam_touched_body(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, unsigned char* __restrict__ active,
+                                                  unsigned char* __restrict__ touched, int64_t n, const AdamScalars& a,
+                                                  bool skip, int64_t wave, int64_t nwaves) {
   const int lane = threadIdx.x & 63, q = lane >> 4;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t nchunks = (n + ADAM_CHUNK - 1) / ADAM_CHUNK, nslab = n / ADAM_SLAB;
   const int64_t nwords = (nchunks + 3) / 4;                // slabs, a ragged last one included
   const int64_t ngroups = (nwords + ADAM_GROUP - 1) / ADAM_GROUP;
   uint32_t* active32 = reinterpret_cast<uint32_t*>(active);
   uint32_t* touched32 = reinterpret_cast<uint32_t*>(touched);
-  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];
-  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
   for (int64_t base = 0; base < ngroups; base += nwaves * ADAM_SLOTS) {
     uint32_t w[ADAM_LOADS], tw[ADAM_LOADS];                 // byte c of word k = chunk c of this lane's slab of load k
 #pragma unroll
@@ -347,6 +315,54 @@ __global__ __launch_bounds__(256) void adam_touched_kernel(float* __restrict__ p
   }
 }
 
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_touched_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          unsigned char* __restrict__ active,
+                                                          unsigned char* __restrict__ touched, int64_t n,
+                                                          AdamScalars a, const float* __restrict__ guard,
+                                                          AdamDevK dev) {
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];
+  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
+  adam_touched_body<ZERO>(p, g, m, v, active, touched, n, a, skip, wave, nwaves);
+}
+
+// Several tensors in ONE launch (miso_adam_step_dev_multi), each stepped by its gradient or by its `touched` flags: the
+// levels of a grid differ by a factor of eight each, and as
+// launches of their own the two coarse ones of cfg-2 are 8.5 + 13.4 us of ramp and tail for 67 MB (the fine one: 74.5 us
+// for 469 MB).  Every wavefront walks the tensors in turn, the grid sized for the largest.
+struct AdamSegK {
+  float* p; float* g; float* m; float* v;
+  unsigned char* active;
+  unsigned char* touched;      // or nullptr: the tensor is stepped by reading its gradient
+  int64_t n;
+  int zero;
+};
+struct AdamMultiK {
+  int count;
+  AdamSegK seg[MISO_ADAM_MAX_TENSORS];
+};
+__global__ __launch_bounds__(256) void adam_active_multi_kernel(AdamMultiK k, AdamScalars a, const float* __restrict__ guard,
+                                                               AdamDevK dev) {
+  if (dev.table) a = dev.table[min(max(dev.step[0], 1), dev.table_len) - 1];
+  const bool skip = guard != nullptr && !(guard[0] == guard[0]);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int t = 0; t < k.count; ++t) {
+    const AdamSegK& sg = k.seg[t];
+    if (sg.touched) {
+      if (sg.zero) adam_touched_body<true>(sg.p, sg.g, sg.m, sg.v, sg.active, sg.touched, sg.n, a, skip, wave, nwaves);
+      else adam_touched_body<false>(sg.p, sg.g, sg.m, sg.v, sg.active, sg.touched, sg.n, a, skip, wave, nwaves);
+    } else if (sg.zero) {
+      adam_active_body<true>(sg.p, sg.g, sg.m, sg.v, sg.active, sg.n, a, skip, wave, nwaves);
+    } else {
+      adam_active_body<false>(sg.p, sg.g, sg.m, sg.v, sg.active, sg.n, a, skip, wave, nwaves);
+    }
+  }
+}
+
 static AdamScalars adam_scalars(double lr, double b1, double b2, double eps, int step) {
   const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   AdamScalars a;
@@ -402,13 +418,23 @@ hipError_t launch_adam_active_multi(const miso_adam_tensor_t* t, int count, doub
     if (t[i].numel == 0) continue;
     AdamSegK& sg = k.seg[k.count++];
     sg.p = t[i].param; sg.g = t[i].grad; sg.m = t[i].exp_avg; sg.v = t[i].exp_avg_sq; sg.active = t[i].active;
+    sg.touched = t[i].touched;
     sg.n = t[i].numel; sg.zero = t[i].zero_grad;
-    most = t[i].numel > most ? t[i].numel : most;
+    // the grid each tensor would get as a launch of its own (launch_adam_active / launch_adam_touched); the largest wins
+    int64_t b;
+    if (sg.touched) {
+      const int64_t nwords = ((sg.n + ADAM_CHUNK - 1) / ADAM_CHUNK + 3) / 4;
+      const int64_t per_block = 4 * (int64_t)ADAM_SLOTS * ADAM_GROUP;
+      b = (nwords + per_block - 1) / per_block;
+    } else {
+      const int64_t nslabs = (sg.n + ADAM_SLAB - 1) / ADAM_SLAB;
+      b = (nslabs + 4 * ADAM_UN - 1) / (4 * ADAM_UN);
+    }
+    most = b > most ? b : most;
   }
   if (k.count == 0) return hipSuccess;
   const AdamDevK dev{reinterpret_cast<const AdamScalars*>(table), step_dev, table_len};
-  const int64_t nslabs = (most + ADAM_SLAB - 1) / ADAM_SLAB;
-  int64_t blocks = (nslabs + 4 * ADAM_UN - 1) / (4 * ADAM_UN);
+  int64_t blocks = most < 1 ? 1 : most;
   if (blocks > 256 * 16) blocks = 256 * 16;
   adam_active_multi_kernel<<<(unsigned)blocks, 256, 0, s>>>(k, adam_scalars(lr, b1, b2, eps, step), guard, dev);
   return hipGetLastError();

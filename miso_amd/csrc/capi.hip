@@ -982,6 +982,7 @@ static int adam_tensors_ok(const miso_adam_tensor_t* tensors, int32_t n_tensors)
     const miso_adam_tensor_t& t = tensors[i];
     if (t.numel < 0 || (t.numel > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq || !t.active))) return 0;
     if ((((uintptr_t)t.param) | ((uintptr_t)t.grad) | ((uintptr_t)t.exp_avg) | ((uintptr_t)t.exp_avg_sq)) & 15u) return 0;
+    if (t.touched && ((((uintptr_t)t.active) | ((uintptr_t)t.touched)) & 3u)) return 0;      // four flag bytes at a time
   }
   return 1;
 }

@@ -798,17 +798,23 @@ def adam_active_(param, grad, exp_avg, exp_avg_sq, active, step: int, lr: float,
 
 def adam_tensors(tensors):
     """The argument block of adam_active_multi_ / AdamDeviceStep.step_multi_ for ``tensors`` = [(param, grad, exp_avg,
-    exp_avg_sq, active, zero_grad)]: built once for buffers whose addresses do not change.  Returns (block, keep-alive)."""
+    exp_avg_sq, active, zero_grad[, touched])]: built once for buffers whose addresses do not change.  touched: the flags
+    the scatter kernels left for that gradient (adam_active_'s ``touched``), or None.  Returns (block, keep-alive)."""
     assert 1 <= len(tensors) <= _lib.ADAM_MAX_TENSORS
     arr = (_lib.AdamTensor * len(tensors))()
-    for a, (p, g, m, v, act, zero) in zip(arr, tensors):
+    for a, t7 in zip(arr, tensors):
+        p, g, m, v, act, zero = t7[:6]
+        tch = t7[6] if len(t7) > 6 else None
         _require_hip(p, g, m, v)
         for t in (g, m, v):
             assert t.shape == p.shape and t.stride() == p.stride(), "Adam state must share the param layout"
         assert act.dtype == torch.uint8 and act.numel() * _lib.ADAM_CHUNK >= p.numel()
+        if tch is not None:
+            assert tch.dtype == torch.uint8 and tch.numel() == act.numel() and tch.is_contiguous()
         a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
         a.active, a.numel, a.zero_grad = act.data_ptr(), p.numel(), int(bool(zero))
-    return arr, [t[:5] for t in tensors]
+        a.touched = None if tch is None else tch.data_ptr()
+    return arr, [tuple(t7[:5]) + ((t7[6],) if len(t7) > 6 else ()) for t7 in tensors]
 
 
 def adam_active_multi_(packed, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,

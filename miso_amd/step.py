@@ -212,19 +212,19 @@ class MappingStep:
                             self.need_levels, self.grads, touched=self.touched)
         if self.adam_device is not None:
             self.adam_device.total_and_bump(self.loss_slots, self.total)      # loss sum + step count: one launch
-            # levels stepped by their gradient (no `touched` flags) share ONE launch: as launches of their own the coarse
+            # all levels share ONE launch (each stepped by its gradient or by its `touched` flags): as launches of their own the coarse
             # levels of a pyramid are all ramp and tail (cfg-2: 8.5 + 13.4 us for 67 MB next to 74.5 us for 469 MB)
             multi = self.__dict__.get("_adam_multi")
             if multi is None:
-                dense = [(p, g, st[0], st[1], st[2], self.sorted is None or bool((self._adam_clears >> l) & 1))
+                dense = [(p, g, st[0], st[1], st[2], self.sorted is None or bool((self._adam_clears >> l) & 1), tch)
                          for l, (p, g, st, tch) in enumerate(zip(self.features, self.grads, self.adam_state, self.touched))
-                         if g is not None and tch is None]
+                         if g is not None]
                 multi = self._adam_multi = (self.adam_device.multi(dense) if 2 <= len(dense) <= ops._lib.ADAM_MAX_TENSORS
                                             and os.environ.get("MISO_ADAM_PER_LEVEL") is None else False)
             if multi:
                 self.adam_device.step_multi_(multi, guard=self.total)
             for l, (p, g, st, tch) in enumerate(zip(self.features, self.grads, self.adam_state, self.touched)):
-                if g is None or (multi and tch is None):
+                if g is None or multi:
                     continue
                 self.adam_device.step_(p, g, st[0], st[1], st[2], touched=tch, guard=self.total,
                                        zero_grad=self.sorted is None or bool((self._adam_clears >> l) & 1))
@@ -232,16 +232,16 @@ class MappingStep:
             self.t += 1
             multi = self.__dict__.get("_adam_multi")
             if multi is None:
-                dense = [(p.data, g, m, v, act, self.sorted is None)
+                dense = [(p.data, g, m, v, act, self.sorted is None, tch)
                          for p, g, m, v, act, tch in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq,
-                                                         self.active, self.touched) if g is not None and tch is None]
+                                                         self.active, self.touched) if g is not None]
                 multi = self._adam_multi = (ops.adam_tensors(dense) if 2 <= len(dense) <= ops._lib.ADAM_MAX_TENSORS
                                             and os.environ.get("MISO_ADAM_PER_LEVEL") is None else False)
             if multi:
                 ops.adam_active_multi_(multi, self.t, **self.adam)
             for p, g, m, v, act, tch in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq, self.active,
                                             self.touched):
-                if g is None or (multi and tch is None):
+                if g is None or multi:
                     continue
                 # zero_grad=True: the gradient is cleared in the same pass, so the next
                 # iteration needs no memset

@@ -1417,7 +1417,11 @@ def test_adam_device_step_host_ring_and_multi_tensor_launch():
             gr = torch.randn(nfl, generator=g).to(DEV)
             gr[nfl // 3: 2 * nfl // 3] = 0.0                                   # chunks without a gradient
             m, v = torch.zeros(nfl, device=DEV), torch.zeros(nfl, device=DEV)
-            ts.append([p, gr, m, v, ops.adam_active_flags(p), i % 2 == 0])
+            tch = None
+            if i == 3:      # the big one is stepped by `touched` flags, as the scatter kernels would have left them
+                tch = ops.adam_active_flags(p)
+                tch.copy_((gr.reshape(-1, ops._lib.ADAM_CHUNK) != 0).any(dim=1).to(torch.uint8))
+            ts.append([p, gr, m, v, ops.adam_active_flags(p), i % 2 == 0, tch])
         return ts
     g.manual_seed(3)
     one = fresh()
@@ -1429,12 +1433,14 @@ def test_adam_device_step_host_ring_and_multi_tensor_launch():
         guard = torch.full((1,), guard_val, device=DEV)
         for d_ in devs:
             d_.bump(guard)
-        for p, gr, m, v, act, zero in one:
-            devs[0].step_(p, gr, m, v, act, zero_grad=zero, guard=guard)
+        for p, gr, m, v, act, zero, tch in one:
+            devs[0].step_(p, gr, m, v, act, zero_grad=zero, guard=guard, touched=tch)
         devs[1].step_multi_(packed, guard=guard)
         for a_, b_ in zip(one, many):
             for x_, y_ in zip(a_[:5], b_[:5]):
                 assert torch.equal(x_, y_)
+            if a_[6] is not None:
+                assert torch.equal(a_[6], b_[6]) and int(a_[6].sum()) == 0      # consumed: the flags are cleared
             if not a_[5]:      # a gradient that was kept: give both the next step's
                 new = torch.randn(a_[1].shape, generator=g).to(DEV)
                 a_[1].copy_(new), b_[1].copy_(new)
@@ -1442,4 +1448,7 @@ def test_adam_device_step_host_ring_and_multi_tensor_launch():
                 assert int((a_[1] != 0).sum()) == 0
                 new = torch.randn(a_[1].shape, generator=g).to(DEV)
                 a_[1].copy_(new), b_[1].copy_(new)
+            if a_[6] is not None:      # the next step's flags for the new gradient
+                fl = (a_[1].reshape(-1, ops._lib.ADAM_CHUNK) != 0).any(dim=1).to(torch.uint8)
+                a_[6].copy_(fl), b_[6].copy_(fl)
     assert devs[0].step.tolist()[0] == 3 and float(one[0][2].abs().sum()) > 0
