@@ -694,7 +694,11 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
 // every level of an unbinned batch, perm == nullptr) are scattered from here with float atomics exactly as
 // sdf_bwd_kernel<.., true, false> does it -- per-point cell records kept in LDS from the forward's gather, lanes
 // (point slot, dx, channel) walking the chunk's d-feat tile.  dfeat_out may then be null (nothing deferred).
-template <int C, int L, int H, int NH, bool SCAT, int NW = 4>
+// HALF: 32 points per wavefront and trip instead of 64 -- lanes 32..63 mirror lanes 0..31 (the same point, the same gather),
+// only the first of the two 32-point matrix tiles is computed.  For batches that are one chunk per wavefront anyway (a
+// few thousand samples: Newer College's 6 144, the tracker's windows): the wavefront's chain of matrix instructions halves,
+// twice as many wavefronts share the batch.  Same arithmetic per point.
+template <int C, int L, int H, int NH, bool SCAT, int NW = 4, bool HALF = false>
 __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kernel(GridK g, const float* __restrict__ packed,
                                                           const float* __restrict__ x, int64_t n,
                                                           float* __restrict__ sdf, const int* __restrict__ perm,
@@ -712,7 +716,8 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + i);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hi = lane >> 5;
-  const int64_t nchunks = (n + 63) / 64;
+  constexpr int PTS = HALF ? 32 : 64;      // points per wavefront and trip
+  const int64_t nchunks = (n + PTS - 1) / PTS;
   const float* w0p = smem + pl.o_w0;
   const float* whp = smem + pl.o_wh;
   const float* b0 = smem + pl.o_b0;
@@ -734,7 +739,8 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
   ChunkSched sched(nchunks, wave, NW, true);
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     asm volatile("" ::: "memory");      // see sdf_fwd_kernel: keeps the LDS reads of weights / biases inside the loop
-    const int64_t p = chunk * 64 + lane;
+    const int64_t p = HALF ? chunk * 32 + (lane & 31) : chunk * 64 + lane;
+    const int row_l = HALF ? (lane & 31) : lane;      // this lane's row of the wavefront's LDS tile / records
     const bool valid = p < n;
     int64_t po = p;
     if (valid && perm) po = (int64_t)perm[p];
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
           // the record sdf_bwd_kernel forms from the point again: base offset, in-bound bits, the six weights
           const int flags = (c.inx[0] ? 1 : 0) | (c.inx[1] ? 2 : 0) | (c.iny[0] ? 4 : 0) | (c.iny[1] ? 8 : 0) |
                             (c.inz[0] ? 16 : 0) | (c.inz[1] ? 32 : 0);
-          int* r = rec + (lane * L + l) * REC;
+          int* r = rec + (row_l * L + l) * REC;
           *reinterpret_cast<int4*>(r) = make_int4(c.k0 * lv.sZ + c.j0 * lv.sY + c.i0 * lv.sX, flags,
                                                   __float_as_int(c.wx[1]), __float_as_int(c.wy[1]));
           *reinterpret_cast<int4*>(r + 4) = make_int4(__float_as_int(c.wz[1]), __float_as_int(c.wx[0]),
@@ -774,7 +780,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
       }
     } else if (SCAT) {
 #pragma unroll
-      for (int l = 0; l < L; ++l) rec[(lane * L + l) * REC + 1] = 0;      // a row past the batch: no corner in bound
+      for (int l = 0; l < L; ++l) rec[(row_l * L + l) * REC + 1] = 0;      // a row past the batch: no corner in bound
     }
     memory_phase(false, g.tune);
     // ================================ forward =====================================================================
@@ -790,13 +796,18 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
           for (int j = 0; j < 16; ++j) bias[r][j] = b0[32 * r + row_of(j, hi)];
 #pragma unroll
         for (int s = 0; s < KS0; ++s) {
-          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[2 * s]), __float_as_uint(f[2 * s + 1]), false, false);
-          float bt0 = __uint_as_float(sw[0]), bt1 = __uint_as_float(sw[1]);
+          float bt0, bt1 = 0.0f;
+          if (HALF) {      // both halves hold the same point: k = 0 from the low half, k = 1 from the high one
+            bt0 = hi ? f[2 * s + 1] : f[2 * s];
+          } else {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[2 * s]), __float_as_uint(f[2 * s + 1]), false, false);
+            bt0 = __uint_as_float(sw[0]); bt1 = __uint_as_float(sw[1]);
+          }
 #pragma unroll
           for (int r = 0; r < RT; ++r) {
             float a = w0p[(s * 64 + lane) * RT + r];
             buf[0][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt0, s == 0 ? bias[r] : buf[0][r][0], 0, 0, 0);
-            buf[0][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt1, s == 0 ? bias[r] : buf[0][r][1], 0, 0, 0);
+            if (!HALF) buf[0][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt1, s == 0 ? bias[r] : buf[0][r][1], 0, 0, 0);
           }
         }
       }
@@ -804,13 +815,13 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
       for (int r = 0; r < RT; ++r) {
         uint32_t m = 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < (HALF ? 1 : 2); ++t)
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
             buf[0][r][t][j] = relu1(buf[0][r][t][j]);
             push_gt0(m, buf[0][r][t][j]);
           }
-        mw[r] = m;
+        mw[r] = HALF ? (m << 16) : m;      // (tile 0's bits at 31..16 either way: mask_bit)
       }
 #pragma unroll
       for (int h = 0; h + 1 < NH; ++h) {
@@ -829,20 +840,20 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
             for (int r = 0; r < RT; ++r) {
               float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
               buf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias[r] : buf[ni][r][0], 0, 0, 0);
-              buf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias[r] : buf[ni][r][1], 0, 0, 0);
+              if (!HALF) buf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias[r] : buf[ni][r][1], 0, 0, 0);
             }
           }
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
           uint32_t m = 0;
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < (HALF ? 1 : 2); ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
               buf[ni][r][t][j] = relu1(buf[ni][r][t][j]);
               push_gt0(m, buf[ni][r][t][j]);
             }
-          mw[(h + 1) * RT + r] = m;
+          mw[(h + 1) * RT + r] = HALF ? (m << 16) : m;
         }
       }
       if (NH == 0) {
@@ -852,7 +863,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
           for (int j = 0; j < 16; ++j) {
             float wv = wo[32 * r + row_of(j, hi)];
             p0 += wv * buf[0][r][0][j];
-            p1 += wv * buf[0][r][1][j];
+            if (!HALF) p1 += wv * buf[0][r][1][j];
           }
       } else {
         constexpr int h = NH > 0 ? NH - 1 : 0, ci = h & 1;
@@ -868,29 +879,30 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
               const int ks = rp * 16 + j;
               float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
               a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias : a0, 0, 0, 0);
-              a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias : a1, 0, 0, 0);
+              if (!HALF) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias : a1, 0, 0, 0);
             }
           uint32_t m = 0, m1 = 0;
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            const float y0 = relu1(a0[j]), y1 = relu1(a1[j]);
+            const float y0 = relu1(a0[j]), y1 = HALF ? 0.0f : relu1(a1[j]);
             push_gt0(m, y0);
-            push_gt0(m1, y1);
+            if (!HALF) push_gt0(m1, y1);
             float wv = wo[32 * r + row_of(j, hi)];
             p0 += wv * y0;
-            p1 += wv * y1;
+            if (!HALF) p1 += wv * y1;
           }
           mw[(h + 1) * RT + r] = (m << 16) | m1;
         }
       }
     }
     p0 += __shfl_xor(p0, 32);
-    p1 += __shfl_xor(p1, 32);
-    const float sdf_v = (hi ? p1 : p0) + bo;
-    if (valid && sdf) sdf[po] = sdf_v;
+    if (!HALF) p1 += __shfl_xor(p1, 32);
+    const float sdf_v = ((!HALF && hi) ? p1 : p0) + bo;
+    const bool mine = !(HALF && hi);      // HALF: the high half mirrors the low one -- stored / counted once
+    if (valid && sdf && mine) sdf[po] = sdf_v;
     // ================================ loss: lane = point ============================================================
     float gl = 0.0f;
-    if (valid) {
+    if (valid && mine) {
       float gsd, gfs;
       map_loss_one(lin.p, sdf_v, l_in.x, l_in.w, l_in.y == 1.0f, lin.p.w_fs > 0.f && l_in.z == 1.0f, gsd, gfs,
                    loss_sdf, loss_fs);
@@ -899,7 +911,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     // the backward works on two tiles of 32 points, lane (hi, c) on point 32 t + c of tile t
     float ds[2];
     ds[0] = __shfl(gl, lane & 31);
-    ds[1] = __shfl(gl, 32 + (lane & 31));
+    ds[1] = HALF ? 0.0f : __shfl(gl, 32 + (lane & 31));
     // ================================ backward ======================================================================
     f32x16 df[2];
     {
@@ -910,7 +922,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
         for (int j = 0; j < 16; ++j) {
           float wv = wo[32 * r + row_of(j, hi)];
 #pragma unroll
-          for (int t = 0; t < 2; ++t) dbuf[0][r][t][j] = gate(wv * ds[t], mw[NH * RT + r], t, j);
+          for (int t = 0; t < (HALF ? 1 : 2); ++t) dbuf[0][r][t][j] = gate(wv * ds[t], mw[NH * RT + r], t, j);
         }
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh) {
@@ -919,7 +931,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int j = 0; j < 16; ++j) { dbuf[ni][r][0][j] = 0.0f; dbuf[ni][r][1][j] = 0.0f; }
+          for (int j = 0; j < 16; ++j) { dbuf[ni][r][0][j] = 0.0f; if (!HALF) dbuf[ni][r][1][j] = 0.0f; }
 #pragma unroll
         for (int rp = 0; rp < RT; ++rp)
 #pragma unroll
@@ -929,32 +941,32 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
             for (int r = 0; r < RT; ++r) {
               float a = whT[((h * KS1 + ks) * 64 + lane) * RT + r];
               dbuf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dbuf[ci][rp][0][j], dbuf[ni][r][0], 0, 0, 0);
-              dbuf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dbuf[ci][rp][1][j], dbuf[ni][r][1], 0, 0, 0);
+              if (!HALF) dbuf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dbuf[ci][rp][1][j], dbuf[ni][r][1], 0, 0, 0);
             }
           }
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < (HALF ? 1 : 2); ++t)
 #pragma unroll
             for (int j = 0; j < 16; ++j) dbuf[ni][r][t][j] = gate(dbuf[ni][r][t][j], mw[h * RT + r], t, j);
       }
       f32x16 (&d)[RT][2] = dbuf[NH & 1];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { df[0][j] = 0.0f; df[1][j] = 0.0f; }
+      for (int j = 0; j < 16; ++j) { df[0][j] = 0.0f; if (!HALF) df[1][j] = 0.0f; }
 #pragma unroll
       for (int rp = 0; rp < RT; ++rp)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           float a = w0T[(rp * 16 + j) * 64 + lane];
           df[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][0][j], df[0], 0, 0, 0);
-          df[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][1][j], df[1], 0, 0, 0);
+          if (!HALF) df[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][1][j], df[1], 0, 0, 0);
         }
     }
     // ---- d-feat rows: accumulator layout -> LDS tile -> 64 contiguous rows of the (N, F) buffer, 16-B stores --------
     memory_phase(true, g.tune);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < (HALF ? 1 : 2); ++t)
 #pragma unroll
       for (int gq = 0; gq < (F + 7) / 8; ++gq) {
         const int f0 = 8 * gq + 4 * hi;
@@ -966,9 +978,9 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!SCAT || dfeat_out) {
-      float* dst = dfeat_out + chunk * 64 * F;
-      const int64_t rows_left = n - chunk * 64;
-      for (int i = lane; i < 64 * F / 4; i += 64) {
+      float* dst = dfeat_out + chunk * PTS * F;
+      const int64_t rows_left = n - chunk * PTS;
+      for (int i = lane; i < PTS * F / 4; i += 64) {
         const int row = (i * 4) / F, col = (i * 4) % F;
         if (row < rows_left)
           *reinterpret_cast<float4*>(dst + row * F + col) = *reinterpret_cast<const float4*>(dF + row * FP + col);
@@ -979,7 +991,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
       constexpr int LPR = 2 * C, SLOTS = 64 / LPR;
       const int slot = lane / LPR, dx = (lane / C) & 1, ch = lane % C;
 #pragma unroll 1
-      for (int pg = 0; pg < (scatter_mask ? 64 / SLOTS : 0); ++pg) {
+      for (int pg = 0; pg < (scatter_mask ? PTS / SLOTS : 0); ++pg) {
         const int pt = pg * SLOTS + slot;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -1101,6 +1113,19 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
     hipError_t e8 = allow_lds((const void*)k8, lds8);
     if (e8 != hipSuccess) return e8;
     k8<<<blocks8, 512, lds8, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
+    return hipGetLastError();
+  }
+  // an unbinned batch of at most one 64-point chunk per SIMD (<= 65 536 samples): 32-point trips -- the batch is latency, not
+  // throughput, and half the matrix chain per wavefront on twice the wavefronts is what shortens it (MISO_TRAIN_NO_HALF: dev)
+  static const bool no_half = getenv("MISO_TRAIN_NO_HALF") != nullptr;
+  if (scat && !perm && !dfeat_out && nchunks <= 1024 && !no_half) {
+    const int64_t nhalf = (n + 31) / 32;
+    unsigned bh_ = (unsigned)((nhalf + 3) / 4);
+    if (bh_ > MISO_LOSS_SLOTS) bh_ = MISO_LOSS_SLOTS;
+    auto kh = sdf_train_kernel<C, L, H, NH, true, 4, true>;
+    hipError_t eh = allow_lds((const void*)kh, lds);
+    if (eh != hipSuccess) return eh;
+    kh<<<bh_, 256, lds, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
     return hipGetLastError();
   }
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
