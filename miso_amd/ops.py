@@ -925,12 +925,14 @@ def mapping_batch(R, t, table, frame_ids, coords_frame, target, valid, sign, wei
     n = x_out.shape[0]
     strides = (C.c_int64 * 4)(1, 1, 1, 1)
 
+    # (no views are formed here: a (N,1) column starts where its (N,) slice would, and this function is most of the host's
+    # work in a 6 144-sample trainer step -- every tensor view is 1 - 2 us)
     def col(c, i, dtypes=(torch.float32,)):
         if c is None:
             return None
-        if c.dim() == 2 and c.shape[1] == 1:
-            c = c[:, 0]
-        if not (c.dim() == 1 and c.shape[0] == n and c.is_cuda and c.dtype in dtypes and (n < 2 or c.stride(0) >= 0)):
+        d = c.dim()
+        if not ((d == 1 or (d == 2 and c.shape[1] == 1)) and c.shape[0] == n and c.is_cuda and c.dtype in dtypes
+                and (n < 2 or c.stride(0) >= 0)):
             raise ValueError("mapping_batch wants device columns (N,) or (N,1) of the batch's length")
         strides[i] = c.stride(0) if n > 1 else 1
         return c
@@ -938,12 +940,12 @@ def mapping_batch(R, t, table, frame_ids, coords_frame, target, valid, sign, wei
     cols = [col(target, 0), col(valid, 1, (torch.float32, torch.bool)), col(sign, 2), col(weight, 3)]
     if target is None:
         raise ValueError("mapping_batch needs the target column")
-    fid = frame_ids.reshape(-1)
-    cf = coords_frame.reshape(-1, 3)
+    fid = frame_ids if frame_ids.is_contiguous() else frame_ids.reshape(-1)
+    cf = coords_frame if coords_frame.is_contiguous() else coords_frame.reshape(-1, 3)
     if not (fid.dtype == torch.int64 and fid.is_contiguous() and fid.numel() == n and cf.is_contiguous()
-            and cf.dtype == torch.float32 and cf.shape[0] == n and table.dtype == torch.int64 and fid.is_cuda):
+            and cf.dtype == torch.float32 and cf.numel() == 3 * n and cf.shape[-1] == 3 and table.dtype == torch.int64
+            and fid.is_cuda):
         raise ValueError("mapping_batch: frame ids int64 (N,), coords fp32 (N,3)")
-    R, t = R.detach(), t.detach()
     if not (R.is_contiguous() and t.is_contiguous() and R.dtype == torch.float32 and t.dtype == torch.float32):
         raise ValueError("mapping_batch: poses fp32 contiguous")
     _lib.check(_lib.load().miso_mapping_batch(_ptr(R), _ptr(t), R.shape[0], _ptr(table), table.numel(), _ptr(fid),
