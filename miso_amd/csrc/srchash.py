@@ -1,4 +1,4 @@
-"""sha256 over the kernel sources (file name + bytes, sorted by name): what miso_version() embeds, so that a
+"""sha256 over the kernel sources and their Makefile (file name + bytes, sorted by name): what miso_version() embeds, so that a
 stale libmiso_hip.so cannot pass for the tree it travels with (tests/test_capi_symbols.py compares)."""
 import hashlib
 import os
@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def source_files():
     files = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith((".hip", ".hpp", ".inc"))
              and f != "version.inc"]
+    files.append(os.path.join(HERE, "Makefile"))      # (per-file compiler flags are part of what the library is)
     files.append(os.path.normpath(os.path.join(HERE, "..", "..", "include", "miso_hip.h")))
     return files
 
