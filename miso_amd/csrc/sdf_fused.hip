@@ -128,6 +128,7 @@ struct PackLayout {
 };
 
 
+#ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 __global__ void mlp_pack_kernel(MlpK m, int F, int H, int NH, float* __restrict__ out) {
   PackLayout pl(F, H, NH);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,6 +174,7 @@ __global__ void mlp_pack_kernel(MlpK m, int F, int H, int NH, float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+#endif
 template <int C>
 __device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, float* f) {
   // lane-per-point gather of one level: 8 corners x C channels, channels-last.
@@ -192,6 +194,7 @@ __device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, fl
   }
 }
 
+#ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 template <int C, int L, int H, int NH>
 __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
                                                         const float* __restrict__ x, int64_t n,
@@ -676,6 +679,8 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
   }
 }
 
+#endif
+#ifdef MISO_SDF_TRAIN_TU       // (compiled into sdf_train.o, under the max-ILP machine scheduler: Makefile)
 // ---------------------------------------------------------------------------
 // Training step in ONE kernel (binned batches, frozen decoder, every level's grid gradient left to the pull / push):
 // gather -> decoder forward -> mapping loss -> decoder backward -> d-feat rows, per 64-point chunk, per wavefront.
@@ -1039,11 +1044,13 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
   }
 }
 
+#endif
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
 static hipError_t allow_lds(const void* k, size_t lds) { return allow_dynamic_lds(k, lds); }
 
+#ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 template <int C, int L, int H, int NH>
 static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
                                float* sdf, uint32_t* mask, const int* perm, const LossInK& lin, hipStream_t s) {
@@ -1092,6 +1099,8 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
 }
 
 
+#endif
+#ifdef MISO_SDF_TRAIN_TU       // (compiled into sdf_train.o, under the max-ILP machine scheduler: Makefile)
 template <int C, int L, int H, int NH>
 static hipError_t launch_train_t(const GridK& g, const float* packed, const float* x, int64_t n, float* sdf,
                                  const int* perm, const LossInK& lin, float* dfeat_out, uint32_t defer_mask, bool scat,
@@ -1138,10 +1147,12 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
   return hipGetLastError();
 }
 
+#endif
 #define MISO_FUSED_SHAPES(X) \
   X(4, 1, 32, 1) X(4, 1, 64, 1) X(4, 2, 32, 1) X(4, 2, 64, 1) X(4, 3, 64, 1) X(4, 4, 64, 1) \
   X(8, 1, 64, 1) X(8, 2, 64, 1) X(8, 3, 64, 1) X(8, 4, 64, 1) X(8, 3, 32, 1)
 
+#ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 bool fused_shape_supported(int C, int L, int H, int NH) {
 #define X(c, l, h, nh) if (C == c && L == l && H == h && NH == nh) return true;
   MISO_FUSED_SHAPES(X)
@@ -1175,6 +1186,8 @@ hipError_t launch_sdf_bwd(int C, int L, int H, int NH, const GridK& g, const flo
 }
 
 
+#endif
+#ifdef MISO_SDF_TRAIN_TU       // (compiled into sdf_train.o, under the max-ILP machine scheduler: Makefile)
 // forward + mapping loss + decoder backward of a batch in one launch (sdf_train_kernel): d-feat rows for the levels in
 // defer_mask (formed by the pull / push afterwards), float atomics for the other levels with a gradient (scat: there
 // are such levels), loss slots; sdf (caller order) optional; perm == nullptr: an unbinned batch
@@ -1190,6 +1203,8 @@ hipError_t launch_sdf_train(int C, int L, int H, int NH, const GridK& g, const f
   return hipErrorInvalidValue;
 }
 
+#endif
+#ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 hipError_t launch_mlp_pack(const MlpK& m, int F, int H, int NH, float* out, hipStream_t s) {
   PackLayout pl(F, H, NH);
   mlp_pack_kernel<<<(pl.total + 255) / 256, 256, 0, s>>>(m, F, H, NH, out);
@@ -1209,4 +1224,5 @@ int64_t sdf_train_lds_bytes(int C, int L, int H, int NH, bool scat) {
   return (int64_t)sizeof(float) * (scat ? four : (eight > four ? eight : four));
 }
 
+#endif
 }  // namespace miso
