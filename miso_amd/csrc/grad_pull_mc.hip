@@ -579,8 +579,17 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           f32x4 o = v;
           if (fl_touched && (o[0] != 0.0f || o[1] != 0.0f || o[2] != 0.0f || o[3] != 0.0f))
             *(gu8*)(fl_touched + (eo >> ADAM_CHUNK_SHIFT)) = 1;
-          if (add_mode) o += *dst;
-          *dst = o;
+          if (add_mode) {
+            o += *dst;
+            *dst = o;
+          } else {
+            // a STREAMING store (the `nt` bit): this gradient is read once, by the optimizer (itself with streaming loads,
+            // adam.hip) or by nobody (a step without one), and as ordinary stores its 76 MB per step at cfg-2 displace the
+            // feature grids the next forward gathers: headline step 143.6 -> 142.1 us, cfg-2 trainer step 245 -> 241.5, three
+            // runs each way twice (tools/experiments/pull_nt_store_r5.sh.txt).  As assembly: __builtin_nontemporal_store
+            // does not survive here -- the two branches' stores are sunk into one and the mark is dropped.
+            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
+          }
         };
 
         // one staged pair per lane, in registers until the previous chunk's MFMAs are through with the LDS area.  Two
