@@ -76,6 +76,11 @@ extern "C" {
 #define MISO_F_CROWDED 64u         /* hint: the batch crowds a few tiles (ray samples around surfaces and cameras), so
                                      miso_sdf_bwd_sorted pushes every eligible coarse level through the matrix
                                      cores whatever the average density per tile (default: from 100 samples per tile) */
+#define MISO_F_EXACT_F32 128u      /* fused encode+decoder entries (miso_sdf_*): evaluate the decoder's products as exact fp32
+                                     FMA chains on v_mfma_f32_32x32x2_f32 (rounds 1-5).  Default since round 6: every fp32 operand
+                                     as three bf16 pieces, six piece products on v_mfma_f32_32x32x16_bf16 with fp32
+                                     accumulation -- the same 2^-24 class of error against float64 (tests/test_split_precision.py),
+                                     2.7 x fewer matrix clocks.  Results of the two forms differ in the last bits. */
 #define MISO_F_GRAD_SDF_SORTED 16u  /* miso_sdf_bwd_sorted: grad_sdf is in the binned order (what
                                        miso_sdf_fwd_sorted_loss writes), not the caller's */
 #define MISO_F_GRAD_ZEROED 32u      /* with MISO_F_GRAD_OVERWRITE: the levels miso_sdf_bwd_sorted ADDS to with atomics

@@ -21,13 +21,9 @@
 // features with one v_permlane32_swap per k-pair.
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "decoder.hpp"
 
 namespace miso {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ int row_of(int j, int hi) { return (j & 3) + 8 * (j >> 2) + 4 * hi; }
 
 // Chunk schedule of the persistent waves.  Plain batches: chunk = global wave id,
 // grid-strided.  Tile-sorted batches (perm != nullptr): the chunk range is cut into 8
@@ -51,33 +47,7 @@ __device__ __forceinline__ void memory_phase(bool on, uint32_t tune) {
 #ifndef MISO_FWD_OCC
 #define MISO_FWD_OCC 2
 #endif
-
-// On gfx950 the fp32 MFMA shares the vector FMA datapath (tools/ubench/mfma_valu.hip): every VALU
-// instruction between two MFMAs costs matrix throughput, so the MLP phase is trimmed of them.
-// * ReLU on the raw bits: max_i32(bits, 0) is ONE instruction and exact (negative floats, -0 included,
-//   are negative integers); fmaxf(x, 0) costs two (a canonicalising v_max x,x first).
-// * Sign bit for the backward from the ReLU output: min_u32(bits, 1) then shift-or -- two instructions
-//   instead of compare + select + or.
-// * The bias enters as the C operand of the first MFMA of each chain (no accumulator init moves).
-// (Inline-asm variants were tried: the hazard recogniser does not see that the asm reads MFMA results,
-//  and the missing wait states returned stale accumulators.)
 #define MISO_FUSED_KERNEL_ATTR
-__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
-// y = relu1(x): bit <- (x > 0)
-// The bits are SHIFTED IN (the k-th of 32 pushes ends at bit 31 - k): y's bits are a non-negative integer, so
-// bit 31 of y + 0x7fffffff is (y != 0) and v_alignbit(m, that, 31) = (m << 1) | bit -- two instructions.  (min(y, 1)
-// << k | m is canonicalised by the compiler into compare + select + or, with a wait state after every compare.)
-__device__ __forceinline__ void push_gt0(uint32_t& m, float y) {
-  m = __builtin_amdgcn_alignbit(m, __float_as_uint(y) + 0x7fffffffu, 31);
-}
-__device__ __forceinline__ bool mask_bit(uint32_t m, int t, int j) { return (m >> (31 - (t * 16 + j))) & 1u; }
-// mask_bit ? x : 0 as v_bfe_i32 (the bit, sign-extended: 0 or ~0) + v_and -- the select form costs and + compare +
-// select and a wait state per element
-__device__ __forceinline__ float gate(float x, uint32_t m, int t, int j) {
-  int e = __builtin_amdgcn_sbfe((int)m, 31 - (t * 16 + j), 1);
-  asm("" : "+v"(e));      // opaque: and(x, sext(bit)) would be folded back into compare + select
-  return __uint_as_float(__float_as_uint(x) & (uint32_t)e);
-}
 
 struct ChunkSched {
   int64_t cur, end, step;
@@ -98,41 +68,49 @@ struct ChunkSched {
   }
 };
 
-// ---------------------------------------------------------------------------
-// Packed decoder layout (floats).  RT = H/32 row tiles, KS0 = ceil(F/2),
-// KS1 = H/2 k-steps for an HxH layer, NH hidden (HxH) layers.
-//   fwd: W0p [KS0][64][RT]   A(l) = W0[32r + (l&31)][2s + (l>>5)]
-//        Whp [NH][KS1][64][RT] A(l) = Wh[32r + (l&31)][32rp + row_of(j, l>>5)], ks = 16rp + j
-//        b0 [H], bh [NH][H], wo [H], bo [4]
-//   bwd: WhTp [NH][KS1][64][RT] A(l) = Wh[32rp + row_of(j, l>>5)][32r + (l&31)]
-//        W0Tp [KS1][64]         A(l) = W0[32rp + row_of(j, l>>5)][l&31]   (0 for l&31 >= F)
-// ---------------------------------------------------------------------------
-struct PackLayout {
-  int F, H, NH, RT, KS0, KS1;
-  int o_w0, o_wh, o_b0, o_bh, o_wo, o_bo, fwd_end;
-  int o_whT, o_w0T, total;
-  __host__ __device__ PackLayout(int F_, int H_, int NH_) {
-    F = F_; H = H_; NH = NH_; RT = H / 32; KS0 = (F + 1) / 2; KS1 = H / 2;
-    int o = 0;
-    o_w0 = o; o += KS0 * 64 * RT;
-    o_wh = o; o += NH * KS1 * 64 * RT;
-    o_b0 = o; o += H;
-    o_bh = o; o += NH * H;
-    o_wo = o; o += H;
-    o_bo = o; o += 4;
-    fwd_end = o;
-    o_whT = o; o += NH * KS1 * 64 * RT;
-    o_w0T = o; o += KS1 * 64;
-    total = o;
-  }
-};
-
+// (packed decoder layout: decoder.hpp)
 
 #ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 __global__ void mlp_pack_kernel(MlpK m, int F, int H, int NH, float* __restrict__ out) {
   PackLayout pl(F, H, NH);
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= pl.total) return;
+  if (i >= pl.total_all) return;
+  if (i >= pl.total) {
+    // ---- bf16x3 section (decoder.hpp): dword i holds elements 2e, 2e+1 of piece q of one lane's A operand -----------------
+    const float* w0 = m.w[0];
+    const float* wo = m.w[1 + NH];
+    int e = i, rt_m = pl.RT, kind = 0, h = 0;      // kind 0: W0 fwd, 1: Wh[h] fwd, 2: first backward product, 3: Wh[h]^T, 4: W0^T
+    if (i < pl.s_wh) { e -= pl.s_w0; kind = 0; }
+    else if (i < pl.s_fwd_end) { e -= pl.s_wh; kind = 1; h = e / split_matrix_dwords(pl.KBH, pl.RT); e %= split_matrix_dwords(pl.KBH, pl.RT); }
+    else if (i < pl.s_whT) { e -= pl.s_bfirst; kind = 2; if (NH == 0) rt_m = 1; }
+    else if (i < pl.s_w0T) { e -= pl.s_whT; kind = 3; h = e / split_matrix_dwords(pl.KBH, pl.RT); e %= split_matrix_dwords(pl.KBH, pl.RT); }
+    else { e -= pl.s_w0T; kind = 4; rt_m = 1; }
+    const int d = e & 3, lane = (e >> 2) & 63, q = (e >> 8) % 3, kr = (e >> 8) / 3, r = kr % rt_m, kb = kr / rt_m;
+    uint32_t word = 0;
+    for (int half = 0; half < 2; ++half) {
+      const int el = 2 * d + half, hi = lane >> 5, row = 32 * r + (lane & 31);
+      float v = 0.0f;
+      if (kind == 0) {
+        const int k = split_k_feat(kb, hi, el);
+        v = (k < F) ? w0[row * F + k] : 0.0f;
+      } else if (kind == 1) {
+        v = m.w[1 + h][row * H + split_k_acc(kb, hi, el)];
+      } else if (kind == 2) {
+        const int mm = split_k_acc(kb, hi, el);      // the neuron of the last ReLU this element multiplies
+        if (NH >= 1) v = __fmul_rn(m.w[NH][mm * H + row], wo[mm]);
+        else v = (row < F) ? __fmul_rn(w0[mm * F + row], wo[mm]) : 0.0f;
+      } else if (kind == 3) {
+        v = m.w[1 + h][split_k_acc(kb, hi, el) * H + row];
+      } else {
+        v = (row < F) ? w0[split_k_acc(kb, hi, el) * F + row] : 0.0f;
+      }
+      uint32_t pc[3];
+      bf16_split3(v, pc);
+      word |= pc[q] << (16 * half);
+    }
+    reinterpret_cast<uint32_t*>(out)[i] = word;
+    return;
+  }
   float v = 0.0f;
   const int RT = pl.RT;
   if (i < pl.o_wh) {  // W0p
@@ -195,7 +173,7 @@ __device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, fl
 }
 
 #ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
-template <int C, int L, int H, int NH>
+template <int C, int L, int H, int NH, bool SPLIT>
 __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
                                                         const float* __restrict__ x, int64_t n,
                                                         float* __restrict__ sdf,
@@ -210,8 +188,18 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
   constexpr int MW = (NH + 1) * RT;  // mask words per lane
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PackLayout pl(F, H, NH);
-  for (int i = threadIdx.x * 4; i < pl.fwd_end; i += blockDim.x * 4)
-    *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + i);
+  // LDS: the exact form stages the fp32 forward pack [0, fwd_end); the split form the bf16x3 forward block
+  // [s_w0, s_fwd_end) followed by the biases and output weights [o_b0, fwd_end)
+  const int n_split = pl.s_fwd_end - pl.s_w0;
+  if (SPLIT) {
+    for (int i = threadIdx.x * 4; i < n_split; i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + pl.s_w0 + i);
+    for (int i = threadIdx.x * 4; i < pl.n_bias(); i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(smem + n_split + i) = *reinterpret_cast<const float4*>(packed + pl.o_b0 + i);
+  } else {
+    for (int i = threadIdx.x * 4; i < pl.fwd_end; i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + i);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hi = lane >> 5;
   const int64_t nchunks = (n + 63) / 64;
@@ -220,7 +208,9 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
   const float* b0 = smem + pl.o_b0;
   const float* bh = smem + pl.o_bh;
   const float* wo = smem + pl.o_wo;
-  const float bo = smem[pl.o_bo];
+  const uint32_t* s_fwd = reinterpret_cast<const uint32_t*>(smem);      // SPLIT
+  const float* s_bias = smem + n_split;                                 // SPLIT
+  const float bo = SPLIT ? s_bias[pl.o_bo - pl.o_b0] : smem[pl.o_bo];
 
   float loss_sdf = 0.0f, loss_fs = 0.0f;
   float inv_n = lin.inv_n;   // mean over the batch rows -- or over the live rows of a padded batch
@@ -269,6 +259,12 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
       if (valid) sdf[perm ? (int64_t)perm[p] : p] = sum;
       continue;
     }
+    uint32_t mw[MW];
+    float p0 = 0.0f, p1 = 0.0f;
+    if constexpr (SPLIT) {
+      u32x4 no_mask[H / 16][2];
+      decoder_fwd_split<F, H, NH, false, true, false>(s_fwd, s_bias, lane, f, mw, no_mask, p0, p1);
+    } else {
     // ---- layer 0: buf[0][r][t] = b0 + W0 * feats -------------------------------
     // Two accumulator sets ping-pong between layers (ReLU is applied in place, so
     // no third copy of the 64 activation registers is ever live).
@@ -294,7 +290,6 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
         }
       }
     }
-    uint32_t mw[MW];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
       uint32_t m = 0;
@@ -344,7 +339,6 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
     // ---- last hidden layer + output layer (out_dim = 1), one 32-row tile at a time ----------
     // The last hidden activations feed only the output dot product, so each row tile is reduced
     // into (p0, p1) as soon as its MFMA chain ends: 32 accumulator registers live instead of 64.
-    float p0 = 0.0f, p1 = 0.0f;
     if (NH == 0) {
 #pragma unroll
       for (int r = 0; r < RT; ++r)
@@ -383,6 +377,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
         mw[(h + 1) * RT + r] = (m << 16) | m1;
       }
     }
+    }      // exact fp32 chains
     p0 += __shfl_xor(p0, 32);
     p1 += __shfl_xor(p1, 32);
     const float sdf_v = (hi ? p1 : p0) + bo;
@@ -422,7 +417,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
 // gradients and/or grad_x.  Lane (hi, l&31) holds, for tile t, point 32t+(l&31):
 //   C == 8: channels 4hi..4hi+3 of level j>>2      (registers j = 4*level + c)
 //   C == 4: channels 0..3 of level 2*(j>>2) + hi   (registers j = 4*g + c)
-template <int C, int L, int H, int NH, bool WANT_GRID, bool WANT_X>
+template <int C, int L, int H, int NH, bool WANT_GRID, bool WANT_X, bool SPLIT>
 __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(GridK g, const float* __restrict__ packed,
                                                         const float* __restrict__ x, int64_t n,
                                                         const float* __restrict__ gsdf,
@@ -440,10 +435,11 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
   constexpr int MW = (NH + 1) * RT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PackLayout pl(F, H, NH);
-  // stage wo + the transposed weights: [o_wo, o_bo) and [o_whT, total)
-  const int nb = pl.total - pl.o_whT;
+  // stage wo + the transposed weights: [o_wo, o_bo) and [o_whT, total); the split form its backward block
+  // [s_bfirst, total_all) (the output weights are folded into its first matrix; the H floats behind it stay unused)
+  const int nb = SPLIT ? pl.total_all - pl.s_bfirst : pl.total - pl.o_whT;
   for (int i = threadIdx.x * 4; i < nb; i += blockDim.x * 4)
-    *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + pl.o_whT + i);
+    *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + (SPLIT ? pl.s_bfirst : pl.o_whT) + i);
   for (int i = threadIdx.x; i < H; i += blockDim.x) smem[nb + i] = packed[pl.o_wo + i];
   __syncthreads();
   const float* whT = smem;
@@ -478,6 +474,12 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
 #pragma unroll
       for (int i = 0; i < MW; ++i) mw[i] = mi[i];
     }
+    f32x16 df[2];
+    if constexpr (SPLIT) {
+      u32x4 maskB[H / 16][2];
+      mask_operand_from_bits<H, NH, false>(mw, maskB);
+      decoder_bwd_split<F, H, NH, false>(reinterpret_cast<const uint32_t*>(smem), lane, maskB, mw, ds, df);
+    } else {
     // d(last hidden) = wo * ds, gated.  Two accumulator sets ping-pong.
     f32x16 dbuf[2][RT][2];
 #pragma unroll
@@ -519,7 +521,6 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
     }
     f32x16 (&d)[RT][2] = dbuf[NH & 1];
     // d feats = W0^T d   (one 32-row tile; rows >= F are zero)
-    f32x16 df[2];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { df[0][j] = 0.0f; df[1][j] = 0.0f; }
 #pragma unroll
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
         df[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][0][j], df[0], 0, 0, 0);
         df[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, d[rp][1][j], df[1], 0, 0, 0);
       }
+    }      // exact fp32 chains
     // ---- scatter into the level gradients ----------------------------------------
     // The L2 executes fp32 atomics per 64-byte request (~21 G requests/s on MI355X,
     // tools/ubench/atomics.hip), however many of its 16 dwords carry data.  So the
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
 // only the first of the two 32-point matrix tiles is computed.  For batches that are one chunk per wavefront anyway (a
 // few thousand samples: Newer College's 6 144, the tracker's windows): the wavefront's chain of matrix instructions halves,
 // twice as many wavefronts share the batch.  Same arithmetic per point.
-template <int C, int L, int H, int NH, bool SCAT, int NW = 4, bool HALF = false>
+template <int C, int L, int H, int NH, bool SCAT, int NW = 4, bool HALF = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kernel(GridK g, const float* __restrict__ packed,
                                                           const float* __restrict__ x, int64_t n,
                                                           float* __restrict__ sdf, const int* __restrict__ perm,
@@ -716,9 +718,19 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
   constexpr int WAVE_LDS = 64 * FP + (SCAT ? 64 * L * REC : 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PackLayout pl(F, H, NH);
-  // the whole pack: forward part [0, fwd_end), transposed weights [o_whT, total) right behind it
-  for (int i = threadIdx.x * 4; i < pl.total; i += blockDim.x * 4)
-    *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + i);
+  // the whole pack: forward part [0, fwd_end), transposed weights [o_whT, total) right behind it; the split form: the
+  // bf16x3 section [s_w0, total_all), then the biases and output weights [o_b0, fwd_end)
+  const int n_split = pl.total_all - pl.s_w0;
+  const int n_pack = SPLIT ? n_split + ((pl.n_bias() + 3) / 4) * 4 : ((pl.total + 3) / 4) * 4;
+  if (SPLIT) {
+    for (int i = threadIdx.x * 4; i < n_split; i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + pl.s_w0 + i);
+    for (int i = threadIdx.x * 4; i < pl.n_bias(); i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(smem + n_split + i) = *reinterpret_cast<const float4*>(packed + pl.o_b0 + i);
+  } else {
+    for (int i = threadIdx.x * 4; i < pl.total; i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(smem + i) = *reinterpret_cast<const float4*>(packed + i);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hi = lane >> 5;
   constexpr int PTS = HALF ? 32 : 64;      // points per wavefront and trip
@@ -728,10 +740,13 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
   const float* b0 = smem + pl.o_b0;
   const float* bh = smem + pl.o_bh;
   const float* wo = smem + pl.o_wo;
-  const float bo = smem[pl.o_bo];
+  const uint32_t* s_fwd = reinterpret_cast<const uint32_t*>(smem);                                   // SPLIT
+  const uint32_t* s_bwd = reinterpret_cast<const uint32_t*>(smem) + (pl.s_bfirst - pl.s_w0);        // SPLIT
+  const float* s_bias = smem + n_split;                                                              // SPLIT
+  const float bo = SPLIT ? s_bias[pl.o_bo - pl.o_b0] : smem[pl.o_bo];
   const float* whT = smem + pl.o_whT;
   const float* w0T = smem + pl.o_w0T;
-  float* dF = smem + ((pl.total + 3) / 4) * 4 + wave * WAVE_LDS;       // this wavefront's d-feat tile [64][FP]
+  float* dF = smem + n_pack + wave * WAVE_LDS;       // this wavefront's d-feat tile [64][FP]
   int* rec = reinterpret_cast<int*>(dF + 64 * FP);                      // SCAT: its cell records [64][L][REC]
   uint32_t scatter_mask = 0;
   if (SCAT)
@@ -791,7 +806,10 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     // ================================ forward =====================================================================
     uint32_t mw[MW];
     float p0 = 0.0f, p1 = 0.0f;
-    {
+    u32x4 maskB[H / 16][HALF ? 1 : 2];      // SPLIT: the last ReLU's mask as the first backward product's B operand
+    if constexpr (SPLIT) {
+      decoder_fwd_split<F, H, NH, HALF, false, true>(s_fwd, s_bias, lane, f, mw, maskB, p0, p1);
+    } else {
       f32x16 buf[2][RT][2];
       {
         f32x16 bias[RT];
@@ -919,7 +937,9 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     ds[1] = HALF ? 0.0f : __shfl(gl, 32 + (lane & 31));
     // ================================ backward ======================================================================
     f32x16 df[2];
-    {
+    if constexpr (SPLIT) {
+      decoder_bwd_split<F, H, NH, HALF>(s_bwd, lane, maskB, mw, ds, df);
+    } else {
       f32x16 dbuf[2][RT][2];
 #pragma unroll
       for (int r = 0; r < RT; ++r)
@@ -1050,17 +1070,25 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
 // ---------------------------------------------------------------------------
 static hipError_t allow_lds(const void* k, size_t lds) { return allow_dynamic_lds(k, lds); }
 
+// Decoder arithmetic of a launch: bf16x3 split products (default) or the exact fp32 chains (MISO_F_EXACT_F32 in the grid's
+// flags; MISO_EXACT_F32=1 in the environment forces it for a whole process -- dev A/B)
+static bool use_split(const GridK& g) {
+  static const bool env_exact = [] { const char* e = getenv("MISO_EXACT_F32"); return e && atoi(e) != 0; }();
+  return !(g.flags & MISO_F_EXACT_F32) && !env_exact;
+}
+
 #ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 template <int C, int L, int H, int NH>
 static hipError_t launch_fwd_t(const GridK& g, const float* packed, const float* x, int64_t n,
                                float* sdf, uint32_t* mask, const int* perm, const LossInK& lin, hipStream_t s) {
   PackLayout pl(C * L, H, NH);
-  size_t lds = (size_t)((pl.fwd_end + 3) / 4 * 4) * sizeof(float);
+  const bool split = use_split(g);
+  size_t lds = (size_t)(split ? pl.s_fwd_end - pl.s_w0 + (pl.n_bias() + 3) / 4 * 4 : (pl.fwd_end + 3) / 4 * 4) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   if (blocks > 512u) blocks = 512u;      // persistent: two workgroups per CU
   if (lin.p.loss_type && blocks > MISO_LOSS_SLOTS) blocks = MISO_LOSS_SLOTS;   // one loss slot per block
-  auto k = sdf_fwd_kernel<C, L, H, NH>;
+  auto k = split ? sdf_fwd_kernel<C, L, H, NH, true> : sdf_fwd_kernel<C, L, H, NH, false>;
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
   k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, mask, perm, lin);
@@ -1077,8 +1105,9 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   bool lean = want_grid && !gx && dfeat_out != nullptr;      // every gradient level deferred to the pull?
   for (int l = 0; l < L && lean; ++l)
     if (g.lv[l].grad && !((g.ignore_mask >> l) & 1u) && !((defer_mask >> l) & 1u)) lean = false;
-  size_t lds = (size_t)(((pl.total - pl.o_whT + H + 3) / 4) * 4 + (want_grid ? 4 * (lean ? 64 * FP : WAVE_LDS) : 0)) *
-               sizeof(float);
+  const bool split = use_split(g);
+  const int nb = split ? pl.total_all - pl.s_bfirst : pl.total - pl.o_whT;
+  size_t lds = (size_t)(((nb + H + 3) / 4) * 4 + (want_grid ? 4 * (lean ? 64 * FP : WAVE_LDS) : 0)) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   const unsigned use_cap = lean ? 768u : 512u;
@@ -1089,9 +1118,12 @@ static hipError_t launch_bwd_t(const GridK& g, const float* packed, const float*
   if (lean) debug |= 32;
   void (*k)(GridK, const float*, const float*, int64_t, const float*, const uint32_t*, float*, const int*, int,
             float*, uint32_t) =
-      (want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true>
-      : want_grid       ? sdf_bwd_kernel<C, L, H, NH, true, false>
-                        : sdf_bwd_kernel<C, L, H, NH, false, true>;
+      split ? ((want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true, true>
+               : want_grid       ? sdf_bwd_kernel<C, L, H, NH, true, false, true>
+                                 : sdf_bwd_kernel<C, L, H, NH, false, true, true>)
+            : ((want_grid && gx) ? sdf_bwd_kernel<C, L, H, NH, true, true, false>
+               : want_grid       ? sdf_bwd_kernel<C, L, H, NH, true, false, false>
+                                 : sdf_bwd_kernel<C, L, H, NH, false, true, false>);
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
   k<<<blocks, 256, lds, s>>>(g, packed, x, n, gsdf, mask, gx, perm, debug, dfeat_out, defer_mask);
@@ -1107,7 +1139,9 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
                                  hipStream_t s) {
   PackLayout pl(C * L, H, NH);
   constexpr int F = C * L, FP = ((F + 3) / 4) * 4 + 4;
-  size_t lds = (size_t)(((pl.total + 3) / 4) * 4 + 4 * (64 * FP + (scat ? 64 * L * 8 : 0))) * sizeof(float);
+  const bool split = use_split(g);
+  const int n_pack = split ? pl.total_all - pl.s_w0 + ((pl.n_bias() + 3) / 4) * 4 : ((pl.total + 3) / 4) * 4;
+  size_t lds = (size_t)(n_pack + 4 * (64 * FP + (scat ? 64 * L * 8 : 0))) * sizeof(float);
   int64_t nchunks = (n + 63) / 64;
   // Nothing scattered from the kernel (the mapping step): ONE workgroup of eight wavefronts per CU instead of two of
   // four -- the same two wavefronts per SIMD, half the copies of the 48 KB pack out of L2 at the start of the launch,
@@ -1115,10 +1149,10 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
   // The scattering variant keeps four: its cell records would not fit beside eight d-feat tiles.
   static const bool nw8 = getenv("MISO_TRAIN_NW4") == nullptr;
   if (nw8 && !scat) {
-    size_t lds8 = (size_t)(((pl.total + 3) / 4) * 4 + 8 * 64 * FP) * sizeof(float);
+    size_t lds8 = (size_t)(n_pack + 8 * 64 * FP) * sizeof(float);
     unsigned blocks8 = (unsigned)((nchunks + 7) / 8);
     if (blocks8 > 256u) blocks8 = 256u;
-    auto k8 = sdf_train_kernel<C, L, H, NH, false, 8>;
+    auto k8 = split ? sdf_train_kernel<C, L, H, NH, false, 8, false, true> : sdf_train_kernel<C, L, H, NH, false, 8, false, false>;
     hipError_t e8 = allow_lds((const void*)k8, lds8);
     if (e8 != hipSuccess) return e8;
     k8<<<blocks8, 512, lds8, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
@@ -1131,7 +1165,7 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
     const int64_t nhalf = (n + 31) / 32;
     unsigned bh_ = (unsigned)((nhalf + 3) / 4);
     if (bh_ > MISO_LOSS_SLOTS) bh_ = MISO_LOSS_SLOTS;
-    auto kh = sdf_train_kernel<C, L, H, NH, true, 4, true>;
+    auto kh = split ? sdf_train_kernel<C, L, H, NH, true, 4, true, true> : sdf_train_kernel<C, L, H, NH, true, 4, true, false>;
     hipError_t eh = allow_lds((const void*)kh, lds);
     if (eh != hipSuccess) return eh;
     kh<<<bh_, 256, lds, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
@@ -1140,7 +1174,8 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
   if (blocks > 512u) blocks = 512u;      // persistent: two workgroups per CU (256 .. 1024 measured: 512 and up equal)
   if (blocks > MISO_LOSS_SLOTS) blocks = MISO_LOSS_SLOTS;   // one loss slot per block
-  auto k = scat ? sdf_train_kernel<C, L, H, NH, true> : sdf_train_kernel<C, L, H, NH, false>;
+  auto k = split ? (scat ? sdf_train_kernel<C, L, H, NH, true, 4, false, true> : sdf_train_kernel<C, L, H, NH, false, 4, false, true>)
+                 : (scat ? sdf_train_kernel<C, L, H, NH, true, 4, false, false> : sdf_train_kernel<C, L, H, NH, false, 4, false, false>);
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
   k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
@@ -1207,11 +1242,11 @@ hipError_t launch_sdf_train(int C, int L, int H, int NH, const GridK& g, const f
 #ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 hipError_t launch_mlp_pack(const MlpK& m, int F, int H, int NH, float* out, hipStream_t s) {
   PackLayout pl(F, H, NH);
-  mlp_pack_kernel<<<(pl.total + 255) / 256, 256, 0, s>>>(m, F, H, NH, out);
+  mlp_pack_kernel<<<(pl.total_all + 255) / 256, 256, 0, s>>>(m, F, H, NH, out);
   return hipGetLastError();
 }
 
-int64_t mlp_packed_floats(int F, int H, int NH) { return PackLayout(F, H, NH).total; }
+int64_t mlp_packed_floats(int F, int H, int NH) { return PackLayout(F, H, NH).total_all; }
 
 // dynamic LDS of the sdf_train_kernel launch for this shape (launch_train_t above): the pack, then per wavefront a d-feat
 // tile [64][FP] and, scattering, its cell records [64][L][8] -- four wavefronts, or eight when nothing is scattered
@@ -1219,7 +1254,9 @@ int64_t sdf_train_lds_bytes(int C, int L, int H, int NH, bool scat) {
   if (!fused_shape_supported(C, L, H, NH)) return 0;
   const PackLayout pl(C * L, H, NH);
   const int F = C * L, FP = ((F + 3) / 4) * 4 + 4;
-  const int64_t pack = ((pl.total + 3) / 4) * 4;
+  // the larger of the two decoder forms (the split pack is the larger one for every covered shape)
+  const int64_t pack_exact = ((pl.total + 3) / 4) * 4, pack_split = pl.total_all - pl.s_w0 + ((pl.n_bias() + 3) / 4) * 4;
+  const int64_t pack = pack_split > pack_exact ? pack_split : pack_exact;
   const int64_t four = pack + 4 * (64 * FP + (scat ? 64 * L * 8 : 0)), eight = pack + 8 * 64 * FP;
   return (int64_t)sizeof(float) * (scat ? four : (eight > four ? eight : four));
 }

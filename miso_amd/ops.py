@@ -46,6 +46,34 @@ class GridMeta:
 
 NORMALIZED = GridMeta((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0), 0, _lib.F_COORDS_NORMALIZED)
 
+# Decoder arithmetic of the fused encode + decoder entries (include/miso_hip.h: MISO_F_EXACT_F32).  Default: bf16x3 split
+# products with fp32 accumulation; exact_fp32(True) makes every later call of this process use the exact fp32 chains of
+# rounds 1-5 (a launch captured in a HIP graph keeps the form it was captured with).  A single submap can ask for the exact
+# form through GridMeta.flags | F_EXACT_F32 as well.
+_EXACT_F32 = False
+
+
+def set_exact_fp32(on: bool) -> bool:
+    """Switch the decoder arithmetic for all later fused calls; returns the previous setting."""
+    global _EXACT_F32
+    prev, _EXACT_F32 = _EXACT_F32, bool(on)
+    return prev
+
+
+class exact_fp32:
+    """with ops.exact_fp32(): ... -- the exact fp32 decoder chains inside the block."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = set_exact_fp32(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        set_exact_fp32(self.prev)
+        return False
+
 
 def _require_hip(*tensors):
     for t in tensors:
@@ -78,7 +106,7 @@ def _fill_grid(features: Sequence[torch.Tensor], meta: GridMeta,
     g = _lib.Grid()
     g.n_levels = len(features)
     g.ignore_mask = meta.ignore_mask
-    g.flags = meta.flags
+    g.flags = meta.flags | (_lib.F_EXACT_F32 if _EXACT_F32 else 0)
     for a in range(3):
         g.bound_min[a] = meta.bound_min[a]
         g.bound_max[a] = meta.bound_max[a]

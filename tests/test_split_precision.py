@@ -1,0 +1,126 @@
+"""Admissibility of the split-precision decoder (round 6).
+
+The fused kernels evaluate the decoder's products as bf16x3 pieces on v_mfma_f32_32x32x16_bf16 (miso_amd/csrc/
+mlp_split.hpp) unless MISO_F_EXACT_F32 asks for the exact fp32 FMA chains of rounds 1-5.  `dtype` stays "f32" only if the
+split form is as good an fp32 evaluation as the exact one.  The bar: against the FLOAT64 oracle, the split
+kernel's max and mean error is at most 2x the exact-fp32 kernel's own error against float64 -- for the SDF, the
+coordinate gradient (a per-point linear image of the d-feat rows) and the grid gradients -- on the decoder / grid shapes
+of BASELINE cfg-1, 2, 3 and 5 (cfg-4, the alignment, has no decoder in its path).
+
+Two kinds of inputs:
+ * "dyadic": power-of-two grids on [-1,1]^3, points on a 2^-9 lattice and grid values with 8 significant bits, so that the
+   trilinear encode is EXACT in fp32 and in fp64 alike: what is compared is the decoder arithmetic alone;
+ * the configs' real shapes at uniform random points (the encode's own fp32 rounding is then common to both forms).
+ReLU ties: a point whose pre-activation lies within rounding of zero may be gated differently by ANY two fp32
+evaluations (tests/test_config_shapes.py::test_full_size_cfg2_gradient_outliers_are_relu_ties); such points (float64
+census) carry a zero cotangent here.
+Arithmetic compared: grid_opt/models/modules.py:11-32 (MLPNet), grid_opt/models/grid_net.py:306-325.
+"""
+import pytest
+import torch
+
+from oracle import ref_torch as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N = 65536
+TIE = 1e-6
+
+# (name, level sizes (Z,Y,X) or cells, C, H, bound, dyadic)
+SHAPES = [
+    ("cfg1_dyadic", [(64, 64, 64)], 4, 32, [[-1.0, 1.0]] * 3, True),
+    ("cfg2_dyadic", [(32, 32, 32), (64, 64, 64), (128, 128, 128)], 8, 64, [[-1.0, 1.0]] * 3, True),
+    ("cfg3_dyadic", [(32, 16, 32), (128, 64, 128)], 4, 64, [[-1.0, 1.0]] * 3, True),
+    ("cfg5_dyadic", [(16, 16, 16), (32, 32, 32), (64, 64, 64), (128, 128, 128)], 8, 64, [[-1.0, 1.0]] * 3, True),
+    ("cfg2", [(32, 32, 32), (64, 64, 64), (128, 128, 128)], 8, 64, [[-1.0, 1.0]] * 3, False),
+    ("cfg3", [(40, 20, 40), (200, 100, 200)], 4, 64, [[-10.0, 10.0], [-5.0, 5.0], [-10.0, 10.0]], False),
+    ("cfg5", [(10, 30, 30), (20, 60, 60), (40, 120, 120), (80, 240, 240)], 8, 64,
+     [[-30.0, 30.0], [-30.0, 30.0], [-5.0, 15.0]], False),
+]
+
+
+def _inputs(levels, C, H, bound, dyadic, seed):
+    gen = torch.Generator().manual_seed(seed)
+    b = torch.tensor(bound, dtype=torch.float32)
+    if dyadic:
+        x = torch.randint(-511, 512, (N, 3), generator=gen).float() / 512.0
+        feats = [torch.randint(-128, 128, (1, C) + tuple(s), generator=gen).float() / 4096.0 for s in levels]
+    else:
+        x = b[:, 0] + (b[:, 1] - b[:, 0]) * torch.rand(N, 3, generator=gen)
+        feats = [torch.randn((1, C) + tuple(s), generator=gen) * 3e-2 for s in levels]
+    F_ = C * len(levels)
+    torch.manual_seed(seed)
+    lin = [torch.nn.Linear(F_, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    ws = [l.weight.detach().clone() for l in lin]
+    bs = [l.bias.detach().clone() for l in lin]
+    ws[0] = ws[0] * 8.0          # pre-activations of order one from features of order 1e-2
+    g = torch.randn(N, 1, generator=gen)
+    return x, feats, b, ws, bs, g
+
+
+def _oracle64(x, feats, b, ws, bs, g):
+    xd = x.double().requires_grad_(True)
+    fd = [f.double().requires_grad_(True) for f in feats]
+    wd, bd = [w.double() for w in ws], [v.double() for v in bs]
+    rows = R.encode_stock(fd, b.double(), xd)
+    pre1 = rows @ wd[0].T + bd[0]
+    pre2 = torch.relu(pre1) @ wd[1].T + bd[1]
+    sdf = torch.relu(pre2) @ wd[2].T + bd[2]
+    near = torch.minimum(pre1.detach().abs().min(dim=1).values, pre2.detach().abs().min(dim=1).values) < TIE
+    g = g.clone()
+    g[near] = 0.0
+    got = torch.autograd.grad(sdf, [xd] + fd, g.double())
+    return sdf.detach(), got[0], list(got[1:]), g, int(near.sum())
+
+
+def _device(exact, x, feats, b, ws, bs, g):
+    from miso_amd import ops
+    meta = ops.GridMeta.from_bound(b)
+    fd = [f.to(DEV).contiguous(memory_format=torch.channels_last_3d) for f in feats]
+    pack = ops.DecoderPack([w.to(DEV) for w in ws], [v.to(DEV) for v in bs])
+    xd = x.to(DEV)
+    with ops.exact_fp32(exact):
+        sdf, mask = ops.sdf_fwd_raw(xd, fd, meta, pack, want_mask=True)
+        gx, grads = ops.sdf_bwd_raw(xd, fd, meta, pack, g.to(DEV), mask, True, [True] * len(fd))
+    torch.cuda.synchronize()
+    return sdf.cpu().double(), gx.cpu().double(), [t.cpu().double() for t in grads]
+
+
+def _err(a, ref):
+    d = (a - ref).abs()
+    return d.max().item(), d.mean().item()
+
+
+@pytest.mark.parametrize("name,levels,C,H,bound,dyadic", SHAPES, ids=[s[0] for s in SHAPES])
+def test_split_decoder_error_within_twice_the_exact_fp32_kernels(name, levels, C, H, bound, dyadic):
+    x, feats, b, ws, bs, g = _inputs(levels, C, H, bound, dyadic, seed=len(name) * 7 + C)
+    sdf64, gx64, gf64, g, n_near = _oracle64(x, feats, b, ws, bs, g)
+    assert n_near < 0.01 * N
+    ex = _device(True, x, feats, b, ws, bs, g)
+    sp = _device(False, x, feats, b, ws, bs, g)
+    assert not torch.equal(ex[0], sp[0]), "the two decoder forms returned the same bits: is the switch connected?"
+    report = []
+    # a floor of a few ulps of the quantity's scale: where both errors are at the last bit, their ratio is noise
+    for what, e, s, ref in [("sdf", ex[0], sp[0], sdf64), ("grad_x", ex[1], sp[1], gx64)] + \
+            [(f"grad_level{l}", ex[2][l], sp[2][l], gf64[l]) for l in range(len(feats))]:
+        (emax, emean), (smax, smean) = _err(e, ref), _err(s, ref)
+        scale = ref.abs().max().item()
+        report.append(f"{name} {what}: exact max {emax:.3e} mean {emean:.3e} | split max {smax:.3e} mean {smean:.3e} "
+                      f"| scale {scale:.3e}")
+        assert smax <= 2.0 * emax + 1e-7 * scale, report[-1]
+        assert smean <= 2.0 * emean + 2e-9 * scale, report[-1]
+    print("\n".join(report))
+    if dyadic:
+        # the encode is exact on these inputs: the SDF error IS the decoder's, and it is at the fp32 rounding level
+        assert _err(sp[0], sdf64)[0] <= 2e-6 * max(1.0, sdf64.abs().max().item())
+
+
+def test_exact_fp32_form_still_passes_its_parity_checks():
+    """The exact chains stay in the library behind MISO_F_EXACT_F32: the checks the default (split) form passes in
+    tests/test_train_fused.py and tests/test_hip_parity.py, re-run on the exact form."""
+    from miso_amd import ops
+    import test_train_fused as T
+    with ops.exact_fp32():
+        T.test_unbinned_train_kernel_equals_forward_plus_backward((8, (32, 64, 128), 64), 3000)
+        T.test_unbinned_train_kernel_equals_forward_plus_backward((4, (16, 80), 64), 65)
+        T.test_unbinned_train_kernel_equals_forward_plus_backward((4, (48,), 32), 3000)
