@@ -150,9 +150,19 @@ __device__ __forceinline__ uint32_t mask_pair_from_bits(uint32_t m, int t, int j
 template <int F, int H, int NH, bool HALF, bool BITS_LAST, bool MASKB, int FN>
 __device__ __forceinline__ void decoder_fwd_split(const uint32_t* __restrict__ sw, const float* __restrict__ bias, int lane,
                                                   const float (&f)[FN], uint32_t (&mw)[(NH + 1) * (H / 32)],
-                                                  u32x4 (&maskB)[H / 16][HALF ? 1 : 2], float& p0, float& p1) {
+                                                  u32x4 (&maskB)[H / 16][HALF ? 1 : 2], float& p0, float& p1,
+                                                  float& poison) {
   constexpr int RT = H / 32, KB0 = (F + 15) / 16, KBH = H / 16, NT = HALF ? 1 : 2;
   const int hi = lane >> 5;
+  // A NaN among the features must come out as a NaN SDF (the trainers' NaN guards rely on it: trainer.py:205-211).  The
+  // exact chains propagate it through their FMAs; here a NaN piece can leave the matrix core with its sign set, and the
+  // integer ReLU would clear it.  So: 0 for a finite feature row, NaN otherwise, added to this lane's SDF by the caller.
+  {
+    float acc = f[0];
+#pragma unroll
+    for (int i = 1; i < F; ++i) acc += f[i];
+    poison = acc - acc;
+  }
   const float* b0 = bias;
   const float* bh = bias + H;
   const float* wo = bias + H + NH * H;

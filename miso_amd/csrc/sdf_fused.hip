@@ -260,10 +260,10 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
       continue;
     }
     uint32_t mw[MW];
-    float p0 = 0.0f, p1 = 0.0f;
+    float p0 = 0.0f, p1 = 0.0f, poison = 0.0f;
     if constexpr (SPLIT) {
       u32x4 no_mask[H / 16][2];
-      decoder_fwd_split<F, H, NH, false, true, false>(s_fwd, s_bias, lane, f, mw, no_mask, p0, p1);
+      decoder_fwd_split<F, H, NH, false, true, false>(s_fwd, s_bias, lane, f, mw, no_mask, p0, p1, poison);
     } else {
     // ---- layer 0: buf[0][r][t] = b0 + W0 * feats -------------------------------
     // Two accumulator sets ping-pong between layers (ReLU is applied in place, so
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
     }      // exact fp32 chains
     p0 += __shfl_xor(p0, 32);
     p1 += __shfl_xor(p1, 32);
-    const float sdf_v = (hi ? p1 : p0) + bo;
+    const float sdf_v = SPLIT ? ((hi ? p1 : p0) + bo) + poison : (hi ? p1 : p0) + bo;
     if (valid && sdf) sdf[po] = sdf_v;
     if (lin.p.loss_type && valid) {
       float gsd, gfs;
@@ -805,10 +805,10 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     memory_phase(false, g.tune);
     // ================================ forward =====================================================================
     uint32_t mw[MW];
-    float p0 = 0.0f, p1 = 0.0f;
+    float p0 = 0.0f, p1 = 0.0f, poison = 0.0f;
     u32x4 maskB[H / 16][HALF ? 1 : 2];      // SPLIT: the last ReLU's mask as the first backward product's B operand
     if constexpr (SPLIT) {
-      decoder_fwd_split<F, H, NH, HALF, false, true>(s_fwd, s_bias, lane, f, mw, maskB, p0, p1);
+      decoder_fwd_split<F, H, NH, HALF, false, true>(s_fwd, s_bias, lane, f, mw, maskB, p0, p1, poison);
     } else {
       f32x16 buf[2][RT][2];
       {
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     }
     p0 += __shfl_xor(p0, 32);
     if (!HALF) p1 += __shfl_xor(p1, 32);
-    const float sdf_v = ((!HALF && hi) ? p1 : p0) + bo;
+    const float sdf_v = SPLIT ? (((!HALF && hi) ? p1 : p0) + bo) + poison : ((!HALF && hi) ? p1 : p0) + bo;
     const bool mine = !(HALF && hi);      // HALF: the high half mirrors the low one -- stored / counted once
     if (valid && sdf && mine) sdf[po] = sdf_v;
     // ================================ loss: lane = point ============================================================

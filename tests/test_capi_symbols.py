@@ -225,8 +225,9 @@ def test_train_kernel_lds_fits_for_every_fused_shape():
             assert lib.miso_sdf_train_lds_bytes(ctypes.byref(g), ctypes.byref(m), int(scat)) == want, (C, L, H, scat)
     m.hidden_dim = 48
     assert lib.miso_sdf_train_lds_bytes(ctypes.byref(g), ctypes.byref(m), 1) == 0          # a shape outside the table
-    assert ops.sdf_train_lds_bytes(8, 3, 64, scat=False) == 4 * (11972 + 4 * 64 * 28)       # the headline launch: 76.6 KB
-    assert ops.sdf_train_lds_bytes(8, 4, 64, scat=True) == 4 * (12484 + 4 * (64 * 36 + 64 * 4 * 8))
+    # (round 6: the bf16x3 pack -- 18 432 dwords of matrix pieces + 196 of biases / output weights at 64 x 64 with F in 17..32)
+    assert ops.sdf_train_lds_bytes(8, 3, 64, scat=False) == 4 * (18628 + 4 * 64 * 28)       # four-wavefront form: 101.5 KB
+    assert ops.sdf_train_lds_bytes(8, 4, 64, scat=True) == 4 * (18628 + 4 * (64 * 36 + 64 * 4 * 8))
     feats = [torch.zeros(1, 8, 4, 4, 4)] * 3
     meta = ops.GridMeta((-1.0,) * 3, (1.0,) * 3, 0, 0)
     assert ops.sdf_train_supported(feats, meta, [feats[0], None, None]) and not ops.sdf_train_supported(feats, meta, [None] * 3)

@@ -269,6 +269,17 @@ def test_full_size_properties_cfg2():
     d = (fused - unf).abs()
     assert d.mean().item() <= 1e-6 and d.max().item() <= 1e-5
     go = torch.randn(n, 1, device=DEV, generator=g0) / n
+    # ReLU ties (as tests/test_config_shapes.py::test_full_size_cfg2_gradient_outliers_are_relu_ties): two fp32 evaluations
+    # of the decoder -- rocBLAS here, the kernel's matrix-core products there (bf16x3 pieces since round 6) -- may gate a
+    # ReLU differently where its pre-activation lies within rounding of zero, and such a point moves the gradient of the
+    # fine-level vertices it touches by O(1 %).  Those points (float64 census, a handful of 262 144) carry no cotangent.
+    with torch.no_grad():
+        rows64 = ops.encode(x, [a.detach() for a in Ag], meta).double()
+        pre1 = rows64 @ ws[0].double().T + bs[0].double()
+        pre2 = torch.relu(pre1) @ ws[1].double().T + bs[1].double()
+        near = torch.minimum(pre1.abs().min(dim=1).values, pre2.abs().min(dim=1).values) < 2e-7
+    assert int(near.sum()) < 3e-4 * n
+    go[near] = 0.0
     gf = torch.autograd.grad(fused, Ag, go)
     gu = torch.autograd.grad(unf, Ag, go)
     for a, b in zip(gf, gu):
