@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmiso_hip.so")
+# (MISO_HIP_LIB: a dev override for A/B runs of differently built libraries, tools/train_ab.sh)
+LIB_PATH = os.environ.get("MISO_HIP_LIB") or os.path.join(_HERE, "libmiso_hip.so")
 
 MAX_LEVELS = 8
 MAX_LINEAR = 4

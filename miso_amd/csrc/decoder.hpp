@@ -313,7 +313,7 @@ __device__ __forceinline__ void decoder_bwd_split(const uint32_t* __restrict__ s
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[t][j] = gate(acc[t][j] * ds[t], mw[(NH - 1) * RT + r], t, j);
+        for (int j = 0; j < 16; ++j) acc[t][j] = gate(acc[t][j], mw[(NH - 1) * RT + r], t, j);
 #pragma unroll
       for (int t = 0; t < NT; ++t) { Bd[2 * r][t] = split_acc<0>(acc[t]); Bd[2 * r + 1][t] = split_acc<1>(acc[t]); }
     }
@@ -342,7 +342,9 @@ __device__ __forceinline__ void decoder_bwd_split(const uint32_t* __restrict__ s
     f32x16 acc[NT];
     mma_split_row<KBH, NT>(sw0T, 0, 1, lane, Bd, acc, zero_block());
 #pragma unroll
-    for (int t = 0; t < NT; ++t) df[t] = acc[t];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) df[t][j] = acc[t][j] * ds[t];
   }
 }
 

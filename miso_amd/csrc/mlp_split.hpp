@@ -78,6 +78,10 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {      // v_cv
 
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
 #pragma clang fp contract(off)
+#ifdef MISO_ABL_NO_SPLIT      // dev ablation (wrong results): one instruction instead of nine
+  h = cvt_pk_bf16(a, b); m = h; l = h;
+  return;
+#endif
   h = cvt_pk_bf16(a, b);
   const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
   m = cvt_pk_bf16(ra, rb);
@@ -104,6 +108,9 @@ __device__ __forceinline__ Split3 split_acc(const f32x16& v) {
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+#ifdef MISO_ABL_NO_MFMA       // dev ablation (wrong results): no matrix instructions (their operands' producers go with them)
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 

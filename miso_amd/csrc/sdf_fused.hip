@@ -757,6 +757,11 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
   float inv_n = lin.inv_n;
   if (lin.n_live) { const int live = *lin.n_live; inv_n = 1.0f / (float)(live > 1 ? live : 1); }
   ChunkSched sched(nchunks, wave, NW, true);
+  // dev (MISO_TUNE bits 8..15): the second wavefront of every SIMD starts k x 1024 clocks late
+  if ((g.tune >> 8) & 255u) {
+    if (wave >= NW / 2)
+      for (uint32_t i = 0; i < ((g.tune >> 8) & 255u); ++i) __builtin_amdgcn_s_sleep(16);
+  }
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     asm volatile("" ::: "memory");      // see sdf_fwd_kernel: keeps the LDS reads of weights / biases inside the loop
     const int64_t p = HALF ? chunk * 32 + (lane & 31) : chunk * 64 + lane;
@@ -786,7 +791,11 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
         Axis ay = axis_coord(py, bmn[1], bmx[1], lv.Y, g.flags);
         Axis az = axis_coord(pz, bmn[2], bmx[2], lv.Z, g.flags);
         Cell c = make_cell(ax, ay, az, lv);
+#ifdef MISO_ABL_NO_GATHER     // dev ablation (wrong results): the cell arithmetic without the corner loads
+        for (int q = 0; q < C; ++q) f[l * C + q] = c.wx[0] * (float)(c.i0 + q) + c.wy[1] * (float)c.j0 + c.wz[0] * (float)c.k0;
+#else
         gather_level<C>(lv, c, &f[l * C]);
+#endif
         if (SCAT && ((scatter_mask >> l) & 1u)) {
           // the record sdf_bwd_kernel forms from the point again: base offset, in-bound bits, the six weights
           const int flags = (c.inx[0] ? 1 : 0) | (c.inx[1] ? 2 : 0) | (c.iny[0] ? 4 : 0) | (c.iny[1] ? 8 : 0) |
