@@ -529,6 +529,13 @@ def extras(step, dev):
     feats, meta, pack = step.features, step.meta, step.pack
     t = time_kernel(lambda: ops.sdf_fwd_raw(step.x, feats, meta, pack, False, out=step.sdf))
     ex["forward_only_point_samples_per_s"] = N_POINTS / (t * 1e-6)
+    # the headline step with the exact fp32 decoder chains of rounds 1-5 (MISO_F_EXACT_F32) beside the default split form
+    t_split = time_kernel(step.run, iters=100)
+    with ops.exact_fp32():
+        t_exact = time_kernel(step.run, iters=100)
+    ex["exact_fp32_step"] = {"us": t_exact, "point_samples_per_s": N_POINTS / (t_exact * 1e-6),
+                             "default_split_step_us": t_split,
+                             "what": "the same step with MISO_F_EXACT_F32 (stream launches read the switch per launch)"}
     # full trainer step: bin + forward + loss + backward + dense Adam over all 19.2 M grid floats
     tr = MappingStep([f.clone() for f in feats], meta, pack, N_POINTS, "L1", 1.0, 0.0, 0.0, adam=dict(lr=1e-3),
                      use_graph=False)
@@ -604,6 +611,7 @@ def extras(step, dev):
     for key, fn in (("cfg4_align_8_submaps_28_pairs", cfg4),
                     ("sample_generation_scannet", lambda: sample_generation(dev)),
                     ("mesh_extraction_256", lambda: mesh_extraction(step, dev)),
+                    ("atlas_mesh_extraction_8_submaps_512", lambda: atlas_mesh_extraction(dev)),
                     ("trainer_step_other_shapes", lambda: trainer_steps(dev)),
                     ("slam_components", lambda: slam_components(dev))):
         try:
@@ -611,6 +619,61 @@ def extras(step, dev):
         except Exception as exc:  # noqa: BLE001
             ex[key] = {"error": f"{type(exc).__name__}: {exc}"}
     return ex
+
+
+def atlas_mesh_extraction(dev, res=512, res_loop=192):
+    """The demos' final global mesh (demo/align_submaps.py:99, full_slam_scannet.py:116: save_mesh(atlas, global bound,
+    resolution=512)): the SDF volume of an 8-submap ScanNet-shaped atlas on a res^3 lattice through the fused atlas query
+    (miso_atlas_sdf_fwd: one launch per slab, points generated in the kernel) next to the op-by-op per-submap loop of the
+    reference's structure (grid_atlas.py:374-399; timed at res_loop^3 -- at 512^3 it runs for seconds), and marching cubes
+    on the fused volume.  Bytes: the volume written once (4 B per point); the grids (8 x 16.1 M floats) stay in the caches."""
+    import miso_amd.grid_opt.utils.utils_sdf as US
+    from miso_amd import ops
+    at = scannet_atlas(dev, 8)
+    gb = at.global_bound(device="cpu").detach()
+    lo, hi = gb[:, 0], gb[:, 1]
+
+    def field(r, fused):
+        q = (lambda p: at(p)) if fused else (lambda p: loop(p))
+        with torch.no_grad():
+            return US.extract_fields_device(lo, hi, r, q, dev, lattice_func=at.sdf_on_lattice if fused else None)
+
+    def loop(p):
+        with torch.enable_grad():        # autograd on: GridAtlas.forward runs its per-submap loop
+            return at(p).detach()
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    t_loop = timed(lambda: field(res_loop, False), reps=2)
+    t_fused_small = timed(lambda: field(res_loop, True))
+    t_fused = timed(lambda: field(res, True))
+    vol = field(res, True)
+    inside = float((vol != vol.flatten()[0]).float().mean())          # (corner 0 of the bounding box lies in no submap)
+    iso = float(vol[vol != vol.flatten()[0]].median())
+    t_mc = timed(lambda: ops.marching_cubes(vol, iso), reps=2)
+    v, f = ops.marching_cubes(vol, iso)
+    n = res ** 3
+    out = {"resolution": res, "submaps": 8, "points": n,
+           "fused_ms": t_fused * 1e3, "fused_points_per_s": n / t_fused,
+           "loop_resolution": res_loop, "loop_ms": t_loop * 1e3, "loop_points_per_s": res_loop ** 3 / t_loop,
+           "fused_ms_at_loop_resolution": t_fused_small * 1e3,
+           "speedup_vs_loop_same_lattice": t_loop / t_fused_small,
+           "fraction_of_lattice_inside_a_submap": inside,
+           "volume_write_GBps": 4 * n / t_fused / 1e9, "hbm_frac_on_volume_bytes": 4 * n / t_fused / 8e12,
+           "marching_cubes_ms": t_mc * 1e3, "triangles": int(f.shape[0]), "iso": iso,
+           "note": "compute-bound (one decoder evaluation per point inside any submap): 4 B per point of compulsory HBM traffic"}
+    del vol, at
+    torch.cuda.empty_cache()
+    return out
 
 
 def mesh_extraction(step, dev, res=256):
@@ -1116,10 +1179,32 @@ def headline_record(args, step, dev, world, elapsed):
     F_ = L * C
     mlp_flop = 2.0 * (F_ * HIDDEN + HIDDEN * HIDDEN + HIDDEN) * N_POINTS
     t_bwd_mfma = t_bwd - t_pull
-    mfma = {"peak_TFLOPs": 157.3, "sdf_fwd_kernel": mlp_flop / (t_fwd * 1e-6) / 157.3e12,
-            "sdf_bwd_kernel": mlp_flop / (t_bwd_mfma * 1e-6) / 157.3e12,
-            **({"sdf_train_kernel": 2 * mlp_flop / ((t_train - t_pull) * 1e-6) / 157.3e12} if t_train is not None else {}),
-            "definition": "decoder matrix FLOPs / kernel time / fp32 MFMA peak (live, HIP events)"}
+    exact = bool(ops._EXACT_F32) or os.environ.get("MISO_EXACT_F32", "0") not in ("", "0")
+    if exact:
+        # exact fp32 chains (v_mfma_f32_32x32x2_f32): the decoder's FLOPs over the fp32 matrix peak
+        peak, flop_f, flop_b = 157.3, mlp_flop, mlp_flop
+        definition = "decoder matrix FLOPs / kernel time / fp32 MFMA peak (live, HIP events)"
+    else:
+        # bf16x3 split products (round 6): what the matrix cores are ISSUED -- six 32x32x16 piece products per k-block of 16
+        # in the forward layers and the last backward product, three in the first backward one (its B operand is a 0 / 1
+        # mask) -- over the dense bf16 peak.  (The decoder's own FLOPs over the fp32 matrix peak: `nominal_fp32`.)
+        RT, KB0, KBH = HIDDEN // 32, (F_ + 15) // 16, HIDDEN // 16
+        per_mfma = 32 * 32 * 16 * 2.0
+        peak = 2500.0
+        flop_f = RT * 6 * (KB0 + KBH) * per_mfma / 32 * N_POINTS
+        flop_b = (RT * 3 * KBH + 6 * KBH) * per_mfma / 32 * N_POINTS
+        definition = ("bf16 piece-product FLOPs issued to the matrix cores / kernel time / dense bf16 MFMA peak (live, HIP "
+                      "events); nominal_fp32 = the decoder's own FLOPs / kernel time / fp32 MFMA peak (157.3)")
+    mfma = {"peak_TFLOPs": peak, "arithmetic": "exact fp32 chains" if exact else "bf16x3 split products, fp32 accumulate",
+            "sdf_fwd_kernel": flop_f / (t_fwd * 1e-6) / (peak * 1e12),
+            "sdf_bwd_kernel": flop_b / (t_bwd_mfma * 1e-6) / (peak * 1e12),
+            **({"sdf_train_kernel": (flop_f + flop_b) / ((t_train - t_pull) * 1e-6) / (peak * 1e12)} if t_train is not None else {}),
+            "definition": definition}
+    if not exact:
+        mfma["nominal_fp32"] = {"sdf_fwd_kernel": mlp_flop / (t_fwd * 1e-6) / 157.3e12,
+                                "sdf_bwd_kernel": mlp_flop / (t_bwd_mfma * 1e-6) / 157.3e12,
+                                **({"sdf_train_kernel": 2 * mlp_flop / ((t_train - t_pull) * 1e-6) / 157.3e12}
+                                   if t_train is not None else {})}
     if mfma_pmc:
         mfma["pmc_busy_frac"] = mfma_pmc
     # Both roofs of the dominant kernel, and which one binds: the fused kernels run the decoder on v_mfma_f32_32x32x2_f32
@@ -1127,8 +1212,9 @@ def headline_record(args, step, dev, world, elapsed):
     frac_hbm = achieved / 8000.0
     frac_mfma = mfma.get(dom[0])
     if frac_mfma is not None and frac_mfma > frac_hbm:
-        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": frac_mfma * 157.3, "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": frac_mfma, "flop_per_point": (2 if dom[0] == "sdf_train_kernel" else 1) * mlp_flop / N_POINTS}
+        fpp = {"sdf_fwd_kernel": flop_f, "sdf_bwd_kernel": flop_b, "sdf_train_kernel": flop_f + flop_b}[dom[0]] / N_POINTS
+        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": frac_mfma * peak, "peak": peak, "unit": "TFLOP/s",
+                    "frac": frac_mfma, "flop_per_point": fpp}
     else:
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": frac_hbm}
     roofline.update({"frac_hbm": frac_hbm, "frac_mfma": frac_mfma, "achieved_hbm_GBps": achieved, "peak_hbm_GBps": 8000.0,
@@ -1143,7 +1229,11 @@ def headline_record(args, step, dev, world, elapsed):
         "metric": "3D point-samples/sec (encode+decode fwd+bwd), 262144-pt batch",
         "value": value, "unit": "point-samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "settle_steps": SETTLE_STEPS, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (exact fp32 decoder chains)" if exact else
+                 "f32 (decoder products as bf16x3 pieces on the 16-bit matrix cores, fp32 accumulate: error against float64 "
+                 "equal to the exact fp32 chains', tests/test_split_precision.py; MISO_F_EXACT_F32 selects those)",
+        "data": "synthetic",
         "config": {"workload": "cfg-2: one submap per GPU, 3-level {32,64,128}^3 grid C=8 + MLP 24-64-64-1 "
                                "(frozen, seeded random weights), 262144 uniform-in-bbox points per GPU per "
                                "step, L1 loss, grads to all levels",

@@ -676,6 +676,27 @@ int miso_mapping_batch(const float* R, const float* t, int32_t n_poses, const in
 int miso_mapping_loss_rows(int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* pred,
                            const float* loss_rows, int64_t n, float* grad_pred, float* loss_out, void* stream);
 
+/* --- fused atlas query: GridAtlas.query_feature / GridAtlas.forward in one launch (round 6) ---------------------------
+ * Replaces the per-submap loop of grid_opt/models/grid_atlas.py:374-399 (for each active submap: transfrom_points_from,
+ * coords_in_bound, grid_interp_regular of every point, mask * feats and mask added to running (N,F) / (N,1) tensors; then
+ * count == 0 -> 1, sum / count, submap 0's decoder on the mean) and, with a lattice, the point generation of
+ * utils_sdf.extract_fields (grid_opt/utils/utils_sdf.py:69-86: linspace per axis, meshgrid 'ij', 16^3-point chunks).
+ *   miso_atlas_plan_bytes / miso_atlas_plan_build  the submaps' grids (levels, strides, bound; n_levels and C equal across
+ *       submaps, channels-last) as the kernel reads them, written to HOST memory `plan_host`; the caller copies the bytes
+ *       to the device once per set of feature tensors.  ignore_mask is not applied (the reference passes ignore_level=None).
+ *   miso_atlas_sdf_fwd  `plan`: the device copy.  `shape`: any one of the submaps' grids (host struct: C and the level
+ *       count are read from it).  `poses`: device (n_submaps, 12) floats -- per submap R_submap_world row-major (= R_world_
+ *       submap^T) then t_submap_world (= -R^T t), formed by the caller as transfrom_points_from forms them.  Points: `x`
+ *       (N,3) world coordinates, or x == NULL and a lattice: point (i j k), index (i ny + j) nz + k, sits at (axis_x[i],
+ *       axis_y[j], axis_z[k]) (device arrays; n == nx ny nz < 2^31).  Outputs: `sdf` (N) and / or `feats` (N, ld_feats)
+ *       mean features (either may be NULL; mlp / packed are needed for sdf only).  flags: 0 or MISO_F_EXACT_F32. */
+int64_t miso_atlas_plan_bytes(int32_t n_submaps);
+int miso_atlas_plan_build(const miso_grid_t* grids, int32_t n_submaps, void* plan_host);
+int miso_atlas_sdf_fwd(const void* plan, int32_t n_submaps, const miso_grid_t* shape, const float* poses,
+                       const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n, const float* axis_x,
+                       const float* axis_y, const float* axis_z, int32_t nx, int32_t ny, int32_t nz, float* sdf,
+                       float* feats, int64_t ld_feats, uint32_t flags, void* stream);
+
 /* --- marching cubes on the dense SDF volume ------------------------------------
  * Replaces mcubes.marching_cubes(u, threshold) as called by extract_geometry
  * (grid_opt/utils/utils_sdf.py:89-101; PyMCubes is a third-party dependency of the reference) with the

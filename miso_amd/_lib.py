@@ -140,6 +140,11 @@ SIGNATURES = {
     "miso_sdf_bwd": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_sdf_train_lds_bytes": (C.c_int64, [C.POINTER(Grid), C.POINTER(Mlp), C.c_int32]),
+    "miso_atlas_plan_bytes": (C.c_int64, [C.c_int32]),
+    "miso_atlas_plan_build": (C.c_int, [C.POINTER(Grid), C.c_int32, C.c_void_p]),
+    "miso_atlas_sdf_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Grid), C.c_void_p, C.POINTER(Mlp), C.c_void_p,
+                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p]),
     "miso_grad_pull_on_matrix_cores": (C.c_int, [C.POINTER(Grid), C.c_int32, C.c_int64, C.c_int64]),
     "miso_sort_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "miso_sort_points": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,

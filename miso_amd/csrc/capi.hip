@@ -67,6 +67,7 @@ size_t sample_rays_workspace_bytes(int64_t, int32_t);
 hipError_t launch_sample_rays(const miso_ray_frames_t&, const miso_ray_sampling_t&, const float*, int64_t,
                               const int64_t*, const int64_t*, const int64_t*, const float*, const float*, void*,
                               float*, int64_t*, float*, float*, float*, int32_t*, hipStream_t);
+hipError_t launch_atlas_sdf(int C, int L, int H, int NH, const AtlasK& a, const float* packed, bool exact, hipStream_t s);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
 int64_t mlp_packed_floats(int F, int H, int NH);
 hipError_t launch_adam(float*, float*, float*, float*, int64_t, double, double, double, double, int, int,
@@ -1040,6 +1041,61 @@ static int mc_check_dims(int32_t nx, int32_t ny, int32_t nz) {
 int64_t miso_mc_words(int32_t nx, int32_t ny, int32_t nz) {
   if (mc_check_dims(nx, ny, nz)) return -1;
   return mc_words(nx, ny, nz);
+}
+
+// ---- fused atlas query (atlas.hip) ------------------------------------------------------------------------------------
+int64_t miso_atlas_plan_bytes(int32_t n_submaps) {
+  return n_submaps < 1 ? 0 : (int64_t)n_submaps * (int64_t)sizeof(GridK);
+}
+
+int miso_atlas_plan_build(const miso_grid_t* grids, int32_t n_submaps, void* plan_host) {
+  if (!grids || !plan_host || n_submaps < 1 || n_submaps > 4096) return MISO_E_BADARG;
+  GridK* out = reinterpret_cast<GridK*>(plan_host);
+  for (int s = 0; s < n_submaps; ++s) {
+    bool v4;
+    int rc = convert_grid(&grids[s], &out[s], true, &v4);
+    if (rc) return rc;
+    if (!v4 || (out[s].flags & MISO_F_COORDS_NORMALIZED)) return MISO_E_UNSUPPORTED;
+    if (out[s].n_levels != out[0].n_levels) return MISO_E_UNSUPPORTED;
+    for (int l = 0; l < out[s].n_levels; ++l)
+      if (out[s].lv[l].C != out[0].lv[0].C) return MISO_E_UNSUPPORTED;
+    out[s].ignore_mask = 0;      // query_feature passes ignore_level=None (grid_atlas.py:385)
+  }
+  return MISO_OK;
+}
+
+int miso_atlas_sdf_fwd(const void* plan, int32_t n_submaps, const miso_grid_t* shape, const float* poses,
+                       const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n, const float* axis_x,
+                       const float* axis_y, const float* axis_z, int32_t nx, int32_t ny, int32_t nz, float* sdf,
+                       float* feats, int64_t ld_feats, uint32_t flags, void* stream) {
+  if (!plan || !poses || !shape || n_submaps < 1 || n < 0 || (!sdf && !feats)) return MISO_E_BADARG;
+  if (flags & ~MISO_F_EXACT_F32) return MISO_E_BADARG;
+  GridK g; bool v4;
+  int rc = convert_grid(shape, &g, false, &v4);
+  if (rc) return rc;
+  int C = g.lv[0].C, L = g.n_levels, H = 64, NH = 1;
+  if (sdf) {
+    if (!mlp || !packed || (((uintptr_t)packed) & 15u)) return MISO_E_BADARG;
+    rc = fused_shape(g, true, mlp, &C, &L, &H, &NH);
+    if (rc) return rc;
+  } else {
+    for (int l = 0; l < L; ++l)
+      if (g.lv[l].C != C) return MISO_E_UNSUPPORTED;
+    if (!fused_shape_supported(C, L, H, NH)) return MISO_E_UNSUPPORTED;
+  }
+  if (feats && ld_feats < g.F) return MISO_E_BADARG;
+  AtlasK a;
+  memset(&a, 0, sizeof(a));
+  a.submaps = reinterpret_cast<const GridK*>(plan);
+  a.poses = poses; a.n_submaps = n_submaps; a.n = n; a.sdf = sdf; a.feats = feats; a.ld = ld_feats;
+  if (x) {
+    a.x = x;
+  } else {
+    if (!axis_x || !axis_y || !axis_z || nx < 1 || ny < 1 || nz < 1) return MISO_E_BADARG;
+    if ((int64_t)nx * ny * nz != n || n >= ((int64_t)1 << 31)) return MISO_E_BADARG;
+    a.ax[0] = axis_x; a.ax[1] = axis_y; a.ax[2] = axis_z; a.dim[0] = nx; a.dim[1] = ny; a.dim[2] = nz;
+  }
+  return (int)launch_atlas_sdf(C, L, H, NH, a, packed, (flags & MISO_F_EXACT_F32) != 0, (hipStream_t)stream);
 }
 
 int64_t miso_mc_workspace_bytes(int32_t nx, int32_t ny, int32_t nz) {

@@ -39,6 +39,20 @@ struct GridK {
   LevelK lv[MISO_MAX_LEVELS];
 };
 
+// One fused atlas query (atlas.hip; miso_atlas_sdf_fwd)
+struct AtlasK {
+  const GridK* submaps;      // device, n_submaps entries (miso_atlas_plan_build)
+  const float* poses;        // device, n_submaps x 12: R_submap_world row-major (9), t_submap_world (3)
+  int32_t n_submaps;
+  const float* x;            // (N,3) world points, or nullptr: lattice
+  const float* ax[3];        // lattice axes (device): point p = (i ny + j) nz + k sits at (ax[0][i], ax[1][j], ax[2][k])
+  int32_t dim[3];
+  int64_t n;
+  float* sdf;                // (N) or nullptr
+  float* feats;              // (N, ld) mean features or nullptr
+  int64_t ld;
+};
+
 __device__ __forceinline__ void load_point(const GridK& g, const float* __restrict__ x, int64_t p, float& px,
                                            float& py, float& pz) {
   if (g.xstride == 4) {

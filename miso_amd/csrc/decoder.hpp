@@ -33,6 +33,27 @@ __device__ __forceinline__ float gate(float x, uint32_t m, int t, int j) {
   return __uint_as_float(__float_as_uint(x) & (uint32_t)e);
 }
 
+// lane-per-point trilinear gather of one level (channels-last rows of C floats, 16-B loads): f[0..C) = sum_k w_k v_k
+template <int C>
+__device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, float* f) {
+  // lane-per-point gather of one level: 8 corners x C channels, channels-last.
+#pragma unroll
+  for (int q = 0; q < C; ++q) f[q] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+    bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
+    float w = in ? (c.wx[dx] * c.wy[dy]) * c.wz[dz] : 0.0f;
+    int off = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+#pragma unroll
+    for (int q = 0; q < C; q += 4) {
+      float4 v = *reinterpret_cast<const float4*>(lv.data + off + q);
+      f[q + 0] += v.x * w; f[q + 1] += v.y * w; f[q + 2] += v.z * w; f[q + 3] += v.w * w;
+    }
+  }
+}
+
+
 // ---------------------------------------------------------------------------
 // Packed decoder layout (floats).  RT = H/32 row tiles, KS0 = ceil(F/2),
 // KS1 = H/2 k-steps for an HxH layer, NH hidden (HxH) layers.
@@ -345,6 +366,130 @@ __device__ __forceinline__ void decoder_bwd_split(const uint32_t* __restrict__ s
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int j = 0; j < 16; ++j) df[t][j] = acc[t][j] * ds[t];
+  }
+}
+
+// The exact fp32 chains of the forward (v_mfma_f32_32x32x2_f32; the accumulators of a layer ARE the next layer's B operand:
+// sdf_fused.hip's header), as sdf_fwd_kernel and atlas_sdf_kernel run them behind MISO_F_EXACT_F32.  w0p / whp / b0 / bh / wo:
+// the fp32 pack's forward part in LDS.  Same outputs as decoder_fwd_split (p0 / p1: this lane's partial output sums).
+template <int F, int H, int NH, int FN>
+__device__ __forceinline__ void decoder_fwd_exact(const float* __restrict__ w0p, const float* __restrict__ whp,
+                                                  const float* __restrict__ b0, const float* __restrict__ bh,
+                                                  const float* __restrict__ wo, int lane, const float (&f)[FN],
+                                                  uint32_t (&mw)[(NH + 1) * (H / 32)], float& p0, float& p1) {
+  constexpr int RT = H / 32, KS0 = (F + 1) / 2, KS1 = H / 2;
+  const int hi = lane >> 5;
+  // ---- layer 0: buf[0][r][t] = b0 + W0 * feats -------------------------------
+  // Two accumulator sets ping-pong between layers (ReLU is applied in place, so
+  // no third copy of the 64 activation registers is ever live).
+  f32x16 buf[2][RT][2];
+  {
+    // the bias enters as the C operand of the first MFMA of each chain (one register block per
+    // row tile, shared by both point tiles): no accumulator initialisation moves
+    f32x16 bias[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bias[r][j] = b0[32 * r + row_of(j, hi)];
+#pragma unroll
+    for (int s = 0; s < KS0; ++s) {
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[2 * s]), __float_as_uint(f[2 * s + 1]),
+                                                 false, false);
+      float bt0 = __uint_as_float(sw[0]), bt1 = __uint_as_float(sw[1]);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        float a = w0p[(s * 64 + lane) * RT + r];
+        buf[0][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt0, s == 0 ? bias[r] : buf[0][r][0], 0, 0, 0);
+        buf[0][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt1, s == 0 ? bias[r] : buf[0][r][1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        buf[0][r][t][j] = relu1(buf[0][r][t][j]);
+        push_gt0(m, buf[0][r][t][j]);
+      }
+    mw[r] = m;
+  }
+  // ---- hidden HxH layers but the last ----------------------------------------------
+#pragma unroll
+  for (int h = 0; h + 1 < NH; ++h) {
+    const int ci = h & 1, ni = ci ^ 1;
+    f32x16 bias[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bias[r][j] = bh[h * H + 32 * r + row_of(j, hi)];
+#pragma unroll
+    for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int ks = rp * 16 + j;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
+          buf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias[r] : buf[ni][r][0], 0, 0, 0);
+          buf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias[r] : buf[ni][r][1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          buf[ni][r][t][j] = relu1(buf[ni][r][t][j]);
+          push_gt0(m, buf[ni][r][t][j]);
+        }
+      mw[(h + 1) * RT + r] = m;
+    }
+  }
+  // ---- last hidden layer + output layer (out_dim = 1), one 32-row tile at a time ----------
+  // The last hidden activations feed only the output dot product, so each row tile is reduced
+  // into (p0, p1) as soon as its MFMA chain ends: 32 accumulator registers live instead of 64.
+  if (NH == 0) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float wv = wo[32 * r + row_of(j, hi)];
+        p0 += wv * buf[0][r][0][j];
+        p1 += wv * buf[0][r][1][j];
+      }
+  } else {
+    constexpr int h = NH > 0 ? NH - 1 : 0, ci = h & 1;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      f32x16 a0, a1, bias;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bias[j] = bh[h * H + 32 * r + row_of(j, hi)];
+#pragma unroll
+      for (int rp = 0; rp < RT; ++rp)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int ks = rp * 16 + j;
+          float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
+          a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias : a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias : a1, 0, 0, 0);
+        }
+      uint32_t m = 0, m1 = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float y0 = relu1(a0[j]), y1 = relu1(a1[j]);
+        push_gt0(m, y0);
+        push_gt0(m1, y1);
+        float wv = wo[32 * r + row_of(j, hi)];
+        p0 += wv * y0;
+        p1 += wv * y1;
+      }
+      mw[(h + 1) * RT + r] = (m << 16) | m1;
+    }
   }
 }
 

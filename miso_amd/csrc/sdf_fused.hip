@@ -38,9 +38,10 @@ namespace miso {
 // address arithmetic slip in between the co-resident wave's matrix instructions instead of queueing
 // behind them.  Measured: forward over unsorted points 80 -> 66 us; sorted 46 -> 45 us.  (Fixed
 // per-slot priorities and start delays were tried first: no effect.)
-__device__ __forceinline__ void memory_phase(bool on, uint32_t tune) {
+__device__ __forceinline__ void memory_phase(bool on, uint32_t tune, bool first = false) {
   if (tune & 16u) return;   // dev ablation
   if (on) __builtin_amdgcn_s_setprio(3);
+  else if ((tune & 64u) && first) __builtin_amdgcn_s_setprio(2);      // dev: the SIMD's first wavefront computes ahead of its second
   else __builtin_amdgcn_s_setprio(0);
 }
 
@@ -153,25 +154,6 @@ __global__ void mlp_pack_kernel(MlpK m, int F, int H, int NH, float* __restrict_
 
 // ---------------------------------------------------------------------------
 #endif
-template <int C>
-__device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, float* f) {
-  // lane-per-point gather of one level: 8 corners x C channels, channels-last.
-#pragma unroll
-  for (int q = 0; q < C; ++q) f[q] = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-    bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
-    float w = in ? (c.wx[dx] * c.wy[dy]) * c.wz[dz] : 0.0f;
-    int off = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
-#pragma unroll
-    for (int q = 0; q < C; q += 4) {
-      float4 v = *reinterpret_cast<const float4*>(lv.data + off + q);
-      f[q + 0] += v.x * w; f[q + 1] += v.y * w; f[q + 2] += v.z * w; f[q + 3] += v.w * w;
-    }
-  }
-}
-
 #ifndef MISO_SDF_TRAIN_TU      // (this part is compiled into sdf_fused.o; sdf_train.o holds the training kernel: Makefile)
 template <int C, int L, int H, int NH, bool SPLIT>
 __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_fwd_kernel(GridK g, const float* __restrict__ packed,
@@ -265,118 +247,7 @@ __global__ __launch_bounds__(256, MISO_FWD_OCC) MISO_FUSED_KERNEL_ATTR void sdf_
       u32x4 no_mask[H / 16][2];
       decoder_fwd_split<F, H, NH, false, true, false>(s_fwd, s_bias, lane, f, mw, no_mask, p0, p1, poison);
     } else {
-    // ---- layer 0: buf[0][r][t] = b0 + W0 * feats -------------------------------
-    // Two accumulator sets ping-pong between layers (ReLU is applied in place, so
-    // no third copy of the 64 activation registers is ever live).
-    f32x16 buf[2][RT][2];
-    {
-      // the bias enters as the C operand of the first MFMA of each chain (one register block per
-      // row tile, shared by both point tiles): no accumulator initialisation moves
-      f32x16 bias[RT];
-#pragma unroll
-      for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) bias[r][j] = b0[32 * r + row_of(j, hi)];
-#pragma unroll
-      for (int s = 0; s < KS0; ++s) {
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(f[2 * s]), __float_as_uint(f[2 * s + 1]),
-                                                   false, false);
-        float bt0 = __uint_as_float(sw[0]), bt1 = __uint_as_float(sw[1]);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-          float a = w0p[(s * 64 + lane) * RT + r];
-          buf[0][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt0, s == 0 ? bias[r] : buf[0][r][0], 0, 0, 0);
-          buf[0][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bt1, s == 0 ? bias[r] : buf[0][r][1], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-      uint32_t m = 0;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          buf[0][r][t][j] = relu1(buf[0][r][t][j]);
-          push_gt0(m, buf[0][r][t][j]);
-        }
-      mw[r] = m;
-    }
-    // ---- hidden HxH layers but the last ----------------------------------------------
-#pragma unroll
-    for (int h = 0; h + 1 < NH; ++h) {
-      const int ci = h & 1, ni = ci ^ 1;
-      f32x16 bias[RT];
-#pragma unroll
-      for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) bias[r][j] = bh[h * H + 32 * r + row_of(j, hi)];
-#pragma unroll
-      for (int rp = 0; rp < RT; ++rp)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int ks = rp * 16 + j;
-#pragma unroll
-          for (int r = 0; r < RT; ++r) {
-            float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
-            buf[ni][r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias[r] : buf[ni][r][0], 0, 0, 0);
-            buf[ni][r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias[r] : buf[ni][r][1], 0, 0, 0);
-          }
-        }
-#pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        uint32_t m = 0;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            buf[ni][r][t][j] = relu1(buf[ni][r][t][j]);
-            push_gt0(m, buf[ni][r][t][j]);
-          }
-        mw[(h + 1) * RT + r] = m;
-      }
-    }
-    // ---- last hidden layer + output layer (out_dim = 1), one 32-row tile at a time ----------
-    // The last hidden activations feed only the output dot product, so each row tile is reduced
-    // into (p0, p1) as soon as its MFMA chain ends: 32 accumulator registers live instead of 64.
-    if (NH == 0) {
-#pragma unroll
-      for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float wv = wo[32 * r + row_of(j, hi)];
-          p0 += wv * buf[0][r][0][j];
-          p1 += wv * buf[0][r][1][j];
-        }
-    } else {
-      constexpr int h = NH > 0 ? NH - 1 : 0, ci = h & 1;
-#pragma unroll
-      for (int r = 0; r < RT; ++r) {
-        f32x16 a0, a1, bias;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) bias[j] = bh[h * H + 32 * r + row_of(j, hi)];
-#pragma unroll
-        for (int rp = 0; rp < RT; ++rp)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int ks = rp * 16 + j;
-            float a = whp[((h * KS1 + ks) * 64 + lane) * RT + r];
-            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][0][j], ks == 0 ? bias : a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, buf[ci][rp][1][j], ks == 0 ? bias : a1, 0, 0, 0);
-          }
-        uint32_t m = 0, m1 = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float y0 = relu1(a0[j]), y1 = relu1(a1[j]);
-          push_gt0(m, y0);
-          push_gt0(m1, y1);
-          float wv = wo[32 * r + row_of(j, hi)];
-          p0 += wv * y0;
-          p1 += wv * y1;
-        }
-        mw[(h + 1) * RT + r] = (m << 16) | m1;
-      }
-    }
+      decoder_fwd_exact<F, H, NH>(w0p, whp, b0, bh, wo, lane, f, mw, p0, p1);
     }      // exact fp32 chains
     p0 += __shfl_xor(p0, 32);
     p1 += __shfl_xor(p1, 32);
@@ -811,7 +682,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
 #pragma unroll
       for (int l = 0; l < L; ++l) rec[(row_l * L + l) * REC + 1] = 0;      // a row past the batch: no corner in bound
     }
-    memory_phase(false, g.tune);
+    memory_phase(false, g.tune, wave < NW / 2);
     // ================================ forward =====================================================================
     uint32_t mw[MW];
     float p0 = 0.0f, p1 = 0.0f, poison = 0.0f;
@@ -1054,7 +925,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();      // the next chunk overwrites the tile (and the records)
-    memory_phase(false, g.tune);
+    memory_phase(false, g.tune, wave < NW / 2);
   }
   // loss sums: as sdf_fwd_kernel (every block stores its pair into its own slot, the slots nobody owns are cleared)
   for (int o = 32; o > 0; o >>= 1) { loss_sdf += __shfl_down(loss_sdf, o); loss_fs += __shfl_down(loss_fs, o); }

@@ -10,6 +10,7 @@ import contextlib
 import torch
 from torch import Tensor
 
+from miso_amd import ops
 import miso_amd.grid_opt.utils.utils as utils
 import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
 from .base_net import BaseNet
@@ -265,10 +266,85 @@ class GridAtlas(BaseNet):
         for s in self.submaps:
             s.zero_features()
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ('_atlas_query', '_atlas_poses', '_atlas_eligible'):      # device plan + ctypes structs of the fused query:
+            state.pop(k, None)                                            # rebuilt on demand, never pickled
+        return state
+
     # ---- queries (hot path) ----------------------------------------------------------------------
+    def _fused_query(self, x_world=None, axes=None, want_sdf=True, want_feats=False):
+        """query_feature / forward as ONE launch (ops.AtlasQuery -> miso_atlas_sdf_fwd) when nothing has to be
+        differentiated: the per-submap loop below encodes every point in every submap and moves (N,F) temporaries
+        through HBM per submap; the kernel tests the bound first, encodes where a point is inside, keeps sum, count and
+        mean in registers and decodes them on the spot.  None when the query is not eligible (autograd on, host
+        tensors, a decoder or grid shape the fused kernels do not cover): the caller then runs the loop."""
+        if torch.is_grad_enabled() or not self.active_submaps:
+            return None
+        probe = x_world if x_world is not None else self.get_submap(self.active_submaps[0]).features[0].feature
+        if not probe.is_cuda:
+            return None
+        subs = [self.get_submap(s) for s in self.active_submaps]
+        for sm in subs:
+            for g in sm.features:
+                # (a pickle the reference wrote holds NCDHW features; the kernels read channels-last rows: re-laid once)
+                if g.feature.shape[1] > 1 and g.feature.stride(1) != 1:
+                    g.feature.data = g.feature.data.contiguous(memory_format=torch.channels_last_3d)
+        pack = None
+        if want_sdf:
+            pack = self.submaps[0]._fused_decoder()
+            if pack is None:
+                return None
+        feats = [[g.feature for g in sm.features] for sm in subs]
+        metas = [sm.features[0].grid_meta() for sm in subs]
+        ekey = (id(pack), tuple(f.data_ptr() for fs in feats for f in fs))
+        if self.__dict__.get('_atlas_eligible', (None, False))[0] != ekey:
+            ok = all(ops.sdf_fused_supported(f, m, pack) if pack is not None else (f[0].shape[1] % 4 == 0)
+                     for f, m in zip(feats, metas)) and len({(len(f), f[0].shape[1]) for f in feats}) == 1
+            self.__dict__['_atlas_eligible'] = (ekey, ok)
+        if not self.__dict__['_atlas_eligible'][1]:
+            return None
+        # the pose table, rebuilt when a correction (or an initial pose) changed: S exponential maps and ~10 small
+        # launches per submap otherwise, per query
+        act = tuple(self.active_submaps)
+        pkey = (act,) + tuple((self.rotation_corrections[s]._version, self.translation_corrections[s]._version,
+                               self.R_world_submap_list[s].data_ptr(), self.R_world_submap_list[s]._version,
+                               self.t_world_submap_list[s].data_ptr(), self.t_world_submap_list[s]._version) for s in act)
+        hit = self.__dict__.get('_atlas_poses')
+        if hit is not None and hit[0] == pkey and hit[1].device == probe.device:
+            poses = hit[1]
+        else:
+            rows = []
+            for s in act:
+                R, t = self.updated_submap_pose(s)
+                # transfrom_points_from (utils_geometry.py:227-240): R_src_dst = R^T, t_src_dst = -R^T t
+                Rinv = R.T
+                rows.append(torch.cat((Rinv.reshape(-1), (-(Rinv @ t)).reshape(-1))))
+            poses = torch.stack(rows).to(device=probe.device, dtype=torch.float32).contiguous()
+            self.__dict__['_atlas_poses'] = (pkey, poses)
+        q = self.__dict__.setdefault('_atlas_query', ops.AtlasQuery())
+        try:
+            return q(feats, metas, poses, pack, x=x_world, axes=axes, want_sdf=want_sdf, want_feats=want_feats)
+        except RuntimeError as e:              # a shape outside the kernel table: the loop serves it
+            if "not covered" in str(e):
+                return None
+            raise
+
+    def sdf_on_lattice(self, xs: Tensor, ys: Tensor, zs: Tensor):
+        """forward() on the meshgrid(xs, ys, zs, indexing='ij') lattice as an (nx, ny, nz) volume, the points generated
+        inside the kernel (utils_sdf.extract_fields_device asks for this); None when the fused query is not eligible."""
+        if int(xs.numel()) * int(ys.numel()) * int(zs.numel()) >= 2 ** 31:
+            return None
+        with torch.no_grad():
+            got = self._fused_query(axes=(xs, ys, zs))
+        return None if got is None else got[0].view(xs.numel(), ys.numel(), zs.numel())
+
     def query_feature(self, x_world: Tensor):
         """Mean over the active submaps that contain the point of that submap's features
         (reference :374-391; ignore_level is not applied here, as upstream)."""
+        got = self._fused_query(x_world, want_sdf=False, want_feats=True)
+        if got is not None:
+            return got[1]
         total = 0
         count = 0
         for s in self.active_submaps:
@@ -283,8 +359,12 @@ class GridAtlas(BaseNet):
         return total / count
 
     def forward(self, x_world: Tensor, noise_std=0):
-        feats = self.query_feature(x_world)
-        pred = utils.grid_decode(feats, None, self.submaps[0].decoder, True)
+        got = self._fused_query(x_world)
+        if got is not None:
+            pred = got[0]
+        else:
+            feats = self.query_feature(x_world)
+            pred = utils.grid_decode(feats, None, self.submaps[0].decoder, True)
         if noise_std > 0:
             pred = pred + torch.randn(pred.shape, device=x_world.device) * noise_std
         return pred

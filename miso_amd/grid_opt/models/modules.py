@@ -56,7 +56,13 @@ class MLPNet(nn.Module):
     def decoder_pack(self):
         """Packed weights for the fused encode+decode kernels, or None if the decoder
         cannot take that path (trainable weights, non-ReLU activation)."""
-        if not self._relu_only or not self.is_frozen():
+        relu_only = self.__dict__.get('_relu_only')
+        if relu_only is None:
+            # a module unpickled from a file the reference wrote (torch.save(grid_atlas), demo/build_submaps.py:141) carries
+            # the reference's attributes only: read the activation off the layer list
+            relu_only = self.__dict__['_relu_only'] = all(
+                isinstance(m, (nn.Linear, nn.ReLU)) for m in self.network)
+        if not relu_only or not self.is_frozen():
             return None
         pack = self.__dict__.get('_pack')
         lin = self.linears()

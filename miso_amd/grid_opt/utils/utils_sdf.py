@@ -36,13 +36,29 @@ def extract_fields(bound_min: torch.Tensor, bound_max: torch.Tensor, resolution,
 
 
 def extract_fields_device(bound_min: torch.Tensor, bound_max: torch.Tensor, resolution, query_func,
-                          device=None, max_points=1 << 22) -> torch.Tensor:
-    """extract_fields with the (res, res, res) volume left on the device (what marching cubes reads)."""
+                          device=None, max_points=1 << 22, lattice_func=None) -> torch.Tensor:
+    """extract_fields with the (res, res, res) volume left on the device (what marching cubes reads).
+    lattice_func(xs, ys, zs) -> (nx, ny, nz) volume or None: a model that evaluates a meshgrid lattice itself (GridAtlas.
+    sdf_on_lattice: one launch per slab, the points generated inside the kernel from the three axis vectors); tried
+    first, slabs of at most 2^30 points."""
     lo = bound_min.detach().cpu()
     hi = bound_max.detach().cpu()
     if device is None:
         device = "cuda:0" if torch.cuda.is_available() else "cpu"
     axes = [torch.linspace(float(lo[a]), float(hi[a]), resolution) for a in range(3)]   # host linspace, as upstream
+    if lattice_func is not None:
+        out = torch.empty((resolution, resolution, resolution), dtype=torch.float32, device=device)
+        ys_d, zs_d = axes[1].to(device), axes[2].to(device)
+        slab = max(1, (1 << 30) // (resolution * resolution))
+        ok = True
+        for x0 in range(0, resolution, slab):
+            vol = lattice_func(axes[0][x0:x0 + slab].to(device), ys_d, zs_d)
+            if vol is None:
+                ok = False
+                break
+            out[x0:x0 + vol.shape[0]] = vol
+        if ok:
+            return out
     ys, zs = axes[1].to(device), axes[2].to(device)
     out = torch.empty((resolution, resolution, resolution), dtype=torch.float32, device=device)
     slab = max(1, max_points // (resolution * resolution))
@@ -56,12 +72,12 @@ def extract_fields_device(bound_min: torch.Tensor, bound_max: torch.Tensor, reso
 
 
 def extract_geometry(bound_min: torch.Tensor, bound_max: torch.Tensor, resolution, threshold, query_func,
-                     device=None):
+                     device=None, lattice_func=None):
     """Level set ``threshold`` of the field as (vertices (V,3) float64 in metres, triangles (T,3) int64), numpy
     (reference :89-101).  Vertices in index coordinates are mapped to the bound exactly as upstream:
     ``v / (res - 1) * (max - min) + min``."""
     from miso_amd import ops
-    u = extract_fields_device(bound_min, bound_max, resolution, query_func, device)
+    u = extract_fields_device(bound_min, bound_max, resolution, query_func, device, lattice_func=lattice_func)
     verts, tris = ops.marching_cubes(u, float(threshold))
     lo = bound_min.detach().cpu().numpy()
     hi = bound_max.detach().cpu().numpy()
@@ -139,7 +155,8 @@ def save_mesh(model, bounds: torch.Tensor, save_path=None, resolution=256, devic
             return model(pts.to(device))
 
     vertices, triangles = extract_geometry(bounds[:, 0], bounds[:, 1], resolution=resolution, threshold=0,
-                                           query_func=query_func, device=device)
+                                           query_func=query_func, device=device,
+                                           lattice_func=getattr(model, 'sdf_on_lattice', None))
     if flip_face:
         triangles = triangles[:, [2, 1, 0]]
     mesh = TriangleMesh(vertices, triangles)

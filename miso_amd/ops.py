@@ -789,6 +789,75 @@ def sdf_fused(x, features, meta: GridMeta, pack: DecoderPack) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- #
+# fused atlas query (GridAtlas.query_feature / forward in one launch)
+# --------------------------------------------------------------------------- #
+class AtlasQuery:
+    """The per-submap loop of GridAtlas.query_feature / forward (grid_opt/models/grid_atlas.py:374-399) as ONE launch
+    (miso_atlas_sdf_fwd, csrc/atlas.hip): frame change, bound test, multi-level encode of the points that are inside,
+    mean over the submaps that contain a point, submap 0's decoder -- inference only (no autograd).
+
+    features: per submap the list of level tensors (1,C,Z,Y,X), channels-last; metas: per submap its GridMeta (bound).
+    The device-resident plan is rebuilt when a feature tensor's storage or a bound changes."""
+
+    def __init__(self):
+        self._key = None
+        self._plan = None
+        self._shape = None
+
+    def _prepare(self, features, metas):
+        key = tuple(tuple((f.data_ptr(), tuple(f.shape), f.stride()) for f in fs) for fs in features) + \
+            tuple((m.bound_min, m.bound_max, m.flags) for m in metas)
+        if key == self._key:
+            return
+        S = len(features)
+        grids = (_lib.Grid * S)()
+        for s, (fs, m) in enumerate(zip(features, metas)):
+            _require_hip(*fs)
+            g = _fill_grid(fs, m)
+            C.memmove(C.addressof(grids[s]), C.addressof(g), C.sizeof(_lib.Grid))
+        nbytes = int(_lib.load().miso_atlas_plan_bytes(S))
+        host = (C.c_char * nbytes)()
+        _lib.check(_lib.load().miso_atlas_plan_build(grids, S, C.cast(host, C.c_void_p)), "miso_atlas_plan_build")
+        dev = features[0][0].device
+        self._plan = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
+        self._shape = _fill_grid(features[0], metas[0])
+        self._key = key
+
+    def __call__(self, features, metas, poses, pack: Optional["DecoderPack"], x=None, axes=None, want_sdf=True,
+                 want_feats=False):
+        """poses: (S,12) device floats, per submap R_submap_world row-major then t_submap_world.  x: (N,3) world points,
+        or axes = (xs, ys, zs) device vectors of a lattice (point (i,j,k) -> index (i ny + j) nz + k).
+        -> (sdf (N,1) or None, feats (N,F) or None)."""
+        self._prepare(features, metas)
+        S = len(features)
+        assert poses.shape == (S, 12) and poses.is_contiguous() and poses.dtype == torch.float32
+        _require_hip(poses)
+        dev = poses.device
+        if x is not None:
+            _require_hip(x)
+            x = x.contiguous()
+            n, dims, ax = x.shape[0], (0, 0, 0), (None, None, None)
+        else:
+            ax = tuple(a.to(device=dev, dtype=torch.float32).contiguous() for a in axes)
+            dims = tuple(int(a.numel()) for a in ax)
+            n = dims[0] * dims[1] * dims[2]
+        F_ = _feature_dim(features[0])
+        sdf = torch.empty((n, 1), device=dev, dtype=torch.float32) if want_sdf else None
+        feats = torch.empty((n, F_), device=dev, dtype=torch.float32) if want_feats else None
+        m = packed = None
+        if want_sdf:
+            m, packed = pack.get()
+            if m is None:
+                raise RuntimeError("decoder shape is not covered by the fused kernels")
+        flags = _lib.F_EXACT_F32 if _EXACT_F32 else 0
+        _lib.check(_lib.load().miso_atlas_sdf_fwd(
+            _ptr(self._plan), S, C.byref(self._shape), _ptr(poses), C.byref(m) if m is not None else None, _ptr(packed),
+            _ptr(x), n, _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), dims[0], dims[1], dims[2], _ptr(sdf), _ptr(feats), F_,
+            flags, _stream(poses)), "miso_atlas_sdf_fwd")
+        return sdf, feats
+
+
+# --------------------------------------------------------------------------- #
 # dense Adam
 # --------------------------------------------------------------------------- #
 def adam_dense_(param, grad, exp_avg, exp_avg_sq, step: int, lr: float, beta1: float = 0.9,

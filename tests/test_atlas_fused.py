@@ -1,0 +1,139 @@
+"""The fused atlas query (round 6: miso_atlas_sdf_fwd, csrc/atlas.hip) -- GridAtlas.query_feature / forward and the
+lattice evaluation behind save_mesh as ONE launch -- against
+  * the reference's own outputs (tests/golden/atlas.npz, formats.npz: written by the reference, tools/make_goldens.py),
+  * today's op-by-op loop (the reference's per-submap structure, grid_opt/models/grid_atlas.py:374-399) on the
+    ScanNet-shaped 8-submap atlas of bench.py, points inside several / one / no submap,
+  * itself: the lattice form (points generated in the kernel) equals the point-list form bit for bit, the exact-fp32
+    decoder form stays within 1e-5 of the split one.
+fp32 tolerances as the reference tests of the mirror: features 2e-6, SDF 1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from test_grid_opt_mirror import G, T, close, make_atlas
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _loop(atlas, x):
+    """the per-submap loop (what runs when autograd is on): evaluated with autograd on, detached"""
+    with torch.enable_grad():
+        return atlas(x).detach(), atlas.query_feature(x).detach()
+
+
+def test_fused_atlas_query_vs_reference_goldens():
+    g = G("atlas")
+    atlas = make_atlas(DEV)
+    xw = T(gc.atlas_world_points()).to(DEV)
+    with torch.no_grad():
+        got = atlas._fused_query(xw, want_sdf=True, want_feats=True)
+        assert got is not None, "the fused query was not taken"
+        close(got[1], T(g["query_feature"]), 0, 2e-6)
+        close(got[0], T(g["forward"]), 0, 1e-5)
+        close(atlas.query_feature(xw), T(g["query_feature"]), 0, 2e-6)
+        close(atlas(xw), T(g["forward"]), 0, 1e-5)
+    # the whole-module pickle written by the reference (demo/build_submaps.py:141)
+    import miso_amd.compat  # noqa: F401
+    f = G("formats")
+    ref_atlas = torch.load(os.path.join(gc.GOLDEN_DIR, "ref_atlas.pth"), weights_only=False, map_location="cpu").to(DEV)
+    xr = T(f["atlas_x"]).to(DEV)
+    with torch.no_grad():
+        assert ref_atlas._fused_query(xr) is not None
+        close(ref_atlas(xr), T(f["atlas_forward"]), 0, 1e-5)
+        close(ref_atlas.query_feature(xr), T(f["atlas_query_feature"]), 0, 2e-6)
+
+
+@pytest.fixture(scope="module")
+def scannet8():
+    import bench
+    return bench.scannet_atlas(DEV, 8)
+
+
+def test_fused_atlas_query_vs_the_loop_on_eight_scannet_submaps(scannet8):
+    atlas = scannet8
+    gb = atlas.global_bound(device="cpu")
+    gen = torch.Generator().manual_seed(11)
+    n = 200000
+    lo, hi = gb[:, 0] - 1.0, gb[:, 1] + 1.0                  # a margin: points inside no submap
+    x = (lo + (hi - lo) * torch.rand(n, 3, generator=gen)).to(DEV)
+    sdf_l, feat_l = _loop(atlas, x)
+    with torch.no_grad():
+        sdf_f, feat_f = atlas(x), atlas.query_feature(x)
+        assert atlas._fused_query(x) is not None
+    # the three populations are all present
+    cnt = torch.zeros(n, device=DEV)
+    for s in atlas.active_submaps:
+        import miso_amd.grid_opt.utils.utils_geometry as ug
+        R, t = atlas.updated_submap_pose(s)
+        cnt += ug.coords_in_bound(ug.transfrom_points_from(x, R, t), atlas.get_submap(s).bound.to(DEV)).float().view(-1)
+    assert int((cnt == 0).sum()) > 1000 and int((cnt == 1).sum()) > 1000 and int((cnt >= 2).sum()) > 1000
+    close(feat_f, feat_l, 0, 2e-6)
+    close(sdf_f, sdf_l, 0, 1e-5)
+    # a point inside no submap decodes the zero row
+    zero = atlas.submaps[0].decoder(torch.zeros(1, feat_l.shape[1], device=DEV)).detach()
+    assert (sdf_f[cnt == 0] - zero).abs().max().item() <= 1e-6
+    # exact fp32 decoder chains behind the switch
+    from miso_amd import ops
+    with torch.no_grad(), ops.exact_fp32():
+        sdf_e = atlas(x)
+    assert not torch.equal(sdf_e, sdf_f)
+    close(sdf_e, sdf_l, 0, 1e-5)
+
+
+def test_lattice_form_equals_the_point_list_form_and_feeds_save_mesh(scannet8, tmp_path):
+    import miso_amd.grid_opt.utils.utils_sdf as US
+    atlas = scannet8
+    gb = atlas.global_bound(device="cpu")
+    res = (37, 29, 41)                                       # ragged: the last chunk is partial
+    axes = [torch.linspace(float(gb[a, 0]), float(gb[a, 1]), res[a]) for a in range(3)]
+    vol = atlas.sdf_on_lattice(*[a.to(DEV) for a in axes])
+    assert vol is not None and tuple(vol.shape) == res
+    xx, yy, zz = torch.meshgrid(*[a.to(DEV) for a in axes], indexing="ij")
+    pts = torch.stack((xx, yy, zz), dim=-1).reshape(-1, 3)
+    with torch.no_grad():
+        assert torch.equal(vol.reshape(-1, 1), atlas(pts))
+    close(vol.reshape(-1, 1), _loop(atlas, pts)[0], 0, 1e-5)
+    # extract_fields: the lattice path and the slab-by-slab query_func path give the same volume
+    r = 48
+    q = lambda p: atlas(p)                                   # noqa: E731
+    with torch.no_grad():
+        a = US.extract_fields_device(gb[:, 0], gb[:, 1], r, q, DEV, lattice_func=atlas.sdf_on_lattice)
+        b = US.extract_fields_device(gb[:, 0], gb[:, 1], r, q, DEV)
+    assert torch.equal(a, b)
+    # (random features: shift the decoder's output bias so that the field has a zero level set to mesh)
+    last = atlas.submaps[0].decoder.linears()[-1]
+    with torch.no_grad():
+        shift = a.mean().reshape(1)
+        last.bias -= shift
+    try:
+        mesh = US.save_mesh(atlas, gb, save_path=str(tmp_path / "m" / "atlas.ply"), resolution=r, device=DEV)
+    finally:
+        with torch.no_grad():
+            last.bias += shift
+    assert mesh.vertices.shape[0] > 100 and mesh.triangles.shape[0] > 100
+    assert np.isfinite(mesh.vertices).all()
+
+
+def test_fused_query_is_not_taken_where_autograd_is_needed(scannet8, tmp_path):
+    atlas = scannet8
+    x = torch.zeros(16, 3, device=DEV)
+    with torch.no_grad():
+        before = atlas(x)
+    torch.save(atlas, tmp_path / "atlas.pth")               # the query's device plan stays out of the pickle
+    again = torch.load(tmp_path / "atlas.pth", weights_only=False)
+    with torch.no_grad():
+        assert torch.equal(again(x), before)
+    # a pose correction that moves invalidates the cached pose table
+    with torch.no_grad():
+        atlas.translation_corrections[0] += 0.25
+        moved = atlas(x)
+        atlas.translation_corrections[0] -= 0.25
+        assert not torch.equal(moved, before) and torch.equal(atlas(x), before)
+    assert atlas._fused_query(x) is None                     # autograd on: the differentiable loop serves the call
+    with torch.no_grad():
+        assert atlas._fused_query(x) is not None
+        assert atlas._fused_query(x.cpu()) is None           # host tensors: no device path
