@@ -203,8 +203,12 @@ def cfg4_pmc_traffic(level):
         if js.get("_meta", {}).get("source_hash") == source_hash():
             e = js.get("cfg4_align", {}).get(f"pair_stage_kernel_level{level}") or \
                 js.get("cfg4_align", {}).get(f"pair_latent_batch_kernel_level{level}")
+            # ONE number: tools/ubench/fetch_calib.hip read known byte counts under the counter -- a
+            # coalesced stream, 16-B rows gathered at random and at a 256-B stride, all from HBM: every fill is a 128-B
+            # request (TCC_EA0_RDREQ_128B) and FETCH_SIZE reports 64 B of it, for the gathers exactly as for the stream
             return None if e is None else {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
-                                           "if_fetch_is_not_halved": e["hbm_bytes_per_launch_if_fetch_is_not_halved"],
+                                           "calibration": "2 x FETCH_SIZE KiB + WRITE_SIZE KiB; the x2 holds for 16-byte gathers "
+                                                          "as for streams (tools/ubench/fetch_calib.hip, tools/fetch_calib.sh)",
                                            "source": os.path.basename(pmc)}
     return None
 
@@ -756,8 +760,34 @@ def trainer_steps(dev):
             torch.cuda.synchronize()
             us = min(us, (time.perf_counter() - t0) / 60 * 1e6)
         gc.enable()
+        # roofline of the step at this shape: SURVEY 8(d)'s algorithmic bytes per point-sample over the
+        # whole step, the launches of the mapping step alone (HIP events), and -- where a committed counter summary of
+        # tools/pmc_trainer.sh exists -- the HBM traffic and the fp32 atomic requests of the dominant kernel
+        L_, C_ = n_levels, fdim
+        b_alg = 20 + 64 * L_ * C_
+        roof = {"bound": "hbm", "algorithmic_bytes_per_point": b_alg, "achieved": n * b_alg / (us * 1e-6) / 1e9,
+                "peak": 8000.0, "unit": "GB/s", "frac": n * b_alg / (us * 1e-6) / 8e12, "traffic": None}
+        plan = tr.__dict__.get("_fast_plan")
+        if plan is not None:
+            roof["mapping_launches_us"] = time_kernel(plan.step._launch, iters=30)
+        pmc_file = os.path.join(ROOT, "profiles", "r06_pmc_trainer_%s.json" % ("scannet" if "scannet" in name else "ncd"))
+        if "cfg2" not in name and os.path.exists(pmc_file):
+            js = json.load(open(pmc_file))
+            dom_k = max((k for k in js if k.startswith("sdf_train_kernel")), key=lambda k: js[k].get("avg_us", 0), default=None)
+            if dom_k:
+                d = js[dom_k]
+                req = d.get("TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum", 0.0)
+                roof.update({"dominant_kernel": dom_k, "dominant_kernel_us_profiled": d.get("avg_us"),
+                             "traffic": (2 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024,
+                             "traffic_source": os.path.basename(pmc_file) + " (FETCH_SIZE x 2 + WRITE_SIZE, KiB; gfx950)",
+                             "fp32_atomic_requests_per_launch": req,
+                             "atomics_executed_memory_side": d.get("TCC_EA0_ATOMIC_sum"),
+                             "atomic_floor_us_at_21G_requests_per_s": req / 21e9 * 1e6,
+                             "binding_resource": "memory-side fp32 atomic units: every L2 atomic request leaves for the fabric "
+                                                 "(TCC_EA0_ATOMIC == TCC_ATOMIC == TCP->TCC requests), ~21 G requests/s chip-wide "
+                                                 "(tools/ubench/atomics.hip)" if req > 1e5 else "latency (one chunk per wavefront)"})
         out[name] = {"us_per_step": us, "grid_floats": sum(f.feature.numel() for f in net.features),
-                     "point_samples_per_s": n / (us * 1e-6),
+                     "point_samples_per_s": n / (us * 1e-6), "roofline": roof,
                      "path": ("captured step + optimizer.step()" if tr.__dict__.get("_fast_plan") is None else
                               "one graph replay incl. Adam (_FastMappingPlan)" if tr._fast_plan.step._use_graph else
                               "stream launches incl. Adam (_FastMappingPlan)")}

@@ -424,7 +424,33 @@ class GridAtlas(BaseNet):
                 coords = submap.features[level].vertex_positions().to(submap.device)
                 with torch.no_grad():
                     norm = torch.linalg.norm(submap.query_feature(coords), dim=1)
-                self._coords_for_alignment[f"submap{s}_level{level}"] = coords[norm > norm_thresh].detach()
+                keep = norm > norm_thresh
+                order = self._brick_order(submap.features[level].feature.shape[2:], keep)
+                self._coords_for_alignment[f"submap{s}_level{level}"] = coords[order].detach()
+
+    @staticmethod
+    def _brick_order(dims, keep: Tensor) -> Tensor:
+        """Indices of the kept vertices of a (Z, Y, X) lattice (flat z-major index, as vertex_positions lists them) in BRICK
+        order: 8 x 8 x 8 bricks in raster order, inside a brick its eight 4 x 4 x 4 sub-bricks, inside a sub-brick x fastest.
+        The reference fixes the SET of alignment vertices, not their order (grid_atlas.py:565-579; every consumer sums over
+        them).  The pair stage (csrc/pair_latent.hip) hands a wavefront 8 steps of 64 CONSECUTIVE vertices: in lattice order
+        that is 2.5 lattice rows whose destination corner rows are wanted again by the rows and planes 200 and 20 000
+        vertices later -- by another workgroup on another XCD, i.e. fetched again (counted: 2.1 x the compulsory bytes at
+        cfg-4 level 1, FETCH_SIZE calibrated by tools/ubench/fetch_calib.hip); in brick order a wavefront's 512 vertices are
+        one 8^3 block whose 9^3 destination corners it fetches once, and a step's 64 vertices one 4^3 cube with a tight box
+        for the reach test (miso_align_src_boxes)."""
+        import os
+        Z, Y, X = (int(d) for d in dims)
+        idx = torch.nonzero(keep.view(-1), as_tuple=False).view(-1)
+        if os.environ.get("MISO_ALIGN_ORDER", "brick") != "brick" or idx.numel() == 0:
+            return idx
+        i, j, k = idx % X, (idx // X) % Y, idx // (X * Y)
+        nbx, nby = (X + 7) // 8, (Y + 7) // 8
+        brick = ((k >> 3) * nby + (j >> 3)) * nbx + (i >> 3)
+        sub = (((k >> 2) & 1) * 2 + ((j >> 2) & 1)) * 2 + ((i >> 2) & 1)
+        within = ((k & 3) * 4 + (j & 3)) * 4 + (i & 3)
+        key = (brick * 8 + sub) * 64 + within
+        return idx[torch.argsort(key)]
 
     def coordinates_for_alignment(self, submap_id: int, level: int):
         assert 0 <= submap_id < self.num_submaps

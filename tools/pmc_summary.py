@@ -63,6 +63,10 @@ for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         if nm not in ("pair_stage_kernel", "pair_latent_batch_kernel", "overlap_count_batch_kernel"):
             continue
         align.setdefault(nm, {}).setdefault(int(r["Grid_Size"]), {}).setdefault(cname, []).append(float(r["Counter_Value"]))
+for grid in ("scannet", "ncd"):      # cfg-3 / cfg-5 trainer steps (tools/pmc_trainer.sh)
+    tp = f"gpurun_out/pmc_trainer/{grid}.json"
+    if os.path.exists(tp):
+        out[f"trainer_{grid}"] = json.load(open(tp))
 if align:
     out["cfg4_align"] = {}
     for nm, by_grid in align.items():
@@ -73,9 +77,9 @@ if align:
             out["cfg4_align"][f"{nm}_level{lvl}"] = {
                 "grid_size": grid, "launches_sampled": len(d.get("FETCH_SIZE", [])), "FETCH_SIZE_KiB_avg": f,
                 "WRITE_SIZE_KiB_avg": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
-                "hbm_bytes_per_launch_if_fetch_is_not_halved": (f + w) * 1024,
-                "note": "one launch = all 28 pairs of an iteration; the x2 on FETCH_SIZE is the guide's calibration for wide "
-                        "coalesced reads -- this kernel's 16-byte corner gathers may not share it: both figures given"}
+                "note": "one launch = all 28 pairs of an iteration; the x2 on FETCH_SIZE holds for 16-byte gathers as for "
+                        "coalesced streams (round 6, tools/ubench/fetch_calib.hip: every fill is a 128-byte request of which "
+                        "the counter reports 64 bytes)"}
 # Stamp the summary with the kernel-source hash of the library the counters were COLLECTED with: every pass's log holds
 # the bench line, whose "library" field is miso_version() ("... src=<hash>").  (Stamping the hash of the tree the
 # summary is made in would label stale counters as current after a failed or skipped collection run.)
