@@ -135,7 +135,7 @@ def pairwise_loss_latent_batched(grid_atlas: GridAtlas, pairs, level: int, fdim=
         sub_from, sub_to = grid_atlas.get_submap(src_id), grid_atlas.get_submap(dst_id)
         assert fdim == sub_from.fdim
         nlv = min(level + 1, sub_from.num_levels)
-        coords = grid_atlas.coordinates_for_alignment(submap_id=src_id, level=level)
+        coords = grid_atlas.coordinates_for_alignment(submap_id=src_id, level=level, brick_order=True)
         feats_to = [g.feature.detach() for g in sub_to.features[:nlv]]
         gkey = (dst_id, nlv, tuple(f.data_ptr() for f in feats_to), tuple(bool(v) for v in sub_to.ignore_level_[:nlv]))
         hit = cache.get((dst_id, nlv))
@@ -173,7 +173,7 @@ def latent_pair_inputs(grid_atlas: GridAtlas, pairs, level: int, fdim=4, check_i
         sub_from, sub_to = grid_atlas.get_submap(src_id), grid_atlas.get_submap(dst_id)
         assert fdim == sub_from.fdim
         nlv = min(level + 1, sub_from.num_levels)
-        coords = grid_atlas.coordinates_for_alignment(submap_id=src_id, level=level)
+        coords = grid_atlas.coordinates_for_alignment(submap_id=src_id, level=level, brick_order=True)
         out.append(dict(src=src_id, dst=dst_id, coords=coords,
                         feats_src=_src_features(grid_atlas, src_id, level, coords, nlv),
                         feats_dst=[g.feature.detach() for g in sub_to.features[:nlv]],

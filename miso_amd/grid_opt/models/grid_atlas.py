@@ -425,8 +425,11 @@ class GridAtlas(BaseNet):
                 with torch.no_grad():
                     norm = torch.linalg.norm(submap.query_feature(coords), dim=1)
                 keep = norm > norm_thresh
+                self._coords_for_alignment[f"submap{s}_level{level}"] = coords[keep].detach()
+                # the same set in brick order for the fused pair stage (the reference's order stays what the API returns:
+                # pairwise_loss_latent(subsample_points=...) draws vertex INDICES, align/miso.py:66-68)
                 order = self._brick_order(submap.features[level].feature.shape[2:], keep)
-                self._coords_for_alignment[f"submap{s}_level{level}"] = coords[order].detach()
+                self._coords_for_alignment[f"submap{s}_level{level}_brick"] = coords[order].detach()
 
     @staticmethod
     def _brick_order(dims, keep: Tensor) -> Tensor:
@@ -452,10 +455,14 @@ class GridAtlas(BaseNet):
         key = (brick * 8 + sub) * 64 + within
         return idx[torch.argsort(key)]
 
-    def coordinates_for_alignment(self, submap_id: int, level: int):
+    def coordinates_for_alignment(self, submap_id: int, level: int, brick_order: bool = False):
+        """brick_order: the same vertices ordered for the fused pair stage (_brick_order) -- for consumers that only sum over
+        them; the default is the reference's lattice order."""
         assert 0 <= submap_id < self.num_submaps
         assert 0 <= level < self.num_levels
         key = f"submap{submap_id}_level{level}"
+        if brick_order and (key + "_brick") in self.__dict__.get('_coords_for_alignment', {}):
+            key += "_brick"
         if key not in self.__dict__.get('_coords_for_alignment', {}):
             raise ValueError(f"Coordinates for alignment not found for submap {submap_id} and level {level}. "
                              "Did you call precompute_coordinates_for_alignment()?")
