@@ -616,6 +616,7 @@ def extras(step, dev):
                     ("sample_generation_scannet", lambda: sample_generation(dev)),
                     ("mesh_extraction_256", lambda: mesh_extraction(step, dev)),
                     ("atlas_mesh_extraction_8_submaps_512", lambda: atlas_mesh_extraction(dev)),
+                    ("eikonal_step_262144pts", lambda: eikonal_step(dev)),
                     ("trainer_step_other_shapes", lambda: trainer_steps(dev)),
                     ("slam_components", lambda: slam_components(dev))):
         try:
@@ -623,6 +624,49 @@ def extras(step, dev):
         except Exception as exc:  # noqa: BLE001
             ex[key] = {"error": f"{type(exc).__name__}: {exc}"}
     return ex
+
+
+def eikonal_step(dev):
+    """A second-order step at cfg-2 (grid_opt/loss_isdf.py:96-152,367-377; loss.py:638-665): sdf = fused(x), g = d sdf / d x
+    with create_graph=True, loss = mean (|g| - 1)^2 + mean |sdf|, backward to the three grids.  The double backward stays in
+    the library (ops._SdfFusedBackward: sdf_bwd_kernel keeps its d-feat rows, the second-order encode differentiates them);
+    `torch_linear_chain_us` is the same step with the graph rebuilt from encode + torch.nn.functional.linear (rounds 1-5)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import eikonal_bench as EB
+    from miso_amd import ops
+    args = EB.build(dev)
+    feats, meta, pack, x = args
+
+    def wall(iters=10):
+        for _ in range(3):
+            EB.step(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            EB.step(*args)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e6
+
+    t_fused = wall()
+    ops._BWD2_TORCH = True
+    try:
+        t_torch = wall()
+    finally:
+        ops._BWD2_TORCH = False
+    # the library launches of the step, each alone (HIP events)
+    n = x.shape[0]
+    fd = [f.detach() for f in feats]
+    sdf, mask = ops.sdf_fwd_raw(x, fd, meta, pack, True)
+    gs = torch.ones(n, 1, device=dev)
+    t_fwd = time_kernel(lambda: ops.sdf_fwd_raw(x, fd, meta, pack, True, out=sdf, mask=mask))
+    t_rows = time_kernel(lambda: ops.sdf_bwd_rows_raw(x, fd, meta, pack, gs, mask, True, [False] * 3))
+    _, _, rows = ops.sdf_bwd_rows_raw(x, fd, meta, pack, gs, mask, True, [False] * 3)
+    ggx = torch.randn(n, 3, device=dev)
+    t_bwd2 = time_kernel(lambda: ops.encode_bwd2_raw(x, fd, meta, rows, ggx, None, True, [True] * 3))
+    return {"us": t_fused, "torch_linear_chain_us": t_torch, "speedup": t_torch / t_fused,
+            "kernels_us": {"sdf_fwd_kernel(+sign bits)": t_fwd, "sdf_bwd_kernel(d sdf/d x + d-feat rows)": t_rows,
+                           "encode_bwd2 (double backward: grids + x, incl. its pull)": t_bwd2},
+            "note": "wall time per step incl. autograd's Python; the |sdf| term adds one ordinary fused backward"}
 
 
 def atlas_mesh_extraction(dev, res=512, res_loop=192):

@@ -169,6 +169,14 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
                  const float* x, int64_t n, const float* grad_sdf, const uint32_t* relu_mask,
                  float* grad_x, void* stream);
 
+/* miso_sdf_bwd that also hands out the d-feat rows (N, F) it forms on the way (row n = d loss / d feats of point n, F =
+ * sum of C): the quantity the SECOND backward differentiates when the reference runs torch.autograd.grad(sdf, x,
+ * create_graph=True) for its eikonal / smoothness terms (grid_opt/loss_isdf.py:96-152, :367-377; loss.py:638-665) --
+ * d sdf / d x = J_E(x; G)^T rows, so miso_encode_bwd2 with grad_feats = these rows is the whole double backward (a ReLU
+ * decoder is piecewise linear).  dfeat_rows NULL: exactly miso_sdf_bwd.  Caller-order points only. */
+int miso_sdf_bwd_rows(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n,
+                      const float* grad_sdf, const uint32_t* relu_mask, float* grad_x, float* dfeat_rows, void* stream);
+
 /* --- spatially binned batches ----------------------------------------------
  * Counting sort of a point batch by coarse tile (tiles_per_axis^3 tiles over the
  * bound).  No reference counterpart: the reference gathers every level with

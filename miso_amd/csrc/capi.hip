@@ -380,6 +380,27 @@ int miso_sdf_bwd(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* pa
   return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, stream);
 }
 
+// The first backward with its d-feat rows handed out: what the SECOND backward (create_graph=True: eikonal / smoothness
+// terms, loss_isdf.py:96-152,367-377) differentiates -- d sdf / d x = J_E(x; G)^T rows, and the decoder, piecewise linear,
+// contributes nothing else (miso_encode_bwd2 on these rows is the whole double backward).
+int miso_sdf_bwd_rows(const miso_grid_t* grid, const miso_mlp_t* mlp, const float* packed, const float* x, int64_t n,
+                      const float* grad_sdf, const uint32_t* relu_mask, float* grad_x, float* dfeat_rows, void* stream) {
+  if (!dfeat_rows) return sdf_bwd_impl(grid, mlp, packed, x, n, grad_sdf, relu_mask, grad_x, nullptr, nullptr, stream);
+  if (n < 0 || !packed || (n > 0 && (!grad_sdf || !relu_mask || !x))) return MISO_E_BADARG;
+  if ((((uintptr_t)packed) & 15u) != 0 || (((uintptr_t)dfeat_rows) & 15u) != 0) return MISO_E_BADARG;
+  if (grid->flags & (MISO_F_GRAD_OVERWRITE | MISO_F_GRAD_SDF_SORTED | MISO_F_GRAD_ZEROED)) return MISO_E_BADARG;
+  GridK g; bool v4;
+  int rc = convert_grid(grid, &g, grad_x != nullptr, &v4);
+  if (rc) return rc;
+  int C, L, H, NH;
+  rc = fused_shape(g, v4, mlp, &C, &L, &H, &NH);
+  if (rc) return rc;
+  if (n == 0) return MISO_OK;
+  // want_grid = true selects the kernel form that stages the d-feat tile; levels without a gradient buffer are not scattered
+  return (int)launch_sdf_bwd(C, L, H, NH, g, packed, x, n, grad_sdf, relu_mask, grad_x, true, nullptr, dfeat_rows, 0u, false,
+                             (hipStream_t)stream);
+}
+
 // perm_optional: the entry point can take the original index from xn_sorted[p].w (miso_sdf_train_sorted)
 static int check_sorted(const miso_sorted_t* s, int64_t n, bool perm_optional) {
   if (!s || !s->tile_offsets) return MISO_E_BADARG;

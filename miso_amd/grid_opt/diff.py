@@ -14,5 +14,7 @@ def gradient3d(x, f, method='finitediff', finite_diff_eps=1e-2, create_graph=Tru
     if method == 'autograd':
         assert x.requires_grad, "requires_grad need to be true for autograd!"
         y = f(x)
-        return torch.autograd.grad(y, x, grad_outputs=torch.ones_like(y), create_graph=create_graph)[0]
+        from miso_amd import ops
+        with ops.coordinate_gradient_only():      # (only d y / d x is asked for: no grid gradients on the way)
+            return torch.autograd.grad(y, x, grad_outputs=torch.ones_like(y), create_graph=create_graph)[0]
     raise ValueError("Unknown method: {}".format(method))

@@ -14,8 +14,10 @@ from .models.grid_net import GridNet
 
 def gradient(inputs, outputs):
     """d outputs / d inputs with the graph kept (reference :367-377)."""
-    return grad(outputs=outputs, inputs=inputs, grad_outputs=torch.ones_like(outputs), create_graph=True,
-                retain_graph=True, only_inputs=True)[0]
+    from miso_amd import ops
+    with ops.coordinate_gradient_only():          # (only d outputs / d inputs is asked for: no grid gradients on the way)
+        return grad(outputs=outputs, inputs=inputs, grad_outputs=torch.ones_like(outputs), create_graph=True,
+                    retain_graph=True, only_inputs=True)[0]
 
 
 def full_sdf_loss(sdf, target_sdf, free_space_factor=5.0):

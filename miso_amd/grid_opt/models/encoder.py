@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
+from miso_amd import ops
 import miso_amd.grid_opt.utils.utils as utils
 import miso_amd.grid_opt.utils.utils_geometry as utils_geometry
 from miso_amd.grid_opt.loss import BaseLoss
@@ -151,7 +152,8 @@ class Encoder(torch.nn.Module):
             pts = np.concatenate([np.random.uniform(b[a, 0], b[a, 1], n).reshape(n, 1) for a in range(3)], axis=1)
             pts = torch.from_numpy(pts).to(gt).requires_grad_(True)
             s = self.query_sdf(model, corrections, pts)
-            g = torch.autograd.grad(s, pts, grad_outputs=torch.ones_like(s), create_graph=True)[0]
+            with ops.coordinate_gradient_only():
+                g = torch.autograd.grad(s, pts, grad_outputs=torch.ones_like(s), create_graph=True)[0]
             out['eik_constraint'] = g.norm(dim=-1) - 1
         if not skip_smooth:
             x1 = x
@@ -159,8 +161,9 @@ class Encoder(torch.nn.Module):
             x1.requires_grad_(True)
             x2.requires_grad_(True)
             s1, s2 = self.query_sdf(model, corrections, x1), self.query_sdf(model, corrections, x2)
-            g1 = torch.autograd.grad(s1, x1, grad_outputs=torch.ones_like(s1), create_graph=True)[0]
-            g2 = torch.autograd.grad(s2, x2, grad_outputs=torch.ones_like(s2), create_graph=True)[0]
+            with ops.coordinate_gradient_only():
+                g1 = torch.autograd.grad(s1, x1, grad_outputs=torch.ones_like(s1), create_graph=True)[0]
+                g2 = torch.autograd.grad(s2, x2, grad_outputs=torch.ones_like(s2), create_graph=True)[0]
             out['smooth_constraint'] = torch.where(valid == 1, g1 - g2, torch.zeros_like(g1))
         return out
 

@@ -326,6 +326,8 @@ class _Encode(torch.autograd.Function):
         x, *features = ctx.saved_tensors
         need_x = ctx.needs_input_grad[0]
         need_f = tuple(ctx.needs_input_grad[2:])
+        if _ONLY_X and torch.is_grad_enabled():
+            need_f = (False,) * len(features)          # (coordinate_gradient_only: see there)
         meta = ctx.meta if ctx.sorted is None else (ctx.meta, ctx.sorted)
         res = _EncodeBackward.apply(gout, x, meta, need_x, need_f, *features)
         return (res[0], None, *res[1:])
@@ -577,6 +579,24 @@ def sdf_bwd_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f
     return gx, grads
 
 
+def sdf_bwd_rows_raw(x, features, meta, pack: DecoderPack, gsdf, mask, need_x, need_f, grads=None):
+    """sdf_bwd_raw (caller-order points) that also returns the d-feat rows (N,F) of the decoder backward
+    (miso_sdf_bwd_rows): -> (gx, grads, rows)."""
+    _require_hip(x, gsdf, *features)
+    m, packed = pack.get()
+    x = x.contiguous()
+    gsdf = gsdf.contiguous()
+    n = x.shape[0]
+    if grads is None:
+        grads = [torch.zeros_like(f) if nf else None for f, nf in zip(features, need_f)]
+    gx = torch.empty((n, 3), device=x.device, dtype=torch.float32) if need_x else None
+    rows = torch.empty((n, _feature_dim(features)), device=x.device, dtype=torch.float32)
+    g = _fill_grid(features, meta, grads)
+    _lib.check(_lib.load().miso_sdf_bwd_rows(C.byref(g), C.byref(m), _ptr(packed), _ptr(x), n, _ptr(gsdf), _ptr(mask),
+                                             _ptr(gx), _ptr(rows), _stream(x)), "miso_sdf_bwd_rows")
+    return gx, grads, rows
+
+
 def sdf_bwd_scattered_levels(features, meta, grads, n: int, tiles=None) -> int:
     """Bit l set: sdf_bwd_raw(sorted_batch=..., overwrite=True) forms level l's gradient by adding with atomics (and
     zero-fills it first) rather than by the pull's plain stores (miso_sdf_bwd_scattered_levels).  tiles: the batch's
@@ -740,6 +760,29 @@ def grad_pull_raw(features, meta, sorted_batch: SortedBatch, dfeat, grads, overw
     return grads
 
 
+_BWD2_TORCH = os.environ.get("MISO_BWD2_TORCH", "0") not in ("", "0")
+
+# torch.autograd.grad(sdf, x, create_graph=True) asks for the coordinate gradient only, but a custom Function's backward
+# cannot see which of its inputs the caller listed (ctx.needs_input_grad is fixed at forward time: every grid that
+# requires grad reads True) -- it would form the grid gradients too, a zero fill and an atomic scatter of every level,
+# to have autograd drop them.  The mirror's own gradient helpers (grid_opt/diff.py, loss_isdf.py, models/encoder.py)
+# wrap their call in coordinate_gradient_only(): inside it a differentiable (create_graph) first backward of encode /
+# sdf_fused skips the grids.
+_ONLY_X = False
+
+
+class coordinate_gradient_only:
+    def __enter__(self):
+        global _ONLY_X
+        self.prev, _ONLY_X = _ONLY_X, True
+        return self
+
+    def __exit__(self, *exc):
+        global _ONLY_X
+        _ONLY_X = self.prev
+        return False
+
+
 def _mlp_torch(feats, weights, biases):
     h = feats
     for i, (w, b) in enumerate(zip(weights, biases)):
@@ -747,6 +790,42 @@ def _mlp_torch(feats, weights, biases):
         if i + 1 < len(weights):
             h = torch.relu(h)
     return h
+
+
+class _SdfFusedBackward(torch.autograd.Function):
+    """The fused first backward as a Function, so that create_graph=True stays inside the library (the role of
+    _GridSample3dBackward, cuda_gridsample.py:99-126, for the fused encode + decoder): forward = one launch of
+    sdf_bwd_kernel that keeps its d-feat rows; backward (the double backward) = ONE launch of the second-order encode on those
+    rows.  d sdf / d x = J_E(x; G)^T rows and the grid gradients scatter(w(x) rows) depend on the decoder through `rows`
+    alone, and rows = U(masks) d sdf is piecewise constant in the features (ReLU'' = 0, as autograd has it): nothing of the
+    decoder is differentiated twice.  Rounds 1-5 rebuilt the graph from encode + torch.nn.functional.linear here (two rocBLAS
+    GEMMs per layer, forward and backward, (N, 64) activations through HBM)."""
+
+    @staticmethod
+    def forward(ctx, gsdf, x, mask, meta, pack, need_x, need_f, *features):
+        gx, grads, rows = sdf_bwd_rows_raw(x, features, meta, pack, gsdf, mask, need_x, need_f)
+        ctx.save_for_backward(gsdf, x, mask, rows, *features)
+        ctx.meta, ctx.pack = meta, pack
+        ctx.set_materialize_grads(False)      # (see _EncodeBackward: no zero cotangents the size of a level)
+        return (gx, *grads)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ggx, *ggf):
+        gsdf, x, mask, rows, *features = ctx.saved_tensors
+        need_gsdf, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_f = ctx.needs_input_grad[7:]
+        if ggx is None and all(t is None for t in ggf):
+            return (None,) * (7 + len(features))
+        gg_rows, g_x, g_f = encode_bwd2_raw(x, features, ctx.meta, rows, ggx, ggf, need_x, need_f)
+        g_gsdf = None
+        if need_gsdf:
+            # rows are linear in d sdf: rows = U d sdf with U the rows of a unit cotangent -- one more launch, only when the
+            # cotangent of sdf is itself differentiated
+            _, _, unit = sdf_bwd_rows_raw(x, features, ctx.meta, ctx.pack, torch.ones_like(gsdf), mask, False,
+                                          [False] * len(features))
+            g_gsdf = (gg_rows * unit).sum(dim=1, keepdim=True).view_as(gsdf)
+        return (g_gsdf, g_x, None, None, None, None, None, *g_f)
 
 
 class _SdfFused(torch.autograd.Function):
@@ -769,15 +848,24 @@ class _SdfFused(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         need_f = tuple(ctx.needs_input_grad[3:])
         if torch.is_grad_enabled():
-            # create_graph=True (eikonal / smoothness terms, loss_isdf.py:367-377):
-            # rebuild the differentiable graph from the second-order capable ops.
-            with torch.enable_grad():
-                out = _mlp_torch(encode(x, features, ctx.meta), ctx.pack.weights, ctx.pack.biases)
-                wanted = ([x] if need_x else []) + [f for f, nf in zip(features, need_f) if nf]
-                got = list(torch.autograd.grad(out, wanted, gsdf, create_graph=True, allow_unused=True))
-            gx = got.pop(0) if need_x else None
-            gfs = [got.pop(0) if nf else None for nf in need_f]
-            return (gx, None, None, *gfs)
+            # create_graph=True (eikonal / smoothness terms, loss_isdf.py:367-377): the first backward as a Function whose
+            # own backward is the second-order encode (_SdfFusedBackward).  MISO_BWD2_TORCH=1 (dev A/B): the graph rebuilt
+            # from encode + torch.nn.functional.linear, as rounds 1-5 did
+            if _BWD2_TORCH:
+                with torch.enable_grad():
+                    out = _mlp_torch(encode(x, features, ctx.meta), ctx.pack.weights, ctx.pack.biases)
+                    wanted = ([x] if need_x else []) + [f for f, nf in zip(features, need_f) if nf]
+                    got = list(torch.autograd.grad(out, wanted, gsdf, create_graph=True, allow_unused=True))
+                gx = got.pop(0) if need_x else None
+                gfs = [got.pop(0) if nf else None for nf in need_f]
+                return (gx, None, None, *gfs)
+            if _ONLY_X:
+                need_f = (False,) * len(features)
+            if ctx.sb is not None:
+                # the forward binned the batch: its sign bits are in the binned order -- one more forward for caller-order bits
+                _, mask = sdf_fwd_raw(x, features, ctx.meta, ctx.pack, want_mask=True)
+            res = _SdfFusedBackward.apply(gsdf, x, mask, ctx.meta, ctx.pack, need_x, need_f, *features)
+            return (res[0], None, None, *res[1:])
         gx, grads = sdf_bwd_raw(x, features, ctx.meta, ctx.pack, gsdf, mask, need_x, need_f,
                                 sorted_batch=ctx.sb, overwrite=True)
         return (gx, None, None, *grads)
