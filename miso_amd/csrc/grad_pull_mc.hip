@@ -588,7 +588,9 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
             // feature grids the next forward gathers: headline step 143.6 -> 142.1 us, cfg-2 trainer step 245 -> 241.5, three
             // runs each way twice (tools/experiments/pull_nt_store_r5.sh.txt).  As assembly: __builtin_nontemporal_store
             // does not survive here -- the two branches' stores are sunk into one and the mark is dropped.
-            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(o) : "memory");
+            // (s_nop: a > 64-bit VMEM store followed by a VALU write of its data registers needs a wait state, and the
+            // backend's hazard recogniser does not look inside inline assembly -- ADVICE r5)
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" ::"v"(dst), "v"(o) : "memory");
           }
         };
 

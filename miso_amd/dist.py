@@ -14,7 +14,7 @@ grids, keyframe poses and optimiser state (grid_opt/models/grid_atlas.py:146-150
             (source vertices + in-bound vertices at the start poses, longest first onto the
             least loaded rank: a gated pair costs a fraction of an overlapping one); each
             iteration ends with ONE all-reduce(SUM) of a flat fp32 buffer holding the pose
-            gradients and the loss (6S+1 floats: latency bound, xGMI bandwidth irrelevant)
+            gradients and the loss (7S+1 floats: latency bound, xGMI bandwidth irrelevant)
             between two captured halves, then the identical Adam step everywhere.  A level whose whole
             iteration is cheaper than what sharding adds (the all-reduce + a second graph replay; cfg-4's
             level 0 is 82 us on ONE GPU) runs REPLICATED instead: every rank all pairs, no collective,
@@ -75,7 +75,7 @@ def _needs_host_staging(t: torch.Tensor) -> bool:
 
 
 def all_reduce_sum(t: torch.Tensor, always: bool = False) -> torch.Tensor:
-    """In-place SUM over ranks of a small flat tensor (the 6S + 1 floats of an alignment iteration).
+    """In-place SUM over ranks of a small flat tensor (the 7S + 1 floats of an alignment iteration).
     always: issue the collective even in a group of one rank (the single-GPU RCCL smoke test)."""
     if rank_world()[1] == 1 and not (always and dist.is_available() and dist.is_initialized()):
         return t
@@ -322,7 +322,7 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
     Every rank must hold all submaps (sync_submaps) and identical pose parameters.
 
     The loop is base.fused_alignment_loop: this rank's pairs go through ONE overlap launch and ONE pair launch per
-    iteration (no per-pair Python, no host sync on the overlap test or the NaN guard), the 6S + 1 floats of pose
+    iteration (no per-pair Python, no host sync on the overlap test or the NaN guard), the 7S + 1 floats of pose
     gradients + loss are all-reduced, and the identical regulariser / NaN guard / Adam step runs on every rank, so
     the replicas stay bit-identical.  Results equal the single-process run up to fp32 summation order of the pair
     sums.  A pair loss that carries ``fused`` (align.miso.latent_loss_for_level) runs as that loop; one that does not
@@ -379,5 +379,19 @@ def align_multiple_submaps_distributed(grid_atlas, dataset, pairwise_loss_tuple,
                                              rel_change_thresh, pose_reg_weight, pose_thresh_rad, pose_thresh_m,
                                              verbose and rank == 0, save_iterations, f"{loss_name}[rank {rank}/{world}]",
                                              reduce=reduce, my_pairs=my_pairs if reduce is not None else None)
+    if world > 1 and info['mode'] == 'replicated':
+        # Replicated ranks run the same loop on the same inputs, but the pair sums are fp64 atomics whose order differs from
+        # run to run (reproducible to ~1e-16, i.e. the fp32 gradients to an occasional ulp): after Adam the replicas can
+        # drift by an ulp, or stop one iteration apart under rel_change_thresh, and nothing inside a replicated loop brings
+        # them back (the sharded loop's all-reduce does).  One tiny collective per CALL, outside the loop: rank 0's final
+        # corrections go to everybody.
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in list(grid_atlas.rotation_corrections) +
+                              list(grid_atlas.translation_corrections)])
+            _broadcast(flat, 0)
+            off = 0
+            for p in list(grid_atlas.rotation_corrections) + list(grid_atlas.translation_corrections):
+                p.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
     cpu_time, gpu_time = timer.check()
     return {'cpu_time_sec': cpu_time, 'gpu_time_sec': gpu_time, 'iteration_results': iteration_results, 'dist': info}

@@ -75,7 +75,7 @@ class DenseAdam(torch.optim.Optimizer):
                     # launched the step without MappingStep.run).  The device scalar has the same number.
                     if not self.__dict__.get('_ring_warned'):
                         self.__dict__['_ring_warned'] = True
-                        logger.warning("the loss did not arrive in the host ring: reading the device scalar instead")
+                        logger.warning("the loss had not arrived in the host ring after 0.5 s (a busy GPU is enough): waiting on the device scalar instead")
                     bad = bool(torch.isnan(src).item())
             pending.pop(0)
             if bad:

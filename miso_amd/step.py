@@ -214,13 +214,18 @@ class MappingStep:
             self.adam_device.total_and_bump(self.loss_slots, self.total)      # loss sum + step count: one launch
             # all levels share ONE launch (each stepped by its gradient or by its `touched` flags): as launches of their own the coarse
             # levels of a pyramid are all ramp and tail (cfg-2: 8.5 + 13.4 us for 67 MB next to 74.5 us for 469 MB)
+            # (the block bakes raw pointers in: keyed by them, so a level whose storage was rebound -- f.data = ..., a replaced
+            # gradient or moment buffer -- gets a new block instead of an update of stale memory)
+            akey = tuple(t.data_ptr() for p, g, st, tch in zip(self.features, self.grads, self.adam_state, self.touched)
+                         if g is not None for t in (p, g, st[0], st[1], st[2]))
             multi = self.__dict__.get("_adam_multi")
-            if multi is None:
+            if multi is None or self.__dict__.get("_adam_multi_key") != akey:
                 dense = [(p, g, st[0], st[1], st[2], self.sorted is None or bool((self._adam_clears >> l) & 1), tch)
                          for l, (p, g, st, tch) in enumerate(zip(self.features, self.grads, self.adam_state, self.touched))
                          if g is not None]
                 multi = self._adam_multi = (self.adam_device.multi(dense) if 2 <= len(dense) <= ops._lib.ADAM_MAX_TENSORS
                                             and os.environ.get("MISO_ADAM_PER_LEVEL") is None else False)
+                self._adam_multi_key = akey
             if multi:
                 self.adam_device.step_multi_(multi, guard=self.total)
             for l, (p, g, st, tch) in enumerate(zip(self.features, self.grads, self.adam_state, self.touched)):
@@ -230,8 +235,11 @@ class MappingStep:
                                        zero_grad=self.sorted is None or bool((self._adam_clears >> l) & 1))
         if self.adam is not None:
             self.t += 1
+            akey = tuple(t.data_ptr() for p, g, m, v, act in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq,
+                                                               self.active) if g is not None for t in (p, g, m, v, act))
             multi = self.__dict__.get("_adam_multi")
-            if multi is None:
+            if multi is None or self.__dict__.get("_adam_multi_key") != akey:
+                self._adam_multi_key = akey
                 dense = [(p.data, g, m, v, act, self.sorted is None, tch)
                          for p, g, m, v, act, tch in zip(self.features, self.grads, self.exp_avg, self.exp_avg_sq,
                                                          self.active, self.touched) if g is not None]
