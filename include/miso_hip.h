@@ -81,6 +81,10 @@ extern "C" {
                                      as three bf16 pieces, six piece products on v_mfma_f32_32x32x16_bf16 with fp32
                                      accumulation -- the same 2^-24 class of error against float64 (tests/test_split_precision.py),
                                      2.7 x fewer matrix clocks.  Results of the two forms differ in the last bits. */
+#define MISO_F_FULL_TRIPS 256u     /* miso_sdf_train on a small unbinned batch (<= 65 536 samples): 64-point trips per wavefront as
+                                     for large batches, instead of the default 32-point trips (same arithmetic per point; the
+                                     32-point form halves a wavefront's chain of matrix instructions where the batch is one
+                                     chunk per wavefront anyway).  For tests and A/B runs. */
 #define MISO_F_GRAD_SDF_SORTED 16u  /* miso_sdf_bwd_sorted: grad_sdf is in the binned order (what
                                        miso_sdf_fwd_sorted_loss writes), not the caller's */
 #define MISO_F_GRAD_ZEROED 32u      /* with MISO_F_GRAD_OVERWRITE: the levels miso_sdf_bwd_sorted ADDS to with atomics

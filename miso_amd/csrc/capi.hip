@@ -91,7 +91,7 @@ enum Need { NEED_DATA = 1, NEED_GRAD_OPT = 2 };
 int convert_grid(const miso_grid_t* in, GridK* out, bool need_data, bool* vec4) {
   if (!in || in->n_levels < 1 || in->n_levels > MISO_MAX_LEVELS) return MISO_E_BADARG;
   if (in->flags & ~(MISO_F_ALIGN_CORNERS | MISO_F_PAD_BORDER | MISO_F_COORDS_NORMALIZED | MISO_F_GRAD_OVERWRITE |
-                    MISO_F_GRAD_SDF_SORTED | MISO_F_GRAD_ZEROED | MISO_F_CROWDED | MISO_F_EXACT_F32))
+                    MISO_F_GRAD_SDF_SORTED | MISO_F_GRAD_ZEROED | MISO_F_CROWDED | MISO_F_EXACT_F32 | MISO_F_FULL_TRIPS))
     return MISO_E_BADARG;
   memset(out, 0, sizeof(*out));
   out->n_levels = in->n_levels;

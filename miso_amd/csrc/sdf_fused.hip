@@ -1041,7 +1041,7 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
   // an unbinned batch of at most one 64-point chunk per SIMD (<= 65 536 samples): 32-point trips -- the batch is latency, not
   // throughput, and half the matrix chain per wavefront on twice the wavefronts is what shortens it (MISO_TRAIN_NO_HALF: dev)
   static const bool no_half = getenv("MISO_TRAIN_NO_HALF") != nullptr;
-  if (scat && !perm && !dfeat_out && nchunks <= 1024 && !no_half) {
+  if (scat && !perm && !dfeat_out && nchunks <= 1024 && !no_half && !(g.flags & MISO_F_FULL_TRIPS)) {
     const int64_t nhalf = (n + 31) / 32;
     unsigned bh_ = (unsigned)((nhalf + 3) / 4);
     if (bh_ > MISO_LOSS_SLOTS) bh_ = MISO_LOSS_SLOTS;

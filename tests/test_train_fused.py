@@ -352,3 +352,32 @@ def test_train_kernel_takes_the_index_from_xn_when_the_batch_has_no_perm_array()
         ops.sdf_fwd_raw(x, feats, meta, pack, True, mask=mask, sorted_batch=sb_n)
     with pytest.raises(RuntimeError):
         ops.encode_fwd_raw(x, feats, meta, sorted_batch=sb_n)
+
+
+@pytest.mark.parametrize("shape", [(4, (16, 80), 64), (8, (32, 64, 128), 64)])
+def test_small_batch_32_point_trips_equal_64_point_trips(shape):
+    """an unbinned batch of at most 65 536 samples runs sdf_train_kernel in 32-point trips (HALF: lanes 32-63
+    mirror 0-31, one point tile per wavefront).  Against the 64-point form of the same kernel on the same batch
+    (MISO_F_FULL_TRIPS): SDF bit for bit, loss slots to the order of the per-workgroup sums, gradients to the order of the
+    float atomics, touched flags alike."""
+    from miso_amd import ops
+    import dataclasses
+    C, sizes, H = shape
+    n = 6144
+    feats, meta, pack, x, aux = _setup(C, sizes, H, n, seed=3)
+    aux[7, 0] = 0.0                                          # (_setup plants a NaN label for the guard tests)
+    full = dataclasses.replace(meta, flags=meta.flags | ops._lib.F_FULL_TRIPS)
+    outs = []
+    for m in (meta, full):
+        s_, sdf = torch.zeros(ops._lib.LOSS_SLOTS, 2, device=DEV), torch.empty(n, 1, device=DEV)
+        g = [torch.zeros_like(f) for f in feats]
+        t = [ops.adam_active_flags(f) for f in feats]
+        ops.sdf_train_unsorted_raw(x, feats, m, pack, aux, s_, g, "L1", 1.0, 0.1, 0.15, sdf_out=sdf, touched=t)
+        torch.cuda.synchronize()
+        outs.append((s_, sdf, g, t))
+    (s1, sdf1, g1, t1), (s2, sdf2, g2, t2) = outs
+    assert torch.equal(sdf1, sdf2)
+    assert (s1.sum(0) - s2.sum(0)).abs().max().item() <= 2e-6 * max(s2.sum(0).abs().max().item(), 1e-12)
+    for a, b, ta, tb in zip(g1, g2, t1, t2):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-9
+        assert torch.equal(ta, tb)
