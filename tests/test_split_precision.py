@@ -124,3 +124,49 @@ def test_exact_fp32_form_still_passes_its_parity_checks():
         T.test_unbinned_train_kernel_equals_forward_plus_backward((8, (32, 64, 128), 64), 3000)
         T.test_unbinned_train_kernel_equals_forward_plus_backward((4, (16, 80), 64), 65)
         T.test_unbinned_train_kernel_equals_forward_plus_backward((4, (48,), 32), 3000)
+
+
+@pytest.mark.parametrize("n", [3000, 70000])
+def test_fused_double_backward_equals_the_torch_linear_chain(n):
+    """create_graph=True through the fused decoder (round 6: ops._SdfFusedBackward -- the first backward keeps its d-feat
+    rows, the second-order encode differentiates them) against the graph rebuilt from encode + torch.nn.functional.linear
+    (rounds 1-5, MISO_BWD2_TORCH), on an eikonal + |sdf| loss (grid_opt/loss_isdf.py:96-152,367-377): loss, and the
+    gradient of every level.  n = 70 000 takes the binned forward (its sign bits are in tile order: the double backward
+    re-derives caller-order bits); ReLU-tie points carry no weight."""
+    from miso_amd import ops
+    levels, C, H = [(16, 16, 16), (32, 32, 32), (64, 64, 64)], 8, 64
+    gen = torch.Generator().manual_seed(n)
+    b = torch.tensor([[-1.0, 1.0]] * 3)
+    x = (torch.rand(n, 3, generator=gen) * 1.9 - 0.95).to(DEV)
+    feats = [(torch.randn((1, C) + s, generator=gen) * 3e-2).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+             .requires_grad_(True) for s in levels]
+    torch.manual_seed(1)
+    lin = [torch.nn.Linear(C * 3, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    ws, bs = [l.weight.detach().to(DEV) * (8.0 if i == 0 else 1.0) for i, l in enumerate(lin)], [l.bias.detach().to(DEV) for l in lin]
+    pack = ops.DecoderPack(ws, bs)
+    meta = ops.GridMeta.from_bound(b)
+    with torch.no_grad():      # tie census (float64)
+        rows = ops.encode(x, [f.detach() for f in feats], meta).double()
+        pre1 = rows @ ws[0].double().T + bs[0].double()
+        pre2 = torch.relu(pre1) @ ws[1].double().T + bs[1].double()
+        keep = (torch.minimum(pre1.abs().min(1).values, pre2.abs().min(1).values) >= 1e-6).float()
+
+    def run(torch_chain):
+        ops._BWD2_TORCH = torch_chain
+        try:
+            xd = x.clone().requires_grad_(True)
+            sdf = ops.sdf_fused(xd, feats, meta, pack)
+            with ops.coordinate_gradient_only():
+                g, = torch.autograd.grad(sdf, xd, torch.ones_like(sdf), create_graph=True)
+            loss = (keep * (g.norm(dim=1) - 1) ** 2).mean() + (keep * sdf.abs().view(-1)).mean()
+            gf = torch.autograd.grad(loss, feats)
+            return loss.detach(), [t.detach() for t in gf], g.detach()
+        finally:
+            ops._BWD2_TORCH = False
+
+    l1, g1, gx1 = run(False)
+    l2, g2, gx2 = run(True)
+    assert abs(l1.item() - l2.item()) <= 1e-5 * abs(l2.item())
+    assert (gx1 - gx2).abs().max().item() <= 1e-4 * gx2.abs().max().item()
+    for a, c in zip(g1, g2):
+        assert (a - c).abs().max().item() <= 2e-4 * c.abs().max().item(), (a - c).abs().max().item() / c.abs().max().item()
