@@ -167,6 +167,6 @@ def test_fused_double_backward_equals_the_torch_linear_chain(n):
     l1, g1, gx1 = run(False)
     l2, g2, gx2 = run(True)
     assert abs(l1.item() - l2.item()) <= 1e-5 * abs(l2.item())
-    assert (gx1 - gx2).abs().max().item() <= 1e-4 * gx2.abs().max().item()
+    assert (keep[:, None] * (gx1 - gx2)).abs().max().item() <= 1e-4 * gx2.abs().max().item()      # (a tie point's own d sdf / d x may differ)
     for a, c in zip(g1, g2):
         assert (a - c).abs().max().item() <= 2e-4 * c.abs().max().item(), (a - c).abs().max().item() / c.abs().max().item()
