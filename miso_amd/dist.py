@@ -202,7 +202,8 @@ def pair_costs(grid_atlas, pairs) -> List[float]:
 # unit of pair_costs (1 per source vertex, 30 more per in-bound one) level 1 is 112e6 x (1 + 30 x 0.21) = 8.2e8 units for
 # ~530 us of pair stage: 0.65e-6 us per unit, on top of ~50 us that do not depend on the pair list (three launches, the
 # gate, the epilogues).  Only the first part shrinks when the pairs are dealt over ranks.  (Round 4: 1e-6 and 75.)
-PAIR_US_PER_UNIT = 0.65e-6
+# Round 6 (profiles/r06_bench.json): level 1 464 us with the brick-ordered vertices -> ~415 us of pair stage: 0.51e-6.
+PAIR_US_PER_UNIT = 0.51e-6
 ITERATION_FIXED_US = 50.0
 SHARD_OVERHEAD_US = 15.0       # two graph replays per iteration instead of one eighth of an 8x unrolled one, + the hook
 
