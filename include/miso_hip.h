@@ -688,6 +688,15 @@ int miso_mapping_batch(const float* R, const float* t, int32_t n_poses, const in
 int miso_mapping_loss_rows(int loss_type, float weight_sdf, float weight_fs, float trunc_dist, const float* pred,
                            const float* loss_rows, int64_t n, float* grad_pred, float* loss_out, void* stream);
 
+/* utils.grid_pool_3d_avg (grid_opt/utils/utils.py:239-291; called by models/encoder.py to pool residual signals onto a
+ * level's cells): pooled[(ix ny + iy) nz + iz][c] = mean of features[i][c] over the points i with cell index
+ * clamp(trunc((coords[i] - bound_min) / cell_size), 0, size - 1) per axis, 0 for empty cells.  coords (N,3), features (N,d)
+ * with row stride ld_features, pooled (nx ny nz, d) and counts (nx ny nz) int32 are written by the call (no zero-fill by
+ * the caller); bound_min: three host floats. */
+int miso_grid_pool_avg(const float* coords, const float* features, int64_t n, int32_t d, int64_t ld_features,
+                       const float* bound_min, float cell_size, int32_t nx, int32_t ny, int32_t nz, float* pooled,
+                       int32_t* counts, void* stream);
+
 /* --- fused atlas query: GridAtlas.query_feature / GridAtlas.forward in one launch (round 6) ---------------------------
  * Replaces the per-submap loop of grid_opt/models/grid_atlas.py:374-399 (for each active submap: transfrom_points_from,
  * coords_in_bound, grid_interp_regular of every point, mask * feats and mask added to running (N,F) / (N,1) tensors; then

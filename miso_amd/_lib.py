@@ -143,6 +143,8 @@ SIGNATURES = {
     "miso_sdf_train_lds_bytes": (C.c_int64, [C.POINTER(Grid), C.POINTER(Mlp), C.c_int32]),
     "miso_sdf_bwd_rows": (C.c_int, [C.POINTER(Grid), C.POINTER(Mlp), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "miso_grid_pool_avg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.POINTER(C.c_float), C.c_float,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "miso_atlas_plan_bytes": (C.c_int64, [C.c_int32]),
     "miso_atlas_plan_build": (C.c_int, [C.POINTER(Grid), C.c_int32, C.c_void_p]),
     "miso_atlas_sdf_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(Grid), C.c_void_p, C.POINTER(Mlp), C.c_void_p,

@@ -67,6 +67,8 @@ size_t sample_rays_workspace_bytes(int64_t, int32_t);
 hipError_t launch_sample_rays(const miso_ray_frames_t&, const miso_ray_sampling_t&, const float*, int64_t,
                               const int64_t*, const int64_t*, const int64_t*, const float*, const float*, void*,
                               float*, int64_t*, float*, float*, float*, int32_t*, hipStream_t);
+hipError_t launch_grid_pool_avg(const float*, const float*, int64_t, int32_t, int64_t, const float*, float, int32_t, int32_t,
+                                int32_t, float*, int32_t*, hipStream_t);
 hipError_t launch_atlas_sdf(int C, int L, int H, int NH, const AtlasK& a, const float* packed, bool exact, hipStream_t s);
 hipError_t launch_mlp_pack(const MlpK&, int, int, int, float*, hipStream_t);
 int64_t mlp_packed_floats(int F, int H, int NH);
@@ -1062,6 +1064,16 @@ static int mc_check_dims(int32_t nx, int32_t ny, int32_t nz) {
 int64_t miso_mc_words(int32_t nx, int32_t ny, int32_t nz) {
   if (mc_check_dims(nx, ny, nz)) return -1;
   return mc_words(nx, ny, nz);
+}
+
+int miso_grid_pool_avg(const float* coords, const float* features, int64_t n, int32_t d, int64_t ld_features,
+                       const float* bound_min, float cell_size, int32_t nx, int32_t ny, int32_t nz, float* pooled,
+                       int32_t* counts, void* stream) {
+  if (n < 0 || d < 1 || nx < 1 || ny < 1 || nz < 1 || !bound_min || !pooled || !counts || !(cell_size > 0.0f)) return MISO_E_BADARG;
+  if (n > 0 && (!coords || !features || ld_features < d)) return MISO_E_BADARG;
+  if ((int64_t)nx * ny * nz * d >= ((int64_t)1 << 31)) return MISO_E_TOOLARGE;
+  return (int)launch_grid_pool_avg(coords, features, n, d, ld_features, bound_min, cell_size, nx, ny, nz, pooled, counts,
+                                   (hipStream_t)stream);
 }
 
 // ---- fused atlas query (atlas.hip) ------------------------------------------------------------------------------------

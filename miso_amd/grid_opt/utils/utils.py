@@ -96,6 +96,10 @@ def grid_pool_3d_avg(coords, features, grid_bound, cell_size):
     n, d = features.shape
     extent = (grid_bound[:, 1] - grid_bound[:, 0]).cpu().numpy()
     nx, ny, nz = (int(v) for v in np.ceil(extent / cell_size).astype(int))
+    if coords.is_cuda and features.is_cuda and coords.dtype == torch.float32 and features.dtype == torch.float32 \
+            and not (torch.is_grad_enabled() and (coords.requires_grad or features.requires_grad)):
+        # clear + scatter + normalise in three launches (csrc/pool.hip), same cell arithmetic
+        return ops.grid_pool_avg(coords, features, grid_bound[:, 0].detach().cpu().tolist(), float(cell_size), (nx, ny, nz))
     idx = []
     for axis, size in ((0, nx), (1, ny), (2, nz)):
         idx.append(((coords[:, axis] - grid_bound[axis, 0]) / cell_size).long().clamp(0, size - 1))

@@ -876,6 +876,22 @@ def sdf_fused(x, features, meta: GridMeta, pack: DecoderPack) -> torch.Tensor:
     return _SdfFused.apply(x, meta, pack, *features)
 
 
+def grid_pool_avg(coords, features, bound_min, cell_size: float, dims):
+    """utils.grid_pool_3d_avg on the device in three launches (miso_grid_pool_avg): -> (nx, ny, nz, d)."""
+    _require_hip(coords, features)
+    coords = coords.contiguous()
+    features = features if features.stride(-1) == 1 else features.contiguous()
+    n, d = features.shape
+    nx, ny, nz = (int(v) for v in dims)
+    out = torch.empty((nx, ny, nz, d), device=features.device, dtype=torch.float32)
+    cnt = torch.empty(nx * ny * nz, device=features.device, dtype=torch.int32)
+    bm = (C.c_float * 3)(*[float(v) for v in bound_min])
+    _lib.check(_lib.load().miso_grid_pool_avg(_ptr(coords), _ptr(features), n, d, features.stride(0) if n else d, bm,
+                                              float(cell_size), nx, ny, nz, _ptr(out), _ptr(cnt), _stream(features)),
+               "miso_grid_pool_avg")
+    return out
+
+
 # --------------------------------------------------------------------------- #
 # fused atlas query (GridAtlas.query_feature / forward in one launch)
 # --------------------------------------------------------------------------- #
