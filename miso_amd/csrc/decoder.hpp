@@ -114,7 +114,11 @@ __device__ __forceinline__ void mma_split_row(const uint32_t* __restrict__ A, in
   for (int kb = 0; kb < KB; ++kb) {
     u32x4 a[3];
 #pragma unroll
+#ifdef MISO_ABL_NO_AREAD     // dev ablation (wrong results): no LDS reads of the weights
+    for (int q = 0; q < 3; ++q) a[q] = u32x4{0x3f803f80u + (unsigned)lane, 0x3f803f80u, 0x3e803f80u, 0x3f803f00u + (unsigned)(kb + q)};
+#else
     for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4*>(A + split_a_dword(kb, r, q, lane, RT));
+#endif
 #pragma unroll
     for (int c = 0; c < 6; ++c)
 #pragma unroll
@@ -130,7 +134,11 @@ __device__ __forceinline__ void mma_mask_row(const uint32_t* __restrict__ A, int
   for (int kb = 0; kb < KB; ++kb) {
     u32x4 a[3];
 #pragma unroll
+#ifdef MISO_ABL_NO_AREAD
+    for (int q = 0; q < 3; ++q) a[q] = u32x4{0x3f803f80u + (unsigned)lane, 0x3f803f80u, 0x3e803f80u, 0x3f803f00u + (unsigned)(kb + q)};
+#else
     for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4*>(A + split_a_dword(kb, r, q, lane, RT));
+#endif
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll

@@ -111,6 +111,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 #ifdef MISO_ABL_NO_MFMA       // dev ablation (wrong results): no matrix instructions (their operands' producers go with them)
   return c;
 #endif
+#ifdef MISO_ABL_FAKE_MFMA     // dev ablation (wrong results): operands still produced and read, one vector instruction instead
+  f32x16 r = c;
+  r[0] += __uint_as_float((a[0] ^ b[0] ^ a[1] ^ b[1] ^ a[2] ^ b[2] ^ a[3] ^ b[3]) & 0x007fffffu);
+  return r;
+#endif
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
