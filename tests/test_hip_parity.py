@@ -839,7 +839,44 @@ def test_capi_rejects_bad_arguments_before_launching():
     assert lib.miso_lm_normal_eq(ops._ptr(x), ops._ptr(x), ops._ptr(x), ops._ptr(sdf), ops._ptr(sdf), n, 7, 0.1,
                                  ops._ptr(sdf), st) == UNSUP
     assert b"argument" in lib.miso_error_string(BAD).lower() or len(lib.miso_error_string(BAD)) > 0
+    # round 6 entries: the atlas query, the d-feat rows of the first backward, the pooling
+    host = (C.c_char * int(lib.miso_atlas_plan_bytes(1)))()
+    assert lib.miso_atlas_plan_bytes(0) == 0
+    assert lib.miso_atlas_plan_build(C.byref(g), 0, C.cast(host, C.c_void_p)) == BAD
+    assert lib.miso_atlas_plan_build(C.byref(g), 1, None) == BAD
+    assert lib.miso_atlas_plan_build(C.byref(g), 1, C.cast(host, C.c_void_p)) == 0
+    plan = torch.frombuffer(host, dtype=torch.uint8).clone().to(DEV)
+    poses = torch.tensor([[1., 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]], device=DEV)
+    args = lambda **kw: [kw.get("plan", ops._ptr(plan)), kw.get("S", 1), C.byref(g), kw.get("poses", ops._ptr(poses)),     # noqa: E731
+                         kw.get("mlp", C.byref(m)), ops._ptr(packed), kw.get("x", ops._ptr(x)), kw.get("n", n), None, None,
+                         None, kw.get("nx", 0), 0, 0, kw.get("sdf", ops._ptr(sdf)), None, 0, kw.get("flags", 0), st]
+    assert lib.miso_atlas_sdf_fwd(*args(plan=None)) == BAD
+    assert lib.miso_atlas_sdf_fwd(*args(poses=None)) == BAD
+    assert lib.miso_atlas_sdf_fwd(*args(sdf=None)) == BAD                      # neither sdf nor feats asked for
+    assert lib.miso_atlas_sdf_fwd(*args(flags=1)) == BAD                       # only MISO_F_EXACT_F32 is a flag here
+    assert lib.miso_atlas_sdf_fwd(*args(x=None)) == BAD                        # no points and no lattice
+    assert lib.miso_atlas_sdf_fwd(*args(mlp=C.byref(m2))) == UNSUP
+    assert lib.miso_atlas_sdf_fwd(*args()) == 0
+    rows = torch.empty(n, out.shape[1], device=DEV)
+    mask = torch.zeros(((n + 63) // 64) * 64 * int(lib.miso_sdf_mask_words(C.byref(m))), device=DEV, dtype=torch.int32)
+    gs = torch.ones(n, 1, device=DEV)
+    assert lib.miso_sdf_bwd_rows(C.byref(g), C.byref(m), ops._ptr(packed), ops._ptr(x), n, None, ops._ptr(mask), None,
+                                 ops._ptr(rows), st) == BAD
+    assert lib.miso_sdf_bwd_rows(C.byref(g), C.byref(m), ops._ptr(packed), ops._ptr(x), n, ops._ptr(gs), ops._ptr(mask), None,
+                                 C.c_void_p(rows.data_ptr() + 4), st) == BAD                       # rows must be 16-B aligned
+    g4 = ops._fill_grid(fdd, meta)
+    g4.flags = _lib.F_GRAD_OVERWRITE
+    assert lib.miso_sdf_bwd_rows(C.byref(g4), C.byref(m), ops._ptr(packed), ops._ptr(x), n, ops._ptr(gs), ops._ptr(mask), None,
+                                 ops._ptr(rows), st) == BAD                                        # binned-path flags do not apply
+    bm = (C.c_float * 3)(0.0, 0.0, 0.0)
+    pooled, cnt = torch.empty(8, 3, device=DEV), torch.empty(8, device=DEV, dtype=torch.int32)
+    feats3 = torch.ones(n, 3, device=DEV)
+    assert lib.miso_grid_pool_avg(ops._ptr(x), ops._ptr(feats3), n, 3, 3, bm, 0.0, 2, 2, 2, ops._ptr(pooled), ops._ptr(cnt), st) == BAD
+    assert lib.miso_grid_pool_avg(ops._ptr(x), ops._ptr(feats3), n, 3, 2, bm, 0.5, 2, 2, 2, ops._ptr(pooled), ops._ptr(cnt), st) == BAD
+    assert lib.miso_grid_pool_avg(ops._ptr(x), ops._ptr(feats3), n, 3, 3, bm, 0.5, 2, 2, 0, ops._ptr(pooled), ops._ptr(cnt), st) == BAD
+    assert lib.miso_grid_pool_avg(ops._ptr(x), ops._ptr(feats3), n, 3, 3, bm, 0.5, 2, 2, 2, ops._ptr(pooled), ops._ptr(cnt), st) == 0
     torch.cuda.synchronize()
+    assert int(cnt.sum()) == n and bool(((pooled == 1.0) | (pooled == 0.0)).all())
     # and a well-formed call still works afterwards
     assert lib.miso_encode_fwd(C.byref(g), ops._ptr(x), n, ops._ptr(out), out.stride(0), st) == 0
     torch.cuda.synchronize()
