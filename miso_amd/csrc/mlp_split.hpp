@@ -119,6 +119,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// (the all-row-tiles form; the kernels use decoder.hpp's mma_split_row, one row tile at a time -- this one serves
+// tools/ubench/mlp_split.hip)
 // out[r][t] (+)= A B for KB k-blocks, RT output row tiles, NT point tiles; the six piece products per k-block, smallest
 // first.  FIRST: the very first product of every accumulator takes `init[r]` as its C operand (a bias block shared by the
 // point tiles, or zeros) -- no accumulator initialisation moves.  A: the matrix's split block in LDS (split_a_dword).

@@ -2,9 +2,12 @@
 //
 // Replaces GridNet.forward (grid_opt/models/grid_net.py:306-325) and its autograd
 // backward with a frozen decoder: features never touch HBM, the decoder runs on
-// the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32), and the backward needs
-// only the ReLU sign bits saved by the forward (2*H bits per point) because the
-// decoder's weights take no gradient.
+// the matrix cores -- by default as bf16x3 split products on v_mfma_f32_32x32x16_bf16
+// (decoder.hpp, mlp_split.hpp: error against float64 equal to exact fp32), behind
+// MISO_F_EXACT_F32 as exact fp32 FMA chains on v_mfma_f32_32x32x2_f32 (described
+// below; both forms chain the accumulators of one layer into the next) -- and the
+// backward needs only the ReLU sign bits saved by the forward (2*H bits per point)
+// because the decoder's weights take no gradient.
 //
 // Work decomposition: one 64-lane wavefront owns a chunk of 64 points and never
 // synchronises with other waves (no __syncthreads in the loop), so on one SIMD
