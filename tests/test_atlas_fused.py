@@ -137,3 +137,36 @@ def test_fused_query_is_not_taken_where_autograd_is_needed(scannet8, tmp_path):
     with torch.no_grad():
         assert atlas._fused_query(x) is not None
         assert atlas._fused_query(x.cpu()) is None           # host tensors: no device path
+
+
+@pytest.mark.parametrize("C,L,H", [(8, 3, 64), (4, 1, 32), (8, 4, 64)])
+def test_fused_atlas_query_other_shapes_vs_the_loop(C, L, H):
+    """Three overlapping submaps of the cfg-2 / cfg-1 / cfg-5 channel and level counts (different poses, one of them far
+    rotated), random world points incl. a margin outside every bound: features 2e-6, SDF 1e-5 against the per-submap loop;
+    a ragged point count (the last 64-point chunk is partial)."""
+    from miso_amd.grid_opt.models.grid_atlas import GridAtlas
+    import math
+    cfg = {"name": "grid_net", "spatial_dim": 3,
+           "decoder": {"type": "mlp", "hidden_dim": H, "hidden_layers": 1, "out_dim": 1, "pos_invariant": True,
+                       "fix": True, "pretrained_model": None},
+           "grid": {"type": "regular", "feature_dim": C, "init_stddev": 3e-2, "bound": [[-1.0, 1.0], [-0.5, 0.75], [-1.0, 1.0]],
+                    "base_cell_size": 0.25, "per_level_scale": 2, "n_levels": L},
+           "pose": {"optimize": False, "num_poses": 1}}
+    torch.manual_seed(3)
+    atlas = GridAtlas(cfg, device=DEV)
+    lb = torch.tensor(cfg["grid"]["bound"])
+    for s, (tx, ang) in enumerate(((0.0, 0.0), (1.2, 0.3), (-0.8, -1.1))):
+        Rz = torch.tensor([[math.cos(ang), -math.sin(ang), 0.0], [math.sin(ang), math.cos(ang), 0.0], [0.0, 0.0, 1.0]])
+        atlas.add_submap(lb, Rz, torch.tensor([[tx], [0.1 * s], [-0.2 * s]]), num_poses=1)
+        atlas.add_kf(torch.eye(3), torch.zeros(3, 1))
+    atlas.to(DEV)
+    gb = atlas.global_bound(device="cpu").detach()
+    gen = torch.Generator().manual_seed(L)
+    n = 50001
+    x = ((gb[:, 0] - 0.3) + (gb[:, 1] - gb[:, 0] + 0.6) * torch.rand(n, 3, generator=gen)).to(DEV)
+    sdf_l, feat_l = _loop(atlas, x)
+    with torch.no_grad():
+        got = atlas._fused_query(x, want_sdf=True, want_feats=True)
+    assert got is not None
+    close(got[1], feat_l, 0, 2e-6)
+    close(got[0], sdf_l, 0, 1e-5)

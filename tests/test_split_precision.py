@@ -170,3 +170,35 @@ def test_fused_double_backward_equals_the_torch_linear_chain(n):
     assert (keep[:, None] * (gx1 - gx2)).abs().max().item() <= 1e-4 * gx2.abs().max().item()      # (a tie point's own d sdf / d x may differ)
     for a, c in zip(g1, g2):
         assert (a - c).abs().max().item() <= 2e-4 * c.abs().max().item(), (a - c).abs().max().item() / c.abs().max().item()
+
+
+def test_first_backward_rows_are_the_decoder_cotangent_of_the_feature_rows():
+    """miso_sdf_bwd_rows: the d-feat rows it hands out equal d(sum g sdf) / d(feature rows) of the oracle's decoder on the
+    oracle's feature rows (float64), its coordinate gradient and grid gradients equal miso_sdf_bwd's bit for bit / to the
+    order of the float atomics."""
+    from miso_amd import ops
+    levels, C, H = [(16, 16, 16), (32, 32, 32), (64, 64, 64)], 8, 64
+    x, feats, b, ws, bs, g = _inputs(levels, C, H, [[-1.0, 1.0]] * 3, False, seed=21)
+    n = 20001
+    x, g = x[:n], g[:n]
+    meta = ops.GridMeta.from_bound(b)
+    fd = [f.to(DEV).contiguous(memory_format=torch.channels_last_3d) for f in feats]
+    pack = ops.DecoderPack([w.to(DEV) for w in ws], [v.to(DEV) for v in bs])
+    xd, gd = x.to(DEV), g.to(DEV)
+    sdf, mask = ops.sdf_fwd_raw(xd, fd, meta, pack, want_mask=True)
+    gx1, gr1, rows = ops.sdf_bwd_rows_raw(xd, fd, meta, pack, gd, mask, True, [True] * 3)
+    gx2, gr2 = ops.sdf_bwd_raw(xd, fd, meta, pack, gd, mask, True, [True] * 3)
+    torch.cuda.synchronize()
+    assert torch.equal(gx1, gx2)
+    for a, c in zip(gr1, gr2):
+        assert (a - c).abs().max().item() <= 2e-6 * c.abs().max().item()
+    # oracle: decoder cotangent of the rows, float64, tie points excluded
+    r64 = R.encode_stock([f.double() for f in feats], b.double(), x.double()).requires_grad_(True)
+    wd, bd = [w.double() for w in ws], [v.double() for v in bs]
+    pre1 = r64 @ wd[0].T + bd[0]
+    pre2 = torch.relu(pre1) @ wd[1].T + bd[1]
+    out = torch.relu(pre2) @ wd[2].T + bd[2]
+    keep = torch.minimum(pre1.detach().abs().min(1).values, pre2.detach().abs().min(1).values) >= TIE
+    ref, = torch.autograd.grad(out, r64, g.double())
+    d = (rows.cpu().double() - ref)[keep].abs()
+    assert d.max().item() <= 1e-5 * ref.abs().max().item(), d.max().item() / ref.abs().max().item()
