@@ -81,6 +81,10 @@ extern "C" {
                                      as three bf16 pieces, six piece products on v_mfma_f32_32x32x16_bf16 with fp32
                                      accumulation -- the same 2^-24 class of error against float64 (tests/test_split_precision.py),
                                      2.7 x fewer matrix clocks.  Results of the two forms differ in the last bits. */
+#define MISO_F_ATLAS_NO_BOUND 512u /* miso_atlas_sdf_fwd: skip the coords_in_bound test -- ONE submap with an identity pose row is
+                                     then queried exactly as GridNet.forward queries it (zeros padding decides what a point
+                                     outside the grid sees; the level mask of the plan's grid is honoured): save_mesh(submap,
+                                     submap.bound, ...) on a lattice generated in the kernel */
 #define MISO_F_FULL_TRIPS 256u     /* miso_sdf_train on a small unbinned batch (<= 65 536 samples): 64-point trips per wavefront as
                                      for large batches, instead of the default 32-point trips (same arithmetic per point; the
                                      32-point form halves a wavefront's chain of matrix instructions where the batch is one
@@ -710,7 +714,8 @@ int miso_grid_pool_avg(const float* coords, const float* features, int64_t n, in
  *       submap^T) then t_submap_world (= -R^T t), formed by the caller as transfrom_points_from forms them.  Points: `x`
  *       (N,3) world coordinates, or x == NULL and a lattice: point (i j k), index (i ny + j) nz + k, sits at (axis_x[i],
  *       axis_y[j], axis_z[k]) (device arrays; n == nx ny nz < 2^31).  Outputs: `sdf` (N) and / or `feats` (N, ld_feats)
- *       mean features (either may be NULL; mlp / packed are needed for sdf only).  flags: 0 or MISO_F_EXACT_F32. */
+ *       mean features (either may be NULL; mlp / packed are needed for sdf only).  flags: MISO_F_EXACT_F32,
+ *       MISO_F_ATLAS_NO_BOUND. */
 int64_t miso_atlas_plan_bytes(int32_t n_submaps);
 int miso_atlas_plan_build(const miso_grid_t* grids, int32_t n_submaps, void* plan_host);
 int miso_atlas_sdf_fwd(const void* plan, int32_t n_submaps, const miso_grid_t* shape, const float* poses,

@@ -31,6 +31,7 @@ F_GRAD_ZEROED = 32
 F_CROWDED = 64
 F_EXACT_F32 = 128
 F_FULL_TRIPS = 256
+F_ATLAS_NO_BOUND = 512
 LOSS_SLOTS = 512
 
 E_BADARG = 2001

@@ -102,14 +102,15 @@ __global__ __launch_bounds__(256, 2) void atlas_sdf_kernel(AtlasK a, const float
         xl[j] = __fadd_rn(v, ps[9 + j]);
       }
       // coords_in_bound (utils_geometry.py:11-27): min <= x <= max on every axis
-      const bool inside = valid && xl[0] >= g.bmin[0] && xl[0] <= g.bmax[0] && xl[1] >= g.bmin[1] && xl[1] <= g.bmax[1] &&
-                          xl[2] >= g.bmin[2] && xl[2] <= g.bmax[2];
+      const bool inside = valid && (a.no_bound || (xl[0] >= g.bmin[0] && xl[0] <= g.bmax[0] && xl[1] >= g.bmin[1] &&
+                                                   xl[1] <= g.bmax[1] && xl[2] >= g.bmin[2] && xl[2] <= g.bmax[2]));
       if (!__any(inside)) continue;
       any_inside = true;
       if (inside) {
         cnt += 1.0f;
 #pragma unroll
         for (int l = 0; l < L; ++l) {
+          if ((g.ignore_mask >> l) & 1u) continue;      // (zeros: utils.py:160-163; the atlas queries never set it)
           const LevelK lv = g.lv[l];
           Axis ax = axis_coord(xl[0], g.bmin[0], g.bmax[0], lv.X, g.flags);
           Axis ay = axis_coord(xl[1], g.bmin[1], g.bmax[1], lv.Y, g.flags);

@@ -1092,7 +1092,8 @@ int miso_atlas_plan_build(const miso_grid_t* grids, int32_t n_submaps, void* pla
     if (out[s].n_levels != out[0].n_levels) return MISO_E_UNSUPPORTED;
     for (int l = 0; l < out[s].n_levels; ++l)
       if (out[s].lv[l].C != out[0].lv[0].C) return MISO_E_UNSUPPORTED;
-    out[s].ignore_mask = 0;      // query_feature passes ignore_level=None (grid_atlas.py:385)
+    // (ignore_mask is the caller's: GridAtlas.query_feature passes ignore_level=None, grid_atlas.py:385 -- its grids come
+    // without one; a single GridNet queried through MISO_F_ATLAS_NO_BOUND keeps its own)
   }
   return MISO_OK;
 }
@@ -1102,7 +1103,7 @@ int miso_atlas_sdf_fwd(const void* plan, int32_t n_submaps, const miso_grid_t* s
                        const float* axis_y, const float* axis_z, int32_t nx, int32_t ny, int32_t nz, float* sdf,
                        float* feats, int64_t ld_feats, uint32_t flags, void* stream) {
   if (!plan || !poses || !shape || n_submaps < 1 || n < 0 || (!sdf && !feats)) return MISO_E_BADARG;
-  if (flags & ~MISO_F_EXACT_F32) return MISO_E_BADARG;
+  if (flags & ~(MISO_F_EXACT_F32 | MISO_F_ATLAS_NO_BOUND)) return MISO_E_BADARG;
   GridK g; bool v4;
   int rc = convert_grid(shape, &g, false, &v4);
   if (rc) return rc;
@@ -1121,6 +1122,7 @@ int miso_atlas_sdf_fwd(const void* plan, int32_t n_submaps, const miso_grid_t* s
   memset(&a, 0, sizeof(a));
   a.submaps = reinterpret_cast<const GridK*>(plan);
   a.poses = poses; a.n_submaps = n_submaps; a.n = n; a.sdf = sdf; a.feats = feats; a.ld = ld_feats;
+  a.no_bound = (flags & MISO_F_ATLAS_NO_BOUND) ? 1 : 0;
   if (x) {
     a.x = x;
   } else {

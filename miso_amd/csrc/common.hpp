@@ -51,6 +51,7 @@ struct AtlasK {
   float* sdf;                // (N) or nullptr
   float* feats;              // (N, ld) mean features or nullptr
   int64_t ld;
+  int32_t no_bound;          // MISO_F_ATLAS_NO_BOUND: no coords_in_bound test (one submap queried as GridNet.forward does)
 };
 
 __device__ __forceinline__ void load_point(const GridK& g, const float* __restrict__ x, int64_t p, float& px,

@@ -26,7 +26,7 @@ class BaseNet(nn.Module):
     # device-side caches (ctypes structs with raw pointers, pose tables, vertex tables) are rebuilt on demand and must
     # not travel with ``torch.save(model)`` -- the whole-module pickle the demos exchange (demo/build_submaps.py:141)
     _TRANSIENT = ('_pose_cache', '_vertex_cache', '_align_src_cache', '_align_grid_cache', '_align_plan_const',
-                  '_kf_pose_cache', '_kf_table', '_fast_plans')
+                  '_kf_pose_cache', '_kf_table', '_fast_plans', '_atlas_query', '_atlas_poses', '_atlas_eligible')
 
     def __getstate__(self):
         state = self.__dict__.copy()

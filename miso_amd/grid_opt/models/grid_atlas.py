@@ -266,12 +266,6 @@ class GridAtlas(BaseNet):
         for s in self.submaps:
             s.zero_features()
 
-    def __getstate__(self):
-        state = self.__dict__.copy()
-        for k in ('_atlas_query', '_atlas_poses', '_atlas_eligible'):      # device plan + ctypes structs of the fused query:
-            state.pop(k, None)                                            # rebuilt on demand, never pickled
-        return state
-
     # ---- queries (hot path) ----------------------------------------------------------------------
     def _fused_query(self, x_world=None, axes=None, want_sdf=True, want_feats=False):
         """query_feature / forward as ONE launch (ops.AtlasQuery -> miso_atlas_sdf_fwd) when nothing has to be

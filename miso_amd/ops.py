@@ -910,7 +910,7 @@ class AtlasQuery:
 
     def _prepare(self, features, metas):
         key = tuple(tuple((f.data_ptr(), tuple(f.shape), f.stride()) for f in fs) for fs in features) + \
-            tuple((m.bound_min, m.bound_max, m.flags) for m in metas)
+            tuple((m.bound_min, m.bound_max, m.flags, m.ignore_mask) for m in metas)
         if key == self._key:
             return
         S = len(features)
@@ -928,7 +928,7 @@ class AtlasQuery:
         self._key = key
 
     def __call__(self, features, metas, poses, pack: Optional["DecoderPack"], x=None, axes=None, want_sdf=True,
-                 want_feats=False):
+                 want_feats=False, no_bound=False):
         """poses: (S,12) device floats, per submap R_submap_world row-major then t_submap_world.  x: (N,3) world points,
         or axes = (xs, ys, zs) device vectors of a lattice (point (i,j,k) -> index (i ny + j) nz + k).
         -> (sdf (N,1) or None, feats (N,F) or None)."""
@@ -953,7 +953,7 @@ class AtlasQuery:
             m, packed = pack.get()
             if m is None:
                 raise RuntimeError("decoder shape is not covered by the fused kernels")
-        flags = _lib.F_EXACT_F32 if _EXACT_F32 else 0
+        flags = (_lib.F_EXACT_F32 if _EXACT_F32 else 0) | (_lib.F_ATLAS_NO_BOUND if no_bound else 0)
         _lib.check(_lib.load().miso_atlas_sdf_fwd(
             _ptr(self._plan), S, C.byref(self._shape), _ptr(poses), C.byref(m) if m is not None else None, _ptr(packed),
             _ptr(x), n, _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), dims[0], dims[1], dims[2], _ptr(sdf), _ptr(feats), F_,

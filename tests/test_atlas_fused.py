@@ -170,3 +170,31 @@ def test_fused_atlas_query_other_shapes_vs_the_loop(C, L, H):
     assert got is not None
     close(got[1], feat_l, 0, 2e-6)
     close(got[0], sdf_l, 0, 1e-5)
+
+
+def test_one_submap_without_the_bound_test_is_gridnet_forward():
+    """MISO_F_ATLAS_NO_BOUND: the atlas kernel with ONE submap, an identity pose row and no bound test gives GridNet.forward on
+    a lattice (a margin outside the bound included: zeros padding decides) bit for bit, an ignored level included.
+    (Measured as the field of save_mesh(submap, ...) at 256^3: 1.85 ms against 1.75 ms for slabs of 4 M meshgrid points
+    through sdf_fwd_kernel -- a single submap's slabs were never the bottleneck, so GridNet keeps the slab path.)"""
+    from miso_amd import ops
+    from test_grid_opt_mirror import make_gridnet
+    case = gc.CASES["cfg2"]
+    net = make_gridnet(case, DEV)
+    b = net.bound.detach().cpu()
+    res = (33, 20, 47)
+    axes = [torch.linspace(float(b[a, 0]) - 0.1, float(b[a, 1]) + 0.1, res[a]).to(DEV) for a in range(3)]
+    xx, yy, zz = torch.meshgrid(*axes, indexing="ij")
+    pts = torch.stack((xx, yy, zz), dim=-1).reshape(-1, 3)
+    ident = torch.tensor([[1., 0., 0., 0., 1., 0., 0., 0., 1., 0., 0., 0.]], device=DEV)
+    q = ops.AtlasQuery()
+    feats = [g.feature.detach() for g in net.features]
+    for ignore in (None, 1):
+        if ignore is not None:
+            net.ignore_level(ignore)
+        meta = net.features[0].grid_meta(net.ignore_level_)
+        with torch.no_grad():
+            vol, _ = q([feats], [meta], ident, net._fused_decoder(), axes=tuple(axes), no_bound=True)
+            assert torch.equal(vol, net(pts))
+            bounded, _ = q([feats], [meta], ident, net._fused_decoder(), axes=tuple(axes))
+            assert not torch.equal(bounded, vol)             # with the test on, the margin decodes the zero row
