@@ -45,6 +45,12 @@ __device__ __forceinline__ void gather_level(const LevelK& lv, const Cell& c, fl
     bool in = c.inx[dx] && c.iny[dy] && c.inz[dz];
     float w = in ? (c.wx[dx] * c.wy[dy]) * c.wz[dz] : 0.0f;
     int off = in ? (c.k0 + dz) * lv.sZ + (c.j0 + dy) * lv.sY + (c.i0 + dx) * lv.sX : 0;
+#ifdef MISO_ABL_UNIFORM_GATHER      // dev ablation (wrong results): every lane reads lane 0's rows -- perfectly coalesced gathers
+    off = __builtin_amdgcn_readfirstlane(off);
+#endif
+#ifdef MISO_ABL_QUAD_GATHER         // dev ablation (wrong results): groups of four lanes read one lane's rows
+    off = __builtin_amdgcn_mov_dpp(off, 0x00, 0xf, 0xf, true);
+#endif
 #pragma unroll
     for (int q = 0; q < C; q += 4) {
       float4 v = *reinterpret_cast<const float4*>(lv.data + off + q);
