@@ -37,7 +37,8 @@
 namespace miso {
 
 constexpr int MC_WAVES = 8;
-constexpr int MC_CAND = 1024;          // table entries (a uniform cfg-2 batch: ~1000 per block)
+constexpr int MC_CAND = 1152;          // table entries (a uniform cfg-2 batch: 1000 +- 32 per block: at 1024 every fifth block ran a
+                                       // second epoch)
 constexpr int MC_POOL = 4608;          // (sample, sub-brick) pairs incl. padding (uniform cfg-2: 3830 +- 130, max 4200; more: halved ranges)
 constexpr int MC_ITEMS = 512;          // sub-brick code space: level (2 bits) | sz (3) | sy (2) | sx (2)
 constexpr int MC_UN = 8;               // 64-sample steps in flight per wavefront in the sweep
@@ -87,8 +88,7 @@ template <int C, int NLV> struct McLds {
   static constexpr int O_POOL = O_CAND + (MC_CAND + 1) * 4;          // uint32[MC_POOL]: table slot | sub-brick code << 16
   static constexpr int O_CNT = O_POOL + MC_POOL;                     // int[MC_ITEMS]: pairs per sub-brick
   static constexpr int O_CUR = O_CNT + MC_ITEMS;                     // int[MC_ITEMS]: fill cursors (absolute)
-  static constexpr int O_OFF = O_CUR + MC_ITEMS;                     // int[MC_ITEMS]: first pair of every sub-brick
-  static constexpr int O_MISC = O_OFF + MC_ITEMS;                    // 96 ints
+  static constexpr int O_MISC = O_CUR + MC_ITEMS;                    // 96 ints
   static constexpr int O_LVL = O_MISC + 96;                          // MC_MAXL block-geometry records of MC_LVL words
   static constexpr int O_LVG = O_LVL + MC_MAXL * MC_LVL;             // MC_MAXL records of 8 words: grad, strides, touched
   static constexpr int O_STAGE = O_LVG + MC_MAXL * 8;                // per wavefront: (8 + ZS weights + C d-feats) x MC_CS
@@ -143,7 +143,6 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
   unsigned* pool = reinterpret_cast<unsigned*>(ismem + L::O_POOL);
   int* cnt = ismem + L::O_CNT;
   int* cur = ismem + L::O_CUR;
-  int* off = ismem + L::O_OFF;
   int* misc = ismem + L::O_MISC;
   int* coff = ismem + L::O_COST;                 // (in the staging area: idle while routing runs)
   int* lvl = ismem + L::O_LVL;
@@ -215,6 +214,8 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           if (B) {
             v0 = t0 * B; E = (t1 - t0) * B;
             lo = t0 - 1; hi = t1;                      // exact for size = B T
+            if ((pk.debug & 32) && a > 0) hi = t1 - 1;      // dev (timing only): no upper sliver in y, z
+            if ((pk.debug & 256) && a == 2) lo = t0;        // dev (timing only): two tile layers in z
           } else {
             v0 = t0 * sz / T3[a];
             E = t1 * sz / T3[a] - v0;
@@ -396,7 +397,8 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
           int run = (inc & 0xffff) - tot, nzr = (inc >> 16) - nz;
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            off[lane * 8 + k] = run; cur[lane * 8 + k] = run;       // cursors are absolute pool positions
+            cur[lane * 8 + k] = run;                                // cursors are absolute pool positions (until the fill: the
+                                                                    // sub-brick's first pair)
             coff[lane * 8 + k] = (run >> 1) + MC_FLUSH * nzr;
             run += c8[k]; nzr += c8[k] ? 1 : 0;
           }
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
               for (int st = MC_ITEMS / 2; st > 0; st >>= 1)
                 if (coff[i + st] <= target) i += st;
               const int groups = (cnt[i] + 3) >> 2;
-              bound = (off[i] >> 2) + min((target - coff[i]) >> 1, groups);
+              bound = (cur[i] >> 2) + min((target - coff[i]) >> 1, groups);
             }
             misc[M_BOUND + lane] = bound;
           }
