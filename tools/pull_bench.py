@@ -25,7 +25,8 @@ def main():
     grads = [torch.empty_like(f) for f in feats]
     t_s = timeit(lambda: sb.sort(x, meta))
     out = [f"sort {t_s:.1f}"]
-    for mask in (0b111, 0b001, 0b010, 0b100, 0b011, 0b110):
+    masks = [int(m, 2) for m in os.environ.get("MASKS", "111,001,010,100,011,110").split(",")]
+    for mask in masks:
         gl = [grads[l] if (mask >> l) & 1 else None for l in range(L)]
         t = timeit(lambda: ops.grad_pull_raw(feats, meta, sb, df, gl, overwrite=True))
         out.append(f"levels {mask:03b}: {t:.1f}")
