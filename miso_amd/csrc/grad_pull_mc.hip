@@ -91,7 +91,8 @@ template <int C, int NLV> struct McLds {
   static constexpr int O_MISC = O_CUR + MC_ITEMS;                    // 96 ints
   static constexpr int O_LVL = O_MISC + 96;                          // MC_MAXL block-geometry records of MC_LVL words
   static constexpr int O_LVG = O_LVL + MC_MAXL * MC_LVL;             // MC_MAXL records of 8 words: grad, strides, touched
-  static constexpr int O_STAGE = O_LVG + MC_MAXL * 8;                // per wavefront: (8 + ZS weights + C d-feats) x MC_CS
+  static constexpr int O_GEO = O_LVG + MC_MAXL * 8;                  // the block's catchment box and tile-row bounds (G_*)
+  static constexpr int O_STAGE = O_GEO + 144;                        // per wavefront: (8 + ZS weights + C d-feats) x MC_CS
   static constexpr int NCOMP = 8 + ZS + C;
   static constexpr int STAGE = NCOMP * MC_CS;
   static constexpr int WORDS = O_STAGE + MC_WAVES * STAGE;
@@ -105,6 +106,8 @@ template <int C, int NLV> struct McLds {
 constexpr int M_NSURV = 0, M_FULL = 1, M_MORE = 2, M_PTOT = 3, M_A = 8, M_B = 16, M_CONT = 24, M_EMPTY = 32, M_BOUND = 40,
               M_PROF = 64;
 // a share's cost: 2 per group of four pairs + MC_FLUSH per sub-brick that ends in it (storing a tile costs ~2.5 groups)
+// O_GEO slots
+constexpr int G_ULO = 0, G_UHI = 4, G_NROWS = 8, G_RS = 16, G_RE = 80;
 constexpr int MC_FLUSH = 5;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
   int* coff = ismem + L::O_COST;                 // (in the staging area: idle while routing runs)
   int* lvl = ismem + L::O_LVL;
   int* lvg = ismem + L::O_LVG;
+  int* geo = ismem + L::O_GEO;
   uint16_t* codes = reinterpret_cast<uint16_t*>(ismem + L::O_STAGE);      // [NLV][MC_CAND]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* stg = smem + L::O_STAGE + wave * L::STAGE;       // [12 + C][MC_CS]: wx[4], wy[4], wz[4], d[C]; pair (g, k) at k 16 + g
@@ -184,68 +188,79 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
     // ---- per-block geometry -> LDS records (computed by the first threads, read back where needed) ----------------
     // level d, axis a: the block owns vertices [v0, v0 + E) = the bricks of its two tiles; points that touch them lie in
     // tiles [tlo, thi] (widened by one numerator unit against the rounding of the sort's tile_of)
-    int tlo[3], thi[3];
-    float ulo[3], uhi[3];
-    {
-      const int b3[3] = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};      // one workgroup per block of tiles
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { tlo[a] = 1 << 20; thi[a] = -1; ulo[a] = 3e30f; uhi[a] = -3e30f; }
-      // (all kernel-argument fields first: one batch of scalar loads instead of a dependent load per level and axis)
-      int size_[NLV][3], bdiv_[NLV][3], foff_[NLV], live_[NLV];
-      float inv_[NLV][3];
+    // Wavefront 0 forms it lane-parallel, lane = (level, axis) -- as ~600 scalar instructions per wavefront, eight times
+    // per block, it was 2 us of every block's chain -- and leaves the block's catchment and the bounds of its tile rows in
+    // `geo`; the others clear the counters meanwhile and read `geo` behind the epoch's first barrier.
+    if (wave == 0) {
+      int sz = 1, B = 0, foff = 0, live_i = 0, Ta = 1, ba = 0;
+      float inv = 1.0f;
 #pragma unroll
       for (int d = 0; d < NLV; ++d) {
         const McLv& lv = pk.lv[d];
-        size_[d][0] = lv.X; size_[d][1] = lv.Y; size_[d][2] = lv.Z; foff_[d] = lv.foff; live_[d] = lv.live;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { bdiv_[d][a] = lv.bdiv[a]; inv_[d][a] = lv.inv_size[a]; }
+        for (int a = 0; a < 3; ++a)
+          if (lane == 3 * d + a) {
+            sz = (a == 0) ? lv.X : (a == 1) ? lv.Y : lv.Z;
+            B = lv.bdiv[a]; inv = lv.inv_size[a]; foff = lv.foff; live_i = lv.live;
+          }
       }
-      const int T3[3] = {pk.T[0], pk.T[1], pk.T[2]};
+      const int d_ = lane / 3, a_ = lane - 3 * d_;
 #pragma unroll
-      for (int d = 0; d < NLV; ++d) {
-        if (d >= pk.nl) continue;
-        const bool live = live_[d] != 0;
+      for (int a = 0; a < 3; ++a)
+        if (a_ == a) { Ta = pk.T[a]; ba = (a == 0) ? (int)blockIdx.x : (a == 1) ? (int)blockIdx.y : (int)blockIdx.z; }
+      const bool in = lane < 3 * pk.nl;
+      const int t0 = 2 * ba, t1 = min(2 * ba + 2, Ta);
+      int lo, hi, v0, E;
+      if (B) {
+        v0 = t0 * B; E = (t1 - t0) * B;
+        lo = t0 - 1; hi = t1;                      // exact for size = B T
+      } else {
+        v0 = t0 * sz / Ta;
+        E = t1 * sz / Ta - v0;
+        lo = floor_div((2 * v0 - 1) * Ta - 1, 2 * sz);
+        hi = floor_div((2 * (v0 + E) + 1) * Ta + 1, 2 * sz);
+      }
+      if (in) {
+        lvl[d_ * MC_LVL + a_] = sz; lvl[d_ * MC_LVL + 4 + a_] = v0; lvl[d_ * MC_LVL + 8 + a_] = E;
+        if (a_ == 0) { lvl[d_ * MC_LVL + 3] = foff; lvl[d_ * MC_LVL + 7] = live_i; }
+        // the routing's position relative to the block, one fma: xn size/2 + ((size - 1)/2 - v0)
+        reinterpret_cast<float*>(lvl)[d_ * MC_LVL + 12 + a_] = 0.5f * (float)sz;
+        reinterpret_cast<float*>(lvl)[d_ * MC_LVL + 16 + a_] = 0.5f * (float)(sz - 1) - (float)v0;
+      }
+      // (an ignored level is still zero-filled, its points are just not routed)
+      const bool use = in && live_i != 0;
+      int c_lo = use ? max(lo, 0) : (1 << 20), c_hi = use ? min(hi, Ta - 1) : -1;
+      float c_ul = use ? (2.0f * v0 - 1.0f) * inv - 1.0f - 8e-6f : 3e30f;
+      float c_uh = use ? (2.0f * (v0 + E) + 1.0f) * inv - 1.0f + 8e-6f : -3e30f;
+      {     // lane a (< 3) gathers its axis over the levels
+        const int l0 = c_lo, h0 = c_hi;
+        const float ul0 = c_ul, uh0 = c_uh;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const int sz = size_[d][a];
-          const int t0 = 2 * b3[a], t1 = min(2 * b3[a] + 2, T3[a]);
-          const int B = bdiv_[d][a];
-          int lo, hi, v0, E;
-          if (B) {
-            v0 = t0 * B; E = (t1 - t0) * B;
-            lo = t0 - 1; hi = t1;                      // exact for size = B T
-            if ((pk.debug & 32) && a > 0) hi = t1 - 1;      // dev (timing only): no upper sliver in y, z
-            if ((pk.debug & 256) && a == 2) lo = t0;        // dev (timing only): two tile layers in z
-          } else {
-            v0 = t0 * sz / T3[a];
-            E = t1 * sz / T3[a] - v0;
-            lo = floor_div((2 * v0 - 1) * T3[a] - 1, 2 * sz);
-            hi = floor_div((2 * (v0 + E) + 1) * T3[a] + 1, 2 * sz);
-          }
-          if (threadIdx.x == 0) {
-            lvl[d * MC_LVL + a] = sz; lvl[d * MC_LVL + 4 + a] = v0; lvl[d * MC_LVL + 8 + a] = E;
-            if (a == 0) { lvl[d * MC_LVL + 3] = foff_[d]; lvl[d * MC_LVL + 7] = live_[d]; }
-            // the routing's position relative to the block, one fma: xn size/2 + ((size - 1)/2 - v0)
-            reinterpret_cast<float*>(lvl)[d * MC_LVL + 12 + a] = 0.5f * (float)sz;
-            reinterpret_cast<float*>(lvl)[d * MC_LVL + 16 + a] = 0.5f * (float)(sz - 1) - (float)v0;
-          }
-          if (live) {        // (an ignored level is still zero-filled, its points are just not routed)
-            tlo[a] = min(tlo[a], max(lo, 0)); thi[a] = max(thi[a], min(hi, T3[a] - 1));
-            ulo[a] = fminf(ulo[a], (2.0f * v0 - 1.0f) * inv_[d][a] - 1.0f - 8e-6f);
-            uhi[a] = fmaxf(uhi[a], (2.0f * (v0 + E) + 1.0f) * inv_[d][a] - 1.0f + 8e-6f);
-          }
+        for (int k = 1; k < NLV; ++k) {
+          c_lo = min(c_lo, __shfl_down(l0, 3 * k)); c_hi = max(c_hi, __shfl_down(h0, 3 * k));
+          c_ul = fminf(c_ul, __shfl_down(ul0, 3 * k)); c_uh = fmaxf(c_uh, __shfl_down(uh0, 3 * k));
         }
       }
+      if (lane < 3) {
+        geo[G_ULO + lane] = __float_as_int(c_ul); geo[G_UHI + lane] = __float_as_int(c_uh);
+      }
+      int tlo[3], thi[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { tlo[a] = __builtin_amdgcn_readlane(c_lo, a); thi[a] = __builtin_amdgcn_readlane(c_hi, a); }
+      const bool any_rows = thi[0] >= tlo[0] && thi[1] >= tlo[1] && thi[2] >= tlo[2];
+      const int ny = any_rows ? thi[1] - tlo[1] + 1 : 0;
+      const int nrows_ = any_rows ? ny * (thi[2] - tlo[2] + 1) : 0;      // <= 49 (launcher: 3 size >= 2 T on every axis)
+      int rs = 0, re = 0;
+      if (lane < nrows_) {
+        const int ry = tlo[1] + lane % ny, rz = tlo[2] + lane / ny;
+        rs = pk.tile_off[(rz * pk.T[1] + ry) * pk.T[0] + tlo[0]];
+        re = pk.tile_off[(rz * pk.T[1] + ry) * pk.T[0] + thi[0] + 1];
+      }
+      geo[G_RS + lane] = rs; geo[G_RE + lane] = re;
+      if (lane == 0) geo[G_NROWS] = nrows_;
     }
-    const bool any_rows = thi[0] >= tlo[0] && thi[1] >= tlo[1] && thi[2] >= tlo[2];
-    const int ny = any_rows ? thi[1] - tlo[1] + 1 : 0;
-    const int nrows = any_rows ? ny * (thi[2] - tlo[2] + 1) : 0;      // <= 49 (launcher: 3 size >= 2 T on every axis)
-    int rs_v = 0, re_v = 0;
-    if (lane < nrows) {
-      const int ry = tlo[1] + lane % ny, rz = tlo[2] + lane / ny;
-      rs_v = pk.tile_off[(rz * pk.T[1] + ry) * pk.T[0] + tlo[0]];
-      re_v = pk.tile_off[(rz * pk.T[1] + ry) * pk.T[0] + thi[0] + 1];
-    }
+    float ulo[3] = {0.f, 0.f, 0.f}, uhi[3] = {0.f, 0.f, 0.f};
+    int nrows = 0, rs_v = 0, re_v = 0;
     int r_cur = wave;                                            // this wavefront's rows: wave, wave + 8, ...
     int p_cur = -1;                                              // (read from rs_v after the barrier below)
     bool first = true;                                           // nothing of this block has been stored yet
@@ -258,7 +273,16 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
       for (int i = threadIdx.x; i < MC_ITEMS; i += NT) cnt[i] = 0;
       for (int i = threadIdx.x; i < MC_POOL; i += NT) pool[i] = 0xFFFFFFFFu;
       __syncthreads();
-      if (p_cur < 0) p_cur = (r_cur < nrows) ? __builtin_amdgcn_readlane(rs_v, min(r_cur, 63)) : 0;
+      if (p_cur < 0) {      // the first epoch: the block's catchment and row bounds, as wavefront 0 left them
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          ulo[a] = __int_as_float(__builtin_amdgcn_readfirstlane(geo[G_ULO + a]));
+          uhi[a] = __int_as_float(__builtin_amdgcn_readfirstlane(geo[G_UHI + a]));
+        }
+        nrows = __builtin_amdgcn_readfirstlane(geo[G_NROWS]);
+        rs_v = geo[G_RS + lane]; re_v = geo[G_RE + lane];
+        p_cur = (r_cur < nrows) ? __builtin_amdgcn_readlane(rs_v, min(r_cur, 63)) : 0;
+      }
       MC_STAMP(0)
       // ---- (1) sweep ------------------------------------------------------------------------------------------------
       while (r_cur < nrows) {
