@@ -709,19 +709,19 @@ def sample_generation(dev):
     from miso_amd.grid_opt.datasets.sdf_rgbd import PosedSdfRgbd
     from miso_amd.grid_opt.utils.utils_data import CameraParameters
     from oracle import ref_torch as R
-    B, H, W, rays, n_strat, n_surf = 100, 480, 640, 200, 19, 8
+    NF, H, W, rays, n_strat, n_surf = 100, 480, 640, 200, 19, 8
     g = torch.Generator().manual_seed(3)
-    depth = torch.rand(B, H, W, generator=g) * 4.0 + 0.5
-    depth[torch.rand(B, H, W, generator=g) < 0.1] = 0.0
-    ang = torch.rand(B, generator=g) * 6.28
-    Rm = torch.eye(3).repeat(B, 1, 1)
+    depth = torch.rand(NF, H, W, generator=g) * 4.0 + 0.5
+    depth[torch.rand(NF, H, W, generator=g) < 0.1] = 0.0
+    ang = torch.rand(NF, generator=g) * 6.28
+    Rm = torch.eye(3).repeat(NF, 1, 1)
     Rm[:, 0, 0], Rm[:, 0, 2], Rm[:, 2, 0], Rm[:, 2, 2] = ang.cos(), ang.sin(), -ang.sin(), ang.cos()
-    t = torch.rand(B, 3, 1, generator=g) * 10 - 5
+    t = torch.rand(NF, 3, 1, generator=g) * 10 - 5
     cp = CameraParameters(fx=577.6, fy=578.7, cx=318.9, cy=242.7, H=H, W=W)
-    normals = torch.ones(B, H, W, 3)          # estimation is one-time set-up, not part of the per-iteration cost
+    normals = torch.ones(NF, H, W, 3)          # estimation is one-time set-up, not part of the per-iteration cost
     ds = PosedSdfRgbd.from_frames(depth, Rm, t, cp, n_rays=rays, n_strat_samples=n_strat, n_surf_samples=n_surf,
                                   trunc_dist=0.15, device=dev, normals=normals)
-    n = B * rays
+    n = NF * rays
     ph = torch.randint(0, H, (n,), generator=g)
     pw = torch.randint(0, W, (n,), generator=g)
     u = torch.rand(n, n_strat, generator=g)
@@ -738,9 +738,9 @@ def sample_generation(dev):
         ds[0]
     torch.cuda.synchronize()
     t_item = (time.perf_counter() - t0) / 10 * 1e6
-    pb = torch.arange(B).repeat_interleave(rays)
+    pb = torch.arange(NF).repeat_interleave(rays)
     knobs = dict(min_depth=0.07, dist_behind_surf=0.1, trunc_dist=0.15, n_strat=n_strat, n_surf=n_surf)
-    Tm = torch.eye(4).repeat(B, 1, 1)
+    Tm = torch.eye(4).repeat(NF, 1, 1)
     Tm[:, :3, :3], Tm[:, :3, 3:] = Rm, t
     t0 = time.perf_counter()
     for _ in range(3):
