@@ -689,13 +689,15 @@ def slam_components(dev):
             out["tracker_lm_step_16384pts"] = {"us_per_step": best}
         else:
             trk.track_window([1], iterations=15)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(4):
-                trk.track_window([1], iterations=15)
-            torch.cuda.synchronize()
-            out["tracker_adam_window_16384pts"] = {"us_per_iteration": (time.perf_counter() - t0) / 60 * 1e6,
-                                                   "iterations_per_window": 15}
+            best = float("inf")
+            for _ in range(2):                      # (best of two loops, as above)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    trk.track_window([1], iterations=15)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / 60 * 1e6)
+            out["tracker_adam_window_16384pts"] = {"us_per_iteration": best, "iterations_per_window": 15}
         del trk
     torch.cuda.empty_cache()
     return out
