@@ -154,7 +154,10 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
   uint16_t* codes = reinterpret_cast<uint16_t*>(ismem + L::O_STAGE);      // [NLV][MC_CAND]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* stg = smem + L::O_STAGE + wave * L::STAGE;       // [12 + C][MC_CS]: wx[4], wy[4], wz[4], d[C]; pair (g, k) at k 16 + g
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // set bits of a ballot below this lane (v_mbcnt: no lane mask to keep in registers)
+  auto below = [](unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  };
   // accumulator-tile coordinates of this lane: column (vx, vy) = lane & 15, rows 4 (lane >> 4) .. + 3 = (vz, c)
   const int a_vx = lane & 3, a_vy = (lane >> 2) & 3;
   const int a_vz = (C == 8) ? (lane >> 5) : (lane >> 4), a_c0 = (C == 8) ? ((lane >> 4) & 1) * 4 : 0;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
             const int nin = (int)__popcll(m[u]);
             if (run + nin > pk.cand_cap) { done = u; continue; }   // table full: steps u.. are redone next epoch
             if ((m[u] >> lane) & 1ull)
-              cand[run + (int)__popcll(m[u] & lt_mask)] =
+              cand[run + below(m[u])] =
                   make_float4(c4[u].x, c4[u].y, c4[u].z, __int_as_float(p_cur + u * 64 + lane));
             run += nin;
           }
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
               for (int j = 0; j < 4; ++j) {
                 if (j < n && mm[j]) {
                   const int b = __builtin_amdgcn_readlane(base, j), cj = __builtin_amdgcn_readlane(mycode, j);
-                  if ((mm[j] >> lane) & 1ull) pool[b + (int)__popcll(mm[j] & lt_mask)] = (unsigned)t | ((unsigned)cj << 16);
+                  if ((mm[j] >> lane) & 1ull) pool[b + below(mm[j])] = (unsigned)t | ((unsigned)cj << 16);
                 }
               }
             } else {
