@@ -14,9 +14,10 @@ for numel, name in ((1_152_000, "cfg-5 coarse 120x120x20x4"), (16_777_216, "cfg-
     for frac in (0.02, 0.3, 1.0):
         p = torch.randn(numel, device=dev)
         m, v = torch.zeros_like(p), torch.zeros_like(p)
-        nch = (numel + 255) // 256
+        ch = ops._lib.ADAM_CHUNK                      # floats per flag
+        nch = (numel + ch - 1) // ch
         on = (torch.rand(nch, device=dev) < frac)
-        g = torch.randn(numel, device=dev) * on.repeat_interleave(256)[:numel]
+        g = torch.randn(numel, device=dev) * on.repeat_interleave(ch)[:numel]
         res = []
         for kind in ("active", "touched"):
             act = ops.adam_active_flags(p)
