@@ -802,10 +802,23 @@ class _SdfFusedBackward(torch.autograd.Function):
     GEMMs per layer, forward and backward, (N, 64) activations through HBM)."""
 
     @staticmethod
-    def forward(ctx, gsdf, x, mask, meta, pack, need_x, need_f, *features):
-        gx, grads, rows = sdf_bwd_rows_raw(x, features, meta, pack, gsdf, mask, need_x, need_f)
+    def _rows(x, features, meta, pack, gsdf, mask, need_x, need_f, sb):
+        """sdf_bwd_rows_raw; with the forward's binned batch ``sb`` (whose ``mask`` is then in the binned order) the launch
+        runs on the points in that order -- x and d sdf gathered by perm, d sdf / d x and the rows put back -- instead
+        of on a second forward's caller-order sign bits."""
+        if sb is None:
+            return sdf_bwd_rows_raw(x, features, meta, pack, gsdf, mask, need_x, need_f)
+        perm = sb.perm.long()
+        gx_s, grads, rows_s = sdf_bwd_rows_raw(x.index_select(0, perm), features, meta, pack,
+                                               gsdf.reshape(-1, 1).index_select(0, perm), mask, need_x, need_f)
+        gx = None if gx_s is None else torch.empty_like(gx_s).index_copy_(0, perm, gx_s)
+        return gx, grads, torch.empty_like(rows_s).index_copy_(0, perm, rows_s)
+
+    @staticmethod
+    def forward(ctx, gsdf, x, mask, meta, pack, need_x, need_f, sb, *features):
+        gx, grads, rows = _SdfFusedBackward._rows(x, features, meta, pack, gsdf, mask, need_x, need_f, sb)
         ctx.save_for_backward(gsdf, x, mask, rows, *features)
-        ctx.meta, ctx.pack = meta, pack
+        ctx.meta, ctx.pack, ctx.sb = meta, pack, sb
         ctx.set_materialize_grads(False)      # (see _EncodeBackward: no zero cotangents the size of a level)
         return (gx, *grads)
 
@@ -814,18 +827,19 @@ class _SdfFusedBackward(torch.autograd.Function):
     def backward(ctx, ggx, *ggf):
         gsdf, x, mask, rows, *features = ctx.saved_tensors
         need_gsdf, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        need_f = ctx.needs_input_grad[7:]
+        need_f = ctx.needs_input_grad[8:]
         if ggx is None and all(t is None for t in ggf):
-            return (None,) * (7 + len(features))
-        gg_rows, g_x, g_f = encode_bwd2_raw(x, features, ctx.meta, rows, ggx, ggf, need_x, need_f)
+            return (None,) * (8 + len(features))
+        # (the forward's binned batch serves the second-order encode and its pull as well: no second sort)
+        gg_rows, g_x, g_f = encode_bwd2_raw(x, features, ctx.meta, rows, ggx, ggf, need_x, need_f, sorted_batch=ctx.sb)
         g_gsdf = None
         if need_gsdf:
             # rows are linear in d sdf: rows = U d sdf with U the rows of a unit cotangent -- one more launch, only when the
             # cotangent of sdf is itself differentiated
-            _, _, unit = sdf_bwd_rows_raw(x, features, ctx.meta, ctx.pack, torch.ones_like(gsdf), mask, False,
-                                          [False] * len(features))
+            _, _, unit = _SdfFusedBackward._rows(x, features, ctx.meta, ctx.pack, torch.ones_like(gsdf), mask, False,
+                                                 [False] * len(features), ctx.sb)
             g_gsdf = (gg_rows * unit).sum(dim=1, keepdim=True).view_as(gsdf)
-        return (g_gsdf, g_x, None, None, None, None, None, *g_f)
+        return (g_gsdf, g_x, None, None, None, None, None, None, *g_f)
 
 
 class _SdfFused(torch.autograd.Function):
@@ -861,10 +875,9 @@ class _SdfFused(torch.autograd.Function):
                 return (gx, None, None, *gfs)
             if _ONLY_X:
                 need_f = (False,) * len(features)
-            if ctx.sb is not None:
-                # the forward binned the batch: its sign bits are in the binned order -- one more forward for caller-order bits
-                _, mask = sdf_fwd_raw(x, features, ctx.meta, ctx.pack, want_mask=True)
-            res = _SdfFusedBackward.apply(gsdf, x, mask, ctx.meta, ctx.pack, need_x, need_f, *features)
+            # (a forward that binned the batch left its sign bits in the binned order: the first backward then runs in
+            # that order too, _SdfFusedBackward._rows)
+            res = _SdfFusedBackward.apply(gsdf, x, mask, ctx.meta, ctx.pack, need_x, need_f, ctx.sb, *features)
             return (res[0], None, None, *res[1:])
         gx, grads = sdf_bwd_raw(x, features, ctx.meta, ctx.pack, gsdf, mask, need_x, need_f,
                                 sorted_batch=ctx.sb, overwrite=True)

@@ -131,8 +131,8 @@ def test_fused_double_backward_equals_the_torch_linear_chain(n):
     """create_graph=True through the fused decoder (round 6: ops._SdfFusedBackward -- the first backward keeps its d-feat
     rows, the second-order encode differentiates them) against the graph rebuilt from encode + torch.nn.functional.linear
     (rounds 1-5, MISO_BWD2_TORCH), on an eikonal + |sdf| loss (grid_opt/loss_isdf.py:96-152,367-377): loss, and the
-    gradient of every level.  n = 70 000 takes the binned forward (its sign bits are in tile order: the double backward
-    re-derives caller-order bits); ReLU-tie points carry no weight."""
+    gradient of every level.  n = 70 000 takes the binned forward (its sign bits are in tile order: the first backward
+    then runs in that order too, _SdfFusedBackward._rows); ReLU-tie points carry no weight."""
     from miso_amd import ops
     levels, C, H = [(16, 16, 16), (32, 32, 32), (64, 64, 64)], 8, 64
     gen = torch.Generator().manual_seed(n)
@@ -170,6 +170,43 @@ def test_fused_double_backward_equals_the_torch_linear_chain(n):
     assert (keep[:, None] * (gx1 - gx2)).abs().max().item() <= 1e-4 * gx2.abs().max().item()      # (a tie point's own d sdf / d x may differ)
     for a, c in zip(g1, g2):
         assert (a - c).abs().max().item() <= 2e-4 * c.abs().max().item(), (a - c).abs().max().item() / c.abs().max().item()
+
+
+def test_binned_double_backward_equals_the_caller_order_one():
+    """A training-size batch is binned by the forward (SortedBatch.AUTO_MIN_POINTS) and the first backward under
+    create_graph=True then runs in the binned order: d sdf / d x, the level gradients of an eikonal loss and the gradient
+    with respect to the cotangent of sdf (rows are linear in it) equal those of the caller-order path."""
+    from miso_amd import ops
+    levels, C, H, n = [(16, 16, 16), (32, 32, 32), (64, 64, 64)], 8, 64, 70000
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(n, 3, generator=gen) * 1.9 - 0.95).to(DEV)
+    feats = [(torch.randn((1, C) + s, generator=gen) * 3e-2).to(DEV).contiguous(memory_format=torch.channels_last_3d)
+             .requires_grad_(True) for s in levels]
+    torch.manual_seed(2)
+    lin = [torch.nn.Linear(C * 3, H), torch.nn.Linear(H, H), torch.nn.Linear(H, 1)]
+    pack = ops.DecoderPack([l.weight.detach().to(DEV) for l in lin], [l.bias.detach().to(DEV) for l in lin])
+    meta = ops.GridMeta.from_bound(torch.tensor([[-1.0, 1.0]] * 3))
+    wgt = torch.rand(n, 1, generator=gen).to(DEV)
+
+    def run(auto_min):
+        saved = ops.SortedBatch.AUTO_MIN_POINTS
+        ops.SortedBatch.AUTO_MIN_POINTS = auto_min
+        try:
+            xd = x.clone().requires_grad_(True)
+            cot = wgt.clone().requires_grad_(True)
+            sdf = ops.sdf_fused(xd, feats, meta, pack)
+            g, = torch.autograd.grad(sdf, xd, cot, create_graph=True)
+            loss = ((g.norm(dim=1) - 0.5) ** 2).mean()
+            got = torch.autograd.grad(loss, feats + [cot])
+            return g.detach(), [t.detach() for t in got]
+        finally:
+            ops.SortedBatch.AUTO_MIN_POINTS = saved
+
+    g_b, d_b = run(65536)
+    g_c, d_c = run(None)
+    assert torch.equal(g_b, g_c)                     # per point the same launch arithmetic, whatever the order
+    for a, c in zip(d_b, d_c):
+        assert (a - c).abs().max().item() <= 1e-5 * c.abs().max().item() + 1e-12
 
 
 def test_first_backward_rows_are_the_decoder_cotangent_of_the_feature_rows():
