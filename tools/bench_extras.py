@@ -407,14 +407,18 @@ def eikonal_step(dev):
     feats, meta, pack, x = args
 
     def wall(iters=10):
-        for _ in range(3):
+        # (the first ~15 steps of either form run 10 - 60 % slower: allocator growth and the device's clock ramp)
+        for _ in range(20):
             EB.step(*args)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            EB.step(*args)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters * 1e6
+        best = float("inf")
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                EB.step(*args)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / iters * 1e6)
+        return best
 
     t_fused = wall()
     ops._BWD2_TORCH = True
