@@ -191,9 +191,10 @@ __global__ __launch_bounds__(64 * MC_WAVES, 4) void grad_pull_mc_kernel(McK pk) 
     // ---- per-block geometry -> LDS records (computed by the first threads, read back where needed) ----------------
     // level d, axis a: the block owns vertices [v0, v0 + E) = the bricks of its two tiles; points that touch them lie in
     // tiles [tlo, thi] (widened by one numerator unit against the rounding of the sort's tile_of)
-    // Wavefront 0 forms it lane-parallel, lane = (level, axis) -- as ~600 scalar instructions per wavefront, eight times
-    // per block, it was 2 us of every block's chain -- and leaves the block's catchment and the bounds of its tile rows in
-    // `geo`; the others clear the counters meanwhile and read `geo` behind the epoch's first barrier.
+    // Wavefront 0 forms it lane-parallel, lane = (level, axis), and leaves the block's catchment and the bounds of its tile
+    // rows in `geo`; the others read `geo` behind the epoch's first barrier.  (As ~600 scalar instructions in each of
+    // the eight wavefronts it took the same time -- the set-up waits for the kernel arguments and the tile offsets --
+    // but cost seven more spilled registers.)
     if (wave == 0) {
       int sz = 1, B = 0, foff = 0, live_i = 0, Ta = 1, ba = 0;
       float inv = 1.0f;
