@@ -80,7 +80,8 @@ def test_fused_atlas_query_vs_the_loop_on_eight_scannet_submaps(scannet8):
     from miso_amd import ops
     with torch.no_grad(), ops.exact_fp32():
         sdf_e = atlas(x)
-    assert not torch.equal(sdf_e, sdf_f)
+    if not os.environ.get("MISO_EXACT_F32"):       # (MISO_EXACT_F32=1 runs the whole suite on the exact chains: both are then the same launch)
+        assert not torch.equal(sdf_e, sdf_f)
     close(sdf_e, sdf_l, 0, 1e-5)
 
 

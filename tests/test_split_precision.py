@@ -16,6 +16,8 @@ evaluations (tests/test_config_shapes.py::test_full_size_cfg2_gradient_outliers_
 census) carry a zero cotangent here.
 Arithmetic compared: grid_opt/models/modules.py:11-32 (MLPNet), grid_opt/models/grid_net.py:306-325.
 """
+import os
+
 import pytest
 import torch
 
@@ -91,6 +93,7 @@ def _err(a, ref):
     return d.max().item(), d.mean().item()
 
 
+@pytest.mark.skipif(bool(os.environ.get("MISO_EXACT_F32")), reason="MISO_EXACT_F32 forces the exact chains: nothing to compare")
 @pytest.mark.parametrize("name,levels,C,H,bound,dyadic", SHAPES, ids=[s[0] for s in SHAPES])
 def test_split_decoder_error_within_twice_the_exact_fp32_kernels(name, levels, C, H, bound, dyadic):
     x, feats, b, ws, bs, g = _inputs(levels, C, H, bound, dyadic, seed=len(name) * 7 + C)
