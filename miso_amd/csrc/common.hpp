@@ -25,6 +25,12 @@ struct LevelK {
 // sorted point p is the integer in xn[p].w (miso_sort_points with perm == NULL; sdf_train_kernel)
 constexpr uint32_t MISO_F_INDEX_IN_XN = 1u << 20;
 
+// GridK::tune bit 31: sdf_train_kernel<SCAT> has a second block of cell records in LDS and requests the next chunk's
+// gathers in front of this chunk's atomics (set by its launcher when the shape leaves room)
+constexpr uint32_t MISO_TUNE_ROTATE = 1u << 31;
+constexpr int MISO_ROTATE_MAX_F = 12;        // ... for feature rows up to 12 floats (wider rows: the rotated loop spills)
+constexpr size_t MISO_LDS_LIMIT = 160 * 1024;      // LDS of a CDNA4 compute unit = the most one workgroup can have
+
 struct GridK {
   int32_t n_levels;
   uint32_t ignore_mask;
@@ -35,7 +41,7 @@ struct GridK {
   // flags carry COORDS_NORMALIZED and gscale = 2/len restores d xn / d x for the pose gradient
   float gscale[3];
   int32_t xstride;
-  uint32_t tune;   // dev-only ablation bits from $MISO_TUNE (0 in production)
+  uint32_t tune;   // dev-only ablation bits from $MISO_TUNE (0 in production), and MISO_TUNE_ROTATE (set by launch_train_t)
   LevelK lv[MISO_MAX_LEVELS];
 };
 

@@ -579,6 +579,60 @@ __global__ __launch_bounds__(256, 2) MISO_FUSED_KERNEL_ATTR void sdf_bwd_kernel(
 // only the first of the two 32-point matrix tiles is computed.  For batches that are one chunk per wavefront anyway (a
 // few thousand samples: Newer College's 6 144, the tracker's windows): the wavefront's chain of matrix instructions halves,
 // twice as many wavefronts share the batch.  Same arithmetic per point.
+#ifdef MISO_ABL_NO_GATHER     // dev ablation (wrong results): the cell arithmetic without the corner loads
+#define MISO_TRAIN_GATHER_LEVEL(lv, c, fo) \
+  for (int q = 0; q < C; ++q) (fo)[q] = c.wx[0] * (float)(c.i0 + q) + c.wy[1] * (float)c.j0 + c.wz[0] * (float)c.k0
+#else
+#define MISO_TRAIN_GATHER_LEVEL(lv, c, fo) gather_level<C>(lv, c, fo)
+#endif
+// A chunk's input side (sdf_train_kernel): its point, label row and corner gathers (-> f) and, scattering, its cell records
+// (-> recw: base offset, in-bound bits, the six weights, as sdf_bwd_kernel forms them from the point again).  A macro, not a
+// lambda: the non-scattering instantiations must compile to the loop they had before the scattering ones learnt to
+// request a chunk's gathers one chunk early.
+#define MISO_TRAIN_GATHER(CHUNK_, RECW_, P_O_, PO_O_, VALID_O_, LIN_O_)                                        \
+  {                                                                                                         \
+    const int64_t gp_ = HALF ? (CHUNK_) * 32 + (lane & 31) : (CHUNK_) * 64 + lane; \
+    const bool gvalid_ = gp_ < n; \
+    int64_t gpo_ = gp_; \
+    if (gvalid_ && perm) gpo_ = (int64_t)perm[gp_]; \
+    else if (gvalid_ && (g.flags & MISO_F_INDEX_IN_XN)) gpo_ = (int64_t)__float_as_int(reinterpret_cast<const float4*>(x)[gp_].w); \
+    float4 glin_ = make_float4(0.f, 1.f, 0.f, 1.f); \
+    if (gvalid_) glin_ = lin.aux[gpo_]; \
+_Pragma("unroll") \
+    for (int i = 0; i < 2 * KS0; ++i) f[i] = 0.0f; \
+    memory_phase(true, g.tune); \
+    if (gvalid_) { \
+      float px, py, pz; \
+      load_point(g, x, gp_, px, py, pz); \
+      float bmn[3] = {g.bmin[0], g.bmin[1], g.bmin[2]}, bmx[3] = {g.bmax[0], g.bmax[1], g.bmax[2]}; \
+      asm volatile("" : "+s"(bmn[0]), "+s"(bmn[1]), "+s"(bmn[2]), "+s"(bmx[0]), "+s"(bmx[1]), "+s"(bmx[2])); \
+_Pragma("unroll") \
+      for (int l = 0; l < L; ++l) { \
+        LevelK lv = g.lv[l]; \
+        if ((g.ignore_mask >> l) & 1u) continue; \
+        asm volatile("" : "+s"(lv.X), "+s"(lv.Y), "+s"(lv.Z)); \
+        Axis ax = axis_coord(px, bmn[0], bmx[0], lv.X, g.flags); \
+        Axis ay = axis_coord(py, bmn[1], bmx[1], lv.Y, g.flags); \
+        Axis az = axis_coord(pz, bmn[2], bmx[2], lv.Z, g.flags); \
+        Cell c = make_cell(ax, ay, az, lv); \
+      MISO_TRAIN_GATHER_LEVEL(lv, c, &f[l * C]); \
+        if (SCAT && ((scatter_mask >> l) & 1u)) { \
+          const int flags = (c.inx[0] ? 1 : 0) | (c.inx[1] ? 2 : 0) | (c.iny[0] ? 4 : 0) | (c.iny[1] ? 8 : 0) | \
+                            (c.inz[0] ? 16 : 0) | (c.inz[1] ? 32 : 0); \
+          int* r = (RECW_) + (row_l * L + l) * REC; \
+          *reinterpret_cast<int4*>(r) = make_int4(c.k0 * lv.sZ + c.j0 * lv.sY + c.i0 * lv.sX, flags, \
+                                                  __float_as_int(c.wx[1]), __float_as_int(c.wy[1])); \
+          *reinterpret_cast<int4*>(r + 4) = make_int4(__float_as_int(c.wz[1]), __float_as_int(c.wx[0]), \
+                                                      __float_as_int(c.wy[0]), __float_as_int(c.wz[0])); \
+        } \
+      } \
+    } else if (SCAT) { \
+_Pragma("unroll") \
+      for (int l = 0; l < L; ++l) (RECW_)[(row_l * L + l) * REC + 1] = 0; \
+    } \
+    memory_phase(false, g.tune, wave < NW / 2); \
+    P_O_ = gp_; PO_O_ = gpo_; VALID_O_ = gvalid_; LIN_O_ = glin_; \
+  }
 template <int C, int L, int H, int NH, bool SCAT, int NW = 4, bool HALF = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_kernel(GridK g, const float* __restrict__ packed,
                                                           const float* __restrict__ x, int64_t n,
@@ -589,7 +643,10 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
   constexpr int MW = (NH + 1) * RT;
   constexpr int FP = ((F + 3) / 4) * 4 + 4;      // d-feat row pitch in LDS: 16-B aligned, conflict-free b128 writes
   constexpr int REC = 8;                         // ints per (point, level) cell record (SCAT)
-  constexpr int WAVE_LDS = 64 * FP + (SCAT ? 64 * L * REC : 0);
+  // SCAT: the cell records are double-buffered when the launcher found room for a second block (MISO_TUNE_ROTATE) -- the
+  // next chunk's gathers are then issued in FRONT of this chunk's atomics, see the loop
+  const bool rotate = SCAT && C * L <= MISO_ROTATE_MAX_F && (g.tune & MISO_TUNE_ROTATE) != 0;
+  const int WAVE_LDS = 64 * FP + (SCAT ? (rotate ? 2 : 1) * 64 * L * REC : 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PackLayout pl(F, H, NH);
   // the whole pack: forward part [0, fwd_end), transposed weights [o_whT, total) right behind it; the split form: the
@@ -636,56 +693,27 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     if (wave >= NW / 2)
       for (uint32_t i = 0; i < ((g.tune >> 8) & 255u); ++i) __builtin_amdgcn_s_sleep(16);
   }
+  // A chunk's input side: its point, label row and corner gathers (-> f) and, scattering, its cell records (-> recw).
+  const int row_l = HALF ? (lane & 31) : lane;      // this lane's row of the wavefront's LDS tile / records
+  float f[2 * KS0];
+  // Rotated (scattering, room for two record blocks): chunk k+1's gathers are requested between chunk k's decoder
+  // backward and its atomics.  The atomics execute at the memory side at a fixed rate and queue up in the CU's memory
+  // pipeline; a gather requested behind them waits for all of them, and with every wavefront of the launch in the same
+  // phase the kernel took (decoder time) + (atomic time).  Requested in front of them, the next chunk's rows arrive
+  // while the atomics drain and its decoder runs under them (cfg-3: 199 -> see DESIGN 4.2).
+  int* rec_cur = rec;
+  int* rec_nxt = rotate ? rec + 64 * L * REC : rec;
+  int64_t p_n = 0, po_n = 0;      // (rotated) the coming chunk's point index (binned / caller order), ...
+  bool valid_n = false;
+  float4 l_in_n = make_float4(0.f, 1.f, 0.f, 1.f);
+  if (rotate && sched.cur < sched.end) MISO_TRAIN_GATHER(sched.cur, rec_cur, p_n, po_n, valid_n, l_in_n)
   for (int64_t chunk = sched.cur; chunk < sched.end; chunk += sched.step) {
     asm volatile("" ::: "memory");      // see sdf_fwd_kernel: keeps the LDS reads of weights / biases inside the loop
-    const int64_t p = HALF ? chunk * 32 + (lane & 31) : chunk * 64 + lane;
-    const int row_l = HALF ? (lane & 31) : lane;      // this lane's row of the wavefront's LDS tile / records
-    const bool valid = p < n;
-    int64_t po = p;
-    if (valid && perm) po = (int64_t)perm[p];
-    // (a binned batch without perm[]: the sort left the original index in xn[p].w)
-    else if (valid && (g.flags & MISO_F_INDEX_IN_XN)) po = (int64_t)__float_as_int(reinterpret_cast<const float4*>(x)[p].w);
-    float4 l_in = make_float4(0.f, 1.f, 0.f, 1.f);
-    if (valid) l_in = lin.aux[po];
-    float f[2 * KS0];
-#pragma unroll
-    for (int i = 0; i < 2 * KS0; ++i) f[i] = 0.0f;
-    memory_phase(true, g.tune);
-    if (valid) {
-      float px, py, pz;
-      load_point(g, x, p, px, py, pz);
-      float bmn[3] = {g.bmin[0], g.bmin[1], g.bmin[2]}, bmx[3] = {g.bmax[0], g.bmax[1], g.bmax[2]};
-      asm volatile("" : "+s"(bmn[0]), "+s"(bmn[1]), "+s"(bmn[2]), "+s"(bmx[0]), "+s"(bmx[1]), "+s"(bmx[2]));
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
-        LevelK lv = g.lv[l];
-        if ((g.ignore_mask >> l) & 1u) continue;
-        asm volatile("" : "+s"(lv.X), "+s"(lv.Y), "+s"(lv.Z));
-        Axis ax = axis_coord(px, bmn[0], bmx[0], lv.X, g.flags);
-        Axis ay = axis_coord(py, bmn[1], bmx[1], lv.Y, g.flags);
-        Axis az = axis_coord(pz, bmn[2], bmx[2], lv.Z, g.flags);
-        Cell c = make_cell(ax, ay, az, lv);
-#ifdef MISO_ABL_NO_GATHER     // dev ablation (wrong results): the cell arithmetic without the corner loads
-        for (int q = 0; q < C; ++q) f[l * C + q] = c.wx[0] * (float)(c.i0 + q) + c.wy[1] * (float)c.j0 + c.wz[0] * (float)c.k0;
-#else
-        gather_level<C>(lv, c, &f[l * C]);
-#endif
-        if (SCAT && ((scatter_mask >> l) & 1u)) {
-          // the record sdf_bwd_kernel forms from the point again: base offset, in-bound bits, the six weights
-          const int flags = (c.inx[0] ? 1 : 0) | (c.inx[1] ? 2 : 0) | (c.iny[0] ? 4 : 0) | (c.iny[1] ? 8 : 0) |
-                            (c.inz[0] ? 16 : 0) | (c.inz[1] ? 32 : 0);
-          int* r = rec + (row_l * L + l) * REC;
-          *reinterpret_cast<int4*>(r) = make_int4(c.k0 * lv.sZ + c.j0 * lv.sY + c.i0 * lv.sX, flags,
-                                                  __float_as_int(c.wx[1]), __float_as_int(c.wy[1]));
-          *reinterpret_cast<int4*>(r + 4) = make_int4(__float_as_int(c.wz[1]), __float_as_int(c.wx[0]),
-                                                      __float_as_int(c.wy[0]), __float_as_int(c.wz[0]));
-        }
-      }
-    } else if (SCAT) {
-#pragma unroll
-      for (int l = 0; l < L; ++l) rec[(row_l * L + l) * REC + 1] = 0;      // a row past the batch: no corner in bound
-    }
-    memory_phase(false, g.tune, wave < NW / 2);
+    int64_t p, po;
+    bool valid;
+    float4 l_in;
+    if (!rotate) MISO_TRAIN_GATHER(chunk, rec_cur, p, po, valid, l_in)
+    else { p = p_n; po = po_n; valid = valid_n; l_in = l_in_n; }
     // ================================ forward =====================================================================
     uint32_t mw[MW];
     float p0 = 0.0f, p1 = 0.0f, poison = 0.0f;
@@ -894,6 +922,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
           *reinterpret_cast<float4*>(dst + row * F + col) = *reinterpret_cast<const float4*>(dF + row * FP + col);
       }
     }
+    if (rotate && chunk + sched.step < sched.end) MISO_TRAIN_GATHER(chunk + sched.step, rec_nxt, p_n, po_n, valid_n, l_in_n)
     if (SCAT) {
       // the scatter of sdf_bwd_kernel: 64 / SLOTS trips, lane = (point slot, dx, channel), four (dy, dz) atomics each
       constexpr int LPR = 2 * C, SLOTS = 64 / LPR;
@@ -905,7 +934,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
         for (int l = 0; l < L; ++l) {
           const LevelK& lv = g.lv[l];
           if (!((scatter_mask >> l) & 1u)) continue;
-          const int* r = rec + (pt * L + l) * REC;
+          const int* r = rec_cur + (pt * L + l) * REC;
           const int4 r0 = *reinterpret_cast<const int4*>(r);
           const int4 r1 = *reinterpret_cast<const int4*>(r + 4);
           const int fl = r0.y;
@@ -919,7 +948,11 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
           for (int q = 0; q < 4; ++q) {
             const int dy = q & 1, dz = q >> 1;
             if (((fl >> (2 + dy)) & 1) && ((fl >> (4 + dz)) & 1)) {
+#ifndef MISO_ABL_NO_SCATTER      // dev ablation (wrong results): everything of the scatter but the atomics
               atomic_add_f32(base + dy * lv.sY + dz * lv.sZ, v * ((wx * wy[dy]) * wz[dz]));
+#else
+              asm volatile("" ::"v"(base + dy * lv.sY + dz * lv.sZ), "v"(v * ((wx * wy[dy]) * wz[dz])));
+#endif
               if (ch == 0) touch_chunk(lv, r0.x + dx * lv.sX + dy * lv.sY + dz * lv.sZ);   // C floats: one chunk
             }
           }
@@ -929,6 +962,7 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();      // the next chunk overwrites the tile (and the records)
     memory_phase(false, g.tune, wave < NW / 2);
+    if (rotate) { int* t_ = rec_cur; rec_cur = rec_nxt; rec_nxt = t_; }
   }
   // loss sums: as sdf_fwd_kernel (every block stores its pair into its own slot, the slots nobody owns are cleared)
   for (int o = 32; o > 0; o >>= 1) { loss_sdf += __shfl_down(loss_sdf, o); loss_fs += __shfl_down(loss_fs, o); }
@@ -1025,6 +1059,13 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
   const bool split = use_split(g);
   const int n_pack = split ? pl.total_all - pl.s_w0 + ((pl.n_bias() + 3) / 4) * 4 : ((pl.total + 3) / 4) * 4;
   size_t lds = (size_t)(n_pack + 4 * (64 * FP + (scat ? 64 * L * 8 : 0))) * sizeof(float);
+  GridK gr = g;      // (the scattering forms: with room for a second block of cell records the kernel rotates its loop)
+  gr.tune &= ~MISO_TUNE_ROTATE;
+  static const bool no_rotate = getenv("MISO_TRAIN_NO_ROTATE") != nullptr;      // dev A/B
+  if (scat && !no_rotate && C * L <= MISO_ROTATE_MAX_F && lds + (size_t)4 * 64 * L * 8 * sizeof(float) <= (size_t)MISO_LDS_LIMIT) {
+    lds += (size_t)4 * 64 * L * 8 * sizeof(float);
+    gr.tune |= MISO_TUNE_ROTATE;
+  }
   int64_t nchunks = (n + 63) / 64;
   // Nothing scattered from the kernel (the mapping step): ONE workgroup of eight wavefronts per CU instead of two of
   // four -- the same two wavefronts per SIMD, half the copies of the 48 KB pack out of L2 at the start of the launch,
@@ -1051,7 +1092,7 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
     auto kh = split ? sdf_train_kernel<C, L, H, NH, true, 4, true, true> : sdf_train_kernel<C, L, H, NH, true, 4, true, false>;
     hipError_t eh = allow_lds((const void*)kh, lds);
     if (eh != hipSuccess) return eh;
-    kh<<<bh_, 256, lds, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
+    kh<<<bh_, 256, lds, s>>>(gr, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
     return hipGetLastError();
   }
   unsigned blocks = (unsigned)((nchunks + 3) / 4);
@@ -1061,7 +1102,7 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
                  : (scat ? sdf_train_kernel<C, L, H, NH, true, 4, false, false> : sdf_train_kernel<C, L, H, NH, false, 4, false, false>);
   hipError_t e = allow_lds((const void*)k, lds);
   if (e != hipSuccess) return e;
-  k<<<blocks, 256, lds, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
+  k<<<blocks, 256, lds, s>>>(gr, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
   return hipGetLastError();
 }
 
@@ -1140,7 +1181,11 @@ int64_t sdf_train_lds_bytes(int C, int L, int H, int NH, bool scat) {
   // the larger of the two decoder forms (the split pack is the larger one for every covered shape)
   const int64_t pack_exact = ((pl.total + 3) / 4) * 4, pack_split = pl.total_all - pl.s_w0 + ((pl.n_bias() + 3) / 4) * 4;
   const int64_t pack = pack_split > pack_exact ? pack_split : pack_exact;
-  const int64_t four = pack + 4 * (64 * FP + (scat ? 64 * L * 8 : 0)), eight = pack + 8 * 64 * FP;
+  int64_t four = pack + 4 * (64 * FP + (scat ? 64 * L * 8 : 0));
+  const int64_t eight = pack + 8 * 64 * FP;
+  // (scattering: a second block of cell records where it fits, launch_train_t)
+  if (scat && F <= MISO_ROTATE_MAX_F && (four + 4 * 64 * L * 8) * (int64_t)sizeof(float) <= (int64_t)MISO_LDS_LIMIT)
+    four += 4 * 64 * L * 8;
   return (int64_t)sizeof(float) * (scat ? four : (eight > four ? eight : four));
 }
 

@@ -664,7 +664,7 @@ LDS_PER_WORKGROUP = 160 * 1024      # gfx950
 
 def sdf_train_lds_bytes(C: int, L: int, H: int, scat: bool, hidden_layers: int = 1) -> int:
     """Dynamic LDS of sdf_train_kernel<C, L, H, NH, SCAT> (sdf_fused.hip: PackLayout + four wavefronts' d-feat tiles
-    [64][FP] and, scattering, their cell records [64][L][8])."""
+    [64][FP] and, scattering, their cell records [64][L][8] -- two blocks of them where 160 KB allow)."""
     F, RT, KS0, KS1, NH = C * L, H // 32, (C * L + 1) // 2, H // 2, hidden_layers
     exact = KS0 * 64 * RT + 2 * NH * KS1 * 64 * RT + H + NH * H + H + 4 + KS1 * 64
     # the bf16x3 form (decoder.hpp): its matrices as [k-block][row tile][3 pieces][64 lanes][4 dwords] + biases and output
@@ -675,7 +675,10 @@ def sdf_train_lds_bytes(C: int, L: int, H: int, scat: bool, hidden_layers: int =
              + (smd(KBH, 1) if NH >= 1 else 0) + (H + NH * H + H + 4 + 3) // 4 * 4)
     pack = max((exact + 3) // 4 * 4, split)
     FP = (F + 3) // 4 * 4 + 4
-    return 4 * (pack + 4 * (64 * FP + (64 * L * 8 if scat else 0)))
+    words = pack + 4 * (64 * FP + (64 * L * 8 if scat else 0))
+    if scat and F <= 12 and 4 * (words + 4 * 64 * L * 8) <= LDS_PER_WORKGROUP:
+        words += 4 * 64 * L * 8          # a second block of cell records where it fits (the rotated loop, launch_train_t)
+    return 4 * words
 
 
 def sdf_train_scattered_levels(features, meta, grads, tiles=None) -> int:
