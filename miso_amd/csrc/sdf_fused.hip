@@ -1082,6 +1082,23 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
     k8<<<blocks8, 512, lds8, s>>>(g, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
     return hipGetLastError();
   }
+  // Scattering, narrow feature rows (cfg-3's C = 4, L = 2): eight wavefronts and their two record blocks each fit beside the
+  // pack, and the four-wavefront form is ONE workgroup per CU there (the bf16x3 pack is 67 KB) -- one wavefront per SIMD.
+  // Binned batches only (the unbinned small-batch forms below stay as they are).
+  if constexpr (C * L <= MISO_ROTATE_MAX_F) {
+    static const bool nw8s = getenv("MISO_TRAIN_SCAT_NW4") == nullptr;      // dev A/B
+    const size_t lds8 = (size_t)(n_pack + 8 * (64 * FP + 2 * 64 * L * 8)) * sizeof(float);
+    if (scat && nw8s && !no_rotate && (perm || (g.flags & MISO_F_INDEX_IN_XN)) && lds8 <= (size_t)MISO_LDS_LIMIT) {
+      unsigned blocks8 = (unsigned)((nchunks + 7) / 8);
+      if (blocks8 > 256u) blocks8 = 256u;
+      auto k8 = split ? sdf_train_kernel<C, L, H, NH, true, 8, false, true> : sdf_train_kernel<C, L, H, NH, true, 8, false, false>;
+      hipError_t e8 = allow_lds((const void*)k8, lds8);
+      if (e8 != hipSuccess) return e8;
+      gr.tune |= MISO_TUNE_ROTATE;
+      k8<<<blocks8, 512, lds8, s>>>(gr, packed, x, n, sdf, perm, lin, dfeat_out, defer_mask);
+      return hipGetLastError();
+    }
+  }
   // an unbinned batch of at most one 64-point chunk per SIMD (<= 65 536 samples): 32-point trips -- the batch is latency, not
   // throughput, and half the matrix chain per wavefront on twice the wavefronts is what shortens it (MISO_TRAIN_NO_HALF: dev)
   static const bool no_half = getenv("MISO_TRAIN_NO_HALF") != nullptr;
@@ -1186,6 +1203,9 @@ int64_t sdf_train_lds_bytes(int C, int L, int H, int NH, bool scat) {
   // (scattering: a second block of cell records where it fits, launch_train_t)
   if (scat && F <= MISO_ROTATE_MAX_F && (four + 4 * 64 * L * 8) * (int64_t)sizeof(float) <= (int64_t)MISO_LDS_LIMIT)
     four += 4 * 64 * L * 8;
+  // (and its eight-wavefront form where that fits)
+  const int64_t eight_s = pack + 8 * (64 * FP + 2 * 64 * L * 8);
+  if (scat && F <= MISO_ROTATE_MAX_F && eight_s * (int64_t)sizeof(float) <= (int64_t)MISO_LDS_LIMIT && eight_s > four) four = eight_s;
   return (int64_t)sizeof(float) * (scat ? four : (eight > four ? eight : four));
 }
 

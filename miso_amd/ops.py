@@ -678,6 +678,9 @@ def sdf_train_lds_bytes(C: int, L: int, H: int, scat: bool, hidden_layers: int =
     words = pack + 4 * (64 * FP + (64 * L * 8 if scat else 0))
     if scat and F <= 12 and 4 * (words + 4 * 64 * L * 8) <= LDS_PER_WORKGROUP:
         words += 4 * 64 * L * 8          # a second block of cell records where it fits (the rotated loop, launch_train_t)
+        eight = pack + 8 * (64 * FP + 2 * 64 * L * 8)          # ... and the eight-wavefront form of it
+        if 4 * eight <= LDS_PER_WORKGROUP:
+            words = max(words, eight)
     return 4 * words
 
 

@@ -135,7 +135,7 @@ def test_train_kernel_with_the_matrix_core_push_on_a_crowded_batch():
 def test_levels_the_pull_cannot_own_are_scattered_from_the_train_kernel():
     """A level with bricks beyond the pull's reach (200 vertices over 16 tiles: 12.5 per tile and axis; cfg-3's fine
     level) no longer forces the two launches: sdf_train_kernel<.., SCAT> scatters it with float atomics itself, the
-    other level still goes through the d-feat rows.  Against the two-launch form: SDF and loss bit for bit, the pulled
+    other level still goes through the d-feat rows.  Against the two-launch form: SDF bit for bit, the loss to the regrouping of the slots, the pulled
     level to the pull's summation order, the scattered one to the order of the atomics."""
     from miso_amd import ops
     from miso_amd.step import MappingStep
@@ -144,7 +144,9 @@ def test_levels_the_pull_cannot_own_are_scattered_from_the_train_kernel():
     grads = [torch.empty_like(f) for f in feats]
     assert ops.sdf_train_supported(feats, meta, grads) and ops.sdf_train_scattered_levels(feats, meta, grads) == 2
     (s1, sdf1, g1), (s2, sdf2, g2) = _both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.15)
-    assert torch.equal(s1, s2) and torch.equal(sdf1, sdf2)
+    # (the loss slots: eight wavefronts per workgroup in the one-launch kernel where its records fit, four in the forward
+    # kernel -- the totals agree to the rounding of that regrouping, as in _check)
+    assert torch.allclose(s1.double().sum(0), s2.double().sum(0), rtol=2e-6, atol=1e-12) and torch.equal(sdf1, sdf2)
     assert (g1[0] - g2[0]).abs().max().item() <= 2e-6 * g2[0].abs().max().item()
     assert (g1[1] - g2[1]).abs().max().item() <= 2e-5 * g2[1].abs().max().item() and float(g2[1].abs().max()) > 0
     # only the scattered level wanted: nothing goes through the workspace at all
