@@ -693,14 +693,13 @@ __global__ __launch_bounds__(64 * NW, 2) MISO_FUSED_KERNEL_ATTR void sdf_train_k
     if (wave >= NW / 2)
       for (uint32_t i = 0; i < ((g.tune >> 8) & 255u); ++i) __builtin_amdgcn_s_sleep(16);
   }
-  // A chunk's input side: its point, label row and corner gathers (-> f) and, scattering, its cell records (-> recw).
   const int row_l = HALF ? (lane & 31) : lane;      // this lane's row of the wavefront's LDS tile / records
   float f[2 * KS0];
   // Rotated (scattering, room for two record blocks): chunk k+1's gathers are requested between chunk k's decoder
   // backward and its atomics.  The atomics execute at the memory side at a fixed rate and queue up in the CU's memory
   // pipeline; a gather requested behind them waits for all of them, and with every wavefront of the launch in the same
   // phase the kernel took (decoder time) + (atomic time).  Requested in front of them, the next chunk's rows arrive
-  // while the atomics drain and its decoder runs under them (cfg-3: 199 -> see DESIGN 4.2).
+  // while the atomics drain and its decoder runs under them (cfg-3 trainer step 295 -> 279 us).
   int* rec_cur = rec;
   int* rec_nxt = rotate ? rec + 64 * L * REC : rec;
   int64_t p_n = 0, po_n = 0;      // (rotated) the coming chunk's point index (binned / caller order), ...
@@ -1070,7 +1069,8 @@ static hipError_t launch_train_t(const GridK& g, const float* packed, const floa
   // Nothing scattered from the kernel (the mapping step): ONE workgroup of eight wavefronts per CU instead of two of
   // four -- the same two wavefronts per SIMD, half the copies of the 48 KB pack out of L2 at the start of the launch,
   // one barrier per CU (cfg-2: 72.9 -> 72.0 us, A/B in one process; MISO_TRAIN_NW4 keeps the four-wavefront form).
-  // The scattering variant keeps four: its cell records would not fit beside eight d-feat tiles.
+  // The scattering variant keeps four where its cell records would not fit beside eight d-feat tiles (wide feature
+  // rows); for narrow ones see below.
   static const bool nw8 = getenv("MISO_TRAIN_NW4") == nullptr;
   if (nw8 && !scat) {
     size_t lds8 = (size_t)(n_pack + 8 * 64 * FP) * sizeof(float);
