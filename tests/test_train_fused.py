@@ -162,6 +162,22 @@ def test_levels_the_pull_cannot_own_are_scattered_from_the_train_kernel():
         assert (a_ - b_).abs().max().item() <= 2e-5 * b_.abs().max().item()
 
 
+@pytest.mark.parametrize("n", [1, 65, 3000, 40000])
+def test_rotated_scattering_kernel_on_small_and_ragged_binned_batches(n):
+    """sdf_train_kernel<.., SCAT> with narrow feature rows runs eight wavefronts per workgroup with its loop rotated (the next
+    chunk's gathers in front of this chunk's atomics, two blocks of cell records): batches with fewer chunks than
+    wavefronts (a wavefront without a chunk), one ragged chunk, and several chunks per wavefront -- against the two-launch
+    form, the scattered level to the order of the atomics."""
+    feats, meta, pack, x, aux = _setup(4, (40, 200), 64, n, seed=50 + n)
+    if n > 7:
+        aux[7, 0] = 0.0
+    (s1, sdf1, g1), (s2, sdf2, g2) = _both(feats, meta, pack, x, aux, "L1", 1.0, 0.1, 0.15)
+    assert torch.allclose(s1.double().sum(0), s2.double().sum(0), rtol=2e-6, atol=1e-12) and torch.equal(sdf1, sdf2)
+    for a, b in zip(g1, g2):
+        scale = max(b.abs().max().item(), 1e-30)
+        assert (a - b).abs().max().item() <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("shape", [(4, (16, 80), 64), (8, (32, 64, 128), 64), (4, (48,), 32), (4, (16, 32, 48, 64), 64)])
 @pytest.mark.parametrize("n", [1, 65, 3000])
 def test_unbinned_train_kernel_equals_forward_plus_backward(shape, n):
